@@ -1,0 +1,206 @@
+/*
+ * asd_hip.h — C ABI of libasd_hip.so: the MI355X (gfx950) implementation of ScaleDreamer's
+ * Asynchronous-Score-Distillation inner loop.
+ *
+ * The reference (theEricMa/ScaleDreamer) defines no C symbols of its own: every native call on this
+ * path goes into a pip-installed third-party CUDA package.  Each entry point below therefore cites the
+ * *reference call site* whose native callee it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers + sizes only, no torch types; every pointer is DEVICE memory unless marked [host]
+ *   - the CALLER owns all memory (outputs, workspaces); nothing is allocated or freed in here
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); no call synchronises
+ *   - return value: 0 = ok, non-zero = error; text via asd_last_error() (thread local)
+ *   - sample arrays are "packed": samples of ray r occupy [ray_offset[r], ray_offset[r]+ray_count[r])
+ *   - sizes that only exist on the device (number of marched / kept samples) are passed as
+ *     `const int32_t* n_dev`; the launch is sized by the host-known upper bound `n_max`
+ */
+#ifndef ASD_HIP_H
+#define ASD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASD_MAX_LEVELS 16
+#define ASD_OK 0
+#define ASD_ERR_ARG 1
+#define ASD_ERR_LAUNCH 2
+#define ASD_ERR_UNSUPPORTED 3
+
+/* ------------------------------------------------------------------------------------------------
+ * Multiresolution hash grid (replaces tinycudann `tcnn.Encoding(n_in, {"otype":"HashGrid",...})`,
+ * threestudio/models/networks.py:55-64; behaviour spec SURVEY.md Appendix B.1)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_grid_meta {
+    uint32_t n_levels;            /* L */
+    uint32_t n_features;          /* F, must be 2 */
+    uint32_t n_params;            /* total floats = sum(size[l]) * F */
+    uint32_t reserved;
+    float    scale[ASD_MAX_LEVELS];       /* 2^(l*log2(per_level_scale)) * base_res - 1 */
+    uint32_t resolution[ASD_MAX_LEVELS];  /* ceil(scale)+1 */
+    uint32_t offset[ASD_MAX_LEVELS];      /* first entry (in F-tuples) of the level's table */
+    uint32_t size[ASD_MAX_LEVELS];        /* entries in the level's table (hashmap size) */
+    uint32_t dense[ASD_MAX_LEVELS];       /* 1: res^3 <= size (direct index), 0: hashed */
+} asd_grid_meta;
+
+/* [host] fill `meta`; returns the number of fp32 parameters (12 599 920 for the asd_sd_nerf geometry). */
+uint32_t asd_grid_meta_init(asd_grid_meta* meta, uint32_t n_levels, uint32_t n_features,
+                            uint32_t log2_hashmap_size, uint32_t base_resolution, double per_level_scale);
+
+/* out[n, L*F] = encode(x[n,3] in [0,1]);  tcnn.Encoding.forward (networks.py:64). */
+int asd_hashgrid_fwd(const asd_grid_meta* meta, const float* params, const float* x, int32_t n,
+                     float* out, void* stream);
+/* dparams += scatter(dout[n, L*F]);  autograd backward of the call above (tcnn kernel_grid_backward). */
+int asd_hashgrid_bwd(const asd_grid_meta* meta, const float* x, const float* dout, int32_t n,
+                     float* dparams, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused field: contract -> hash grid -> VanillaMLP(32->H->1) + density bias + activation,
+ * VanillaMLP(32->H->C) features, finite-difference normal.
+ * Replaces ImplicitVolume.forward / forward_density (threestudio/models/geometry/implicit_volume.py:
+ * 109-207) = TCNNEncoding + 2x VanillaMLP (networks.py:214-251) + get_activated_density (:80-107).
+ * ---------------------------------------------------------------------------------------------- */
+enum { ASD_BIAS_CONST = 0, ASD_BIAS_BLOB_MAGIC3D = 1, ASD_BIAS_BLOB_DREAMFUSION = 2 };
+enum { ASD_ACT_SOFTPLUS = 0, ASD_ACT_EXP = 1, ASD_ACT_TRUNC_EXP = 2, ASD_ACT_NONE = 3 };
+
+typedef struct asd_field_cfg {
+    float   bbox_min[3], bbox_max[3];   /* geometry.bbox (geometry/base.py:72-83) */
+    float   radius;                     /* clamp range of finite-difference offsets */
+    int32_t bias_mode;                  /* ASD_BIAS_* */
+    float   bias_value;                 /* ASD_BIAS_CONST */
+    float   blob_scale, blob_std;
+    int32_t activation;                 /* ASD_ACT_* */
+    float   fd_eps;                     /* finite_difference_normal_eps */
+    int32_t n_hidden;                   /* 64 */
+    int32_t n_feature_dims;             /* 3 (0: no feature network) */
+} asd_field_cfg;
+
+/* sigma[n] only (no_grad): geometry.forward_density — used by the marcher's sigma_fn
+ * (nerf_volume_renderer.py:153-167) and the occupancy update (:436-439).
+ * If n_dev != NULL the live count is read on the device and n is the launch bound. */
+int asd_field_density(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                      const float* w1_density /*[H,32]*/, const float* w2_density /*[1,H]*/,
+                      const float* points /*[n,3]*/, int32_t n, const int32_t* n_dev,
+                      float* sigma /*[n]*/, void* stream);
+
+/* Training forward at kept samples: geometry(points, output_normal) (nerf_volume_renderer.py:282-284).
+ * Outputs: sigma[n], features[n,C] (pre-activation), normal[n,3] (NULL: skip the 3 offset evaluations).
+ * enc_save[n, L*F] keeps the centre encoding for the backward pass. */
+int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                  const float* w1_density, const float* w2_density,
+                  const float* w1_feature /*[H,32]*/, const float* w2_feature /*[C,H]*/,
+                  const float* points, int32_t n, const int32_t* n_dev,
+                  float* sigma, float* features, float* normal, float* enc_save, void* stream);
+
+/* Backward: given dL/dsigma[n], dL/dfeatures[n,C], dL/dnormal[n,3] (any may be NULL) accumulate
+ * d_grid_params (atomic scatter) and write per-block partial MLP weight gradients into
+ * `wgrad_partials[n_blocks, wgrad_stride]` (see asd_field_bwd_workspace); asd_field_bwd_reduce sums
+ * them deterministically into dw1_density/dw2_density/dw1_feature/dw2_feature (+=). */
+int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t* n_blocks, int32_t* wgrad_stride);
+int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                  const float* w1_density, const float* w2_density,
+                  const float* w1_feature, const float* w2_feature,
+                  const float* points, const float* enc_save, const float* sigma /* forward output */,
+                  int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
+                  float* d_grid_params, float* wgrad_partials, void* stream);
+int asd_field_bwd_reduce(const asd_field_cfg* cfg, const float* wgrad_partials, int32_t n_blocks,
+                         float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Background: (d+1)/2 -> hash grid (L levels) -> VanillaMLP(2L -> H -> H -> 3) -> sigmoid.
+ * Replaces NeuralEnvironmentMapBackground.forward
+ * (threestudio/models/background/neural_environment_map_background.py:46-67).
+ * ---------------------------------------------------------------------------------------------- */
+int asd_envmap_fwd(const asd_grid_meta* meta, const float* grid_params,
+                   const float* w0 /*[H,2L]*/, const float* w1 /*[H,H]*/, const float* w2 /*[3,H]*/,
+                   int32_t n_hidden, const float* dirs /*[n,3]*/, int32_t n, float* color /*[n,3]*/,
+                   void* stream);
+/* backward: d_grid_params / dw0 / dw1 / dw2 are accumulated with atomics (caller zeroes them). */
+int asd_envmap_bwd(const asd_grid_meta* meta, const float* grid_params,
+                   const float* w0, const float* w1, const float* w2, int32_t n_hidden,
+                   const float* dirs, const float* d_color, int32_t n,
+                   float* d_grid_params, float* dw0, float* dw1, float* dw2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy-grid ray marching (replaces nerfacc.OccGridEstimator.sampling -> CUDA traverse_grids /
+ * ray_aabb_intersect / render_visibility_from_density; call site nerf_volume_renderer.py:139-180).
+ * Sample placement convention (nerfacc's is unpinned): per ray the samples lie on the
+ * lattice t_k = t_begin + k*step, t_begin = max(t_aabb_enter, near + jitter*step); interval k is emitted
+ * iff its midpoint is inside the aabb, t_mid <= min(t_aabb_exit, far) and its grid cell is occupied.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_march_cfg {
+    float   aabb[6];        /* xmin ymin zmin xmax ymax zmax */
+    int32_t resolution;     /* 32 */
+    float   near_plane, far_plane;
+    float   step;           /* render_step_size */
+    int32_t max_steps;      /* lattice points examined per ray (>= ceil(diag/step)+1) */
+} asd_march_cfg;
+
+/* pass 1: count[r] = number of lattice intervals of ray r in occupied cells.
+ * `occ_bits`: resolution^3 bits, cell (ix,iy,iz) -> bit ix*res*res + iy*res + iz (nerfacc binaries layout),
+ * jitter[n_rays] in [0,1) or NULL (stratified=False). */
+int asd_march_count(const asd_march_cfg* cfg, const float* rays_o, const float* rays_d, int32_t n_rays,
+                    const uint32_t* occ_bits, const float* jitter, int32_t* count, void* stream);
+/* exclusive scan of count[n] -> offset[n], total[0]; single launch. */
+int asd_scan_i32(const int32_t* count, int32_t n, int32_t* offset, int32_t* total, void* stream);
+/* pass 2: write the packed candidates. */
+int asd_march_write(const asd_march_cfg* cfg, const float* rays_o, const float* rays_d, int32_t n_rays,
+                    const uint32_t* occ_bits, const float* jitter, const int32_t* offset,
+                    int32_t* ray_idx, float* t_start, float* t_end, float* points /*[.,3] midpoints*/,
+                    void* stream);
+/* visibility pruning (nerfacc render_visibility_from_density): keep[i] = T_i >= early_stop_eps &&
+ * alpha_i >= alpha_thre, T exclusive per ray; kept_count[r]. */
+int asd_prune_count(const float* sigma, const float* t_start, const float* t_end,
+                    const int32_t* offset, const int32_t* count, int32_t n_rays,
+                    float early_stop_eps, float alpha_thre, uint8_t* keep, int32_t* kept_count,
+                    void* stream);
+/* compaction of kept samples into a second packed set (+ per-sample positions and directions). */
+int asd_compact(const float* rays_o, const float* rays_d, int32_t n_rays,
+                const int32_t* offset, const int32_t* count, const uint8_t* keep,
+                const float* t_start, const float* t_end, const int32_t* kept_offset,
+                int64_t* ray_idx_out, float* t_start_out, float* t_end_out,
+                float* points_out /*[.,3]*/, float* dirs_out /*[.,3]*/, void* stream);
+
+/* occupancy update (nerfacc update_every_n_steps -> _update):
+ * occs[c] = max(occs[c]*decay, occ_new[c]) for the listed cells; then
+ * threshold = min(mean(occs), occ_thre) and bits = occs > threshold (two launches inside). */
+int asd_occgrid_update(float* occs, int32_t n_cells, const int32_t* cell_idx, const float* occ_new,
+                       int32_t n_update, float decay, float occ_thre, uint32_t* occ_bits,
+                       uint8_t* binaries /*[n_cells] bool mirror*/, float* scratch /*[2]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Compositing (replaces nerfacc.render_weight_from_density + 5x accumulate_along_rays and the glue in
+ * nerf_volume_renderer.py:312-364).
+ * ---------------------------------------------------------------------------------------------- */
+/* per ray r: T,alpha,w over its packed samples;
+ *   opacity=sum w, depth=sum w t, rgb_fg=sum w sigmoid?(c) (colors are passed already activated),
+ *   z_mean = sum (w/max(op,1e-5)) t, z_var = [op>0.5] * sum (w/max(op,1e-5)) (t-z_mean)^2,
+ *   comp_rgb = rgb_fg + bg*(1-opacity).   t = (t_start+t_end)/2.
+ * mode 0: sigma is a density (alpha = 1-exp(-sigma*dt)); mode 1: `sigma` already holds alpha
+ *   (nerfacc.render_weight_from_alpha, generative_space_volsdf_volume_renderer.py:362-366). */
+int asd_composite_fwd(int32_t mode, const float* sigma, const float* t_start, const float* t_end,
+                      const float* rgb /*[n,3]*/, const int32_t* offset, const int32_t* count,
+                      int32_t n_rays, const float* bg /*[n_rays,3]*/,
+                      float* weights /*[n]*/, float* opacity, float* depth, float* rgb_fg /*[.,3]*/,
+                      float* z_var, float* comp_rgb /*[.,3]*/, void* stream);
+/* gradients w.r.t. sigma (or alpha), rgb and bg given upstream grads of the per-ray outputs and of
+ * the per-sample weights (any upstream pointer may be NULL). */
+int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, const float* t_end,
+                      const float* rgb, const int32_t* offset, const int32_t* count, int32_t n_rays,
+                      const float* bg, const float* weights, const float* opacity, const float* depth,
+                      const float* d_comp_rgb, const float* d_rgb_fg, const float* d_opacity,
+                      const float* d_depth, const float* d_z_var, const float* d_weights,
+                      float* d_sigma, float* d_rgb, float* d_bg, void* stream);
+
+/* library info */
+const char* asd_version(void);
+const char* asd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASD_HIP_H */

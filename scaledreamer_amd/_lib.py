@@ -1,0 +1,131 @@
+"""ctypes binding of libasd_hip.so (C ABI: include/asd_hip.h).
+
+The product path has no fallback: if the HIP library is missing or a call fails, an exception is raised.
+PyTorch only supplies device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasd_hip.so")
+ASD_MAX_LEVELS = 16
+
+ASD_BIAS_CONST, ASD_BIAS_BLOB_MAGIC3D, ASD_BIAS_BLOB_DREAMFUSION = 0, 1, 2
+ASD_ACT_SOFTPLUS, ASD_ACT_EXP, ASD_ACT_TRUNC_EXP, ASD_ACT_NONE = 0, 1, 2, 3
+
+
+class AsdError(RuntimeError):
+    pass
+
+
+class GridMeta(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32),
+        ("n_features", C.c_uint32),
+        ("n_params", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("scale", C.c_float * ASD_MAX_LEVELS),
+        ("resolution", C.c_uint32 * ASD_MAX_LEVELS),
+        ("offset", C.c_uint32 * ASD_MAX_LEVELS),
+        ("size", C.c_uint32 * ASD_MAX_LEVELS),
+        ("dense", C.c_uint32 * ASD_MAX_LEVELS),
+    ]
+
+
+class FieldCfg(C.Structure):
+    _fields_ = [
+        ("bbox_min", C.c_float * 3),
+        ("bbox_max", C.c_float * 3),
+        ("radius", C.c_float),
+        ("bias_mode", C.c_int32),
+        ("bias_value", C.c_float),
+        ("blob_scale", C.c_float),
+        ("blob_std", C.c_float),
+        ("activation", C.c_int32),
+        ("fd_eps", C.c_float),
+        ("n_hidden", C.c_int32),
+        ("n_feature_dims", C.c_int32),
+    ]
+
+
+class MarchCfg(C.Structure):
+    _fields_ = [
+        ("aabb", C.c_float * 6),
+        ("resolution", C.c_int32),
+        ("near_plane", C.c_float),
+        ("far_plane", C.c_float),
+        ("step", C.c_float),
+        ("max_steps", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/asd_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "asd_grid_meta_init", "asd_hashgrid_fwd", "asd_hashgrid_bwd",
+    "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd", "asd_field_bwd_reduce",
+    "asd_envmap_fwd", "asd_envmap_bwd",
+    "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
+    "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
+    "asd_version", "asd_last_error",
+]
+
+
+def lib() -> C.CDLL:
+    """Load libasd_hip.so (once). Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AsdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C scaledreamer_amd/csrc). The HIP path has no fallback."
+            )
+        l = C.CDLL(LIB_PATH)
+        l.asd_last_error.restype = C.c_char_p
+        l.asd_version.restype = C.c_char_p
+        l.asd_grid_meta_init.restype = C.c_uint32
+        l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+        _lib = l
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise AsdError(f"libasd_hip error {status}: {lib().asd_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_contiguous():
+        raise AsdError("non-contiguous tensor passed to the C ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(v: float) -> C.c_float:
+    return C.c_float(v)
+
+
+def i32(v: int) -> C.c_int32:
+    return C.c_int32(v)
+
+
+def make_grid_meta(n_levels: int, n_features: int, log2_hashmap_size: int, base_resolution: int,
+                   per_level_scale: float) -> GridMeta:
+    m = GridMeta()
+    n = lib().asd_grid_meta_init(C.byref(m), n_levels, n_features, log2_hashmap_size, base_resolution,
+                                 float(per_level_scale))
+    if n == 0:
+        raise AsdError(lib().asd_last_error().decode())
+    return m

@@ -1,0 +1,156 @@
+// asd_common.h — shared host/device helpers for libasd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/asd_hip.h"
+
+#define ASD_WAVE 64
+
+void asd_set_error(const char* fmt, ...);
+
+#define ASD_CHECK_ARG(cond, msg)                          \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            asd_set_error("%s: %s", __func__, msg);       \
+            return ASD_ERR_ARG;                           \
+        }                                                 \
+    } while (0)
+
+#define ASD_LAUNCH_CHECK()                                                         \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            asd_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return ASD_ERR_LAUNCH;                                                 \
+        }                                                                          \
+    } while (0)
+
+static inline int asd_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Memory-bound grid sizing (guide G11): cap at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int asd_grid_for(int64_t n, int block) {
+    int g = asd_div_up(n, block);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return g;
+}
+
+#ifdef __HIPCC__
+// ---- wave64 primitives -------------------------------------------------------------------------
+__device__ __forceinline__ int asd_lane() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float asd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ float asd_wave_incl_scan(float v) {
+    const int lane = asd_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float asd_wave_incl_prod(float v) {
+    const int lane = asd_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+// number of set bits of a wave ballot strictly below this lane
+__device__ __forceinline__ int asd_ballot_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ float asd_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float asd_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float asd_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- hash grid ---------------------------------------------------------------------------------
+// Table index of integer corner (cx,cy,cz).  Branch-free so that the 8 gathers of a level stay in one
+// basic block: both the dense and the hashed index are formed and selected with a scalar condition.
+// Inputs are clamped to [0,1] by the callers (asd_unit), so a dense index is < 2*size and one
+// conditional subtract implements tcnn's `% hashmap_size`.
+__device__ __forceinline__ uint32_t asd_grid_index(const asd_grid_meta& m, int l, uint32_t cx, uint32_t cy,
+                                                   uint32_t cz) {
+    const uint32_t res = m.resolution[l];
+    const uint32_t size = m.size[l];
+    uint32_t di = cx + cy * res + cz * res * res;
+    di -= (di >= size) ? size : 0u;
+    const uint32_t hi = ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
+    return m.dense[l] ? di : hi;
+}
+// out-of-range rule of this implementation: clamp to the unit cube (tcnn wraps through an unsigned cast)
+__device__ __forceinline__ float asd_unit(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
+// Gather-interpolate all levels of one point. enc[2L] stays in VGPRs (L is a compile-time constant).
+template <int L>
+__device__ __forceinline__ void asd_encode(const asd_grid_meta& m, const float* __restrict__ params, float x,
+                                           float y, float z, float (&enc)[2 * L]) {
+    x = asd_unit(x); y = asd_unit(y); z = asd_unit(z);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float s = m.scale[l];
+        const float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f), pz = fmaf(s, z, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        const float2* __restrict__ tab = reinterpret_cast<const float2*>(params) + m.offset[l];
+        float2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)  // issue the 8 independent 8-byte gathers first
+            v[c] = tab[asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1))];
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float ax = (c & 1) ? wx : 1.f - wx;
+            const float ay = (c & 2) ? wy : 1.f - wy;
+            const float az = (c & 4) ? wz : 1.f - wz;
+            const float wt = ax * ay * az;
+            f0 = fmaf(wt, v[c].x, f0);
+            f1 = fmaf(wt, v[c].y, f1);
+        }
+        enc[2 * l] = f0;
+        enc[2 * l + 1] = f1;
+        // keep at most 4 levels (32 gathers, 64 VGPRs) in flight: without this fence hipcc hoists all
+        // 128 gathers of the 16 levels to the top and spills (256 VGPRs, occupancy 1)
+        if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Scatter-add d_enc into the table gradient (fp32 hardware atomics; build with -munsafe-fp-atomics).
+template <int L>
+__device__ __forceinline__ void asd_scatter(const asd_grid_meta& m, float* __restrict__ dparams, float x, float y,
+                                            float z, const float (&denc)[2 * L]) {
+    x = asd_unit(x); y = asd_unit(y); z = asd_unit(z);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float g0 = denc[2 * l], g1 = denc[2 * l + 1];
+        if (g0 == 0.f && g1 == 0.f) continue;
+        const float s = m.scale[l];
+        const float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f), pz = fmaf(s, z, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float ax = (c & 1) ? wx : 1.f - wx;
+            const float ay = (c & 2) ? wy : 1.f - wy;
+            const float az = (c & 4) ? wz : 1.f - wz;
+            const float wt = ax * ay * az;
+            const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
+            atomicAdd(tab + 2u * (size_t)idx, wt * g0);
+            atomicAdd(tab + 2u * (size_t)idx + 1, wt * g1);
+        }
+    }
+}
+#endif  // __HIPCC__

@@ -1,0 +1,735 @@
+// field.hip — hash-grid encode + tiny-MLP field kernels for gfx950 (wave64, one thread per point).
+//
+// Replaces, behind the C ABI of include/asd_hip.h:
+//   tcnn.Encoding forward/backward          (reference threestudio/models/networks.py:55-64)
+//   ImplicitVolume.forward/forward_density  (threestudio/models/geometry/implicit_volume.py:109-207)
+//   NeuralEnvironmentMapBackground.forward  (threestudio/models/background/neural_environment_map_background.py:46-67)
+//
+// Roofline: HBM/L2 gather bound — 16 levels x 8 corners x 8 B = 1024 B gathered per encode
+// (SURVEY.md §8d); the MLPs (2112 / 2240 MAC per point) run on the VALU with the weights read through
+// the scalar cache (uniform addresses -> s_load), so no LDS or VGPR is spent on weights.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "asd_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// generic tcnn.Encoding forward / backward: one thread per (point, level)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const asd_grid_meta m, const float* __restrict__ params,
+                                                           const float* __restrict__ x, int n,
+                                                           float* __restrict__ out) {
+    const int L = (int)m.n_levels;
+    const int64_t total = (int64_t)n * L;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        // level-major inside a block-sized tile of points keeps one level's table hot per wave
+        const int64_t tile = t / (256 * (int64_t)L);
+        const int r = (int)(t - tile * 256 * L);
+        const int l = r / 256;
+        const int64_t i = tile * 256 + (r % 256);
+        if (i >= n) continue;
+        const float s = m.scale[l];
+        const float px = fmaf(s, asd_unit(x[3 * i]), 0.5f), py = fmaf(s, asd_unit(x[3 * i + 1]), 0.5f),
+                    pz = fmaf(s, asd_unit(x[3 * i + 2]), 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        const float2* __restrict__ tab = reinterpret_cast<const float2*>(params) + m.offset[l];
+        float2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[c] = tab[asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1))];
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+            f0 = fmaf(wt, v[c].x, f0);
+            f1 = fmaf(wt, v[c].y, f1);
+        }
+        reinterpret_cast<float2*>(out)[i * L + l] = make_float2(f0, f1);
+    }
+}
+
+__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const asd_grid_meta m, const float* __restrict__ x,
+                                                           const float* __restrict__ dout, int n,
+                                                           float* __restrict__ dparams) {
+    const int L = (int)m.n_levels;
+    const int64_t total = (int64_t)n * L;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tile = t / (256 * (int64_t)L);
+        const int r = (int)(t - tile * 256 * L);
+        const int l = r / 256;
+        const int64_t i = tile * 256 + (r % 256);
+        if (i >= n) continue;
+        const float2 g = reinterpret_cast<const float2*>(dout)[i * L + l];
+        if (g.x == 0.f && g.y == 0.f) continue;
+        const float s = m.scale[l];
+        const float px = fmaf(s, asd_unit(x[3 * i]), 0.5f), py = fmaf(s, asd_unit(x[3 * i + 1]), 0.5f),
+                    pz = fmaf(s, asd_unit(x[3 * i + 2]), 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+            const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
+            atomicAdd(tab + 2u * (size_t)idx, wt * g.x);
+            atomicAdd(tab + 2u * (size_t)idx + 1, wt * g.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// field helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float field_bias(const asd_field_cfg& c, float px, float py, float pz) {
+    const float r2 = px * px + py * py + pz * pz;
+    if (c.bias_mode == ASD_BIAS_BLOB_MAGIC3D) return c.blob_scale * (1.f - sqrtf(r2) / c.blob_std);
+    if (c.bias_mode == ASD_BIAS_BLOB_DREAMFUSION) return c.blob_scale * expf(-0.5f * r2 / (c.blob_std * c.blob_std));
+    return c.bias_value;
+}
+__device__ __forceinline__ float field_act(const asd_field_cfg& c, float raw) {
+    switch (c.activation) {
+        case ASD_ACT_SOFTPLUS: return asd_softplus(raw);
+        case ASD_ACT_EXP:
+        case ASD_ACT_TRUNC_EXP: return expf(raw);
+        default: return raw;
+    }
+}
+__device__ __forceinline__ float field_act_grad(const asd_field_cfg& c, float raw) {
+    switch (c.activation) {
+        case ASD_ACT_SOFTPLUS: return raw > 20.f ? 1.f : asd_sigmoid(raw);
+        case ASD_ACT_EXP: return expf(raw);
+        case ASD_ACT_TRUNC_EXP: return expf(fminf(raw, 15.f));
+        default: return 1.f;
+    }
+}
+
+// out = W2 . relu(W1 . enc), single output.  Weight addresses are wave-uniform (scalar loads).
+template <int NIN, int H>
+__device__ __forceinline__ float mlp1(const float* __restrict__ w1, const float* __restrict__ w2,
+                                      const float (&enc)[NIN]) {
+    float out = 0.f;
+#pragma unroll 4
+    for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) a = fmaf(w1[h * NIN + k], enc[k], a);
+        out = fmaf(w2[h], fmaxf(a, 0.f), out);
+    }
+    return out;
+}
+template <int NIN, int H, int C>
+__device__ __forceinline__ void mlpC(const float* __restrict__ w1, const float* __restrict__ w2,
+                                     const float (&enc)[NIN], float (&out)[C]) {
+#pragma unroll
+    for (int o = 0; o < C; ++o) out[o] = 0.f;
+#pragma unroll 4
+    for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) a = fmaf(w1[h * NIN + k], enc[k], a);
+        a = fmaxf(a, 0.f);
+#pragma unroll
+        for (int o = 0; o < C; ++o) out[o] = fmaf(w2[o * H + h], a, out[o]);
+    }
+}
+
+template <int L, int H>
+__device__ __forceinline__ float field_raw(const asd_grid_meta& m, const asd_field_cfg& c,
+                                           const float* __restrict__ grid, const float* __restrict__ w1d,
+                                           const float* __restrict__ w2d, float px, float py, float pz,
+                                           float (&enc)[2 * L]) {
+    const float x = (px - c.bbox_min[0]) / (c.bbox_max[0] - c.bbox_min[0]);
+    const float y = (py - c.bbox_min[1]) / (c.bbox_max[1] - c.bbox_min[1]);
+    const float z = (pz - c.bbox_min[2]) / (c.bbox_max[2] - c.bbox_min[2]);
+    asd_encode<L>(m, grid, x, y, z, enc);
+    return mlp1<2 * L, H>(w1d, w2d, enc) + field_bias(c, px, py, pz);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sigma only (marcher sigma_fn, occupancy update)
+// ---------------------------------------------------------------------------------------------------
+template <int L, int H>
+__global__ __launch_bounds__(256, 4) void field_density_kernel(const asd_grid_meta m, const asd_field_cfg c,
+                                                            const float* __restrict__ grid,
+                                                            const float* __restrict__ w1d,
+                                                            const float* __restrict__ w2d,
+                                                            const float* __restrict__ points, int n,
+                                                            const int* __restrict__ n_dev,
+                                                            float* __restrict__ sigma) {
+    const int nn = n_dev ? min(*n_dev, n) : n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nn; i += gridDim.x * 256) {
+        float enc[2 * L];
+        const float raw = field_raw<L, H>(m, c, grid, w1d, w2d, points[3 * i], points[3 * i + 1], points[3 * i + 2], enc);
+        sigma[i] = field_act(c, raw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// training forward: sigma, features, finite-difference normal; saves the centre encoding
+// ---------------------------------------------------------------------------------------------------
+template <int L, int H, int C>
+__global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m, const asd_field_cfg c,
+                                                        const float* __restrict__ grid,
+                                                        const float* __restrict__ w1d, const float* __restrict__ w2d,
+                                                        const float* __restrict__ w1f, const float* __restrict__ w2f,
+                                                        const float* __restrict__ points, int n,
+                                                        const int* __restrict__ n_dev, float* __restrict__ sigma,
+                                                        float* __restrict__ features, float* __restrict__ normal,
+                                                        float* __restrict__ enc_save) {
+    const int nn = n_dev ? min(*n_dev, n) : n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nn; i += gridDim.x * 256) {
+        const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+        float enc[2 * L];
+        const float raw = field_raw<L, H>(m, c, grid, w1d, w2d, px, py, pz, enc);
+        const float s = field_act(c, raw);
+        sigma[i] = s;
+        if (enc_save) {
+            float4* dst = reinterpret_cast<float4*>(enc_save + (size_t)i * 2 * L);
+#pragma unroll
+            for (int q = 0; q < L / 2; ++q) dst[q] = make_float4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3]);
+        }
+        if (features) {
+            float f[C];
+            mlpC<2 * L, H, C>(w1f, w2f, enc, f);
+#pragma unroll
+            for (int o = 0; o < C; ++o) features[(size_t)i * C + o] = f[o];
+        }
+        if (normal) {
+            float nr[3];
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const float qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                float e2[2 * L];
+                const float sk = field_act(c, field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2));
+                nr[k] = -(sk - s) / c.fd_eps;
+            }
+            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+            const float inv = 1.f / fmaxf(len, 1e-12f);
+            normal[3 * (size_t)i] = nr[0] * inv;
+            normal[3 * (size_t)i + 1] = nr[1] * inv;
+            normal[3 * (size_t)i + 2] = nr[2] * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// training backward.  One thread per sample; the weight gradients dW1[h][k] = sum_t da_h(t) enc_k(t)
+// are reduced across the 256 samples of a block through LDS (enc transposed, padded to 257 to keep
+// the k-strided reads conflict-free) and written as one partial slab per block; asd_field_bwd_reduce
+// sums the slabs deterministically.
+// slab layout: [dW1d (H*NIN) | dW2d (H) | dW1f (H*NIN) | dW2f (C*H)]
+// ---------------------------------------------------------------------------------------------------
+#define FB_T 256
+#define FB_PAD 257
+#define FB_G 8  // hidden units processed per LDS round
+
+template <int NIN, int H, int NOUT>
+__device__ __forceinline__ void mlp_bwd_block(const float* __restrict__ w1, const float* __restrict__ w2,
+                                              const float (&enc)[NIN], const float (&dout)[NOUT], bool active,
+                                              float (&denc)[NIN], float* __restrict__ enc_lds /*[NIN][FB_PAD]*/,
+                                              float* __restrict__ da_lds /*[FB_G][FB_T]*/,
+                                              float* __restrict__ w2_lds /*[NOUT*H]*/,
+                                              float* __restrict__ slab_w1, float* __restrict__ slab_w2,
+                                              bool accumulate) {
+    const int tid = threadIdx.x;
+    const int kk = tid % NIN;        // which input feature this thread reduces (NIN == 32)
+    const int hh = tid / NIN;        // which hidden unit of the group (256/32 = 8 = FB_G)
+#pragma unroll 1
+    for (int g = 0; g < H / FB_G; ++g) {
+        float dav[FB_G];
+#pragma unroll
+        for (int j = 0; j < FB_G; ++j) {
+            const int h = g * FB_G + j;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) a = fmaf(w1[h * NIN + k], enc[k], a);
+            const float hv = fmaxf(a, 0.f);
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                dh = fmaf(dout[o], w2[o * H + h], dh);
+                // dW2[o][h] += dout[o] * relu(a): wave reduction, one LDS atomic per wave
+                const float v = asd_wave_sum(active ? dout[o] * hv : 0.f);
+                if ((tid & 63) == 0) atomicAdd(&w2_lds[o * H + h], v);
+            }
+            const float da = (active && a > 0.f) ? dh : 0.f;
+            dav[j] = da;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1[h * NIN + k], denc[k]);
+        }
+        __syncthreads();  // previous round's readers are done with da_lds
+#pragma unroll
+        for (int j = 0; j < FB_G; ++j) da_lds[j * FB_T + tid] = dav[j];
+        __syncthreads();
+        // thread (kk, hh): dW1[g*8+hh][kk] = sum_t da[hh][t] * enc[kk][t]
+        float acc = 0.f;
+        const float* er = enc_lds + kk * FB_PAD;
+        const float* dr = da_lds + hh * FB_T;
+#pragma unroll 8
+        for (int t = 0; t < FB_T; ++t) acc = fmaf(dr[t], er[t], acc);
+        float* dst = &slab_w1[(g * FB_G + hh) * NIN + kk];  // same thread owns this word in every pass
+        *dst = accumulate ? *dst + acc : acc;
+    }
+    __syncthreads();
+    for (int q = tid; q < NOUT * H; q += FB_T) slab_w2[q] = accumulate ? slab_w2[q] + w2_lds[q] : w2_lds[q];
+    __syncthreads();
+}
+
+template <int L, int H, int C>
+__global__ __launch_bounds__(FB_T, 2) void field_bwd_kernel(
+    const asd_grid_meta m, const asd_field_cfg c, const float* __restrict__ grid, const float* __restrict__ w1d,
+    const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
+    const float* __restrict__ points, const float* __restrict__ enc_save, const float* __restrict__ sigma, int n,
+    const int* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_features,
+    const float* __restrict__ d_normal, float* __restrict__ d_grid, float* __restrict__ slabs, int slab_stride) {
+    constexpr int NIN = 2 * L;
+    static_assert(NIN == 32, "block reduction layout assumes 32 encoded features");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* enc_lds = smem;                       // NIN * FB_PAD
+    float* da_lds = enc_lds + NIN * FB_PAD;      // FB_G * FB_T
+    float* w2_lds = da_lds + FB_G * FB_T;        // max(1, C) * H
+
+    const int nn = n_dev ? min(*n_dev, n) : n;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * FB_T + tid;
+    float* slab = slabs + (size_t)blockIdx.x * slab_stride;
+    float* slab_w1d = slab;
+    float* slab_w2d = slab_w1d + H * NIN;
+    float* slab_w1f = slab_w2d + H;
+    float* slab_w2f = slab_w1f + H * NIN;
+    if (blockIdx.x * FB_T >= nn) {  // whole block beyond the live sample count: publish a zero slab
+        for (int q = tid; q < slab_stride; q += FB_T) slab[q] = 0.f;
+        return;
+    }
+    const bool active = i < nn;
+    float px = 0.f, py = 0.f, pz = 0.f, s = 0.f, ds = 0.f;
+    float enc[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) enc[k] = 0.f;
+    if (active) {
+        px = points[3 * i]; py = points[3 * i + 1]; pz = points[3 * i + 2];
+        s = sigma[i];
+        ds = d_sigma ? d_sigma[i] : 0.f;
+        const float4* src = reinterpret_cast<const float4*>(enc_save + (size_t)i * NIN);
+#pragma unroll
+        for (int q = 0; q < NIN / 4; ++q) {
+            const float4 v = src[q];
+            enc[4 * q] = v.x; enc[4 * q + 1] = v.y; enc[4 * q + 2] = v.z; enc[4 * q + 3] = v.w;
+        }
+    }
+    const float bx = c.bbox_max[0] - c.bbox_min[0], by = c.bbox_max[1] - c.bbox_min[1], bz = c.bbox_max[2] - c.bbox_min[2];
+
+    // ---- optional: gradient through the finite-difference normal (3 extra density evaluations) ----
+    float dsk[3] = {0.f, 0.f, 0.f}, rawk[3] = {0.f, 0.f, 0.f};
+    if (d_normal) {
+        float nr[3] = {0.f, 0.f, 0.f};
+        if (active) {
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const float qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
+                float e2[NIN];
+                rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
+                nr[k] = -(field_act(c, rawk[k]) - s) / c.fd_eps;
+            }
+            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+            const float g0 = d_normal[3 * (size_t)i], g1 = d_normal[3 * (size_t)i + 1], g2 = d_normal[3 * (size_t)i + 2];
+            float dnr[3];
+            if (len > 1e-12f) {
+                const float inv = 1.f / len;
+                const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
+                const float dot = n0 * g0 + n1 * g1 + n2 * g2;
+                dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
+            } else {
+                dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dsk[k] = -dnr[k] / c.fd_eps;
+                ds += dnr[k] / c.fd_eps;
+            }
+        }
+    }
+
+    // ---- pass over the (1 or 4) density evaluations + the feature MLP -----------------------------
+    const int n_pts = d_normal ? 4 : 1;
+#pragma unroll 1
+    for (int pt = 0; pt < n_pts; ++pt) {
+        float qx = px, qy = py, qz = pz, draw;
+        float e[NIN];
+        if (pt == 0) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) e[k] = enc[k];
+            // d sigma / d raw from sigma itself (softplus: 1-exp(-sigma)); raw is not stored
+            float ag;
+            if (c.activation == ASD_ACT_SOFTPLUS) ag = 1.f - expf(-s);
+            else if (c.activation == ASD_ACT_EXP) ag = s;
+            else if (c.activation == ASD_ACT_TRUNC_EXP) ag = fminf(s, 3269017.37f /* e^15 */);
+            else ag = 1.f;
+            draw = ds * ag;
+        } else {
+            const int k = pt - 1;
+            qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            if (active) asd_encode<L>(m, grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, e);
+            else {
+#pragma unroll
+                for (int q = 0; q < NIN; ++q) e[q] = 0.f;
+            }
+            draw = dsk[k] * field_act_grad(c, rawk[k]);
+        }
+        // stage enc transposed for the block-level weight-gradient reduction
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) enc_lds[k * FB_PAD + tid] = active ? e[k] : 0.f;
+        for (int q = tid; q < (C > 0 ? C : 1) * H; q += FB_T) w2_lds[q] = 0.f;
+        __syncthreads();
+
+        float denc[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) denc[k] = 0.f;
+        const float dout1[1] = {draw};
+        // density MLP; the 3 finite-difference points accumulate on top of the centre point's slab
+        mlp_bwd_block<NIN, H, 1>(w1d, w2d, e, dout1, active, denc, enc_lds, da_lds, w2_lds, slab_w1d, slab_w2d, pt > 0);
+        if (pt == 0) {
+            if (C > 0 && d_features) {
+                float df[C > 0 ? C : 1];
+#pragma unroll
+                for (int o = 0; o < C; ++o) df[o] = active ? d_features[(size_t)i * C + o] : 0.f;
+                for (int q = tid; q < C * H; q += FB_T) w2_lds[q] = 0.f;
+                __syncthreads();
+                mlp_bwd_block<NIN, H, (C > 0 ? C : 1)>(w1f, w2f, e, df, active, denc, enc_lds, da_lds, w2_lds, slab_w1f,
+                                                       slab_w2f, false);
+            } else {
+                for (int q = tid; q < H * NIN + C * H; q += FB_T) slab_w1f[q] = 0.f;
+            }
+        }
+        if (active)
+            asd_scatter<L>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, denc);
+    }
+}
+
+// sum the per-block slabs: out[j] += sum_b slabs[b][j]   (deterministic order)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int n_blocks, int stride,
+                                                          int len, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += slabs[(size_t)b * stride + j];
+    out[j] += acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// background environment map (L levels, H hidden, 2 hidden layers, 3 outputs)
+// ---------------------------------------------------------------------------------------------------
+template <int L, int H>
+__global__ __launch_bounds__(256) void envmap_fwd_kernel(const asd_grid_meta m, const float* __restrict__ grid,
+                                                         const float* __restrict__ w0, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ dirs,
+                                                         int n, float* __restrict__ color) {
+    constexpr int NIN = 2 * L;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float enc[NIN], h0[H], h1[H];
+        asd_encode<L>(m, grid, (dirs[3 * i] + 1.f) / 2.f, (dirs[3 * i + 1] + 1.f) / 2.f, (dirs[3 * i + 2] + 1.f) / 2.f, enc);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) a = fmaf(w0[h * NIN + k], enc[k], a);
+            h0[h] = fmaxf(a, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) a = fmaf(w1[h * H + k], h0[k], a);
+            h1[h] = fmaxf(a, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) a = fmaf(w2[o * H + k], h1[k], a);
+            color[3 * (size_t)i + o] = asd_sigmoid(a);
+        }
+    }
+}
+
+// backward: per-thread gradients, weight grads reduced per wave with shuffles then global atomics
+// (n = number of rays = a few thousand: this kernel is latency-, not throughput-bound)
+template <int L, int H>
+__global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, const float* __restrict__ grid,
+                                                         const float* __restrict__ w0, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ dirs,
+                                                         const float* __restrict__ d_color, int n,
+                                                         float* __restrict__ d_grid, float* __restrict__ dw0,
+                                                         float* __restrict__ dw1, float* __restrict__ dw2) {
+    constexpr int NIN = 2 * L;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n;
+    const bool lead = (threadIdx.x & 63) == 0;
+    float enc[NIN], a0[H], a1[H], dout[3], dh1[H], dh0[H], denc[NIN];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (active) {
+        x = (dirs[3 * i] + 1.f) / 2.f; y = (dirs[3 * i + 1] + 1.f) / 2.f; z = (dirs[3 * i + 2] + 1.f) / 2.f;
+        asd_encode<L>(m, grid, x, y, z, enc);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) enc[k] = 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) a = fmaf(w0[h * NIN + k], enc[k], a);
+        a0[h] = a;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) a = fmaf(w1[h * H + k], fmaxf(a0[k], 0.f), a);
+        a1[h] = a;
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) a = fmaf(w2[o * H + k], fmaxf(a1[k], 0.f), a);
+        const float s = asd_sigmoid(a);
+        dout[o] = active ? d_color[3 * (size_t)i + o] * s * (1.f - s) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float v = asd_wave_sum(dout[o] * fmaxf(a1[k], 0.f));
+            if (lead) atomicAdd(&dw2[o * H + k], v);
+            acc = fmaf(dout[o], w2[o * H + k], acc);
+        }
+        dh1[k] = a1[k] > 0.f ? acc : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float v = asd_wave_sum(dh1[h] * fmaxf(a0[k], 0.f));
+            if (lead) atomicAdd(&dw1[h * H + k], v);
+            acc = fmaf(dh1[h], w1[h * H + k], acc);
+        }
+        dh0[k] = a0[k] > 0.f ? acc : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float v = asd_wave_sum(dh0[h] * enc[k]);
+            if (lead) atomicAdd(&dw0[h * NIN + k], v);
+            acc = fmaf(dh0[h], w0[h * NIN + k], acc);
+        }
+        denc[k] = acc;
+    }
+    if (active) asd_scatter<L>(m, d_grid, x, y, z, denc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void asd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* asd_last_error(void) { return g_err; }
+const char* asd_version(void) { return "asd_hip 0.1 (gfx950)"; }
+
+uint32_t asd_grid_meta_init(asd_grid_meta* m, uint32_t n_levels, uint32_t n_features, uint32_t log2_hashmap_size,
+                            uint32_t base_resolution, double per_level_scale) {
+    memset(m, 0, sizeof(*m));
+    if (n_levels == 0 || n_levels > ASD_MAX_LEVELS || n_features != 2) {
+        asd_set_error("asd_grid_meta_init: need 1..%d levels and 2 features per level", ASD_MAX_LEVELS);
+        return 0;
+    }
+    m->n_levels = n_levels;
+    m->n_features = n_features;
+    uint32_t offset = 0;
+    const float log2_scale = log2f((float)per_level_scale);
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        const float scale = exp2f((float)l * log2_scale) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        const uint64_t dense = (uint64_t)res * res * res;
+        uint64_t size = (dense + 7u) / 8u * 8u;
+        const uint64_t cap = 1ull << log2_hashmap_size;
+        if (size > cap) size = cap;
+        m->scale[l] = scale;
+        m->resolution[l] = res;
+        m->offset[l] = offset;
+        m->size[l] = (uint32_t)size;
+        m->dense[l] = dense <= size ? 1u : 0u;
+        offset += (uint32_t)size;
+    }
+    m->n_params = offset * n_features;
+    return m->n_params;
+}
+
+int asd_hashgrid_fwd(const asd_grid_meta* meta, const float* params, const float* x, int32_t n, float* out,
+                     void* stream) {
+    ASD_CHECK_ARG(meta && params && x && out && n >= 0, "null argument");
+    if (n == 0) return ASD_OK;
+    const int64_t total = (int64_t)asd_div_up(n, 256) * 256 * meta->n_levels;
+    hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3(asd_grid_for(total, 256) * 4), dim3(256), 0, (hipStream_t)stream, *meta,
+                       params, x, n, out);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_hashgrid_bwd(const asd_grid_meta* meta, const float* x, const float* dout, int32_t n, float* dparams,
+                     void* stream) {
+    ASD_CHECK_ARG(meta && x && dout && dparams && n >= 0, "null argument");
+    if (n == 0) return ASD_OK;
+    const int64_t total = (int64_t)asd_div_up(n, 256) * 256 * meta->n_levels;
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3(asd_grid_for(total, 256) * 4), dim3(256), 0, (hipStream_t)stream, *meta,
+                       x, dout, n, dparams);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+static int field_supported(const asd_grid_meta* m, const asd_field_cfg* c) {
+    if (m->n_levels != 16 || c->n_hidden != 64 || !(c->n_feature_dims == 3 || c->n_feature_dims == 0)) {
+        asd_set_error("field kernels are built for 16 levels x 2 features, 64 hidden units, 0/3 feature dims "
+                      "(got %u levels, %d hidden, %d feature dims)", m->n_levels, c->n_hidden, c->n_feature_dims);
+        return 0;
+    }
+    return 1;
+}
+
+int asd_field_density(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                      const float* w1_density, const float* w2_density, const float* points, int32_t n,
+                      const int32_t* n_dev, float* sigma, void* stream) {
+    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n >= 0, "null argument");
+    if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
+    if (n == 0) return ASD_OK;
+    hipLaunchKernelGGL((field_density_kernel<16, 64>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *meta, *cfg, grid_params, w1_density, w2_density, points, n, n_dev, sigma);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                  const float* w1_density, const float* w2_density, const float* w1_feature,
+                  const float* w2_feature, const float* points, int32_t n, const int32_t* n_dev, float* sigma,
+                  float* features, float* normal, float* enc_save, void* stream) {
+    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n >= 0, "null argument");
+    if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
+    ASD_CHECK_ARG(cfg->n_feature_dims == 0 || !features || (w1_feature && w2_feature), "feature weights missing");
+    if (n == 0) return ASD_OK;
+    hipLaunchKernelGGL((field_fwd_kernel<16, 64, 3>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *meta, *cfg, grid_params, w1_density, w2_density, w1_feature, w2_feature, points, n, n_dev,
+                       sigma, cfg->n_feature_dims == 3 ? features : nullptr, normal, enc_save);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t* n_blocks, int32_t* wgrad_stride) {
+    ASD_CHECK_ARG(cfg && n_blocks && wgrad_stride, "null argument");
+    const int H = cfg->n_hidden, C = cfg->n_feature_dims;
+    *n_blocks = asd_div_up(n > 0 ? n : 1, FB_T);
+    *wgrad_stride = H * 32 + H + H * 32 + C * H;
+    return ASD_OK;
+}
+
+int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
+                  const float* w1_density, const float* w2_density, const float* w1_feature,
+                  const float* w2_feature, const float* points, const float* enc_save, const float* sigma, int32_t n,
+                  const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
+                  float* d_grid_params, float* wgrad_partials, void* stream) {
+    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && enc_save && sigma &&
+                      d_grid_params && wgrad_partials && n >= 0,
+                  "null argument");
+    if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
+    ASD_CHECK_ARG(cfg->n_feature_dims == 3 || !d_features, "d_features given but no feature network");
+    if (n == 0) return ASD_OK;
+    int nb, stride;
+    asd_field_bwd_workspace(cfg, n, &nb, &stride);
+    const size_t lds = sizeof(float) * (32 * FB_PAD + FB_G * FB_T + 3 * 64);
+    if (cfg->n_feature_dims == 3)
+        hipLaunchKernelGGL((field_bwd_kernel<16, 64, 3>), dim3(nb), dim3(FB_T), lds, (hipStream_t)stream, *meta, *cfg,
+                           grid_params, w1_density, w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev,
+                           d_sigma, d_features, d_normal, d_grid_params, wgrad_partials, stride);
+    else
+        hipLaunchKernelGGL((field_bwd_kernel<16, 64, 0>), dim3(nb), dim3(FB_T), lds, (hipStream_t)stream, *meta, *cfg,
+                           grid_params, w1_density, w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev,
+                           d_sigma, d_features, d_normal, d_grid_params, wgrad_partials, stride);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_field_bwd_reduce(const asd_field_cfg* cfg, const float* wgrad_partials, int32_t n_blocks, float* dw1_density,
+                         float* dw2_density, float* dw1_feature, float* dw2_feature, void* stream) {
+    ASD_CHECK_ARG(cfg && wgrad_partials && dw1_density && dw2_density && n_blocks >= 0, "null argument");
+    const int H = cfg->n_hidden, C = cfg->n_feature_dims;
+    const int stride = H * 32 + H + H * 32 + C * H;
+    if (n_blocks == 0) return ASD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(H * 32, 256)), dim3(256), 0, s, wgrad_partials, n_blocks, stride,
+                       H * 32, dw1_density);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, s, wgrad_partials + H * 32, n_blocks, stride, H,
+                       dw2_density);
+    if (C > 0 && dw1_feature && dw2_feature) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(H * 32, 256)), dim3(256), 0, s,
+                           wgrad_partials + H * 32 + H, n_blocks, stride, H * 32, dw1_feature);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, s, wgrad_partials + H * 32 + H + H * 32, n_blocks,
+                           stride, C * H, dw2_feature);
+    }
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_envmap_fwd(const asd_grid_meta* meta, const float* grid_params, const float* w0, const float* w1,
+                   const float* w2, int32_t n_hidden, const float* dirs, int32_t n, float* color, void* stream) {
+    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && color && n >= 0, "null argument");
+    if (meta->n_levels != 4 || n_hidden != 16) {
+        asd_set_error("envmap kernels are built for 4 levels and 16 hidden units (got %u, %d)", meta->n_levels, n_hidden);
+        return ASD_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return ASD_OK;
+    hipLaunchKernelGGL((envmap_fwd_kernel<4, 16>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *meta,
+                       grid_params, w0, w1, w2, dirs, n, color);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_envmap_bwd(const asd_grid_meta* meta, const float* grid_params, const float* w0, const float* w1,
+                   const float* w2, int32_t n_hidden, const float* dirs, const float* d_color, int32_t n,
+                   float* d_grid_params, float* dw0, float* dw1, float* dw2, void* stream) {
+    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && d_color && d_grid_params && dw0 && dw1 && dw2 && n >= 0,
+                  "null argument");
+    if (meta->n_levels != 4 || n_hidden != 16) {
+        asd_set_error("envmap kernels are built for 4 levels and 16 hidden units (got %u, %d)", meta->n_levels, n_hidden);
+        return ASD_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return ASD_OK;
+    hipLaunchKernelGGL((envmap_bwd_kernel<4, 16>), dim3(asd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *meta,
+                       grid_params, w0, w1, w2, dirs, d_color, n, d_grid_params, dw0, dw1, dw2);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+}  // extern "C"

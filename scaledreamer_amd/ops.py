@@ -1,0 +1,210 @@
+"""Raw (non-autograd) tensor-level wrappers of the C ABI in include/asd_hip.h.
+
+Every function takes CUDA(HIP) float32 tensors, allocates the outputs with torch (so the caching allocator
+and the current stream own them) and enqueues the kernels on the current stream.  No synchronisation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import FieldCfg, GridMeta, MarchCfg, check, f32, i32, lib, ptr, stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.AsdError("the HIP path needs device tensors (there is no CPU fallback)")
+
+
+def _c(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# ---- hash grid --------------------------------------------------------------------------------
+def hashgrid_fwd(meta: GridMeta, params: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(params, x)
+    x = _c(x)
+    out = torch.empty((x.shape[0], meta.n_levels * meta.n_features), device=x.device, dtype=torch.float32)
+    check(lib().asd_hashgrid_fwd(C.byref(meta), ptr(_c(params)), ptr(x), i32(x.shape[0]), ptr(out), stream()))
+    return out
+
+
+def hashgrid_bwd(meta: GridMeta, x: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x, dout)
+    x, dout = _c(x), _c(dout)
+    dparams = torch.zeros(meta.n_params, device=x.device, dtype=torch.float32)
+    check(lib().asd_hashgrid_bwd(C.byref(meta), ptr(x), ptr(dout), i32(x.shape[0]), ptr(dparams), stream()))
+    return dparams
+
+
+# ---- field ------------------------------------------------------------------------------------
+def field_density(meta, cfg: FieldCfg, grid, w1d, w2d, points, n_dev: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(grid, points)
+    points = _c(points)
+    n = points.shape[0]
+    sigma = out if out is not None else torch.empty(n, device=points.device, dtype=torch.float32)
+    check(lib().asd_field_density(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(points), i32(n),
+                                  ptr(n_dev), ptr(sigma), stream()))
+    return sigma
+
+
+def field_fwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, want_normal: bool,
+              n_dev: Optional[torch.Tensor] = None):
+    _need_cuda(grid, points)
+    points = _c(points)
+    n, dev = points.shape[0], points.device
+    sigma = torch.empty(n, device=dev, dtype=torch.float32)
+    feats = torch.empty((n, cfg.n_feature_dims), device=dev, dtype=torch.float32) if cfg.n_feature_dims > 0 else None
+    normal = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    enc = torch.empty((n, meta.n_levels * 2), device=dev, dtype=torch.float32)
+    check(lib().asd_field_fwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
+                              ptr(points), i32(n), ptr(n_dev), ptr(sigma), ptr(feats), ptr(normal), ptr(enc),
+                              stream()))
+    return sigma, feats, normal, enc
+
+
+def field_bwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma, d_sigma, d_features, d_normal,
+              d_grid: torch.Tensor, n_dev: Optional[torch.Tensor] = None):
+    """Accumulates into d_grid (atomics); returns (dw1d, dw2d, dw1f, dw2f)."""
+    points = _c(points)
+    n, dev = points.shape[0], points.device
+    nb, stride = C.c_int32(0), C.c_int32(0)
+    check(lib().asd_field_bwd_workspace(C.byref(cfg), i32(n), C.byref(nb), C.byref(stride)))
+    slabs = torch.empty((nb.value, stride.value), device=dev, dtype=torch.float32)
+    check(lib().asd_field_bwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
+                              ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), ptr(_c(d_sigma)),
+                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(d_grid), ptr(slabs), stream()))
+    H, Cf = cfg.n_hidden, cfg.n_feature_dims
+    dw1d = torch.zeros((H, 32), device=dev, dtype=torch.float32)
+    dw2d = torch.zeros((1, H), device=dev, dtype=torch.float32)
+    dw1f = torch.zeros((H, 32), device=dev, dtype=torch.float32) if Cf > 0 else None
+    dw2f = torch.zeros((Cf, H), device=dev, dtype=torch.float32) if Cf > 0 else None
+    check(lib().asd_field_bwd_reduce(C.byref(cfg), ptr(slabs), i32(nb.value), ptr(dw1d), ptr(dw2d), ptr(dw1f),
+                                     ptr(dw2f), stream()))
+    return dw1d, dw2d, dw1f, dw2f
+
+
+# ---- background -------------------------------------------------------------------------------
+def envmap_fwd(meta, grid, w0, w1, w2, dirs) -> torch.Tensor:
+    _need_cuda(grid, dirs)
+    dirs = _c(dirs)
+    color = torch.empty((dirs.shape[0], 3), device=dirs.device, dtype=torch.float32)
+    check(lib().asd_envmap_fwd(C.byref(meta), ptr(grid), ptr(w0), ptr(w1), ptr(w2), i32(w1.shape[0]), ptr(dirs),
+                               i32(dirs.shape[0]), ptr(color), stream()))
+    return color
+
+
+def envmap_bwd(meta, grid, w0, w1, w2, dirs, d_color):
+    dirs, d_color = _c(dirs), _c(d_color)
+    dev = dirs.device
+    dgrid = torch.zeros(meta.n_params, device=dev, dtype=torch.float32)
+    dw0, dw1, dw2 = torch.zeros_like(w0), torch.zeros_like(w1), torch.zeros_like(w2)
+    check(lib().asd_envmap_bwd(C.byref(meta), ptr(grid), ptr(w0), ptr(w1), ptr(w2), i32(w1.shape[0]), ptr(dirs),
+                               ptr(d_color), i32(dirs.shape[0]), ptr(dgrid), ptr(dw0), ptr(dw1), ptr(dw2), stream()))
+    return dgrid, dw0, dw1, dw2
+
+
+# ---- marching ---------------------------------------------------------------------------------
+def scan_i32(count: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    offset = torch.empty_like(count)
+    total = torch.empty(1, device=count.device, dtype=torch.int32)
+    check(lib().asd_scan_i32(ptr(count), i32(count.shape[0]), ptr(offset), ptr(total), stream()))
+    return offset, total
+
+
+def march(cfg: MarchCfg, rays_o, rays_d, occ_bits, jitter=None, n_max: Optional[int] = None):
+    """Two-pass marcher. Returns (count, offset, total_dev, ray_idx, t0, t1, points); the sample arrays are
+    sized n_max (default: exact, which costs one host sync)."""
+    _need_cuda(rays_o, rays_d, occ_bits)
+    rays_o, rays_d, jitter = _c(rays_o), _c(rays_d), _c(jitter)
+    nr, dev = rays_o.shape[0], rays_o.device
+    count = torch.empty(nr, device=dev, dtype=torch.int32)
+    check(lib().asd_march_count(C.byref(cfg), ptr(rays_o), ptr(rays_d), i32(nr), ptr(occ_bits), ptr(jitter),
+                                ptr(count), stream()))
+    offset, total = scan_i32(count)
+    if n_max is None:
+        n_max = int(total.item())
+    ray_idx = torch.empty(n_max, device=dev, dtype=torch.int32)
+    t0 = torch.empty(n_max, device=dev, dtype=torch.float32)
+    t1 = torch.empty(n_max, device=dev, dtype=torch.float32)
+    pts = torch.empty((n_max, 3), device=dev, dtype=torch.float32)
+    check(lib().asd_march_write(C.byref(cfg), ptr(rays_o), ptr(rays_d), i32(nr), ptr(occ_bits), ptr(jitter),
+                                ptr(offset), ptr(ray_idx), ptr(t0), ptr(t1), ptr(pts), stream()))
+    return count, offset, total, ray_idx, t0, t1, pts
+
+
+def prune(sigma, t0, t1, offset, count, early_stop_eps: float, alpha_thre: float):
+    nr = count.shape[0]
+    keep = torch.empty(sigma.shape[0], device=sigma.device, dtype=torch.uint8)
+    kept = torch.empty(nr, device=sigma.device, dtype=torch.int32)
+    check(lib().asd_prune_count(ptr(sigma), ptr(t0), ptr(t1), ptr(offset), ptr(count), i32(nr), f32(early_stop_eps),
+                                f32(alpha_thre), ptr(keep), ptr(kept), stream()))
+    return keep, kept
+
+
+def compact(rays_o, rays_d, offset, count, keep, t0, t1, kept_offset, n_out: int):
+    nr, dev = count.shape[0], t0.device
+    ray_idx = torch.empty(n_out, device=dev, dtype=torch.int64)
+    t0o = torch.empty(n_out, device=dev, dtype=torch.float32)
+    t1o = torch.empty(n_out, device=dev, dtype=torch.float32)
+    pts = torch.empty((n_out, 3), device=dev, dtype=torch.float32)
+    dirs = torch.empty((n_out, 3), device=dev, dtype=torch.float32)
+    check(lib().asd_compact(ptr(_c(rays_o)), ptr(_c(rays_d)), i32(nr), ptr(offset), ptr(count), ptr(keep), ptr(t0),
+                            ptr(t1), ptr(kept_offset), ptr(ray_idx), ptr(t0o), ptr(t1o), ptr(pts), ptr(dirs),
+                            stream()))
+    return ray_idx, t0o, t1o, pts, dirs
+
+
+def occgrid_update(occs, cell_idx, occ_new, decay: float, occ_thre: float, occ_bits, binaries):
+    scratch = torch.empty(2, device=occs.device, dtype=torch.float32)
+    n_up = 0 if cell_idx is None else cell_idx.shape[0]
+    check(lib().asd_occgrid_update(ptr(occs), i32(occs.numel()), ptr(cell_idx), ptr(occ_new), i32(n_up), f32(decay),
+                                   f32(occ_thre), ptr(occ_bits), ptr(binaries), ptr(scratch), stream()))
+
+
+# ---- compositing ------------------------------------------------------------------------------
+def composite_fwd(sigma, t0, t1, rgb, offset, count, bg, mode: int = 0):
+    nr, n, dev = count.shape[0], sigma.shape[0], sigma.device
+    w = torch.empty(n, device=dev, dtype=torch.float32)
+    op = torch.empty(nr, device=dev, dtype=torch.float32)
+    dp = torch.empty(nr, device=dev, dtype=torch.float32)
+    zv = torch.empty(nr, device=dev, dtype=torch.float32)
+    fg = torch.empty((nr, 3), device=dev, dtype=torch.float32)
+    comp = torch.empty((nr, 3), device=dev, dtype=torch.float32)
+    check(lib().asd_composite_fwd(i32(mode), ptr(_c(sigma)), ptr(t0), ptr(t1), ptr(_c(rgb)), ptr(offset), ptr(count),
+                                  i32(nr), ptr(_c(bg)), ptr(w), ptr(op), ptr(dp), ptr(fg), ptr(zv), ptr(comp),
+                                  stream()))
+    return dict(weights=w, opacity=op, depth=dp, rgb_fg=fg, z_var=zv, comp_rgb=comp)
+
+
+def composite_bwd(sigma, t0, t1, rgb, offset, count, bg, fwd, d_comp_rgb=None, d_rgb_fg=None, d_opacity=None,
+                  d_depth=None, d_z_var=None, d_weights=None, mode: int = 0):
+    nr, n, dev = count.shape[0], sigma.shape[0], sigma.device
+    d_sigma = torch.empty(n, device=dev, dtype=torch.float32)
+    d_rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    d_bg = torch.empty((nr, 3), device=dev, dtype=torch.float32)
+    check(lib().asd_composite_bwd(i32(mode), ptr(_c(sigma)), ptr(t0), ptr(t1), ptr(_c(rgb)), ptr(offset), ptr(count),
+                                  i32(nr), ptr(_c(bg)), ptr(fwd["weights"]), ptr(fwd["opacity"]), ptr(fwd["depth"]),
+                                  ptr(_c(d_comp_rgb)), ptr(_c(d_rgb_fg)), ptr(_c(d_opacity)), ptr(_c(d_depth)),
+                                  ptr(_c(d_z_var)), ptr(_c(d_weights)), ptr(d_sigma), ptr(d_rgb), ptr(d_bg), stream()))
+    return d_sigma, d_rgb, d_bg
+
+
+def pack_bits(binaries: torch.Tensor) -> torch.Tensor:
+    """bool[res^3] -> uint32 words (bit i of word i>>5), stored as int32 on the device."""
+    b = binaries.reshape(-1).to(torch.int64)
+    pad = (-b.numel()) % 32
+    if pad:
+        b = torch.cat([b, b.new_zeros(pad)])
+    w = (b.view(-1, 32) << torch.arange(32, device=b.device, dtype=torch.int64)).sum(1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
+    return w.to(torch.int32).contiguous()

@@ -1,0 +1,291 @@
+"""GPU parity: every renderer kernel of libasd_hip.so, called through the C ABI, against the CPU oracle.
+
+Tolerances: marcher outputs (integer / lattice work) bit-exact; field values 1e-5 abs (north_star asks 1e-3
+on rendered RGB/sigma); gradients 1e-4 rel (atomic scatter order differs from the oracle's serial order).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _metas(oracle, args):
+    from scaledreamer_amd import _lib
+
+    return oracle.grid_meta(*args), _lib.make_grid_meta(*args)
+
+
+def _hip_cfg(oc):
+    import ctypes
+    from scaledreamer_amd import _lib
+
+    c = _lib.FieldCfg()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(oc), ctypes.sizeof(c))
+    return c
+
+
+def _weights(rng, scale=0.3):
+    return (rng.normal(0, scale, (64, 32)).astype(np.float32), rng.normal(0, scale, (1, 64)).astype(np.float32),
+            rng.normal(0, scale, (64, 32)).astype(np.float32), rng.normal(0, scale, (3, 64)).astype(np.float32))
+
+
+GEOM = (16, 2, 19, 16, 1.447269237440378)
+BG = (4, 2, 19, 4, 4.0)
+
+
+@pytest.mark.parametrize("args,n", [(GEOM, 5000), (BG, 3000), ((7, 2, 12, 4, 1.7), 1000), (GEOM, 0), (GEOM, 1)])
+def test_hashgrid_fwd_bwd(oracle, args, n):
+    from scaledreamer_amd import ops
+
+    om, hm = _metas(oracle, args)
+    rng = np.random.default_rng(10)
+    p = rng.uniform(-1, 1, om.n_params).astype(np.float32)
+    x = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    if n > 10:
+        x[0] = [1.0, 1.0, 1.0]      # upper boundary: dense index wraps (tcnn % hashmap_size)
+        x[1] = [0.0, 0.0, 0.0]
+        x[2] = [1.3, -0.2, 0.5]     # out of range: clamped
+    out = ops.hashgrid_fwd(hm, _dev(p), _dev(x)).cpu().numpy()
+    want = oracle.hashgrid_fwd(om, p, x)
+    np.testing.assert_array_equal(out, want)  # same fmaf chain -> bit exact
+    dout = rng.normal(size=(n, om.n_levels * 2)).astype(np.float32)
+    g = ops.hashgrid_bwd(hm, _dev(x), _dev(dout)).cpu().numpy()
+    np.testing.assert_allclose(g, oracle.hashgrid_bwd(om, x, dout), rtol=1e-4, atol=1e-5)
+
+
+def test_field_density_and_forward(oracle):
+    from scaledreamer_amd import ops
+
+    om, hm = _metas(oracle, GEOM)
+    oc = oracle.field_cfg()
+    hc = _hip_cfg(oc)
+    rng = np.random.default_rng(11)
+    grid = rng.uniform(-0.1, 0.1, om.n_params).astype(np.float32)
+    w = _weights(rng)
+    pts = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    pts[0] = [0.995, -1.0, 1.0]
+    dg, dw = _dev(grid), [_dev(a) for a in w]
+    s = ops.field_density(hm, hc, dg, dw[0], dw[1], _dev(pts)).cpu().numpy()
+    s_ref = oracle.field_density(om, oc, grid, w[0], w[1], pts)
+    np.testing.assert_allclose(s, s_ref, rtol=1e-5, atol=1e-6)
+    sig, feat, nrm, enc = ops.field_fwd(hm, hc, dg, *dw, _dev(pts), want_normal=True)
+    s2, f2, n2, e2 = oracle.field_fwd(om, oc, grid, *w, pts, want_normal=True)
+    np.testing.assert_array_equal(enc.cpu().numpy(), e2)
+    np.testing.assert_allclose(sig.cpu().numpy(), s2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(feat.cpu().numpy(), f2, rtol=1e-5, atol=1e-6)
+    # the normal divides an fp32 difference by eps=0.01 then normalises: expf ulp differences are amplified
+    assert np.abs(nrm.cpu().numpy() - n2).max() < 2e-3
+    # device-side count: only the first 1234 samples are live
+    n_dev = torch.tensor([1234], dtype=torch.int32, device="cuda")
+    out = torch.full((20000,), -7.0, device="cuda")
+    ops.field_density(hm, hc, dg, dw[0], dw[1], _dev(pts), n_dev=n_dev, out=out)
+    np.testing.assert_allclose(out[:1234].cpu().numpy(), s_ref[:1234], rtol=1e-5, atol=1e-6)
+    assert (out[1234:] == -7.0).all()
+
+
+@pytest.mark.parametrize("with_normal,n", [(False, 3000), (True, 1500), (False, 1), (False, 257)])
+def test_field_backward(oracle, with_normal, n):
+    from scaledreamer_amd import ops
+
+    om, hm = _metas(oracle, GEOM)
+    oc = oracle.field_cfg()
+    hc = _hip_cfg(oc)
+    rng = np.random.default_rng(12)
+    grid = rng.uniform(-0.1, 0.1, om.n_params).astype(np.float32)
+    w = _weights(rng)
+    pts = rng.uniform(-0.7, 0.7, (n, 3)).astype(np.float32)
+    ds = rng.normal(size=n).astype(np.float32)
+    df = rng.normal(size=(n, 3)).astype(np.float32)
+    dn = rng.normal(size=(n, 3)).astype(np.float32) if with_normal else None
+    dg, dw = _dev(grid), [_dev(a) for a in w]
+    sig, feat, nrm, enc = ops.field_fwd(hm, hc, dg, *dw, _dev(pts), want_normal=with_normal)
+    d_grid = torch.zeros(om.n_params, device="cuda")
+    got = ops.field_bwd(hm, hc, dg, *dw, _dev(pts), enc, sig, _dev(ds), _dev(df), None if dn is None else _dev(dn),
+                        d_grid)
+    want = oracle.field_bwd(om, oc, grid, *w, pts, ds, df, dn)
+    tol = dict(rtol=5e-3, atol=5e-3) if with_normal else dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(d_grid.cpu().numpy(), want[0], **tol)
+    for a, b in zip(got, want[1:]):
+        scale = max(1.0, float(np.abs(b).max()))
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b / scale, **tol)
+
+
+def test_envmap(oracle):
+    from scaledreamer_amd import ops
+
+    om, hm = _metas(oracle, BG)
+    rng = np.random.default_rng(13)
+    grid = rng.uniform(-0.5, 0.5, om.n_params).astype(np.float32)
+    w0 = rng.normal(0, 0.5, (16, 8)).astype(np.float32)
+    w1 = rng.normal(0, 0.5, (16, 16)).astype(np.float32)
+    w2 = rng.normal(0, 0.5, (3, 16)).astype(np.float32)
+    d = rng.normal(size=(4096 + 37, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dc = rng.normal(size=d.shape).astype(np.float32)
+    args = [_dev(a) for a in (grid, w0, w1, w2)]
+    col = ops.envmap_fwd(hm, *args, _dev(d)).cpu().numpy()
+    np.testing.assert_allclose(col, oracle.envmap_fwd(om, grid, w0, w1, w2, d), rtol=1e-5, atol=1e-6)
+    got = ops.envmap_bwd(hm, *args, _dev(d), _dev(dc))
+    want = oracle.envmap_bwd(om, grid, w0, w1, w2, d, dc)
+    for a, b in zip(got, want):
+        scale = max(1.0, float(np.abs(b).max()))
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b / scale, rtol=1e-4, atol=1e-4)
+
+
+def _scene(oracle, rng, n_rays, spp):
+    ix, iy, iz = np.meshgrid(*[np.arange(32)] * 3, indexing="ij")
+    centre = (np.stack([ix, iy, iz], -1) + 0.5) / 32 * 2 - 1
+    binaries = (np.linalg.norm(centre, axis=-1) < 0.5) | (rng.uniform(size=(32, 32, 32)) < 0.02)
+    o = rng.normal(size=(n_rays, 3))
+    o = (o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(1.0, 1.5, (n_rays, 1))).astype(np.float32)
+    d = rng.uniform(-0.6, 0.6, (n_rays, 3)).astype(np.float32) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    if n_rays > 3:
+        o[1] = [3, 3, 3]; d[1] = [1, 0, 0]               # miss
+        o[2] = [0.01, 0.02, -2.0]; d[2] = [0, 0, 1]      # axis aligned
+    return binaries, o, d
+
+
+def _hip_march_cfg(oc):
+    import ctypes
+    from scaledreamer_amd import _lib
+
+    c = _lib.MarchCfg()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(oc), ctypes.sizeof(c))
+    return c
+
+
+@pytest.mark.parametrize("n_rays,spp,stratified", [(4096, 512, True), (1024, 16, False), (257, 128, True), (1, 64, False)])
+def test_march_bit_exact(oracle, n_rays, spp, stratified):
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(14)
+    binaries, o, d = _scene(oracle, rng, n_rays, spp)
+    oc = oracle.march_cfg(num_samples_per_ray=spp)
+    bits = oracle.pack_bits(binaries)
+    jit = rng.uniform(0, 1, n_rays).astype(np.float32) if stratified else None
+    count, offset, ray_idx, t0, t1, pts = oracle.march(oc, o, d, bits, jit)
+    hb = ops.pack_bits(_dev(binaries.astype(np.uint8)))
+    np.testing.assert_array_equal(hb.cpu().numpy().view(np.uint32), bits)
+    hc, ho, ht, hr, h0, h1, hp = ops.march(_hip_march_cfg(oc), _dev(o), _dev(d), hb, None if jit is None else _dev(jit))
+    assert int(ht.item()) == int(count.sum())
+    np.testing.assert_array_equal(hc.cpu().numpy(), count)
+    np.testing.assert_array_equal(ho.cpu().numpy(), offset)
+    np.testing.assert_array_equal(hr.cpu().numpy(), ray_idx)
+    np.testing.assert_array_equal(h0.cpu().numpy(), t0)
+    np.testing.assert_array_equal(h1.cpu().numpy(), t1)
+    np.testing.assert_array_equal(hp.cpu().numpy(), pts)
+
+
+def test_scan_sizes():
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(15)
+    for n in [1, 63, 1024, 4096, 65536, 262144 + 5]:
+        c = rng.integers(0, 513, n).astype(np.int32)
+        off, tot = ops.scan_i32(_dev(c))
+        want = np.concatenate([[0], np.cumsum(c)[:-1]])
+        np.testing.assert_array_equal(off.cpu().numpy(), want)
+        assert int(tot.item()) == int(c.sum())
+
+
+def test_prune_and_compact(oracle):
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(16)
+    binaries, o, d = _scene(oracle, rng, 2048, 512)
+    oc = oracle.march_cfg(num_samples_per_ray=512)
+    count, offset, ray_idx, t0, t1, pts = oracle.march(oc, o, d, oracle.pack_bits(binaries), None)
+    sigma = (rng.uniform(0, 1, t0.shape[0]) ** 4 * 300).astype(np.float32)
+    keep, kept = oracle.prune(sigma, t0, t1, offset, count, 1e-4, 0.01)
+    hk, hkc = ops.prune(_dev(sigma), _dev(t0), _dev(t1), _dev(offset), _dev(count), 1e-4, 0.01)
+    hk = hk.cpu().numpy()
+    # expf may differ by an ulp between libm and the device: allow flips only at the thresholds
+    acc = np.zeros_like(sigma, np.float64)
+    for r in range(2048):
+        sl = slice(offset[r], offset[r] + count[r])
+        sd = (sigma[sl] * (t1[sl] - t0[sl])).astype(np.float64)
+        acc[sl] = np.concatenate([[0], np.cumsum(sd)[:-1]])
+    T = np.exp(-acc)
+    alpha = 1 - np.exp(-(sigma * (t1 - t0)).astype(np.float64))
+    near_tie = (np.abs(T - 1e-4) < 1e-8) | (np.abs(alpha - 0.01) < 1e-6)
+    assert ((hk == keep) | near_tie).all()
+    assert (hk != keep).sum() <= 3
+    # compaction of the HIP mask
+    koff, ktot = ops.scan_i32(hkc)
+    n_out = int(ktot.item())
+    assert n_out == int(hk.sum())
+    ri, k0, k1, kp, kd = ops.compact(_dev(o), _dev(d), _dev(offset), _dev(count), _dev(hk), _dev(t0), _dev(t1), koff,
+                                     n_out)
+    sel = hk.astype(bool)
+    np.testing.assert_array_equal(ri.cpu().numpy(), ray_idx[sel].astype(np.int64))
+    np.testing.assert_array_equal(k0.cpu().numpy(), t0[sel])
+    np.testing.assert_array_equal(k1.cpu().numpy(), t1[sel])
+    # positions = o + d * (t0+t1)/2  (nerf_volume_renderer.py:276-278), same fp32 operation order as torch
+    want_pts = o[ray_idx[sel]] + d[ray_idx[sel]] * ((t0[sel] + t1[sel]) / np.float32(2.0))[:, None]
+    np.testing.assert_array_equal(kp.cpu().numpy(), want_pts)
+    np.testing.assert_array_equal(kd.cpu().numpy(), d[ray_idx[sel]])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_composite_fwd_bwd(oracle, mode):
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(17)
+    counts = rng.integers(0, 300, 1000).astype(np.int32)
+    counts[:4] = [0, 1, 64, 65]
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    n = int(counts.sum())
+    t0 = np.concatenate([np.sort(rng.uniform(0.2, 2.0, c)) for c in counts]).astype(np.float32)
+    t1 = (t0 + 0.0068).astype(np.float32)
+    sig = (rng.uniform(0, 1, n) ** 3 * 100 if mode == 0 else rng.uniform(0, 0.2, n)).astype(np.float32)
+    rgb = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    bg = rng.uniform(0, 1, (1000, 3)).astype(np.float32)
+    want = oracle.composite_fwd(sig, t0, t1, rgb, offs, counts, bg, mode=mode)
+    dv = [_dev(a) for a in (sig, t0, t1, rgb, offs, counts, bg)]
+    got = ops.composite_fwd(*dv, mode=mode)
+    for k in want:
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    ups = dict(d_comp_rgb=rng.normal(size=(1000, 3)), d_rgb_fg=rng.normal(size=(1000, 3)),
+               d_opacity=rng.normal(size=1000), d_depth=rng.normal(size=1000), d_z_var=rng.normal(size=1000),
+               d_weights=rng.normal(size=n))
+    ups = {k: v.astype(np.float32) for k, v in ups.items()}
+    w_sig, w_rgb, w_bg = oracle.composite_bwd(sig, t0, t1, rgb, offs, counts, bg, want, mode=mode, **ups)
+    g_sig, g_rgb, g_bg = ops.composite_bwd(*dv, got, mode=mode, **{k: _dev(v) for k, v in ups.items()})
+    scale = max(1.0, float(np.abs(w_sig).max()))
+    np.testing.assert_allclose(g_sig.cpu().numpy() / scale, w_sig / scale, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(g_rgb.cpu().numpy(), w_rgb, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g_bg.cpu().numpy(), w_bg, rtol=1e-4, atol=1e-6)
+    # only some upstream gradients present (the ASD step: comp_rgb and opacity)
+    g2 = ops.composite_bwd(*dv, got, mode=mode, d_comp_rgb=_dev(ups["d_comp_rgb"]), d_opacity=_dev(ups["d_opacity"]))
+    w2 = oracle.composite_bwd(sig, t0, t1, rgb, offs, counts, bg, want, mode=mode, d_comp_rgb=ups["d_comp_rgb"],
+                              d_opacity=ups["d_opacity"])
+    scale = max(1.0, float(np.abs(w2[0]).max()))
+    np.testing.assert_allclose(g2[0].cpu().numpy() / scale, w2[0] / scale, rtol=1e-3, atol=2e-5)
+
+
+def test_occgrid_update(oracle):
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(18)
+    occs = rng.uniform(0, 0.02, 32768).astype(np.float32)
+    idx = rng.permutation(32768)[:8192].astype(np.int32)
+    new = rng.uniform(0, 0.05, 8192).astype(np.float32)
+    w_occs, w_bits, w_bin = oracle.occgrid_update(occs, idx, new, 0.95, 0.01)
+    d_occs = _dev(occs)
+    bits = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    binaries = torch.zeros(32768, dtype=torch.uint8, device="cuda")
+    ops.occgrid_update(d_occs, _dev(idx), _dev(new), 0.95, 0.01, bits, binaries)
+    np.testing.assert_array_equal(d_occs.cpu().numpy(), w_occs)
+    mism = (binaries.cpu().numpy() != w_bin).sum()
+    assert mism <= 2  # mean in fp32 (device) vs fp64 (oracle) can move the threshold by an ulp
+    if mism == 0:
+        np.testing.assert_array_equal(bits.cpu().numpy().view(np.uint32), w_bits)
