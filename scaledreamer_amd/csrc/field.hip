@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const asd_grid_meta m
                                                            const float* __restrict__ x, int n,
                                                            float* __restrict__ out) {
     const int L = (int)m.n_levels;
-    const int64_t total = (int64_t)n * L;
+    const int64_t total = (int64_t)((n + 255) / 256) * 256 * L;  // whole 256-point tiles, level-major inside
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         // level-major inside a block-sized tile of points keeps one level's table hot per wave
         const int64_t tile = t / (256 * (int64_t)L);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(const asd_grid_meta m
                                                            const float* __restrict__ dout, int n,
                                                            float* __restrict__ dparams) {
     const int L = (int)m.n_levels;
-    const int64_t total = (int64_t)n * L;
+    const int64_t total = (int64_t)((n + 255) / 256) * 256 * L;  // whole 256-point tiles, level-major inside
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t tile = t / (256 * (int64_t)L);
         const int r = (int)(t - tile * 256 * L);
@@ -591,8 +591,8 @@ uint32_t asd_grid_meta_init(asd_grid_meta* m, uint32_t n_levels, uint32_t n_feat
 
 int asd_hashgrid_fwd(const asd_grid_meta* meta, const float* params, const float* x, int32_t n, float* out,
                      void* stream) {
-    ASD_CHECK_ARG(meta && params && x && out && n >= 0, "null argument");
     if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && params && x && out && n > 0, "null argument");
     const int64_t total = (int64_t)asd_div_up(n, 256) * 256 * meta->n_levels;
     hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3(asd_grid_for(total, 256) * 4), dim3(256), 0, (hipStream_t)stream, *meta,
                        params, x, n, out);
@@ -602,8 +602,8 @@ int asd_hashgrid_fwd(const asd_grid_meta* meta, const float* params, const float
 
 int asd_hashgrid_bwd(const asd_grid_meta* meta, const float* x, const float* dout, int32_t n, float* dparams,
                      void* stream) {
-    ASD_CHECK_ARG(meta && x && dout && dparams && n >= 0, "null argument");
     if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && x && dout && dparams && n > 0, "null argument");
     const int64_t total = (int64_t)asd_div_up(n, 256) * 256 * meta->n_levels;
     hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3(asd_grid_for(total, 256) * 4), dim3(256), 0, (hipStream_t)stream, *meta,
                        x, dout, n, dparams);
@@ -623,9 +623,9 @@ static int field_supported(const asd_grid_meta* m, const asd_field_cfg* c) {
 int asd_field_density(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
                       const float* w1_density, const float* w2_density, const float* points, int32_t n,
                       const int32_t* n_dev, float* sigma, void* stream) {
-    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n >= 0, "null argument");
-    if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n > 0, "null argument");
+    if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((field_density_kernel<16, 64>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        *meta, *cfg, grid_params, w1_density, w2_density, points, n, n_dev, sigma);
     ASD_LAUNCH_CHECK();
@@ -636,10 +636,10 @@ int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* w1_density, const float* w2_density, const float* w1_feature,
                   const float* w2_feature, const float* points, int32_t n, const int32_t* n_dev, float* sigma,
                   float* features, float* normal, float* enc_save, void* stream) {
-    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n >= 0, "null argument");
+    if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n > 0, "null argument");
     if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     ASD_CHECK_ARG(cfg->n_feature_dims == 0 || !features || (w1_feature && w2_feature), "feature weights missing");
-    if (n == 0) return ASD_OK;
     hipLaunchKernelGGL((field_fwd_kernel<16, 64, 3>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        *meta, *cfg, grid_params, w1_density, w2_density, w1_feature, w2_feature, points, n, n_dev,
                        sigma, cfg->n_feature_dims == 3 ? features : nullptr, normal, enc_save);
@@ -660,8 +660,9 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* w2_feature, const float* points, const float* enc_save, const float* sigma, int32_t n,
                   const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
                   float* d_grid_params, float* wgrad_partials, void* stream) {
+    if (n == 0) return ASD_OK;
     ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && enc_save && sigma &&
-                      d_grid_params && wgrad_partials && n >= 0,
+                      d_grid_params && wgrad_partials && n > 0,
                   "null argument");
     if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     ASD_CHECK_ARG(cfg->n_feature_dims == 3 || !d_features, "d_features given but no feature network");
@@ -704,7 +705,8 @@ int asd_field_bwd_reduce(const asd_field_cfg* cfg, const float* wgrad_partials, 
 
 int asd_envmap_fwd(const asd_grid_meta* meta, const float* grid_params, const float* w0, const float* w1,
                    const float* w2, int32_t n_hidden, const float* dirs, int32_t n, float* color, void* stream) {
-    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && color && n >= 0, "null argument");
+    if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && color && n > 0, "null argument");
     if (meta->n_levels != 4 || n_hidden != 16) {
         asd_set_error("envmap kernels are built for 4 levels and 16 hidden units (got %u, %d)", meta->n_levels, n_hidden);
         return ASD_ERR_UNSUPPORTED;
@@ -719,7 +721,8 @@ int asd_envmap_fwd(const asd_grid_meta* meta, const float* grid_params, const fl
 int asd_envmap_bwd(const asd_grid_meta* meta, const float* grid_params, const float* w0, const float* w1,
                    const float* w2, int32_t n_hidden, const float* dirs, const float* d_color, int32_t n,
                    float* d_grid_params, float* dw0, float* dw1, float* dw2, void* stream) {
-    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && d_color && d_grid_params && dw0 && dw1 && dw2 && n >= 0,
+    if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(meta && grid_params && w0 && w1 && w2 && dirs && d_color && d_grid_params && dw0 && dw1 && dw2 && n > 0,
                   "null argument");
     if (meta->n_levels != 4 || n_hidden != 16) {
         asd_set_error("envmap kernels are built for 4 levels and 16 hidden units (got %u, %d)", meta->n_levels, n_hidden);

@@ -430,8 +430,8 @@ int asd_scan_i32(const int32_t* count, int32_t n, int32_t* offset, int32_t* tota
 int asd_march_write(const asd_march_cfg* cfg, const float* rays_o, const float* rays_d, int32_t n_rays,
                     const uint32_t* occ_bits, const float* jitter, const int32_t* offset, int32_t* ray_idx,
                     float* t_start, float* t_end, float* points, void* stream) {
-    ASD_CHECK_ARG(cfg && rays_o && rays_d && occ_bits && offset && ray_idx && t_start && t_end && n_rays >= 0,
-                  "null argument");
+    // the sample arrays may be NULL when the marcher found nothing (zero-sized tensors)
+    ASD_CHECK_ARG(cfg && rays_o && rays_d && occ_bits && offset && n_rays >= 0, "null argument");
     if (n_rays == 0) return ASD_OK;
     hipLaunchKernelGGL((march_kernel<true>), dim3(asd_div_up(n_rays, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
                        *cfg, rays_o, rays_d, n_rays, occ_bits, jitter, nullptr, offset, ray_idx, t_start, t_end, points);
@@ -442,7 +442,7 @@ int asd_march_write(const asd_march_cfg* cfg, const float* rays_o, const float* 
 int asd_prune_count(const float* sigma, const float* t_start, const float* t_end, const int32_t* offset,
                     const int32_t* count, int32_t n_rays, float early_stop_eps, float alpha_thre, uint8_t* keep,
                     int32_t* kept_count, void* stream) {
-    ASD_CHECK_ARG(sigma && t_start && t_end && offset && count && keep && kept_count && n_rays >= 0, "null argument");
+    ASD_CHECK_ARG(offset && count && kept_count && n_rays >= 0, "null argument");
     if (n_rays == 0) return ASD_OK;
     hipLaunchKernelGGL(prune_kernel, dim3(asd_div_up(n_rays, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, sigma,
                        t_start, t_end, offset, count, n_rays, early_stop_eps, alpha_thre, keep, kept_count);
@@ -454,9 +454,7 @@ int asd_compact(const float* rays_o, const float* rays_d, int32_t n_rays, const 
                 const uint8_t* keep, const float* t_start, const float* t_end, const int32_t* kept_offset,
                 int64_t* ray_idx_out, float* t_start_out, float* t_end_out, float* points_out, float* dirs_out,
                 void* stream) {
-    ASD_CHECK_ARG(rays_o && rays_d && offset && count && t_start && t_end && kept_offset && ray_idx_out && t_start_out &&
-                      t_end_out && n_rays >= 0,
-                  "null argument");
+    ASD_CHECK_ARG(rays_o && rays_d && offset && count && kept_offset && n_rays >= 0, "null argument");
     if (n_rays == 0) return ASD_OK;
     hipLaunchKernelGGL(compact_kernel, dim3(asd_div_up(n_rays, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, rays_o,
                        rays_d, n_rays, offset, count, keep, t_start, t_end, kept_offset, ray_idx_out, t_start_out,
@@ -468,8 +466,7 @@ int asd_compact(const float* rays_o, const float* rays_d, int32_t n_rays, const 
 int asd_composite_fwd(int32_t mode, const float* sigma, const float* t_start, const float* t_end, const float* rgb,
                       const int32_t* offset, const int32_t* count, int32_t n_rays, const float* bg, float* weights,
                       float* opacity, float* depth, float* rgb_fg, float* z_var, float* comp_rgb, void* stream) {
-    ASD_CHECK_ARG(sigma && t_start && t_end && rgb && offset && count && bg && weights && opacity && depth && rgb_fg &&
-                      z_var && comp_rgb && n_rays >= 0,
+    ASD_CHECK_ARG(offset && count && bg && opacity && depth && rgb_fg && z_var && comp_rgb && n_rays >= 0,
                   "null argument");
     ASD_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (density) or 1 (alpha)");
     if (n_rays == 0) return ASD_OK;
@@ -489,9 +486,7 @@ int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, co
                       const float* weights, const float* opacity, const float* depth, const float* d_comp_rgb,
                       const float* d_rgb_fg, const float* d_opacity, const float* d_depth, const float* d_z_var,
                       const float* d_weights, float* d_sigma, float* d_rgb, float* d_bg, void* stream) {
-    ASD_CHECK_ARG(sigma && t_start && t_end && rgb && offset && count && bg && weights && opacity && depth && d_sigma &&
-                      d_rgb && n_rays >= 0,
-                  "null argument");
+    ASD_CHECK_ARG(offset && count && bg && opacity && depth && n_rays >= 0, "null argument");
     ASD_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (density) or 1 (alpha)");
     if (n_rays == 0) return ASD_OK;
     const dim3 g(asd_div_up(n_rays, RAYS_PER_BLOCK)), blk(256);
