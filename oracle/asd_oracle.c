@@ -481,10 +481,11 @@ ORC_API int32_t orc_march(const asd_march_cfg* c, const float* rays_o, const flo
             for (int k = 0; k < c->max_steps; ++k) {
                 const float t0 = fmaf((float)k, c->step, t_begin);
                 const float t1 = fmaf((float)(k + 1), c->step, t_begin);
-                const float tm = (t0 + t1) * 0.5f;
+                const float tm = (t0 + t1) / 2.0f;
                 if (!(tm <= t_exit)) break;
                 float p[3];
-                for (int a = 0; a < 3; ++a) p[a] = fmaf(tm, d[a], o[a]);
+                /* positions = t_origins + t_dirs * t_positions (nerf_volume_renderer.py:157-158): mul, then add */
+                for (int a = 0; a < 3; ++a) p[a] = o[a] + d[a] * tm;
                 const int cell = orc_cell_of(c, p);
                 if (cell < 0) continue;
                 if (!((occ_bits[cell >> 5] >> (cell & 31)) & 1u)) continue;

@@ -72,11 +72,12 @@ __global__ __launch_bounds__(256) void march_kernel(const asd_march_cfg c, const
             const int k = k0 + lane;
             const float t0 = fmaf((float)k, c.step, t_begin);
             const float t1 = fmaf((float)(k + 1), c.step, t_begin);
-            const float tm = (t0 + t1) * 0.5f;
+            const float tm = (t0 + t1) / 2.0f;
             const bool in_range = (k < c.max_steps) && (tm <= t_exit);
             // lane 0 holds the smallest t of the chunk: if it is past the exit, every later one is too
             if (!__shfl((int)in_range, 0, 64)) break;
-            const float px = fmaf(tm, d[0], o[0]), py = fmaf(tm, d[1], o[1]), pz = fmaf(tm, d[2], o[2]);
+            // = t_origins + t_dirs * (t0+t1)/2 exactly as the reference forms it (separate mul and add)
+            const float px = o[0] + d[0] * tm, py = o[1] + d[1] * tm, pz = o[2] + d[2] * tm;
             bool emit = false;
             if (in_range) {
                 const int cell = cell_of(c, px, py, pz);

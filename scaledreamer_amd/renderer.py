@@ -1,0 +1,265 @@
+"""`nerf-volume-renderer` (threestudio/models/renderers/nerf_volume_renderer.py:20-470) on the HIP path.
+
+Same Config, forward signature and output dictionary as the reference class.  With the occupancy-grid
+estimator (the shipped single-prompt configs) the sampling / pruning / compaction / compositing all run in
+the HIP kernels of csrc/render.hip; geometry and background are called through their module interface, so
+any registered geometry works, and the HIP `implicit-volume` / `neural-environment-map-background` plug in
+with their fused kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import nerfacc_api, ops
+from .base import BaseModule
+from .registry import register, warn
+
+
+class Renderer(BaseModule):
+    """threestudio/models/renderers/base.py:15-72"""
+
+    @dataclass
+    class Config(BaseModule.Config):
+        radius: float = 1.0
+
+    cfg: Config
+
+    def configure(self, geometry, material, background) -> None:
+        @dataclass
+        class SubModules:
+            geometry: Any
+            material: Any
+            background: Any
+
+        self.sub_modules = SubModules(geometry, material, background)
+        r = self.cfg.radius
+        self.register_buffer("bbox", torch.as_tensor([[-r, -r, -r], [r, r, r]], dtype=torch.float32))
+
+    @property
+    def geometry(self):
+        return self.sub_modules.geometry
+
+    @property
+    def material(self):
+        return self.sub_modules.material
+
+    @property
+    def background(self):
+        return self.sub_modules.background
+
+    def set_geometry(self, geometry) -> None:
+        self.sub_modules.geometry = geometry
+
+    def set_material(self, material) -> None:
+        self.sub_modules.material = material
+
+    def set_background(self, background) -> None:
+        self.sub_modules.background = background
+
+
+class VolumeRenderer(Renderer):
+    pass
+
+
+def chunk_batch(func, chunk_size: int, *args, **kwargs):
+    """threestudio/utils/ops.py:116-180 for tensor / dict-of-tensor outputs."""
+    if chunk_size <= 0:
+        return func(*args, **kwargs)
+    B = next(a.shape[0] for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor))
+    outs = []
+    for i in range(0, max(1, B), chunk_size):
+        sl = lambda a: a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a
+        outs.append(func(*[sl(a) for a in args], **{k: sl(v) for k, v in kwargs.items()}))
+    if isinstance(outs[0], dict):
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    return torch.cat(outs, 0)
+
+
+def validate_empty_rays(ray_indices, t_start, t_end):
+    """threestudio/utils/ops.py:514-520: substitute one dummy sample when nothing was sampled."""
+    if ray_indices.nelement() == 0:
+        warn("Empty rays_indices!")
+        ray_indices = torch.zeros(1, dtype=torch.long, device=ray_indices.device)
+        t_start = torch.zeros(1, device=ray_indices.device)
+        t_end = torch.zeros(1, device=ray_indices.device)
+    return ray_indices, t_start, t_end
+
+
+@register("nerf-volume-renderer")
+class NeRFVolumeRenderer(VolumeRenderer):
+    @dataclass
+    class Config(VolumeRenderer.Config):
+        num_samples_per_ray: int = 512
+        eval_chunk_size: int = 160000
+        randomized: bool = True
+        near_plane: float = 0.0
+        far_plane: float = 1e10
+        return_comp_normal: bool = False
+        return_normal_perturb: bool = False
+        estimator: str = "occgrid"  # in ["occgrid", "proposal", "importance"]
+        grid_prune: bool = True
+        prune_alpha_threshold: bool = True
+        proposal_network_config: Optional[dict] = None
+        prop_optimizer_config: Optional[dict] = None
+        prop_scheduler_config: Optional[dict] = None
+        num_samples_per_ray_proposal: int = 64
+        num_samples_per_ray_importance: int = 64
+
+    cfg: Config
+
+    def configure(self, geometry, material, background) -> None:
+        super().configure(geometry, material, background)
+        if self.cfg.estimator == "occgrid":
+            self.estimator = nerfacc_api.OccGridEstimator(roi_aabb=self.bbox.view(-1), resolution=32, levels=1)
+            if not self.cfg.grid_prune:
+                self.estimator.occs.fill_(True)
+                self.estimator.binaries.fill_(True)
+            self.render_step_size = 1.732 * 2 * self.cfg.radius / self.cfg.num_samples_per_ray
+            self.randomized = self.cfg.randomized
+        elif self.cfg.estimator in ("importance", "proposal"):
+            raise NotImplementedError(
+                f"estimator {self.cfg.estimator!r}: the single-prompt ASD configs use 'occgrid' "
+                "(importance sampling belongs to the amortized renderer; proposal is unused — SURVEY.md §2.2 N9/N10)"
+            )
+        else:
+            raise NotImplementedError("Unknown estimator, should be one of ['occgrid', 'proposal', 'importance'].")
+        self.vars_in_forward: Dict[str, Any] = {}
+        self.jitter_fn = lambda n, device: torch.rand(n, device=device)  # injectable
+
+    # ------------------------------------------------------------------------------------------
+    def _sample(self, rays_o_flatten, rays_d_flatten):
+        """(ray_indices int64, t_starts, t_ends, offset int32, count int32) of the kept samples."""
+        n_rays = rays_o_flatten.shape[0]
+        est = self.estimator
+        jitter = self.jitter_fn(n_rays, rays_o_flatten.device) if self.randomized else None
+        cfg = est.march_cfg(self.cfg.near_plane, self.cfg.far_plane, self.render_step_size)
+        bits = est._bits()
+        count, offset, total, ray_idx, t0, t1, pts = ops.march(cfg, rays_o_flatten, rays_d_flatten, bits, jitter)
+        prune = self.cfg.grid_prune and self.cfg.prune_alpha_threshold
+        if self.cfg.grid_prune:
+            early_stop_eps, alpha_thre = 1e-4, (0.01 if self.cfg.prune_alpha_threshold else 0.0)
+        else:
+            early_stop_eps, alpha_thre = 0.0, 0.0
+        if prune and (early_stop_eps > 0 or alpha_thre > 0):
+            alpha_thre = min(alpha_thre, est._occ_mean)
+            if ray_idx.shape[0] > 0:
+                # sigma at the candidate mid-points (the reference's sigma_fn, nerf_volume_renderer.py:153-167);
+                # the marcher already produced the positions o + d*(t0+t1)/2
+                if self.training:
+                    sigma = self.geometry.forward_density(pts)[..., 0]
+                else:
+                    sigma = chunk_batch(self.geometry.forward_density, self.cfg.eval_chunk_size, pts)[..., 0]
+                sigma = sigma.contiguous().float()
+            else:
+                sigma = t0.new_zeros(0)
+            keep, kept = ops.prune(sigma, t0, t1, offset, count, early_stop_eps, alpha_thre)
+            koff, ktot = ops.scan_i32(kept)
+            n_out = int(ktot.item())
+            ri, k0, k1, kp, kd = ops.compact(rays_o_flatten, rays_d_flatten, offset, count, keep, t0, t1, koff, n_out)
+            return ri, k0, k1, kp, kd, koff, kept
+        n_out = ray_idx.shape[0]
+        ri, k0, k1, kp, kd = ops.compact(rays_o_flatten, rays_d_flatten, offset, count, None, t0, t1, offset, n_out)
+        return ri, k0, k1, kp, kd, offset, count
+
+    def forward(self, rays_o: torch.Tensor, rays_d: torch.Tensor, light_positions: torch.Tensor,
+                bg_color: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, torch.Tensor]:
+        batch_size, height, width = rays_o.shape[:3]
+        rays_o_flatten = rays_o.reshape(-1, 3).contiguous().float()
+        rays_d_flatten = rays_d.reshape(-1, 3).contiguous().float()
+        light_positions_flatten = light_positions.reshape(-1, 1, 1, 3).expand(-1, height, width, -1).reshape(-1, 3)
+        n_rays = rays_o_flatten.shape[0]
+
+        with torch.no_grad():
+            ray_indices, t_starts_, t_ends_, positions, t_dirs, offset, count = self._sample(rays_o_flatten, rays_d_flatten)
+        if ray_indices.nelement() == 0:
+            ray_indices, t_starts_, t_ends_ = validate_empty_rays(ray_indices, t_starts_, t_ends_)
+            positions = rays_o_flatten[ray_indices] + rays_d_flatten[ray_indices] * 0.0
+            t_dirs = rays_d_flatten[ray_indices]
+            count = torch.zeros(n_rays, dtype=torch.int32, device=rays_o.device)
+            count[0] = 1
+            offset = torch.ones(n_rays, dtype=torch.int32, device=rays_o.device)
+            offset[0] = 0
+        t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
+        t_light_positions = light_positions_flatten[ray_indices]
+        t_positions = (t_starts + t_ends) / 2.0
+        t_intervals = t_ends - t_starts
+
+        if self.training:
+            geo_out = self.geometry(positions, output_normal=self.material.requires_normal)
+            rgb_fg_all = self.material(viewdirs=t_dirs, positions=positions, light_positions=t_light_positions,
+                                       **geo_out, **kwargs)
+            comp_rgb_bg = self.background(dirs=rays_d)
+        else:
+            geo_out = chunk_batch(self.geometry, self.cfg.eval_chunk_size, positions,
+                                  output_normal=self.material.requires_normal)
+            rgb_fg_all = chunk_batch(self.material, self.cfg.eval_chunk_size, viewdirs=t_dirs, positions=positions,
+                                     light_positions=t_light_positions, **geo_out)
+            comp_rgb_bg = chunk_batch(self.background, self.cfg.eval_chunk_size, dirs=rays_d)
+
+        if bg_color is None:
+            bg_color = comp_rgb_bg
+        else:
+            if bg_color.shape[:-1] == (batch_size,):
+                bg_color = bg_color.unsqueeze(1).unsqueeze(1).expand(-1, height, width, -1)
+        if bg_color.shape[:-1] == (batch_size, height, width):
+            bg_color = bg_color.reshape(batch_size * height * width, -1)
+
+        # T / alpha / weights + all per-ray accumulations (reference :312-364) in one fused pass
+        weights_, opacity_, depth_, comp_rgb_fg, z_variance_, comp_rgb = nerfacc_api.composite(
+            geo_out["density"][..., 0], rgb_fg_all, bg_color.float(), t_starts_, t_ends_, offset, count, 0
+        )
+        weights = weights_[..., None]
+        opacity, depth, z_variance = opacity_[..., None], depth_[..., None], z_variance_[..., None]
+
+        out = {
+            "comp_rgb": comp_rgb.view(batch_size, height, width, -1),
+            "comp_rgb_fg": comp_rgb_fg.view(batch_size, height, width, -1),
+            "comp_rgb_bg": comp_rgb_bg.view(batch_size, height, width, -1),
+            "opacity": opacity.view(batch_size, height, width, 1),
+            "depth": depth.view(batch_size, height, width, 1),
+            "z_variance": z_variance.view(batch_size, height, width, 1),
+        }
+
+        def comp_normal_of(normal):
+            cn = nerfacc_api.accumulate_along_rays(weights[..., 0], values=normal, ray_indices=ray_indices, n_rays=n_rays)
+            cn = F.normalize(cn, dim=-1)
+            return ((cn + 1.0) / 2.0 * opacity).view(batch_size, height, width, 3)
+
+        if self.training:
+            out.update({"weights": weights, "t_points": t_positions, "t_intervals": t_intervals, "t_dirs": t_dirs,
+                        "ray_indices": ray_indices, "points": positions, **geo_out})
+            if "normal" in geo_out:
+                if self.cfg.return_comp_normal:
+                    out["comp_normal"] = comp_normal_of(geo_out["normal"])
+                if self.cfg.return_normal_perturb:
+                    out["normal_perturb"] = self.geometry(positions + torch.randn_like(positions) * 1e-2,
+                                                          output_normal=self.material.requires_normal)["normal"]
+        elif "normal" in geo_out:
+            out["comp_normal"] = comp_normal_of(geo_out["normal"])
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
+        if self.cfg.estimator == "occgrid" and self.cfg.grid_prune:
+
+            def occ_eval_fn(x):
+                # approximates 1 - exp(-density * step) by its first-order term (reference :436-439)
+                return self.geometry.forward_density(x) * self.render_step_size
+
+            if self.training and not on_load_weights:
+                self.estimator.update_every_n_steps(step=global_step, occ_eval_fn=occ_eval_fn)
+
+    def update_step_end(self, epoch: int, global_step: int) -> None:
+        pass
+
+    def train(self, mode=True):
+        self.randomized = mode and self.cfg.randomized
+        return super().train(mode=mode)
+
+    def eval(self):
+        self.randomized = False
+        return super().eval()
