@@ -1,0 +1,243 @@
+"""Architecture description (parameter names + shapes) and seeded random weights for the frozen diffusion
+prior of the ASD step.
+
+Names follow the LDM / Stability state-dict layout of the reference's vendored model
+(extern/mvdream/ldm/modules/diffusionmodules/openaimodel.py:422-808 `UNetModel`, :811-1213
+`MultiViewUNetModel`; extern/mvdream/ldm/modules/diffusionmodules/model.py:452-543 VAE `Encoder`;
+extern/mvdream/ldm/models/autoencoder.py:32 `quant_conv`), so a real SD-2.1-base / MVDream checkpoint in
+that layout loads unchanged.  No pretrained weights exist offline: benchmarks and parity tests use
+`gen_params` (a seeded, name-keyed rule, so any single tensor can be regenerated on its own).
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+@dataclass
+class UNetConfig:
+    """extern/mvdream/configs/sd-v2-base.yaml:13-27 (SD-2.1-base UNet = the same minus camera_dim)."""
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    attention_resolutions: Tuple[int, ...] = (4, 2, 1)
+    num_res_blocks: int = 2
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_head_channels: int = 64
+    transformer_depth: int = 1
+    context_dim: int = 1024
+    camera_dim: Optional[int] = None   # 16 for MVDream
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.model_channels * 4
+
+
+@dataclass
+class VAEConfig:
+    """first_stage_config.ddconfig of sd-v2-base.yaml:33-50"""
+    in_channels: int = 3
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    z_channels: int = 4
+    embed_dim: int = 4
+    scale_factor: float = 0.18215
+
+
+Shapes = Dict[str, Tuple[int, ...]]
+
+
+def _conv(s: Shapes, name: str, cin: int, cout: int, k: int):
+    s[name + ".weight"] = (cout, cin, k, k)
+    s[name + ".bias"] = (cout,)
+
+
+def _lin(s: Shapes, name: str, cin: int, cout: int, bias: bool = True):
+    s[name + ".weight"] = (cout, cin)
+    if bias:
+        s[name + ".bias"] = (cout,)
+
+
+def _norm(s: Shapes, name: str, c: int):
+    s[name + ".weight"] = (c,)
+    s[name + ".bias"] = (c,)
+
+
+def _resblock(s: Shapes, p: str, cin: int, cout: int, emb: int):
+    _norm(s, p + ".in_layers.0", cin)
+    _conv(s, p + ".in_layers.2", cin, cout, 3)
+    _lin(s, p + ".emb_layers.1", emb, cout)
+    _norm(s, p + ".out_layers.0", cout)
+    _conv(s, p + ".out_layers.3", cout, cout, 3)
+    if cin != cout:
+        _conv(s, p + ".skip_connection", cin, cout, 1)
+
+
+def _transformer(s: Shapes, p: str, c: int, ctx: int, depth: int):
+    _norm(s, p + ".norm", c)
+    _lin(s, p + ".proj_in", c, c)
+    for d in range(depth):
+        b = f"{p}.transformer_blocks.{d}"
+        for attn, kv in (("attn1", c), ("attn2", ctx)):
+            _lin(s, f"{b}.{attn}.to_q", c, c, bias=False)
+            _lin(s, f"{b}.{attn}.to_k", kv, c, bias=False)
+            _lin(s, f"{b}.{attn}.to_v", kv, c, bias=False)
+            _lin(s, f"{b}.{attn}.to_out.0", c, c)
+        _lin(s, f"{b}.ff.net.0.proj", c, 8 * c)
+        _lin(s, f"{b}.ff.net.2", 4 * c, c)
+        for n in ("norm1", "norm2", "norm3"):
+            _norm(s, f"{b}.{n}", c)
+    _lin(s, p + ".proj_out", c, c)
+
+
+@dataclass
+class UNetBlock:
+    """One entry of input_blocks / middle_block / output_blocks: an ordered list of (kind, prefix, cin, cout)."""
+    layers: List[Tuple[str, str, int, int]] = field(default_factory=list)
+
+
+def unet_layout(cfg: UNetConfig):
+    """(shapes, input_blocks, middle_block, output_blocks) — the construction loop of openaimodel.py:563-752."""
+    s: Shapes = {}
+    mc, emb = cfg.model_channels, cfg.time_embed_dim
+    _lin(s, "time_embed.0", mc, emb)
+    _lin(s, "time_embed.2", emb, emb)
+    if cfg.camera_dim is not None:
+        _lin(s, "camera_embed.0", cfg.camera_dim, emb)
+        _lin(s, "camera_embed.2", emb, emb)
+    inputs: List[UNetBlock] = []
+    _conv(s, "input_blocks.0.0", cfg.in_channels, mc, 3)
+    inputs.append(UNetBlock([("conv", "input_blocks.0.0", cfg.in_channels, mc)]))
+    chans, ch, ds = [mc], mc, 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            i = len(inputs)
+            blk = UNetBlock()
+            _resblock(s, f"input_blocks.{i}.0", ch, mult * mc, emb)
+            blk.layers.append(("res", f"input_blocks.{i}.0", ch, mult * mc))
+            ch = mult * mc
+            if ds in cfg.attention_resolutions:
+                _transformer(s, f"input_blocks.{i}.1", ch, cfg.context_dim, cfg.transformer_depth)
+                blk.layers.append(("attn", f"input_blocks.{i}.1", ch, ch))
+            inputs.append(blk)
+            chans.append(ch)
+        if level != len(cfg.channel_mult) - 1:
+            i = len(inputs)
+            _conv(s, f"input_blocks.{i}.0.op", ch, ch, 3)
+            inputs.append(UNetBlock([("down", f"input_blocks.{i}.0.op", ch, ch)]))
+            chans.append(ch)
+            ds *= 2
+    middle = UNetBlock()
+    _resblock(s, "middle_block.0", ch, ch, emb)
+    _transformer(s, "middle_block.1", ch, cfg.context_dim, cfg.transformer_depth)
+    _resblock(s, "middle_block.2", ch, ch, emb)
+    middle.layers += [("res", "middle_block.0", ch, ch), ("attn", "middle_block.1", ch, ch), ("res", "middle_block.2", ch, ch)]
+    outputs: List[UNetBlock] = []
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            j = len(outputs)
+            blk = UNetBlock()
+            _resblock(s, f"output_blocks.{j}.0", ch + ich, mc * mult, emb)
+            blk.layers.append(("res", f"output_blocks.{j}.0", ch + ich, mc * mult))
+            ch = mc * mult
+            n = 1
+            if ds in cfg.attention_resolutions:
+                _transformer(s, f"output_blocks.{j}.{n}", ch, cfg.context_dim, cfg.transformer_depth)
+                blk.layers.append(("attn", f"output_blocks.{j}.{n}", ch, ch))
+                n += 1
+            if level and i == cfg.num_res_blocks:
+                _conv(s, f"output_blocks.{j}.{n}.conv", ch, ch, 3)
+                blk.layers.append(("up", f"output_blocks.{j}.{n}.conv", ch, ch))
+                ds //= 2
+            outputs.append(blk)
+    _norm(s, "out.0", ch)
+    _conv(s, "out.2", mc, cfg.out_channels, 3)
+    return s, inputs, middle, outputs
+
+
+def vae_encoder_layout(cfg: VAEConfig):
+    """(shapes, plan) of Encoder (model.py:452-543) + quant_conv; plan = ordered (kind, prefix, cin, cout)."""
+    s: Shapes = {}
+    plan: List[Tuple[str, str, int, int]] = []
+    _conv(s, "encoder.conv_in", cfg.in_channels, cfg.ch, 3)
+    plan.append(("conv", "encoder.conv_in", cfg.in_channels, cfg.ch))
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    block_in = cfg.ch
+    for lvl in range(len(cfg.ch_mult)):
+        block_in, block_out = cfg.ch * in_mult[lvl], cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            p = f"encoder.down.{lvl}.block.{b}"
+            _vae_res(s, p, block_in, block_out)
+            plan.append(("res", p, block_in, block_out))
+            block_in = block_out
+        if lvl != len(cfg.ch_mult) - 1:
+            _conv(s, f"encoder.down.{lvl}.downsample.conv", block_in, block_in, 3)
+            plan.append(("down", f"encoder.down.{lvl}.downsample.conv", block_in, block_in))
+    _vae_res(s, "encoder.mid.block_1", block_in, block_in)
+    plan.append(("res", "encoder.mid.block_1", block_in, block_in))
+    p = "encoder.mid.attn_1"
+    _norm(s, p + ".norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        _conv(s, f"{p}.{n}", block_in, block_in, 1)
+    plan.append(("attn", p, block_in, block_in))
+    _vae_res(s, "encoder.mid.block_2", block_in, block_in)
+    plan.append(("res", "encoder.mid.block_2", block_in, block_in))
+    _norm(s, "encoder.norm_out", block_in)
+    _conv(s, "encoder.conv_out", block_in, 2 * cfg.z_channels, 3)
+    plan.append(("out", "encoder", block_in, 2 * cfg.z_channels))
+    _conv(s, "quant_conv", 2 * cfg.z_channels, 2 * cfg.embed_dim, 1)
+    plan.append(("quant", "quant_conv", 2 * cfg.z_channels, 2 * cfg.embed_dim))
+    return s, plan
+
+
+def _vae_res(s: Shapes, p: str, cin: int, cout: int):
+    _norm(s, p + ".norm1", cin)
+    _conv(s, p + ".conv1", cin, cout, 3)
+    _norm(s, p + ".norm2", cout)
+    _conv(s, p + ".conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(s, p + ".nin_shortcut", cin, cout, 1)
+
+
+def _is_norm(name: str) -> bool:
+    base = name.rsplit(".", 1)[0]
+    leaf = base.rsplit(".", 1)[-1]
+    return (leaf.startswith("norm") or base.endswith("in_layers.0") or base.endswith("out_layers.0") or base == "out.0")
+
+
+def gen_param(name: str, shape: Tuple[int, ...], seed: int, dtype=torch.float32) -> torch.Tensor:
+    """Seeded, name-keyed random value of one parameter.
+      norm scale  : 1 + 0.1 N(0,1)        norm shift / bias : 0.05 N(0,1)
+      weight      : N(0,1) / sqrt(fan_in)  (keeps activations O(1) through ~60 layers; zero-initialised
+                    modules of the reference are randomised too, otherwise the output is identically 0)"""
+    g = torch.Generator().manual_seed((seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    if name.endswith(".bias"):
+        x = x * 0.05
+    elif _is_norm(name):
+        x = 1.0 + 0.1 * x
+    else:
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        x = x / float(fan_in) ** 0.5
+    return x.to(dtype)
+
+
+def gen_params(shapes: Shapes, seed: int, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    return {n: gen_param(n, shp, seed, dtype) for n, shp in shapes.items()}
+
+
+def count_params(shapes: Shapes) -> int:
+    total = 0
+    for shp in shapes.values():
+        n = 1
+        for d in shp:
+            n *= d
+        total += n
+    return total
