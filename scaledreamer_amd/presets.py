@@ -1,0 +1,62 @@
+"""Experiment presets: the values of the reference's shipped YAML files as plain dicts (the GPU box has no
+/root/reference; `config.load_config` reads the YAML files themselves when a ScaleDreamer checkout exists).
+"""
+from __future__ import annotations
+
+import copy
+
+
+def asd_sd_nerf(prompt: str = "synthetic", guidance_backend: str = "hip") -> dict:
+    """configs/single-prompt_benchmark/asd_sd_nerf.yaml (BASELINE config 2: 64x64 render, SD-2.1 guidance,
+    implicit-volume iNGP geometry, occupancy-grid renderer, Perp-Neg, AdamW with 5 parameter groups)."""
+    return copy.deepcopy({
+        "name": "asd_sd_nerf", "seed": 10,
+        "data_type": "random-camera-datamodule",
+        "data": {"batch_size": [1, 1], "width": [64, 256], "height": [64, 256], "resolution_milestones": [10000],
+                 "camera_distance_range": [1.0, 1.5], "fovy_range": [40, 70], "elevation_range": [-10, 45],
+                 "camera_perturb": 0.0, "center_perturb": 0.0, "up_perturb": 0.0, "eval_camera_distance": 1.2,
+                 "eval_fovy_deg": 70.0, "n_val_views": 30},
+        "system_type": "scaledreamer-system",
+        "system": {
+            "visualize_samples": False, "validation_via_video": True,
+            "geometry_type": "implicit-volume",
+            "geometry": {"radius": 1.0, "normal_type": "finite_difference", "density_bias": "blob_magic3d",
+                         "density_activation": "softplus", "density_blob_scale": 10.0, "density_blob_std": 0.5,
+                         "pos_encoding_config": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
+                                                 "log2_hashmap_size": 19, "base_resolution": 16,
+                                                 "per_level_scale": 1.447269237440378}},
+            "material_type": "no-material",
+            "material": {"n_output_dims": 3, "color_activation": "sigmoid", "requires_normal": True},
+            "background_type": "neural-environment-map-background",
+            "background": {"color_activation": "sigmoid", "random_aug": True, "random_aug_prob": 0.5,
+                           "dir_encoding_config": {"otype": "HashGrid", "n_features_per_level": 2, "log2_hashmap_size": 19,
+                                                   "n_levels": 4, "base_resolution": 4, "per_level_scale": 4.0}},
+            "renderer_type": "nerf-volume-renderer",
+            "renderer": {"radius": 1.0, "num_samples_per_ray": 512},
+            "prompt_processor_type": "stable-diffusion-prompt-processor",
+            "prompt_processor": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "prompt": prompt,
+                                 "use_perp_neg": True, "front_threshold": 30.0, "back_threshold": 30.0},
+            "guidance_type": "stable-diffusion-asynchronous-score-distillation-guidance",
+            "guidance": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "guidance_scale": 7.5,
+                         "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 25000],
+                         "max_step_percent": [0, 0.98, 0.5, 25000], "guidance_perp_neg": -0.5,
+                         "backend": guidance_backend},
+            "loggers": {"wandb": {"enable": False, "project": "threestudio", "name": "None"}},
+            "loss": {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 30, "lambda_opaque": [10000, 0.0, 100.0, 10001],
+                     "lambda_z_variance": 0.0},
+            "optimizer": {"name": "AdamW", "args": {"betas": [0.0, 0.99], "eps": 1.0e-15},
+                          "params": {"geometry.encoding": {"lr": 0.01}, "geometry.density_network": {"lr": 0.001},
+                                     "geometry.feature_network": {"lr": 0.001}, "background.encoding": {"lr": 0.01},
+                                     "background.network": {"lr": 0.001}}},
+        },
+        "trainer": {"max_steps": 25000, "precision": 32},
+    })
+
+
+def nerf_only_c1() -> dict:
+    """BASELINE config 1: single prompt, 32x32 rays, 16 samples per ray, NeRF-only render (no diffusion)."""
+    cfg = asd_sd_nerf()
+    cfg["data"].update({"width": 32, "height": 32, "batch_size": 1, "resolution_milestones": []})
+    cfg["system"]["renderer"]["num_samples_per_ray"] = 16
+    cfg["system"]["guidance_type"] = ""
+    return cfg

@@ -183,6 +183,7 @@ class NeRFVolumeRenderer(VolumeRenderer):
             count[0] = 1
             offset = torch.ones(n_rays, dtype=torch.int32, device=rays_o.device)
             offset[0] = 0
+        self.last_n_samples = int(ray_indices.shape[0])
         t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
         t_light_positions = light_positions_flatten[ray_indices]
         t_positions = (t_starts + t_ends) / 2.0
