@@ -196,6 +196,57 @@ int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, co
                       const float* d_depth, const float* d_z_var, const float* d_weights,
                       float* d_sigma, float* d_rgb, float* d_bg, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frozen diffusion prior (SD-2.1 UNet eps-prediction): replaces the cuDNN / cuBLAS / SDPA kernels behind
+ * diffusers' UNet2DConditionModel called at threestudio/models/guidance/stable_diffusion_asd_guidance.py:
+ * 319-331 (forward_unet) — layer inventory SURVEY.md Appendix A.1.  Activations are NHWC fp16, accumulation
+ * fp32 (the reference runs the UNet in fp16, :38,57-59).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_gemm_args {
+    const void* A;          /* fp16: [M,lda] row-major, or NHWC image [B,Hin,Win,Cin] when conv=1 */
+    const void* W;          /* fp16 [N,ldw]: Linear weight, or conv weight packed [Cout][ky][kx][Cin] */
+    void*       C;          /* [M,ldc] fp16 (fp32 when out_f32) */
+    int32_t M, N, K;
+    int32_t lda, ldw, ldc;
+    const void* bias;       /* fp16 [N] or NULL */
+    const void* row_bias;   /* fp16 [M/rows_per_group, N] or NULL (time-embedding add of a ResBlock) */
+    int32_t rows_per_group;
+    const void* residual;   /* fp16 [M,ldr] or NULL, added after the activation */
+    int32_t ldr;
+    int32_t act;            /* 0 none, 1 SiLU */
+    int32_t out_f32;
+    int32_t conv;           /* 0: GEMM, 1: 3x3 convolution (K = 9*Cin) */
+    int32_t Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
+    const void* zero_page;  /* >= 16 B of zeros: source of out-of-range rows / taps */
+    int32_t split_k;        /* >= 1; > 1 needs workspace[split_k, M, N] fp32 */
+    float*  workspace;
+} asd_gemm_args;
+int asd_gemm_f16(const asd_gemm_args* args, void* stream);
+
+/* GroupNorm(32 groups) [+ SiLU] on NHWC fp16 with fp32 statistics (GroupNorm32, diffusionmodules/util.py:229-231);
+ * x may be the channel-concatenation of two tensors (skip connections, openaimodel.py:797-799): x2/c2. */
+int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw,
+                      const void* gamma, const void* beta, float eps, int32_t silu, void* y,
+                      float* stats /*[batch*32*2]*/, void* stream);
+/* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */
+int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma, const void* beta, float eps,
+                      void* y, void* stream);
+/* GEGLU (attention.py:49-56): y[r, j] = h[r, j] * gelu(h[r, c + j]), h = [rows, 2c]. */
+int asd_geglu_f16(const void* h, int32_t rows, int32_t c, void* y, void* stream);
+/* y = silu(x) elementwise (emb_layers, openaimodel.py:213-219). */
+int asd_silu_f16(const void* x, int64_t n, void* y, void* stream);
+/* sinusoidal timestep embedding [n, dim] fp16 (diffusionmodules/util.py:165-186). */
+int asd_timestep_embedding_f16(const float* t, int32_t n, int32_t dim, void* y, void* stream);
+/* channel concat of two NHWC tensors: y[r, :c1] = x1[r], y[r, c1:] = x2[r]. */
+int asd_concat_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int64_t rows, void* y, void* stream);
+/* Multi-head attention (CrossAttention.forward, attention.py:168-194), head_dim 64, flash-style:
+ * q [batch, lq, heads*64] (row stride ldq), k [batch, lk_stride, heads*64] (ldk), vT [heads*64, batch*lk_stride]
+ * (V stored transposed: row = channel, ld = ldv), o [batch, lq, heads*64] (ldo).  Keys >= lk of every batch
+ * entry are masked; lk_stride (>= lk, multiple of 8) is the padded number of key rows per batch entry. */
+int asd_attention_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vT, int32_t ldv,
+                      void* o, int32_t ldo, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
+                      int32_t lk_stride, float scale, const void* zero_page, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -64,6 +64,19 @@ class MarchCfg(C.Structure):
     ]
 
 
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32),
+        ("bias", C.c_void_p), ("row_bias", C.c_void_p), ("rows_per_group", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32),
+        ("conv", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
+        ("Wout", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("upsample", C.c_int32),
+        ("zero_page", C.c_void_p), ("split_k", C.c_int32), ("workspace", C.c_void_p),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/asd_hip.h declares (tests/test_abi.py checks the header against this list)
@@ -73,6 +86,8 @@ SYMBOLS = [
     "asd_envmap_fwd", "asd_envmap_bwd",
     "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
+    "asd_gemm_f16", "asd_groupnorm_f16", "asd_layernorm_f16", "asd_geglu_f16", "asd_silu_f16",
+    "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
     "asd_version", "asd_last_error",
 ]
 

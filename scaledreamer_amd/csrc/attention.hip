@@ -1,0 +1,215 @@
+// attention.hip — flash-style multi-head attention forward for the SD-2.1 UNet (head_dim 64, fp16 in/out,
+// fp32 softmax and accumulation) on gfx950.  Replaces CrossAttention.forward's einsum/softmax/einsum
+// (extern/mvdream/ldm/modules/attention.py:168-194; diffusers' attention processors on the SD path):
+// self-attention over L = 4096/1024/256/64 tokens and cross-attention over 77 text tokens.
+//
+// Everything is computed "transposed" so the probabilities never leave registers:
+//   S^T = K Q^T   (MFMA A = K fragment from LDS, B = Q fragment held in VGPRs)
+//         -> lane (l&15) owns ONE query column, its 4 accumulator rows are 4 consecutive keys
+//   O^T = V^T P^T (MFMA A = V^T fragment from LDS, B = P^T = exp(S^T - m) converted to fp16 in place)
+//         -> the same lane owns the same query, 4 consecutive head-dim rows -> 8-byte stores
+// The k-index of the second MFMA is a permutation of the key order (two 4-key groups of two 16-key
+// sub-tiles); V^T fragments are read with the same permutation, so no LDS round trip / transpose of P.
+// V arrives already transposed ([channel][token]) from its projection GEMM (operands swapped).
+// K and V^T tiles (64 keys) stream through LDS with global_load_lds, double buffered; 16-B chunks are
+// XOR-swizzled (K: chunk ^ (row&7) for ds_read_b128, V^T: chunk ^ ((row>>1)&7) for ds_read_b64).
+#include "asd_common.h"
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+#define HD 64      // head dim
+#define KT 64      // keys per tile
+#define QW 32      // queries per wave
+#define QB 128     // queries per block
+
+struct AttnArgs {
+    const half_t* q; int ldq;
+    const half_t* k; int ldk;
+    const half_t* vT; int ldv;
+    half_t* o; int ldo;
+    int batch, heads, lq, lk, lk_stride;
+    float scale;
+    const char* zero;
+};
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile 8 KB | V^T tile 8 KB]
+    constexpr int TILE_BYTES = KT * HD * 2;                         // 8192
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB + wave * QW;
+    const int lq16 = lane & 15, lg = lane >> 4;
+
+    // ---- Q fragments (B operand): lane holds Q[q = q0 + 16*qs + (l&15)][d = 32*ks + (l>>4)*8 .. +8] --------
+    half8 qf[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        int qi = q0 + qs * 16 + lq16;
+        if (qi >= p.lq) qi = p.lq - 1;
+        const half_t* src = p.q + ((size_t)b * p.lq + qi) * p.ldq + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *(const half8*)(src + ks * 32 + lg * 8);
+    }
+
+    // ---- tile loader: per wave 2 K slabs + 2 V^T slabs of 8 rows x 128 B --------------------------------
+    const int srow = lane >> 3, pch = lane & 7;
+    const size_t kbase = (size_t)b * p.lk_stride;
+    auto issue = [&](int t, int buf) {
+        char* Ks = smem + buf * 2 * TILE_BYTES;
+        char* Vs = Ks + TILE_BYTES;
+        const int key0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + srow;  // key row of the K tile / d row of the V^T tile
+            {   // K: logical chunk = physical ^ (row & 7)
+                const int c = pch ^ (row & 7);
+                const int key = key0 + row;
+                const char* src = key < p.lk_stride ? (const char*)(p.k + (kbase + key) * p.ldk + h * HD) + c * 16 : p.zero;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(Ks + (wave * 2 + i) * 8 * 128), 16, 0, 0);
+            }
+            {   // V^T: logical chunk = physical ^ ((row >> 1) & 7); chunk c covers keys key0 + 8c .. +8
+                const int c = pch ^ ((row >> 1) & 7);
+                const char* src = key0 + c * 8 < p.lk_stride
+                                      ? (const char*)(p.vT + (size_t)(h * HD + row) * p.ldv + kbase + key0) + c * 16 : p.zero;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(Vs + (wave * 2 + i) * 8 * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    floatx4 oacc[2][4];  // [qs][dt]: O[q = 16qs + (l&15)][d = 16dt + (l>>4)*4 + r]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[qs][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+    const int n_tiles = (p.lk + KT - 1) / KT;
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) issue(t + 1, buf ^ 1);
+        const char* Ks = smem + buf * 2 * TILE_BYTES;
+        const char* Vs = Ks + TILE_BYTES;
+
+        // ---- S^T = K Q^T --------------------------------------------------------------------------------
+        floatx4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int row = kt * 16 + lq16;
+            half8 kf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = *(const half8*)(Ks + row * 128 + (((ks * 4 + lg) ^ (row & 7)) * 16));
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[qs][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[qs][1], a, 0, 0, 0);
+                s[kt][qs] = a;
+            }
+        }
+        // ---- online softmax per query column ---------------------------------------------------------------
+        const int key_base = t * KT + lg * 4;
+        half4 pf[4][2];  // probabilities, fp16: [kt][qs] -> 4 consecutive keys
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][qs][r] * p.scale;
+                    if (key_base + kt * 16 + r >= p.lk) v = -1e30f;
+                    s[kt][qs][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qs], mx);
+            const float alpha = __expf(m_run[qs] - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                half4 ph;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[kt][qs][r] - m_new);
+                    sum += e;
+                    ph[r] = (half_t)e;
+                }
+                pf[kt][qs] = ph;
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l_run[qs] = l_run[qs] * alpha + sum;
+            m_run[qs] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                oacc[qs][dt][0] *= alpha; oacc[qs][dt][1] *= alpha; oacc[qs][dt][2] *= alpha; oacc[qs][dt][3] *= alpha;
+            }
+        }
+        // ---- O^T += V^T P^T : k-step j covers keys 32j..32j+31 in the permuted order --------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            half8 pb[2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                const half4 lo = pf[2 * j][qs], hi = pf[2 * j + 1][qs];
+                pb[qs] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int row = dt * 16 + lq16;
+                const int sw = (row >> 1) & 7;
+                // keys 32j + 4*lg .. +4 live in chunk (4j + lg/2), byte (lg&1)*8; keys +16 in chunk (4j + 2 + lg/2)
+                const int c_lo = (4 * j + (lg >> 1)) ^ sw, c_hi = (4 * j + 2 + (lg >> 1)) ^ sw;
+                const half4 v_lo = *(const half4*)(Vs + row * 128 + c_lo * 16 + (lg & 1) * 8);
+                const half4 v_hi = *(const half4*)(Vs + row * 128 + c_hi * 16 + (lg & 1) * 8);
+                const half8 vf = half8{v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[qs], oacc[qs][dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done with this buffer
+    }
+
+    // ---- normalise and store: lane owns query (l&15), 4 consecutive d -----------------------------------------
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int qi = q0 + qs * 16 + lq16;
+        if (qi >= p.lq) continue;
+        const float inv = 1.f / l_run[qs];
+        half_t* dst = p.o + ((size_t)b * p.lq + qi) * p.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const floatx4 v = oacc[qs][dt];
+            const half4 o = {(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv)};
+            *(half4*)(dst + dt * 16 + lg * 4) = o;
+        }
+    }
+}
+
+extern "C" {
+
+int asd_attention_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* vT, int32_t ldv, void* o,
+                      int32_t ldo, int32_t batch, int32_t heads, int32_t lq, int32_t lk, int32_t lk_stride, float scale,
+                      const void* zero_page, void* stream) {
+    ASD_CHECK_ARG(q && k && vT && o && zero_page, "null argument");
+    ASD_CHECK_ARG(batch > 0 && heads > 0 && lq > 0 && lk > 0 && lk_stride >= lk, "bad sizes");
+    ASD_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && lk_stride % 8 == 0,
+                  "leading dimensions / key stride must keep 16-byte alignment");
+    AttnArgs a{(const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vT, ldv, (half_t*)o, ldo,
+               batch, heads, lq, lk, lk_stride, scale, (const char*)zero_page};
+    const dim3 grid(asd_div_up(lq, QB), heads, batch);
+    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 4 * KT * HD * 2, (hipStream_t)stream, a);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+}  // extern "C"

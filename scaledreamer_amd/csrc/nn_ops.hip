@@ -1,0 +1,223 @@
+// nn_ops.hip — bandwidth-bound layers of the SD-2.1 UNet on NHWC fp16 tensors (gfx950): GroupNorm(+SiLU),
+// LayerNorm, GEGLU, SiLU, sinusoidal timestep embedding, channel concat.  All kernels move 16 B per lane
+// (8 halfs), keep statistics in fp32 (GroupNorm32, diffusionmodules/util.py:229-231) and are HBM-bound:
+// algorithmic bytes = 2 B read + 2 B written per element (GroupNorm reads x twice: stats + apply).
+#include "asd_common.h"
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// ---- GroupNorm statistics: grid (batch, chunks); block 256.  Each thread owns one 8-channel slot of the
+// row and walks rows with stride; per-channel partials are folded into per-group sums in LDS, then one
+// atomicAdd pair per (block, group).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
+                                                       int c2, int hw, int rows_per_block, float* __restrict__ stats) {
+    __shared__ float gsum[32], gsq[32];
+    const int C = c1 + c2, slots = C / 8, cg = C / 32;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
+    __syncthreads();
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const int total = (r1 - r0) * slots;
+    for (int i = tid; i < total; i += 256) {
+        const int r = r0 + i / slots, c = (i % slots) * 8;
+        const size_t row = (size_t)b * hw + r;
+        const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+        // the 8 channels of a chunk belong to 1-2 groups (8 when C = 32): flush whenever the group changes
+        int g = c / cg;
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gk = (c + k) / cg;
+            if (gk != g) {
+                atomicAdd(&gsum[g], ss);
+                atomicAdd(&gsq[g], qq);
+                g = gk; ss = 0.f; qq = 0.f;
+            }
+            const float f = (float)v[k];
+            ss += f;
+            qq = fmaf(f, f, qq);
+        }
+        atomicAdd(&gsum[g], ss);
+        atomicAdd(&gsq[g], qq);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        atomicAdd(&stats[(b * 32 + tid) * 2], gsum[tid]);
+        atomicAdd(&stats[(b * 32 + tid) * 2 + 1], gsq[tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
+                                                       int c2, int batch, int hw, const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta, float eps, int silu,
+                                                       const float* __restrict__ stats, half_t* __restrict__ y) {
+    const int C = c1 + c2, slots = C / 8, cg = C / 32;
+    const float inv_cnt = 1.f / ((float)hw * (float)cg);
+    const size_t total = (size_t)batch * hw * slots;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / slots;
+        const int c = (int)(i - row * slots) * 8;
+        const int b = (int)(row / hw);
+        const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+        const half8 gm = *(const half8*)(gamma + c), bt = *(const half8*)(beta + c);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = (c + k) / cg;
+            const float mean = stats[(b * 32 + g) * 2] * inv_cnt;
+            const float var = fmaxf(stats[(b * 32 + g) * 2 + 1] * inv_cnt - mean * mean, 0.f);
+            float f = ((float)v[k] - mean) * rsqrtf(var + eps) * (float)gm[k] + (float)bt[k];
+            if (silu) f = silu_f(f);
+            o[k] = (half_t)f;
+        }
+        *(half8*)(y + row * C + c) = o;
+    }
+}
+
+// ---- LayerNorm: one wave per row ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int rows, int C,
+                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                        float eps, half_t* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const half_t* xr = x + (size_t)row * C;
+    float s = 0.f;
+    half8 v[4];  // C <= 2048
+    int nv = 0;
+    for (int c = lane * 8; c < C; c += 512, ++nv) {
+        v[nv] = *(const half8*)(xr + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (float)v[nv][k];
+    }
+    const float mean = asd_wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int j = 0; j < nv; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = (float)v[j][k] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(asd_wave_sum(q) / (float)C + eps);
+    int j = 0;
+    for (int c = lane * 8; c < C; c += 512, ++j) {
+        const half8 gm = *(const half8*)(gamma + c), bt = *(const half8*)(beta + c);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)(((float)v[j][k] - mean) * rstd * (float)gm[k] + (float)bt[k]);
+        *(half8*)(y + (size_t)row * C + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void geglu_kernel(const half_t* __restrict__ h, int rows, int C, half_t* __restrict__ y) {
+    const int slots = C / 8;
+    const size_t total = (size_t)rows * slots;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / slots;
+        const int c = (int)(i - row * slots) * 8;
+        const half8 a = *(const half8*)(h + row * 2 * C + c), g = *(const half8*)(h + row * 2 * C + C + c);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)((float)a[k] * gelu_f((float)g[k]));
+        *(half8*)(y + row * C + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const half_t* __restrict__ x, size_t n8, half_t* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const half8 v = *(const half8*)(x + i * 8);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)silu_f((float)v[k]);
+        *(half8*)(y + i * 8) = o;
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, half_t* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= n * half) return;
+    const int r = i / half, k = i - r * half;
+    const float freq = expf(-logf(10000.f) * (float)k / (float)half);
+    const float a = t[r] * freq;
+    y[(size_t)r * dim + k] = (half_t)cosf(a);
+    y[(size_t)r * dim + half + k] = (half_t)sinf(a);
+}
+
+__global__ __launch_bounds__(256) void concat_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2, int c2,
+                                                     size_t rows, half_t* __restrict__ y) {
+    const int C = c1 + c2, slots = C / 8;
+    const size_t total = rows * slots;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / slots;
+        const int c = (int)(i - row * slots) * 8;
+        *(half8*)(y + row * C + c) = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+    }
+}
+
+extern "C" {
+
+int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
+                      const void* beta, float eps, int32_t silu, void* y, float* stats, void* stream) {
+    ASD_CHECK_ARG(x1 && gamma && beta && y && stats && batch > 0 && hw > 0, "null argument");
+    const int C = c1 + (x2 ? c2 : 0);
+    if (!x2) c2 = 0;
+    ASD_CHECK_ARG(C % 32 == 0 && C % 8 == 0 && c1 % 8 == 0, "channels must be a multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * 32 * batch, s);
+    int chunks = asd_div_up(hw, 64);
+    if (chunks > 64) chunks = 64;
+    const int rows_per_block = asd_div_up(hw, chunks);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
+                       rows_per_block, stats);
+    const size_t total = (size_t)batch * hw * (C / 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, s, (const half_t*)x1, c1,
+                       (const half_t*)x2, c2, batch, hw, (const half_t*)gamma, (const half_t*)beta, eps, silu, stats,
+                       (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma, const void* beta, float eps, void* y,
+                      void* stream) {
+    ASD_CHECK_ARG(x && gamma && beta && y && rows > 0, "null argument");
+    ASD_CHECK_ARG(c % 8 == 0 && c <= 2048, "channels must be a multiple of 8 and <= 2048");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(asd_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, rows, c,
+                       (const half_t*)gamma, (const half_t*)beta, eps, (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_geglu_f16(const void* h, int32_t rows, int32_t c, void* y, void* stream) {
+    ASD_CHECK_ARG(h && y && rows > 0 && c % 8 == 0, "bad argument");
+    hipLaunchKernelGGL(geglu_kernel, dim3(asd_grid_for((size_t)rows * c / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)h, rows, c, (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_silu_f16(const void* x, int64_t n, void* y, void* stream) {
+    ASD_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "bad argument");
+    hipLaunchKernelGGL(silu_kernel, dim3(asd_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (size_t)(n / 8), (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_timestep_embedding_f16(const float* t, int32_t n, int32_t dim, void* y, void* stream) {
+    ASD_CHECK_ARG(t && y && n > 0 && dim % 2 == 0, "bad argument");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(asd_div_up(n * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t, n,
+                       dim, (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_concat_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int64_t rows, void* y, void* stream) {
+    ASD_CHECK_ARG(x1 && x2 && y && rows > 0 && c1 % 8 == 0 && c2 % 8 == 0, "bad argument");
+    hipLaunchKernelGGL(concat_kernel, dim3(asd_grid_for((size_t)rows * (c1 + c2) / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x1, c1, (const half_t*)x2, c2, (size_t)rows, (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+"""Tensor-level wrappers of the diffusion kernels of the C ABI (include/asd_hip.h: asd_gemm_f16, asd_groupnorm_f16,
+asd_layernorm_f16, asd_geglu_f16, asd_silu_f16, asd_timestep_embedding_f16, asd_concat_f16, asd_attention_f16).
+Activations are NHWC / token-major fp16 tensors; outputs are allocated with torch on the current stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from .._lib import GemmArgs, check, f32, i32, lib, ptr, stream
+
+_zero = {}
+_gn_stats = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _zero:
+        _zero[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _zero[key]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def pick_split_k(M: int, N: int, K: int) -> int:
+    """fill the 256 CUs when the output has few 128x128 tiles and the reduction is long (low-resolution layers)."""
+    bn = 128 if N % 128 == 0 else 64
+    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
+    if tiles >= 192 or K < 1024:
+        return 1
+    s = min(16, max(1, 512 // tiles), K // 512)
+    return max(1, s)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
+         M: Optional[int] = None) -> torch.Tensor:
+    """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv."""
+    dev = a.device
+    N, K = w.shape
+    if conv is None:
+        assert a.stride(-1) == 1 and a.dim() == 2
+        M = a.shape[0]
+        lda = a.stride(0)
+    else:
+        lda = 0
+    if out is None:
+        out = torch.empty((M, N), device=dev, dtype=torch.float32 if out_f32 else torch.float16)
+    g = GemmArgs()
+    g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldc = lda, w.stride(0), out.stride(0)
+    g.bias = None if bias is None else bias.data_ptr()
+    g.row_bias = None if row_bias is None else row_bias.data_ptr()
+    g.rows_per_group = rows_per_group if row_bias is not None else 1
+    g.residual = None if residual is None else residual.data_ptr()
+    g.ldr = 0 if residual is None else residual.stride(0)
+    g.act, g.out_f32 = act, int(out_f32)
+    if conv is not None:
+        g.conv = 1
+        for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "pad", "upsample"):
+            setattr(g, k, int(conv[k]))
+    g.zero_page = zero_page(dev).data_ptr()
+    sk = pick_split_k(M, N, K) if split_k is None else split_k
+    g.split_k = sk
+    ws = None
+    if sk > 1:
+        ws = torch.empty((sk, M, N), device=dev, dtype=torch.float32)
+        g.workspace = ws.data_ptr()
+    check(lib().asd_gemm_f16(C.byref(g), stream()))
+    return out
+
+
+def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1, pad: int = 1, upsample: bool = False,
+            out_hw=None, **kw) -> torch.Tensor:
+    """x: NHWC fp16 [B,H,W,Cin]; w_packed: [Cout, 9*Cin] with k = (ky, kx, cin). Returns [B,Ho,Wo,Cout]."""
+    B, H, W_, Cin = x.shape
+    assert x.is_contiguous()
+    if out_hw is None:
+        if upsample:
+            Ho, Wo = 2 * H, 2 * W_
+        else:
+            Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W_ + 2 * pad - 3) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    conv = dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=int(upsample))
+    y = gemm(x, w_packed, bias=bias, conv=conv, M=B * Ho * Wo, **kw)
+    return y.view(B, Ho, Wo, w_packed.shape[0])
+
+
+def pack_conv3x3_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """PyTorch [Cout, Cin, 3, 3] -> [Cout, 9*Cin'] with k = (ky, kx, cin), Cin' = Cin padded to a multiple of 32."""
+    cout, cin = w.shape[:2]
+    cp = cin_pad or ((cin + 31) // 32 * 32)
+    wp = torch.zeros((cout, 3, 3, cp), dtype=w.dtype, device=w.device)
+    wp[..., :cin] = w.permute(0, 2, 3, 1)
+    return wp.reshape(cout, 9 * cp).contiguous()
+
+
+def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [B, HW, C] (or [B,H,W,C]) NHWC fp16, 32 groups; x2 = second tensor of a channel concat."""
+    B = x1.shape[0]
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    hw = x1.numel() // (B * c1)
+    y = torch.empty(tuple(x1.shape[:-1]) + (c1 + c2,), device=x1.device, dtype=torch.float16)
+    stats = torch.empty(B * 64, device=x1.device, dtype=torch.float32)
+    check(lib().asd_groupnorm_f16(ptr(x1), i32(c1), _p(x2), i32(c2), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps),
+                                  i32(int(silu)), ptr(y), ptr(stats), stream()))
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().asd_layernorm_f16(ptr(x), i32(x.numel() // c), i32(c), ptr(gamma), ptr(beta), f32(eps), ptr(y), stream()))
+    return y
+
+
+def geglu(h: torch.Tensor) -> torch.Tensor:
+    c = h.shape[-1] // 2
+    y = torch.empty(tuple(h.shape[:-1]) + (c,), device=h.device, dtype=torch.float16)
+    check(lib().asd_geglu_f16(ptr(h), i32(h.numel() // (2 * c)), i32(c), ptr(y), stream()))
+    return y
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty_like(x)
+    check(lib().asd_silu_f16(ptr(x), C.c_int64(x.numel()), ptr(y), stream()))
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    t = t.float().contiguous()
+    y = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float16)
+    check(lib().asd_timestep_embedding_f16(ptr(t), i32(t.shape[0]), i32(dim), ptr(y), stream()))
+    return y
+
+
+def concat(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    c1, c2 = x1.shape[-1], x2.shape[-1]
+    y = torch.empty(tuple(x1.shape[:-1]) + (c1 + c2,), device=x1.device, dtype=torch.float16)
+    check(lib().asd_concat_f16(ptr(x1), i32(c1), ptr(x2), i32(c2), C.c_int64(x1.numel() // c1), ptr(y), stream()))
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, batch: int, heads: int, lq: int, lk: int,
+              lk_stride: Optional[int] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """q: [batch*lq, >=heads*64] (row stride ldq), k: [batch*lk_stride, ...], vT: [heads*64, batch*lk_stride]."""
+    lk_stride = lk if lk_stride is None else lk_stride
+    o = torch.empty((batch * lq, heads * 64), device=q.device, dtype=torch.float16)
+    check(lib().asd_attention_f16(C.c_void_p(q.data_ptr()), i32(q.stride(0)), C.c_void_p(k.data_ptr()), i32(k.stride(0)),
+                                  C.c_void_p(vT.data_ptr()), i32(vT.stride(0)), ptr(o), i32(o.stride(0)), i32(batch), i32(heads),
+                                  i32(lq), i32(lk), i32(lk_stride), f32(scale if scale is not None else 64 ** -0.5),
+                                  ptr(zero_page(q.device)), stream()))
+    return o

@@ -1,0 +1,129 @@
+"""GPU parity of the diffusion kernels (called through the C ABI) against a plain PyTorch fp32 reference of the
+same op on the same fp16-rounded inputs.  Tolerance: fp16 output rounding (rel 2^-10) + fp32 accumulation order;
+north_star allows 1e-2 rel on the UNet eps, the single ops are held to ~2e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().cuda()
+
+
+def _close(got, want, tol=3e-3):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= tol * max(ref, 1.0), f"max abs err {err} vs ref max {ref}"
+
+
+@pytest.mark.parametrize("M,N,K", [(20480, 320, 320), (5120, 640, 1280), (385, 1280, 1024), (320, 1280, 5120), (5, 1280, 320),
+                                   (1280, 2560, 320), (4096, 128, 64), (130, 68, 96)])
+def test_gemm_bias_rowbias_residual_silu(M, N, K):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    a, w = _rand(M, K, seed=1), _rand(N, K, scale=K ** -0.5, seed=2)
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    groups = 5 if M % 5 == 0 else 1
+    rb = _rand(groups, N, seed=5)
+    ref = a.float() @ w.float().T + bias.float() + rb.float().repeat_interleave(M // groups, 0)
+    ref = F.silu(ref) + res.float()
+    got = H.gemm(a, w, bias=bias, row_bias=rb, rows_per_group=M // groups, residual=res, act=1)
+    _close(got, ref)
+    for sk in (1, 3):
+        _close(H.gemm(a, w, split_k=sk), a.float() @ w.float().T)
+    _close(H.gemm(a, w, out_f32=True), a.float() @ w.float().T, tol=1e-3)
+
+
+def test_gemm_strided_views():
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    big = _rand(1024, 960, seed=6)
+    a = big[:, 320:640]                      # lda = 960
+    w = _rand(192, 320, scale=0.05, seed=7)
+    outbuf = torch.zeros(1024, 576, dtype=torch.float16, device="cuda")
+    H.gemm(a, w, out=outbuf[:, 192:384])
+    _close(outbuf[:, 192:384], a.float() @ w.float().T)
+    assert float(outbuf[:, :192].abs().max()) == 0 and float(outbuf[:, 384:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,H_,W_,Cin,Cout,stride,pad,up", [
+    (5, 64, 64, 320, 320, 1, 1, False), (2, 32, 32, 640, 1280, 1, 1, False), (5, 8, 8, 2560, 1280, 1, 1, False),
+    (2, 64, 64, 320, 320, 2, 1, False), (2, 16, 16, 1280, 1280, 1, 1, True), (1, 64, 64, 4, 320, 1, 1, False),
+    (1, 64, 64, 320, 4, 1, 1, False), (1, 33, 47, 64, 96, 2, 0, False), (1, 7, 5, 32, 64, 1, 1, False)])
+def test_conv3x3_variants(B, H_, W_, Cin, Cout, stride, pad, up):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(B, Cin, H_, W_, seed=8)
+    w = _rand(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=9)
+    bias = _rand(Cout, seed=10)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+    if pad == 0 and stride == 2:  # VAE Downsample: asymmetric (0,1,0,1) zero pad (model.py:80-85)
+        xin = F.pad(xin, (0, 1, 0, 1))
+        ref = F.conv2d(xin, w.float(), bias.float(), stride=2, padding=0)
+    else:
+        ref = F.conv2d(xin, w.float(), bias.float(), stride=stride, padding=pad)
+    cp = (Cin + 31) // 32 * 32
+    xn = torch.zeros(B, H_, W_, cp, dtype=torch.float16, device="cuda")
+    xn[..., :Cin] = x.permute(0, 2, 3, 1)
+    wp = H.pack_conv3x3_weight(w)
+    out_hw = (ref.shape[2], ref.shape[3])
+    got = H.conv3x3(xn, wp, bias=bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw)
+    _close(got.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(5, 4096, 320, 0, True), (5, 64, 1280, 1280, True), (2, 1024, 640, 320, False),
+                                             (3, 256, 1920, 0, True), (1, 77, 32, 0, False)])
+def test_groupnorm(B, HW, C1, C2, silu):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x1 = _rand(B, HW, C1, scale=2.0, seed=11) + 0.5
+    x2 = _rand(B, HW, C2, scale=0.5, seed=12) if C2 else None
+    gam, bet = _rand(C1 + C2, seed=13) * 0.1 + 1, _rand(C1 + C2, seed=14) * 0.1
+    x = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gam.float(), bet.float(), 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    _close(H.groupnorm(x1, gam, bet, 1e-5, silu, x2), ref, tol=4e-3)
+
+
+def test_layernorm_geglu_silu_concat_timestep():
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    for rows, c in [(20480, 320), (1280, 1280), (77, 640)]:
+        x, g, b = _rand(rows, c, scale=3, seed=15), _rand(c, seed=16) * 0.1 + 1, _rand(c, seed=17) * 0.1
+        _close(H.layernorm(x, g, b), F.layer_norm(x.float(), (c,), g.float(), b.float()))
+    h = _rand(1000, 2 * 1280, seed=18)
+    a, gate = h.float().chunk(2, -1)
+    _close(H.geglu(h), a * F.gelu(gate))
+    x = _rand(5, 1280, seed=19)
+    _close(H.silu(x), F.silu(x.float()))
+    a, b = _rand(300, 640, seed=20), _rand(300, 320, seed=21)
+    assert torch.equal(H.concat(a, b), torch.cat([a, b], -1))
+    t = torch.tensor([1.0, 500.0, 815.0, 999.0, 904.0], device="cuda")
+    half = 160
+    freqs = torch.exp(-np.log(10000) * torch.arange(half, dtype=torch.float32, device="cuda") / half)
+    ref = torch.cat([torch.cos(t[:, None] * freqs), torch.sin(t[:, None] * freqs)], -1)
+    _close(H.timestep_embedding(t, 320), ref, tol=2e-3)
+
+
+@pytest.mark.parametrize("B,heads,lq,lk,lk_stride", [(5, 5, 4096, 4096, 4096), (2, 10, 1024, 1024, 1024), (5, 20, 64, 64, 64),
+                                                     (5, 5, 4096, 77, 80), (3, 20, 256, 77, 80), (1, 2, 100, 50, 56)])
+def test_attention(B, heads, lq, lk, lk_stride):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    C_ = heads * 64
+    q = _rand(B * lq, C_, seed=22)
+    k = _rand(B * lk_stride, C_, seed=23)
+    v = _rand(B * lk_stride, C_, seed=24)
+    vT = v.t().contiguous()
+    got = H.attention(q, k, vT, B, heads, lq, lk, lk_stride)
+    qf = q.float().view(B, lq, heads, 64).transpose(1, 2)
+    kf = k.float().view(B, lk_stride, heads, 64)[:, :lk].transpose(1, 2)
+    vf = v.float().view(B, lk_stride, heads, 64)[:, :lk].transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(B * lq, C_)
+    _close(got, ref, tol=3e-3)
