@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void concat_kernel(const half_t* __restrict__ 
     }
 }
 
+__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 extern "C" {
 
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
@@ -164,7 +169,8 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     if (!x2) c2 = 0;
     ASD_CHECK_ARG(C % 32 == 0 && C % 8 == 0 && c1 % 8 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * 32 * batch, s);
+    // (a kernel, not hipMemsetAsync: the launch sequence is captured into HIP graphs and replayed)
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, stats, 64 * batch);
     int chunks = asd_div_up(hw, 64);
     if (chunks > 64) chunks = 64;
     const int rows_per_block = asd_div_up(hw, chunks);
