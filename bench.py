@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--backend", default=os.environ.get("ASD_BACKEND", "eager"), choices=["hip", "eager"])
+    ap.add_argument("--backend", default=os.environ.get("ASD_BACKEND", "hip"), choices=["hip", "eager"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also report per-phase milliseconds (adds syncs; untimed extra steps)")
     args = ap.parse_args()

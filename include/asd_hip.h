@@ -95,20 +95,18 @@ int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* points, int32_t n, const int32_t* n_dev,
                   float* sigma, float* features, float* normal, float* enc_save, void* stream);
 
-/* Backward: given dL/dsigma[n], dL/dfeatures[n,C], dL/dnormal[n,3] (any may be NULL) accumulate
- * d_grid_params (atomic scatter) and write per-block partial MLP weight gradients into
- * `wgrad_partials[n_blocks, wgrad_stride]` (see asd_field_bwd_workspace); asd_field_bwd_reduce sums
- * them deterministically into dw1_density/dw2_density/dw1_feature/dw2_feature (+=). */
-int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t* n_blocks, int32_t* wgrad_stride);
+/* Backward: given dL/dsigma[n], dL/dfeatures[n,C], dL/dnormal[n,3] (any may be NULL) accumulate (+=)
+ * d_grid_params (atomic scatter) and the MLP weight gradients dw1_density[H,32], dw2_density[1,H],
+ * dw1_feature[H,32], dw2_feature[C,H].  `workspace` holds asd_field_bwd_workspace() floats
+ * (hidden-layer gradients per sample + per-chunk partial sums, reduced in a fixed order). */
+int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats);
 int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
                   const float* w1_density, const float* w2_density,
                   const float* w1_feature, const float* w2_feature,
                   const float* points, const float* enc_save, const float* sigma /* forward output */,
                   int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
-                  float* d_grid_params, float* wgrad_partials, void* stream);
-int asd_field_bwd_reduce(const asd_field_cfg* cfg, const float* wgrad_partials, int32_t n_blocks,
-                         float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
-                         void* stream);
+                  float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
+                  float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Background: (d+1)/2 -> hash grid (L levels) -> VanillaMLP(2L -> H -> H -> 3) -> sigmoid.

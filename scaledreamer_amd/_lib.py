@@ -82,7 +82,7 @@ _lib: Optional[C.CDLL] = None
 # every symbol include/asd_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "asd_grid_meta_init", "asd_hashgrid_fwd", "asd_hashgrid_bwd",
-    "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd", "asd_field_bwd_reduce",
+    "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd",
     "asd_envmap_fwd", "asd_envmap_bwd",
     "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",

@@ -220,95 +220,38 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 }
 
 // ---------------------------------------------------------------------------------------------------
-// training backward.  One thread per sample; the weight gradients dW1[h][k] = sum_t da_h(t) enc_k(t)
-// are reduced across the 256 samples of a block through LDS (enc transposed, padded to 257 to keep
-// the k-strided reads conflict-free) and written as one partial slab per block; asd_field_bwd_reduce
-// sums the slabs deterministically.
-// slab layout: [dW1d (H*NIN) | dW2d (H) | dW1f (H*NIN) | dW2f (C*H)]
+// training backward, two kernels:
+//  (1) field_bwd_sample_kernel — one thread per sample (no block-level synchronisation, full occupancy):
+//      re-evaluates the hidden layers from the saved encoding, forms the hidden-layer gradients
+//      DA[row][0:64] (density MLP) / DA[row][64:128] (feature MLP), back-propagates to the encoding and
+//      scatters into the hash-table gradient (fp32 hardware atomics); second-layer weight gradients are
+//      wave-reduced and accumulated through LDS (one global atomic per block and weight).
+//      With a normal gradient the 3 finite-difference points become 3 extra rows per sample.
+//  (2) field_wgrad_kernel — dW1 = DA^T . ENC as a tall-skinny GEMM over the sample axis (K = rows), 4x4
+//      register tiles fed by 16-byte LDS reads, one partial slab per 2048-row chunk, summed by
+//      slab_reduce_kernel in a fixed order.
+// DA costs 512 B/row of HBM write+read (288 GB of HBM3E: materialise instead of re-synchronising).
 // ---------------------------------------------------------------------------------------------------
-#define FB_T 256
-#define FB_PAD 257
-#define FB_G 8  // hidden units processed per LDS round
-
-template <int NIN, int H, int NOUT>
-__device__ __forceinline__ void mlp_bwd_block(const float* __restrict__ w1, const float* __restrict__ w2,
-                                              const float (&enc)[NIN], const float (&dout)[NOUT], bool active,
-                                              float (&denc)[NIN], float* __restrict__ enc_lds /*[NIN][FB_PAD]*/,
-                                              float* __restrict__ da_lds /*[FB_G][FB_T]*/,
-                                              float* __restrict__ w2_lds /*[NOUT*H]*/,
-                                              float* __restrict__ slab_w1, float* __restrict__ slab_w2,
-                                              bool accumulate) {
-    const int tid = threadIdx.x;
-    const int kk = tid % NIN;        // which input feature this thread reduces (NIN == 32)
-    const int hh = tid / NIN;        // which hidden unit of the group (256/32 = 8 = FB_G)
-#pragma unroll 1
-    for (int g = 0; g < H / FB_G; ++g) {
-        float dav[FB_G];
-#pragma unroll
-        for (int j = 0; j < FB_G; ++j) {
-            const int h = g * FB_G + j;
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < NIN; ++k) a = fmaf(w1[h * NIN + k], enc[k], a);
-            const float hv = fmaxf(a, 0.f);
-            float dh = 0.f;
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                dh = fmaf(dout[o], w2[o * H + h], dh);
-                // dW2[o][h] += dout[o] * relu(a): wave reduction, one LDS atomic per wave
-                const float v = asd_wave_sum(active ? dout[o] * hv : 0.f);
-                if ((tid & 63) == 0) atomicAdd(&w2_lds[o * H + h], v);
-            }
-            const float da = (active && a > 0.f) ? dh : 0.f;
-            dav[j] = da;
-#pragma unroll
-            for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1[h * NIN + k], denc[k]);
-        }
-        __syncthreads();  // previous round's readers are done with da_lds
-#pragma unroll
-        for (int j = 0; j < FB_G; ++j) da_lds[j * FB_T + tid] = dav[j];
-        __syncthreads();
-        // thread (kk, hh): dW1[g*8+hh][kk] = sum_t da[hh][t] * enc[kk][t]
-        float acc = 0.f;
-        const float* er = enc_lds + kk * FB_PAD;
-        const float* dr = da_lds + hh * FB_T;
-#pragma unroll 8
-        for (int t = 0; t < FB_T; ++t) acc = fmaf(dr[t], er[t], acc);
-        float* dst = &slab_w1[(g * FB_G + hh) * NIN + kk];  // same thread owns this word in every pass
-        *dst = accumulate ? *dst + acc : acc;
-    }
-    __syncthreads();
-    for (int q = tid; q < NOUT * H; q += FB_T) slab_w2[q] = accumulate ? slab_w2[q] + w2_lds[q] : w2_lds[q];
-    __syncthreads();
-}
+#define WG_ROWS 2048   // rows per wgrad block
+#define WG_TILE 64     // rows per LDS tile
 
 template <int L, int H, int C>
-__global__ __launch_bounds__(FB_T, 2) void field_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
     const asd_grid_meta m, const asd_field_cfg c, const float* __restrict__ grid, const float* __restrict__ w1d,
     const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
     const float* __restrict__ points, const float* __restrict__ enc_save, const float* __restrict__ sigma, int n,
     const int* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_features,
-    const float* __restrict__ d_normal, float* __restrict__ d_grid, float* __restrict__ slabs, int slab_stride) {
+    const float* __restrict__ d_normal, float* __restrict__ d_grid, float* __restrict__ da_out /*[rows,2H]*/,
+    float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f) {
     constexpr int NIN = 2 * L;
-    static_assert(NIN == 32, "block reduction layout assumes 32 encoded features");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* enc_lds = smem;                       // NIN * FB_PAD
-    float* da_lds = enc_lds + NIN * FB_PAD;      // FB_G * FB_T
-    float* w2_lds = da_lds + FB_G * FB_T;        // max(1, C) * H
-
+    __shared__ float w2_acc[(C > 0 ? C : 1) * H + H];
     const int nn = n_dev ? min(*n_dev, n) : n;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * FB_T + tid;
-    float* slab = slabs + (size_t)blockIdx.x * slab_stride;
-    float* slab_w1d = slab;
-    float* slab_w2d = slab_w1d + H * NIN;
-    float* slab_w1f = slab_w2d + H;
-    float* slab_w2f = slab_w1f + H * NIN;
-    if (blockIdx.x * FB_T >= nn) {  // whole block beyond the live sample count: publish a zero slab
-        for (int q = tid; q < slab_stride; q += FB_T) slab[q] = 0.f;
-        return;
-    }
+    for (int q = tid; q < (C > 0 ? C : 1) * H + H; q += 256) w2_acc[q] = 0.f;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
     const bool active = i < nn;
+    const bool lead = (tid & 63) == 0;
     float px = 0.f, py = 0.f, pz = 0.f, s = 0.f, ds = 0.f;
     float enc[NIN];
 #pragma unroll
@@ -326,55 +269,53 @@ __global__ __launch_bounds__(FB_T, 2) void field_bwd_kernel(
     }
     const float bx = c.bbox_max[0] - c.bbox_min[0], by = c.bbox_max[1] - c.bbox_min[1], bz = c.bbox_max[2] - c.bbox_min[2];
 
-    // ---- optional: gradient through the finite-difference normal (3 extra density evaluations) ----
+    // gradient through the finite-difference normal: d sigma_k and an extra term on d sigma
     float dsk[3] = {0.f, 0.f, 0.f}, rawk[3] = {0.f, 0.f, 0.f};
-    if (d_normal) {
-        float nr[3] = {0.f, 0.f, 0.f};
-        if (active) {
+    if (d_normal && active) {
+        float nr[3];
 #pragma unroll 1
-            for (int k = 0; k < 3; ++k) {
-                const float qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
-                const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
-                const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
-                float e2[NIN];
-                rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
-                nr[k] = -(field_act(c, rawk[k]) - s) / c.fd_eps;
-            }
-            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
-            const float g0 = d_normal[3 * (size_t)i], g1 = d_normal[3 * (size_t)i + 1], g2 = d_normal[3 * (size_t)i + 2];
-            float dnr[3];
-            if (len > 1e-12f) {
-                const float inv = 1.f / len;
-                const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
-                const float dot = n0 * g0 + n1 * g1 + n2 * g2;
-                dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
-            } else {
-                dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
-            }
+        for (int k = 0; k < 3; ++k) {
+            const float qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
+            float e2[NIN];
+            rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
+            nr[k] = -(field_act(c, rawk[k]) - s) / c.fd_eps;
+        }
+        const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+        const float g0 = d_normal[3 * (size_t)i], g1 = d_normal[3 * (size_t)i + 1], g2 = d_normal[3 * (size_t)i + 2];
+        float dnr[3];
+        if (len > 1e-12f) {
+            const float inv = 1.f / len;
+            const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
+            const float dot = n0 * g0 + n1 * g1 + n2 * g2;
+            dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
+        } else {
+            dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
+        }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dsk[k] = -dnr[k] / c.fd_eps;
-                ds += dnr[k] / c.fd_eps;
-            }
+        for (int k = 0; k < 3; ++k) {
+            dsk[k] = -dnr[k] / c.fd_eps;
+            ds += dnr[k] / c.fd_eps;
         }
     }
 
-    // ---- pass over the (1 or 4) density evaluations + the feature MLP -----------------------------
     const int n_pts = d_normal ? 4 : 1;
 #pragma unroll 1
     for (int pt = 0; pt < n_pts; ++pt) {
         float qx = px, qy = py, qz = pz, draw;
         float e[NIN];
+        size_t row;
         if (pt == 0) {
 #pragma unroll
             for (int k = 0; k < NIN; ++k) e[k] = enc[k];
-            // d sigma / d raw from sigma itself (softplus: 1-exp(-sigma)); raw is not stored
-            float ag;
+            float ag;  // d sigma / d raw recovered from sigma itself (softplus: 1 - exp(-sigma))
             if (c.activation == ASD_ACT_SOFTPLUS) ag = 1.f - expf(-s);
             else if (c.activation == ASD_ACT_EXP) ag = s;
             else if (c.activation == ASD_ACT_TRUNC_EXP) ag = fminf(s, 3269017.37f /* e^15 */);
             else ag = 1.f;
             draw = ds * ag;
+            row = (size_t)i;
         } else {
             const int k = pt - 1;
             qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
@@ -386,36 +327,131 @@ __global__ __launch_bounds__(FB_T, 2) void field_bwd_kernel(
                 for (int q = 0; q < NIN; ++q) e[q] = 0.f;
             }
             draw = dsk[k] * field_act_grad(c, rawk[k]);
-        }
-        // stage enc transposed for the block-level weight-gradient reduction
-        __syncthreads();
+            row = (size_t)n + (size_t)k * n + i;  // FD rows live behind the n centre rows
+            if (active) {
+                float4* dst = reinterpret_cast<float4*>(enc_fd + ((size_t)k * n + i) * NIN);
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) enc_lds[k * FB_PAD + tid] = active ? e[k] : 0.f;
-        for (int q = tid; q < (C > 0 ? C : 1) * H; q += FB_T) w2_lds[q] = 0.f;
-        __syncthreads();
-
+                for (int q = 0; q < NIN / 4; ++q) dst[q] = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+            }
+        }
         float denc[NIN];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) denc[k] = 0.f;
-        const float dout1[1] = {draw};
-        // density MLP; the 3 finite-difference points accumulate on top of the centre point's slab
-        mlp_bwd_block<NIN, H, 1>(w1d, w2d, e, dout1, active, denc, enc_lds, da_lds, w2_lds, slab_w1d, slab_w2d, pt > 0);
-        if (pt == 0) {
-            if (C > 0 && d_features) {
-                float df[C > 0 ? C : 1];
+        float* da_row = da_out + row * (2 * H);
+        // ---- density MLP: da_h = draw * w2[h] * [a_h > 0] ------------------------------------------------------
+#pragma unroll 1
+        for (int h0 = 0; h0 < H; h0 += 4) {
+            float dav[4];
 #pragma unroll
-                for (int o = 0; o < C; ++o) df[o] = active ? d_features[(size_t)i * C + o] : 0.f;
-                for (int q = tid; q < C * H; q += FB_T) w2_lds[q] = 0.f;
-                __syncthreads();
-                mlp_bwd_block<NIN, H, (C > 0 ? C : 1)>(w1f, w2f, e, df, active, denc, enc_lds, da_lds, w2_lds, slab_w1f,
-                                                       slab_w2f, false);
-            } else {
-                for (int q = tid; q < H * NIN + C * H; q += FB_T) slab_w1f[q] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int h = h0 + j;
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
+                const float v = asd_wave_sum(active ? draw * fmaxf(a, 0.f) : 0.f);
+                if (lead) atomicAdd(&w2_acc[h], v);
+                const float da = (active && a > 0.f) ? draw * w2d[h] : 0.f;
+                dav[j] = da;
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1d[h * NIN + k], denc[k]);
+            }
+            if (active) *reinterpret_cast<float4*>(da_row + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
+        }
+        // ---- feature MLP (centre point only) -------------------------------------------------------------------
+        if (C > 0) {
+            float df[C > 0 ? C : 1];
+#pragma unroll
+            for (int o = 0; o < C; ++o) df[o] = (pt == 0 && active && d_features) ? d_features[(size_t)i * C + o] : 0.f;
+#pragma unroll 1
+            for (int h0 = 0; h0 < H; h0 += 4) {
+                float dav[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int h = h0 + j;
+                    float da = 0.f;
+                    if (pt == 0 && d_features) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NIN; ++k) a = fmaf(w1f[h * NIN + k], e[k], a);
+                        const float hv = fmaxf(a, 0.f);
+                        float dh = 0.f;
+#pragma unroll
+                        for (int o = 0; o < C; ++o) {
+                            dh = fmaf(df[o], w2f[o * H + h], dh);
+                            const float v = asd_wave_sum(df[o] * hv);
+                            if (lead) atomicAdd(&w2_acc[H + o * H + h], v);
+                        }
+                        da = a > 0.f ? dh : 0.f;
+#pragma unroll
+                        for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1f[h * NIN + k], denc[k]);
+                    }
+                    dav[j] = da;
+                }
+                if (active) *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
         if (active)
             asd_scatter<L>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, denc);
     }
+    __syncthreads();
+    for (int q = tid; q < H; q += 256) atomicAdd(&dw2d[q], w2_acc[q]);
+    if (C > 0 && dw2f)
+        for (int q = tid; q < C * H; q += 256) atomicAdd(&dw2f[q], w2_acc[H + q]);
+}
+
+// slab[b][h][k] = sum over the block's rows of DA[row][h] * ENC[row][k]   (h < HH = 128, k < 32)
+template <int HH, int NIN>
+__global__ __launch_bounds__(256) void field_wgrad_kernel(const float* __restrict__ da, const float* __restrict__ enc_a,
+                                                          const float* __restrict__ enc_b, int rows_a, int rows_total,
+                                                          const int* __restrict__ n_dev, int n_max,
+                                                          float* __restrict__ slabs) {
+    static_assert(HH == 128 && NIN == 32, "tile mapping assumes a 128 x 32 output");
+    __shared__ __attribute__((aligned(16))) float da_s[WG_TILE * HH];   // 32 KB
+    __shared__ __attribute__((aligned(16))) float en_s[WG_TILE * NIN];  //  8 KB
+    const int tid = threadIdx.x;
+    const int h0 = (tid >> 3) * 4, k0 = (tid & 7) * 4;
+    // live rows: with a device-side sample count the centre rows end at *n_dev (rows beyond it hold garbage)
+    const int live_a = n_dev ? min(*n_dev, n_max) : rows_a;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int r_begin = blockIdx.x * WG_ROWS, r_end = min(rows_total, r_begin + WG_ROWS);
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_TILE) {
+        __syncthreads();
+        // stage 64 rows of DA (512 B each) and ENC (128 B each), zero-filling dead rows
+        for (int q = tid; q < WG_TILE * HH / 4; q += 256) {
+            const int r = r0 + q / (HH / 4), cq = q % (HH / 4);
+            const bool ok = r < r_end && (r < rows_a ? r < live_a : true);
+            const float4 v = ok ? reinterpret_cast<const float4*>(da + (size_t)r * HH)[cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(da_s)[q] = v;
+        }
+        for (int q = tid; q < WG_TILE * NIN / 4; q += 256) {
+            const int r = r0 + q / (NIN / 4), cq = q % (NIN / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < r_end) {
+                if (r < rows_a) { if (r < live_a) v = reinterpret_cast<const float4*>(enc_a + (size_t)r * NIN)[cq]; }
+                else v = reinterpret_cast<const float4*>(enc_b + (size_t)(r - rows_a) * NIN)[cq];
+            }
+            reinterpret_cast<float4*>(en_s)[q] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < WG_TILE; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(da_s + t * HH + h0);
+            const float4 e = *reinterpret_cast<const float4*>(en_s + t * NIN + k0);
+            const float av[4] = {a.x, a.y, a.z, a.w}, ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], ev[j], acc[i][j]);
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.x * HH * NIN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(slab + (h0 + i) * NIN + k0) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 }
 
 // sum the per-block slabs: out[j] += sum_b slabs[b][j]   (deterministic order)
@@ -647,11 +683,12 @@ int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     return ASD_OK;
 }
 
-int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t* n_blocks, int32_t* wgrad_stride) {
-    ASD_CHECK_ARG(cfg && n_blocks && wgrad_stride, "null argument");
-    const int H = cfg->n_hidden, C = cfg->n_feature_dims;
-    *n_blocks = asd_div_up(n > 0 ? n : 1, FB_T);
-    *wgrad_stride = H * 32 + H + H * 32 + C * H;
+int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats) {
+    ASD_CHECK_ARG(cfg && n_floats && n >= 0, "bad argument");
+    const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
+    const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs [chunks, 128*32]
+    *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64;
     return ASD_OK;
 }
 
@@ -659,46 +696,39 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* w1_density, const float* w2_density, const float* w1_feature,
                   const float* w2_feature, const float* points, const float* enc_save, const float* sigma, int32_t n,
                   const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
-                  float* d_grid_params, float* wgrad_partials, void* stream) {
+                  float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
+                  float* workspace, void* stream) {
     if (n == 0) return ASD_OK;
     ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && enc_save && sigma &&
-                      d_grid_params && wgrad_partials && n > 0,
+                      d_grid_params && dw1_density && dw2_density && workspace && n > 0,
                   "null argument");
     if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     ASD_CHECK_ARG(cfg->n_feature_dims == 3 || !d_features, "d_features given but no feature network");
-    if (n == 0) return ASD_OK;
-    int nb, stride;
-    asd_field_bwd_workspace(cfg, n, &nb, &stride);
-    const size_t lds = sizeof(float) * (32 * FB_PAD + FB_G * FB_T + 3 * 64);
-    if (cfg->n_feature_dims == 3)
-        hipLaunchKernelGGL((field_bwd_kernel<16, 64, 3>), dim3(nb), dim3(FB_T), lds, (hipStream_t)stream, *meta, *cfg,
-                           grid_params, w1_density, w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev,
-                           d_sigma, d_features, d_normal, d_grid_params, wgrad_partials, stride);
-    else
-        hipLaunchKernelGGL((field_bwd_kernel<16, 64, 0>), dim3(nb), dim3(FB_T), lds, (hipStream_t)stream, *meta, *cfg,
-                           grid_params, w1_density, w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev,
-                           d_sigma, d_features, d_normal, d_grid_params, wgrad_partials, stride);
-    ASD_LAUNCH_CHECK();
-    return ASD_OK;
-}
-
-int asd_field_bwd_reduce(const asd_field_cfg* cfg, const float* wgrad_partials, int32_t n_blocks, float* dw1_density,
-                         float* dw2_density, float* dw1_feature, float* dw2_feature, void* stream) {
-    ASD_CHECK_ARG(cfg && wgrad_partials && dw1_density && dw2_density && n_blocks >= 0, "null argument");
-    const int H = cfg->n_hidden, C = cfg->n_feature_dims;
-    const int stride = H * 32 + H + H * 32 + C * H;
-    if (n_blocks == 0) return ASD_OK;
+    ASD_CHECK_ARG(cfg->n_feature_dims == 0 || (dw1_feature && dw2_feature && w1_feature && w2_feature), "feature gradients missing");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(H * 32, 256)), dim3(256), 0, s, wgrad_partials, n_blocks, stride,
-                       H * 32, dw1_density);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, s, wgrad_partials + H * 32, n_blocks, stride, H,
-                       dw2_density);
-    if (C > 0 && dw1_feature && dw2_feature) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(H * 32, 256)), dim3(256), 0, s,
-                           wgrad_partials + H * 32 + H, n_blocks, stride, H * 32, dw1_feature);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, s, wgrad_partials + H * 32 + H + H * 32, n_blocks,
-                           stride, C * H, dw2_feature);
-    }
+    const int with_normal = d_normal != nullptr;
+    const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
+    const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    float* da = workspace;
+    float* enc_fd = with_normal ? da + rows * 128 : nullptr;
+    float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);
+    const dim3 grid(asd_div_up(n, 256)), block(256);
+    if (cfg->n_feature_dims == 3)
+        hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
+                           w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
+                           d_normal, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+    else
+        hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 0>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
+                           w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
+                           d_normal, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+    hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
+                       slabs);
+    // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 256)), block, 0, s, slabs, chunks, 128 * 32, 64 * 32,
+                       dw1_density);
+    if (cfg->n_feature_dims == 3)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 256)), block, 0, s, slabs + 64 * 32, chunks, 128 * 32,
+                           64 * 32, dw1_feature);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -10,9 +10,10 @@ typedef half_t half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
-// ---- GroupNorm statistics: grid (batch, chunks); block 256.  Each thread owns one 8-channel slot of the
-// row and walks rows with stride; per-channel partials are folded into per-group sums in LDS, then one
-// atomicAdd pair per (block, group).
+// ---- GroupNorm statistics: grid (batch, chunks); block 256.  A thread owns a fixed 8-channel slot (two when
+// C > 2048) and walks the rows of its chunk with stride 256/slots, accumulating per-channel sums in registers;
+// only at the end are they folded into 32 per-group LDS cells and from there into global memory (one atomic
+// pair per block and group).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
                                                        int c2, int hw, int rows_per_block, float* __restrict__ stats) {
     __shared__ float gsum[32], gsq[32];
@@ -21,25 +22,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     if (tid < 32) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
     __syncthreads();
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
-    const int total = (r1 - r0) * slots;
-    for (int i = tid; i < total; i += 256) {
-        const int r = r0 + i / slots, c = (i % slots) * 8;
-        const size_t row = (size_t)b * hw + r;
-        const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
-        // the 8 channels of a chunk belong to 1-2 groups (8 when C = 32): flush whenever the group changes
+    const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
+    const int rsub = slots >= 256 ? 0 : tid / slots;
+    const int slot0 = slots >= 256 ? tid : tid % slots;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // second pass only when more than 256 slots (C = 2560)
+        const int slot = slot0 + j * 256;
+        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
+        float s[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+        const int c = slot * 8;
+        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
+            const size_t row = (size_t)b * hw + r;
+            const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; q[k] = fmaf(f, f, q[k]); }
+        }
         int g = c / cg;
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int gk = (c + k) / cg;
-            if (gk != g) {
-                atomicAdd(&gsum[g], ss);
-                atomicAdd(&gsq[g], qq);
-                g = gk; ss = 0.f; qq = 0.f;
-            }
-            const float f = (float)v[k];
-            ss += f;
-            qq = fmaf(f, f, qq);
+            if (gk != g) { atomicAdd(&gsum[g], ss); atomicAdd(&gsq[g], qq); g = gk; ss = 0.f; qq = 0.f; }
+            ss += s[k]; qq += q[k];
         }
         atomicAdd(&gsum[g], ss);
         atomicAdd(&gsq[g], qq);
@@ -78,34 +84,52 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
-// ---- LayerNorm: one wave per row ------------------------------------------------------------------------
+// ---- LayerNorm: a wave owns a row at a time (grid-stride over rows), NV = ceil(C / 512) 16-byte loads per lane
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int rows, int C,
                                                         const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                         float eps, half_t* __restrict__ y) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const half_t* xr = x + (size_t)row * C;
-    float s = 0.f;
-    half8 v[4];  // C <= 2048
-    int nv = 0;
-    for (int c = lane * 8; c < C; c += 512, ++nv) {
-        v[nv] = *(const half8*)(xr + c);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    half8 gm[NV], bt[NV];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += (float)v[nv][k];
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < C) { gm[j] = *(const half8*)(gamma + c); bt[j] = *(const half8*)(beta + c); }
     }
-    const float mean = asd_wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int j = 0; j < nv; ++j)
+    const float inv_c = 1.f / (float)C;
+    for (int row = wave; row < rows; row += n_waves) {
+        const half_t* xr = x + (size_t)row * C;
+        half8 v[NV];
+        float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = (float)v[j][k] - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(asd_wave_sum(q) / (float)C + eps);
-    int j = 0;
-    for (int c = lane * 8; c < C; c += 512, ++j) {
-        const half8 gm = *(const half8*)(gamma + c), bt = *(const half8*)(beta + c);
-        half8 o;
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane * 8 + j * 512;
+            if (c < C) {
+                v[j] = *(const half8*)(xr + c);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (half_t)(((float)v[j][k] - mean) * rstd * (float)gm[k] + (float)bt[k]);
-        *(half8*)(y + (size_t)row * C + c) = o;
+                for (int k = 0; k < 8; ++k) s += (float)v[j][k];
+            }
+        }
+        const float mean = asd_wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (lane * 8 + j * 512 < C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = (float)v[j][k] - mean; q = fmaf(d, d, q); }
+            }
+        const float rstd = rsqrtf(asd_wave_sum(q) * inv_c + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane * 8 + j * 512;
+            if (c < C) {
+                half8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (half_t)(((float)v[j][k] - mean) * rstd * (float)gm[j][k] + (float)bt[j][k]);
+                *(half8*)(y + (size_t)row * C + c) = o;
+            }
+        }
     }
 }
 
@@ -171,8 +195,8 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     hipStream_t s = (hipStream_t)stream;
     // (a kernel, not hipMemsetAsync: the launch sequence is captured into HIP graphs and replayed)
     hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, stats, 64 * batch);
-    int chunks = asd_div_up(hw, 64);
-    if (chunks > 64) chunks = 64;
+    int chunks = asd_div_up(hw, 16);  // >= 16 rows per block; enough blocks to cover the chip at every resolution
+    if (chunks > 128) chunks = 128;
     const int rows_per_block = asd_div_up(hw, chunks);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
                        rows_per_block, stats);
@@ -188,8 +212,17 @@ int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma,
                       void* stream) {
     ASD_CHECK_ARG(x && gamma && beta && y && rows > 0, "null argument");
     ASD_CHECK_ARG(c % 8 == 0 && c <= 2048, "channels must be a multiple of 8 and <= 2048");
-    hipLaunchKernelGGL(layernorm_kernel, dim3(asd_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, rows, c,
-                       (const half_t*)gamma, (const half_t*)beta, eps, (half_t*)y);
+    int blocks = asd_div_up(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+    const dim3 g(blocks), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(NV) hipLaunchKernelGGL((layernorm_kernel<NV>), g, blk, 0, s, (const half_t*)x, rows, c, (const half_t*)gamma, \
+                                         (const half_t*)beta, eps, (half_t*)y)
+    if (c <= 512) LN_LAUNCH(1);
+    else if (c <= 1024) LN_LAUNCH(2);
+    else if (c <= 1536) LN_LAUNCH(3);
+    else LN_LAUNCH(4);
+#undef LN_LAUNCH
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -77,19 +77,18 @@ def field_bwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma,
     """Accumulates into d_grid (atomics); returns (dw1d, dw2d, dw1f, dw2f)."""
     points = _c(points)
     n, dev = points.shape[0], points.device
-    nb, stride = C.c_int32(0), C.c_int32(0)
-    check(lib().asd_field_bwd_workspace(C.byref(cfg), i32(n), C.byref(nb), C.byref(stride)))
-    slabs = torch.empty((nb.value, stride.value), device=dev, dtype=torch.float32)
-    check(lib().asd_field_bwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
-                              ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), ptr(_c(d_sigma)),
-                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(d_grid), ptr(slabs), stream()))
+    nf = C.c_int64(0)
+    check(lib().asd_field_bwd_workspace(C.byref(cfg), i32(n), i32(int(d_normal is not None)), C.byref(nf)))
+    ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
     H, Cf = cfg.n_hidden, cfg.n_feature_dims
     dw1d = torch.zeros((H, 32), device=dev, dtype=torch.float32)
     dw2d = torch.zeros((1, H), device=dev, dtype=torch.float32)
     dw1f = torch.zeros((H, 32), device=dev, dtype=torch.float32) if Cf > 0 else None
     dw2f = torch.zeros((Cf, H), device=dev, dtype=torch.float32) if Cf > 0 else None
-    check(lib().asd_field_bwd_reduce(C.byref(cfg), ptr(slabs), i32(nb.value), ptr(dw1d), ptr(dw2d), ptr(dw1f),
-                                     ptr(dw2f), stream()))
+    check(lib().asd_field_bwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
+                              ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), ptr(_c(d_sigma)),
+                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(d_grid), ptr(dw1d), ptr(dw2d), ptr(dw1f),
+                              ptr(dw2f), ptr(ws), stream()))
     return dw1d, dw2d, dw1f, dw2f
 
 
