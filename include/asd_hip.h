@@ -214,7 +214,8 @@ typedef struct asd_gemm_args {
     int32_t act;            /* 0 none, 1 SiLU */
     int32_t out_f32;
     int32_t conv;           /* 0: GEMM, 1: 3x3 convolution (K = 9*Cin) */
-    int32_t Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
+    int32_t Hin, Win, Cin, Hout, Wout, stride, pad;
+    int32_t upsample;       /* 0: plain, 1: fused nearest-2x upsample, 2: input gradient of a stride-2 conv */
     const void* zero_page;  /* >= 16 B of zeros: source of out-of-range rows / taps */
     int32_t split_k;        /* >= 1; > 1 needs workspace[split_k, M, N] fp32 */
     float*  workspace;
@@ -226,6 +227,13 @@ int asd_gemm_f16(const asd_gemm_args* args, void* stream);
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw,
                       const void* gamma, const void* beta, float eps, int32_t silu, void* y,
                       float* stats /*[batch*32*2]*/, void* stream);
+/* Input gradient of GroupNorm(+SiLU) with frozen gamma/beta (VAE encoder backward, the reference keeps the
+ * VAE in the autograd graph: stable_diffusion_asd_guidance.py:171-178,225): dx from x, dy and the forward stats. */
+int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,
+                          const void* beta, float eps, int32_t silu, const float* fwd_stats, void* dx,
+                          float* bwd_stats /*[batch*32*2]*/, void* stream);
+/* y[cols, rows] = x[rows, cols]^T, fp16 (operand layout changes for the attention-backward GEMMs). */
+int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream);
 /* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */
 int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma, const void* beta, float eps,
                       void* y, void* stream);

@@ -102,8 +102,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const asd_gemm_args p) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 int yi = a_y[i] * p.stride + ky - p.pad, xi = a_x[i] * p.stride + kx - p.pad;
                 bool ok = a_valid[i];
-                if (p.upsample) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
+                if (p.upsample == 1) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
                     ok = ok && yi >= 0 && xi >= 0 && yi < 2 * p.Hin && xi < 2 * p.Win;
+                    yi >>= 1; xi >>= 1;
+                } else if (p.upsample == 2) {
+                    // input gradient of a stride-2 convolution: dX[y,x] += dY[(y+pad-ky)/2, (x+pad-kx)/2] W[ky,kx]
+                    // for the taps where both numerators are even (the other taps read the zero page)
+                    yi = a_y[i] + p.pad - ky; xi = a_x[i] + p.pad - kx;
+                    ok = ok && yi >= 0 && xi >= 0 && !(yi & 1) && !(xi & 1) && (yi >> 1) < p.Hin && (xi >> 1) < p.Win;
                     yi >>= 1; xi >>= 1;
                 } else {
                     ok = ok && yi >= 0 && xi >= 0 && yi < p.Hin && xi < p.Win;

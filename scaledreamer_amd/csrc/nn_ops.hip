@@ -84,6 +84,121 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
+// ---- GroupNorm(+SiLU) backward w.r.t. the input (frozen gamma/beta: VAE encoder input gradient) -------------
+// y = silu?(z), z = xh * gamma + beta, xh = (x - mean) * rstd.  With g = dy * silu'(z) * gamma:
+//   dx = rstd * (g - mean_grp(g) - xh * mean_grp(g * xh))
+// pass 1 accumulates sum(g) and sum(g*xh) per (batch, group) exactly like the forward statistics kernel,
+// pass 2 applies the formula.  x is re-read instead of saving xh/z (bandwidth is cheaper than HBM capacity
+// is scarce here? no: 288 GB — but x must be kept for the convolution-free recompute anyway).
+__device__ __forceinline__ float silu_grad(float z) {
+    const float sg = 1.f / (1.f + __expf(-z));
+    return sg * (1.f + z * (1.f - sg));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
+                                                           int hw, int rows_per_block, const half_t* __restrict__ gamma,
+                                                           const half_t* __restrict__ beta, float eps, int silu,
+                                                           const float* __restrict__ fstats, float* __restrict__ bstats) {
+    __shared__ float gsum[32], gsq[32];
+    const int slots = C / 8, cg = C / 32;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
+    __syncthreads();
+    const float inv_cnt = 1.f / ((float)hw * (float)cg);
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
+    const int rsub = slots >= 256 ? 0 : tid / slots;
+    const int slot0 = slots >= 256 ? tid : tid % slots;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = slot0 + j * 256;
+        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
+        const int c = slot * 8;
+        float mean[8], rstd[8], gm[8], bt[8], s[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = (c + k) / cg;
+            mean[k] = fstats[(b * 32 + g) * 2] * inv_cnt;
+            rstd[k] = rsqrtf(fmaxf(fstats[(b * 32 + g) * 2 + 1] * inv_cnt - mean[k] * mean[k], 0.f) + eps);
+            gm[k] = (float)gamma[c + k]; bt[k] = (float)beta[c + k];
+            s[k] = 0.f; q[k] = 0.f;
+        }
+        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
+            const size_t off = ((size_t)b * hw + r) * C + c;
+            const half8 xv = *(const half8*)(x + off), dv = *(const half8*)(dy + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = ((float)xv[k] - mean[k]) * rstd[k];
+                float g = (float)dv[k] * gm[k];
+                if (silu) g *= silu_grad(xh * gm[k] + bt[k]);
+                s[k] += g;
+                q[k] = fmaf(g, xh, q[k]);
+            }
+        }
+        int g = c / cg;
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gk = (c + k) / cg;
+            if (gk != g) { atomicAdd(&gsum[g], ss); atomicAdd(&gsq[g], qq); g = gk; ss = 0.f; qq = 0.f; }
+            ss += s[k]; qq += q[k];
+        }
+        atomicAdd(&gsum[g], ss);
+        atomicAdd(&gsq[g], qq);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        atomicAdd(&bstats[(b * 32 + tid) * 2], gsum[tid]);
+        atomicAdd(&bstats[(b * 32 + tid) * 2 + 1], gsq[tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
+                                                           int batch, int hw, const half_t* __restrict__ gamma,
+                                                           const half_t* __restrict__ beta, float eps, int silu,
+                                                           const float* __restrict__ fstats, const float* __restrict__ bstats,
+                                                           half_t* __restrict__ dx) {
+    const int slots = C / 8, cg = C / 32;
+    const float inv_cnt = 1.f / ((float)hw * (float)cg);
+    const size_t total = (size_t)batch * hw * slots;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / slots;
+        const int c = (int)(i - row * slots) * 8;
+        const int b = (int)(row / hw);
+        const half8 xv = *(const half8*)(x + row * C + c), dv = *(const half8*)(dy + row * C + c);
+        const half8 gmv = *(const half8*)(gamma + c), btv = *(const half8*)(beta + c);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = (c + k) / cg;
+            const float mean = fstats[(b * 32 + g) * 2] * inv_cnt;
+            const float rstd = rsqrtf(fmaxf(fstats[(b * 32 + g) * 2 + 1] * inv_cnt - mean * mean, 0.f) + eps);
+            const float xh = ((float)xv[k] - mean) * rstd;
+            float gg = (float)dv[k] * (float)gmv[k];
+            if (silu) gg *= silu_grad(xh * (float)gmv[k] + (float)btv[k]);
+            const float m1 = bstats[(b * 32 + g) * 2] * inv_cnt, m2 = bstats[(b * 32 + g) * 2 + 1] * inv_cnt;
+            o[k] = (half_t)(rstd * (gg - m1 - xh * m2));
+        }
+        *(half8*)(dx + row * C + c) = o;
+    }
+}
+
+// fp16 2-D transpose (rows x cols -> cols x rows), 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __restrict__ x, int rows, int cols, int ldx,
+                                                            half_t* __restrict__ y, int ldy) {
+    __shared__ half_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int q = threadIdx.x; q < 64 * 64; q += 256) {
+        const int r = q / 64, c = q % 64;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? x[(size_t)(r0 + r) * ldx + c0 + c] : (half_t)0.f;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * 64; q += 256) {
+        const int c = q / 64, r = q % 64;
+        if (c0 + c < cols && r0 + r < rows) y[(size_t)(c0 + c) * ldy + r0 + r] = tile[r][c];
+    }
+}
+
 // ---- LayerNorm: a wave owns a row at a time (grid-stride over rows), NV = ceil(C / 512) 16-byte loads per lane
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int rows, int C,
@@ -204,6 +319,34 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     hipLaunchKernelGGL(gn_apply_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, s, (const half_t*)x1, c1,
                        (const half_t*)x2, c2, batch, hw, (const half_t*)gamma, (const half_t*)beta, eps, silu, stats,
                        (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,
+                          const void* beta, float eps, int32_t silu, const float* fwd_stats, void* dx, float* bwd_stats,
+                          void* stream) {
+    ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && dx && bwd_stats && batch > 0 && hw > 0, "null argument");
+    ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, bwd_stats, 64 * batch);
+    int chunks = asd_div_up(hw, 16);
+    if (chunks > 128) chunks = 128;
+    const int rows_per_block = asd_div_up(hw, chunks);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                       rows_per_block, (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
+    const size_t total = (size_t)batch * hw * (c / 8);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, s, (const half_t*)x,
+                       (const half_t*)dy, c, batch, hw, (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats,
+                       bwd_stats, (half_t*)dx);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream) {
+    ASD_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= rows, "bad argument");
+    hipLaunchKernelGGL(transpose_f16_kernel, dim3(asd_div_up(cols, 64), asd_div_up(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, rows, cols, ldx, (half_t*)y, ldy);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

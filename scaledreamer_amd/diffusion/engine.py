@@ -201,13 +201,12 @@ class HipUNet:
 
 
 class HipBackend(DiffusionBackend):
-    """UNet on the hand-written HIP engine.  The VAE encoder (forward + input gradient) still runs on library
-    ops (diffusion/eager.py) this round — DESIGN.md lists it as the next kernel target."""
+    """UNet eps-prediction and VAE encoder (forward + input gradient) on the hand-written HIP kernels."""
 
     def __init__(self, device, dtype=torch.float16, seed: int = 1, unet_cfg: Optional[W.UNetConfig] = None,
                  vae_cfg: Optional[W.VAEConfig] = None, unet_params: Optional[P] = None, vae_params: Optional[P] = None,
                  use_graph: bool = True):
-        from . import eager
+        from .vae_hip import HipVAEEncoder
 
         self.unet_cfg = unet_cfg or W.UNetConfig()
         self.vae_cfg = vae_cfg or W.VAEConfig()
@@ -216,18 +215,16 @@ class HipBackend(DiffusionBackend):
         up = unet_params if unet_params is not None else W.gen_params(layout[0], seed)
         self.hip_unet = HipUNet(up, self.unet_cfg, device, use_graph=use_graph)
         del up
-        self.vae_shapes, self.vae_plan = W.vae_encoder_layout(self.vae_cfg)
-        vp = vae_params if vae_params is not None else W.gen_params(self.vae_shapes, seed + 1)
-        cl = lambda t: t.contiguous(memory_format=torch.channels_last) if t.ndim == 4 else t
-        self.vp = {k: cl(v.to(device=device, dtype=dtype)) for k, v in vp.items()}
-        self._eager = eager
+        vshapes, _ = W.vae_encoder_layout(self.vae_cfg)
+        vp = vae_params if vae_params is not None else W.gen_params(vshapes, seed + 1)
+        self.hip_vae = HipVAEEncoder(vp, self.vae_cfg, device)
 
     @torch.no_grad()
     def unet(self, latents, t, context):
         return self.hip_unet(latents, t, context)
 
     def encode(self, images):
-        return self._eager.vae_encode_moments(self.vp, self.vae_plan, images)
+        return self.hip_vae(images)
 
 
 @register_backend("hip")

@@ -81,13 +81,15 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1,
     B, H, W_, Cin = x.shape
     assert x.is_contiguous()
     if out_hw is None:
+        if upsample == 2:
+            raise ValueError("transposed-conv mode needs out_hw")
         if upsample:
             Ho, Wo = 2 * H, 2 * W_
         else:
             Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W_ + 2 * pad - 3) // stride + 1
     else:
         Ho, Wo = out_hw
-    conv = dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=int(upsample))
+    conv = dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=int(upsample))  # upsample: 0/1/2
     y = gemm(x, w_packed, bias=bias, conv=conv, M=B * Ho * Wo, **kw)
     return y.view(B, Ho, Wo, w_packed.shape[0])
 
@@ -101,7 +103,8 @@ def pack_conv3x3_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch
     return wp.reshape(cout, 9 * cp).contiguous()
 
 
-def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optional[torch.Tensor] = None,
+              return_stats: bool = False):
     """x: [B, HW, C] (or [B,H,W,C]) NHWC fp16, 32 groups; x2 = second tensor of a channel concat."""
     B = x1.shape[0]
     c1 = x1.shape[-1]
@@ -111,6 +114,23 @@ def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optiona
     stats = torch.empty(B * 64, device=x1.device, dtype=torch.float32)
     check(lib().asd_groupnorm_f16(ptr(x1), i32(c1), _p(x2), i32(c2), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps),
                                   i32(int(silu)), ptr(y), ptr(stats), stream()))
+    return (y, stats) if return_stats else y
+
+
+def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor) -> torch.Tensor:
+    B, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c)
+    dx = torch.empty_like(x)
+    bstats = torch.empty(B * 64, device=x.device, dtype=torch.float32)
+    check(lib().asd_groupnorm_bwd_f16(ptr(x), ptr(dy), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)),
+                                      ptr(stats), ptr(dx), ptr(bstats), stream()))
+    return dx
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    rows, cols = x.shape
+    y = torch.empty((cols, rows), device=x.device, dtype=torch.float16)
+    check(lib().asd_transpose_f16(C.c_void_p(x.data_ptr()), i32(rows), i32(cols), i32(x.stride(0)), ptr(y), i32(rows), stream()))
     return y
 
 

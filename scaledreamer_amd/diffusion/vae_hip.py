@@ -1,0 +1,167 @@
+"""HIP execution of the frozen SD VAE encoder, forward AND input-gradient backward.
+
+The reference keeps the VAE encoder inside the autograd graph of the ASD loss (the latents are a function of
+the rendered image: stable_diffusion_asd_guidance.py:171-178,204-208,225; parameters frozen :101-102), so
+every step pays a forward and an input-gradient ("dgrad") pass at 512x512.  Architecture: Encoder
+(extern/mvdream/ldm/modules/diffusionmodules/model.py:452-543), ResnetBlock :88-146, Downsample :66-85,
+AttnBlock :152-203, quant_conv (models/autoencoder.py:32,81-85).
+
+All heavy layers run in the hand-written kernels: 3x3 convolutions forward and dgrad are the same
+implicit-GEMM MFMA kernel (the dgrad uses weights transposed/flipped once at load; the stride-2 dgrad is the
+kernel's "transposed" gather mode), GroupNorm+SiLU forward/backward are the NHWC kernels of nn_ops.hip, 1x1
+convolutions are GEMMs.  torch.autograd only sequences the layers (each layer is a small autograd.Function
+that calls the C ABI); the single-head 512-wide mid-block attention uses torch's SDPA this round.
+conv_out and quant_conv are both linear, so they are folded into one 3x3 convolution at load time.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import hip_ops as H
+from . import weights as W
+
+P = Dict[str, torch.Tensor]
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_fwd, bias, w_bwd, stride, pad):
+        B, Hh, Ww, _ = x.shape
+        if stride == 2:  # asymmetric (0,1,0,1) zero padding, model.py:80-85
+            out_hw = ((Hh + 1 - 3) // 2 + 1, (Ww + 1 - 3) // 2 + 1)
+        else:
+            out_hw = (Hh, Ww)
+        ctx.w_bwd, ctx.stride, ctx.in_hw = w_bwd, stride, (Hh, Ww)
+        return H.conv3x3(x, w_fwd, bias=bias, stride=stride, pad=pad, out_hw=out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if dy.shape[-1] % 32:  # e.g. the 8 moment channels: pad the contraction dim to the kernel's K granularity
+            dy = F.pad(dy, (0, 32 - dy.shape[-1] % 32))
+        if ctx.stride == 1:
+            dx = H.conv3x3(dy, ctx.w_bwd, stride=1, pad=1)
+        else:
+            dx = H.conv3x3(dy, ctx.w_bwd, stride=1, pad=0, upsample=2, out_hw=ctx.in_hw)
+        return dx, None, None, None, None, None
+
+
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, silu):
+        y, stats = H.groupnorm(x, gamma, beta, eps, silu, return_stats=True)
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.eps, ctx.silu = eps, silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma, beta = ctx.saved_tensors
+        return H.groupnorm_bwd(x, dy.contiguous(), gamma, beta, ctx.eps, ctx.silu, stats), None, None, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on [M, Cin] rows (1x1 convolution on NHWC)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, w_t):
+        ctx.w_t = w_t
+        return H.gemm(x, w, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.gemm(dy.contiguous(), ctx.w_t), None, None, None
+
+
+class HipVAEEncoder:
+    def __init__(self, params: P, cfg: Optional[W.VAEConfig] = None, device="cuda"):
+        self.cfg = cfg or W.VAEConfig()
+        self.device = torch.device(device)
+        self.shapes, self.plan = W.vae_encoder_layout(self.cfg)
+        self._pack(params)
+
+    def _pack(self, p: P):
+        dev = self.device
+        f16 = lambda t: t.to(device=dev, dtype=torch.float16).contiguous()
+        w: Dict[str, torch.Tensor] = {}
+
+        def conv(name, weight, bias, stride=1):
+            wt = weight.float()
+            w[name + ".fwd"] = H.pack_conv3x3_weight(f16(wt))
+            cin = wt.shape[1]
+            cin_p = (cin + 31) // 32 * 32
+            wb = wt.permute(1, 0, 2, 3)                     # [Cin, Cout, 3, 3]: roles swapped for the input gradient
+            if stride == 1:
+                wb = wb.flip(2, 3)
+            if cin_p != cin:                                  # gradient w.r.t. the zero-padded input channels
+                wb = torch.cat([wb, wb.new_zeros(cin_p - cin, *wb.shape[1:])], 0)
+            w[name + ".bwd"] = H.pack_conv3x3_weight(f16(wb))
+            w[name + ".bias"] = f16(bias)
+
+        for kind, name, cin, cout in self.plan:
+            if kind == "conv":
+                conv(name, p[name + ".weight"], p[name + ".bias"])
+            elif kind == "res":
+                for n in ("norm1", "norm2"):
+                    w[f"{name}.{n}.weight"], w[f"{name}.{n}.bias"] = f16(p[f"{name}.{n}.weight"]), f16(p[f"{name}.{n}.bias"])
+                conv(name + ".conv1", p[name + ".conv1.weight"], p[name + ".conv1.bias"])
+                conv(name + ".conv2", p[name + ".conv2.weight"], p[name + ".conv2.bias"])
+                if name + ".nin_shortcut.weight" in p:
+                    ws = p[name + ".nin_shortcut.weight"].reshape(cout, cin)
+                    w[name + ".nin.w"], w[name + ".nin.wt"], w[name + ".nin.b"] = f16(ws), f16(ws.t()), f16(p[name + ".nin_shortcut.bias"])
+            elif kind == "down":
+                conv(name, p[name + ".weight"], p[name + ".bias"], stride=2)
+            elif kind == "attn":
+                w[name + ".norm.weight"], w[name + ".norm.bias"] = f16(p[name + ".norm.weight"]), f16(p[name + ".norm.bias"])
+                for n in ("q", "k", "v", "proj_out"):
+                    wm = p[f"{name}.{n}.weight"].reshape(cout, cin)
+                    w[f"{name}.{n}.w"], w[f"{name}.{n}.wt"], w[f"{name}.{n}.b"] = f16(wm), f16(wm.t()), f16(p[f"{name}.{n}.bias"])
+            elif kind == "out":
+                w[name + ".norm_out.weight"], w[name + ".norm_out.bias"] = f16(p[name + ".norm_out.weight"]), f16(p[name + ".norm_out.bias"])
+                # moments = quant_conv(conv_out(h)): compose the two linear maps (exact)
+                wq = p["quant_conv.weight"].float().reshape(p["quant_conv.weight"].shape[0], -1)     # [8, 8]
+                wc = p[name + ".conv_out.weight"].float()                                              # [8, 512, 3, 3]
+                wcomb = torch.einsum("om,mikl->oikl", wq, wc)
+                bcomb = wq @ p[name + ".conv_out.bias"].float() + p["quant_conv.bias"].float()
+                conv(name + ".conv_out_quant", wcomb, bcomb)
+        self.w = w
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        """images [B,3,H,W] in [-1,1] (any float dtype, may require grad) -> moments [B, 2*embed_dim, H/8, W/8] fp32."""
+        w = self.w
+        B, Cin, Hh, Ww = images.shape
+        x = F.pad(images.permute(0, 2, 3, 1), (0, 32 - Cin)).to(torch.float16).contiguous()   # NHWC, channels padded to 32
+        h = x
+        for kind, name, cin, cout in self.plan:
+            if kind == "conv":
+                h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 1, 1)
+            elif kind == "res":
+                t = _GroupNormFn.apply(h, w[name + ".norm1.weight"], w[name + ".norm1.bias"], 1e-6, True)
+                t = _Conv3x3Fn.apply(t, w[name + ".conv1.fwd"], w[name + ".conv1.bias"], w[name + ".conv1.bwd"], 1, 1)
+                t = _GroupNormFn.apply(t, w[name + ".norm2.weight"], w[name + ".norm2.bias"], 1e-6, True)
+                t = _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1)
+                if name + ".nin.w" in w:
+                    s = _LinearFn.apply(h.reshape(-1, cin), w[name + ".nin.w"], w[name + ".nin.b"], w[name + ".nin.wt"]).view(*h.shape[:3], cout)
+                else:
+                    s = h
+                h = s + t
+            elif kind == "down":
+                h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 2, 0)
+            elif kind == "attn":
+                Bh, Hc, Wc, C_ = h.shape
+                t = _GroupNormFn.apply(h, w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-6, False).reshape(-1, C_)
+                q, k, v = (_LinearFn.apply(t, w[f"{name}.{n}.w"], w[f"{name}.{n}.b"], w[f"{name}.{n}.wt"]).view(Bh, 1, Hc * Wc, C_)
+                           for n in ("q", "k", "v"))
+                o = F.scaled_dot_product_attention(q, k, v).reshape(-1, C_)
+                o = _LinearFn.apply(o, w[name + ".proj_out.w"], w[name + ".proj_out.b"], w[name + ".proj_out.wt"])
+                h = h + o.view(Bh, Hc, Wc, C_)
+            elif kind == "out":
+                t = _GroupNormFn.apply(h, w[name + ".norm_out.weight"], w[name + ".norm_out.bias"], 1e-6, True)
+                n = name + ".conv_out_quant"
+                h = _Conv3x3Fn.apply(t, w[n + ".fwd"], w[n + ".bias"], w[n + ".bwd"], 1, 1)
+            elif kind == "quant":
+                pass  # folded into conv_out above
+        return h.permute(0, 3, 1, 2).float()
