@@ -85,14 +85,17 @@ def roofline_field_kernel(system, batch, reps: int = 20):
 
 
 def cpu_baseline(system, batch, seed: int):
-    """The oracle (a scalar/OpenMP C port + torch fp32) timed on this host's cores on ONE full step of the
-    same workload (same camera, same parameters, same synthetic prompt embeddings)."""
+    """The oracle (C/OpenMP renderer port + torch fp32 diffusion restatement) timed on this host's cores on a
+    BOUNDED sample of the same workload: the full render forward+backward of the step's camera, ONE of the five
+    UNet evaluations (x5) and the VAE forward+input-gradient at 256x256 (x4 pixels); scaled to one step."""
     import numpy as np
-    from oracle import oracle as O  # noqa: F401
-    from oracle import ref_step
+    from oracle import diffusion_ref as D
+    from oracle import ref_renderer as R
     from scaledreamer_amd.diffusion import weights as W
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     geo, bg, ren, guid = system.geometry, system.background, system.renderer, system.guidance
     f = lambda t: t.detach().float().cpu().numpy()
     P = dict(h=64, w=64, spp=ren.cfg.num_samples_per_ray, radius=ren.cfg.radius, rays_o=f(batch["rays_o"]), rays_d=f(batch["rays_d"]),
@@ -102,31 +105,37 @@ def cpu_baseline(system, batch, seed: int):
              w1f=f(geo.feature_network.layers[0].weight), w2f=f(geo.feature_network.layers[2].weight),
              bgrid=f(bg.encoding.encoding.encoding.params), bw0=f(bg.network.layers[0].weight),
              bw1=f(bg.network.layers[2].weight), bw2=f(bg.network.layers[4].weight))
+    tm = {}
+    t0 = time.perf_counter()
+    out, ctx = R.forward(P)
+    tm["render_fwd"] = time.perf_counter() - t0
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    R.backward(P, ctx, d_comp_rgb=rng.normal(size=(4096, 3)).astype(np.float32), d_opacity=rng.normal(size=(4096, 1)).astype(np.float32))
+    tm["render_bwd"] = time.perf_counter() - t0
     ucfg, vcfg = W.UNetConfig(), W.VAEConfig()
     layout = W.unet_layout(ucfg)
     vshapes, vplan = W.vae_encoder_layout(vcfg)
-    wseed = guid.cfg.weights_seed
-    up, vp = W.gen_params(layout[0], wseed), W.gen_params(vshapes, wseed + 1)
-    pu = system.prompt_utils
-    el, az, cd = (batch[k].cpu() for k in ("elevation", "azimuth", "camera_distances"))
-    cpu_pu = type(pu)(pu.text_embeddings_vd.cpu(), pu.uncond_text_embeddings_vd.cpu(), front_threshold=pu.front_threshold,
-                      back_threshold=pu.back_threshold)
-    temb, negw = cpu_pu.get_text_embeddings_perp_neg(el, az, cd, True)
-    temb = torch.cat([temb[0:1], temb[1:2], temb[2:4], temb[0:1]], 0)
-    negw = negw * -1 * guid.cfg.guidance_perp_neg
+    up, vp = W.gen_params(layout[0], guid.cfg.weights_seed), W.gen_params(vshapes, guid.cfg.weights_seed + 1)
     g = torch.Generator().manual_seed(seed)
-    noise = torch.randn(1, 4, 64, 64, generator=g)
-    t = torch.randint(guid.min_step, guid.max_step + 1, (1,), generator=g)
-    t_plus = (t + (0.1 * (t - guid.min_step)).long()).clamp(1, 999)
-    timings = {}
+    x, ctx_e = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 1024, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        D.unet_forward(up, layout, ucfg, x, torch.tensor([700]), ctx_e)
+        tm["unet_fwd_b1"] = time.perf_counter() - t0
+    img = torch.rand(1, 3, 256, 256, generator=g).requires_grad_(True)
     t0 = time.perf_counter()
-    ref_step.asd_step(P, up, layout, ucfg, vp, vplan, temb, negw, noise, t, t_plus, torch.randn(1, 4, 64, 64, generator=g),
-                      timings=timings)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 full asd_sd_nerf step (4096 rays x 512 spp render fwd+bwd, VAE 512^2 fwd+bwd, UNet batch 5), "
-                      "oracle C/OpenMP renderer + torch fp32 diffusion, weight generation excluded",
-            "seconds": round(dt, 2), "phases_s": {k: round(v, 3) for k, v in timings.items()}}
+    m = D.vae_encode_moments(vp, vplan, img * 2 - 1)
+    tm["vae_fwd_256"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.sum().backward()
+    tm["vae_bwd_256"] = time.perf_counter() - t0
+    est = tm["render_fwd"] + tm["render_bwd"] + 5 * tm["unet_fwd_b1"] + 4 * (tm["vae_fwd_256"] + tm["vae_bwd_256"])
+    return {"value": round(1.0 / est, 5), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "full render fwd+bwd (4096 rays x 512 spp) + 1 of 5 UNet evaluations (x5) + VAE fwd+input-grad at 256^2 (x4); "
+                      "oracle C/OpenMP renderer + torch fp32 diffusion; weight generation excluded",
+            "estimated_step_seconds": round(est, 2), "measured_seconds": round(sum(tm.values()), 2),
+            "host_cores_available": os.cpu_count(), "phases_s": {k: round(v, 3) for k, v in tm.items()}}
 
 
 def main():

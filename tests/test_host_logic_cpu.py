@@ -1,0 +1,103 @@
+"""Host-side mirror of the reference's interfaces: registry, structured configs, schedules, camera sampler,
+module / state-dict layout.  No GPU."""
+import math
+
+import pytest
+import torch
+
+
+def test_registry_semantics():
+    from scaledreamer_amd.registry import __modules__, find, register
+    import scaledreamer_amd.plugins  # noqa: F401
+
+    for name in ["implicit-volume", "no-material", "neural-environment-map-background", "nerf-volume-renderer",
+                 "stable-diffusion-asynchronous-score-distillation-guidance", "random-camera-datamodule", "scaledreamer-system"]:
+        assert name in __modules__
+    with pytest.raises(ValueError):
+        register("implicit-volume")(object)
+    mixed = find("no-material:implicit-volume")
+    assert mixed.__mro__[1] is __modules__["implicit-volume"]
+
+
+def test_structured_config_rejects_unknown_keys_and_schedules():
+    from scaledreamer_amd.config import C, parse_structured
+    from scaledreamer_amd.renderer import NeRFVolumeRenderer
+
+    with pytest.raises(KeyError):
+        parse_structured(NeRFVolumeRenderer.Config, {"radius": 1.0, "not_a_field": 3})
+    cfg = parse_structured(NeRFVolumeRenderer.Config, {"radius": 2.0})
+    assert cfg.radius == 2.0 and cfg.num_samples_per_ray == 512 and cfg.estimator == "occgrid"
+    assert C([0, 0.5, 0.02, 25000], 0, 12500) == pytest.approx(0.26)
+    assert C([10000, 0.0, 100.0, 10001], 0, 9999) == 0.0 and C([10000, 0.0, 100.0, 10001], 0, 10001) == 100.0
+    assert C(3.5, 0, 0) == 3.5
+
+
+def test_yaml_loader_resolves_interpolations():
+    from scaledreamer_amd.config import load_config
+
+    y = """
+name: x
+tag: "${rmspace:${system.prompt},_}"
+system:
+  prompt: "a b c"
+  geometry: {radius: 1.5}
+  renderer: {radius: "${system.geometry.radius}"}
+trainer: {max_steps: 100}
+checkpoint: {every: "${trainer.max_steps}"}
+"""
+    cfg = load_config(y, from_string=True, cli_args=["system.geometry.radius=2.0"])
+    assert cfg.tag == "a_b_c" and cfg.system.renderer.radius == 2.0 and cfg.checkpoint.every == 100
+    with pytest.raises(ValueError):
+        load_config("a: ???", from_string=True)
+
+
+def test_camera_batch_matches_reference_layout():
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.data import RandomCameraIterableDataset
+
+    torch.manual_seed(0)
+    ds = RandomCameraIterableDataset(presets.asd_sd_nerf()["data"])
+    b = ds.collate()
+    assert b["rays_o"].shape == (1, 64, 64, 3) and b["rays_d"].shape == (1, 64, 64, 3) and b["c2w"].shape == (1, 4, 4)
+    torch.testing.assert_close(b["rays_d"].norm(dim=-1), torch.ones(1, 64, 64))
+    assert -10 <= float(b["elevation"]) <= 45 and 1.0 <= float(b["camera_distances"]) <= 1.5
+    torch.testing.assert_close(b["rays_o"][0, 0, 0], b["camera_positions"][0])
+    # the camera looks at the origin: the central ray passes within half a pixel of it
+    mid = b["rays_d"][0, 31:33, 31:33].mean(dim=(0, 1))
+    d = torch.nn.functional.normalize(-b["camera_positions"][0], dim=0)
+    assert float((torch.nn.functional.normalize(mid, dim=0) * d).sum()) > 0.999
+    ds.update_step(0, 10000)
+    assert ds.collate()["rays_o"].shape == (1, 256, 256, 3)                # resolution milestone (asd_sd_nerf.yaml:11-13)
+
+
+def test_module_and_state_dict_layout_is_the_references():
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.registry import find
+    import scaledreamer_amd.plugins  # noqa: F401
+
+    sysc = presets.asd_sd_nerf()["system"]
+    geo = find("implicit-volume")(sysc["geometry"])
+    bg = find("neural-environment-map-background")(sysc["background"])
+    mat = find("no-material")(sysc["material"])
+    ren = find("nerf-volume-renderer")(sysc["renderer"], geometry=geo, material=mat, background=bg)
+    assert set(geo.state_dict()) == {"bbox", "encoding.encoding.encoding.params", "density_network.layers.0.weight",
+                                     "density_network.layers.2.weight", "feature_network.layers.0.weight",
+                                     "feature_network.layers.2.weight"}
+    assert geo.encoding.encoding.encoding.params.numel() == 12_599_920
+    assert bg.encoding.encoding.encoding.params.numel() == 1_581_184
+    assert set(bg.state_dict()) == {"encoding.encoding.encoding.params", "network.layers.0.weight", "network.layers.2.weight",
+                                    "network.layers.4.weight"}
+    assert {"bbox", "estimator.occs", "estimator.binaries", "estimator.aabbs", "estimator.resolution"} <= set(ren.state_dict())
+    assert sum(p.numel() for p in geo.parameters()) + sum(p.numel() for p in bg.parameters()) == 14_185_888  # 56.7 MB all-reduce payload
+    assert ren.render_step_size == pytest.approx(1.732 * 2 / 512)
+    with pytest.raises(NotImplementedError):
+        find("nerf-volume-renderer")({"estimator": "proposal"}, geometry=geo, material=mat, background=bg)
+
+
+def test_hip_path_fails_loudly_without_a_gpu():
+    """No CPU fallback: asking the HIP ops for CPU tensors raises instead of silently computing elsewhere."""
+    from scaledreamer_amd import _lib, ops
+
+    m = _lib.make_grid_meta(16, 2, 19, 16, 1.447269237440378)
+    with pytest.raises(_lib.AsdError):
+        ops.hashgrid_fwd(m, torch.zeros(m.n_params), torch.zeros(4, 3))
