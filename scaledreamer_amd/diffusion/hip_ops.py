@@ -30,9 +30,9 @@ def pick_split_k(M: int, N: int, K: int) -> int:
     """fill the 256 CUs when the output has few 128x128 tiles and the reduction is long (low-resolution layers)."""
     bn = 128 if N % 128 == 0 else 64
     tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
-    if tiles >= 192 or K < 1024:
+    if tiles >= 256 or K < 1024:
         return 1
-    s = min(16, max(1, 512 // tiles), K // 512)
+    s = min(16, max(1, 640 // tiles), K // 512)
     return max(1, s)
 
 
