@@ -53,6 +53,32 @@ def to_device(batch, dev):
     return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
+def roofline_gemm_kernel(reps: int = 30):
+    """The dominant kernel of the step (rocprofv3: gemm_f16_kernel, conv mode, ~25 % of the step time): average
+    duration of one launch measured with HIP events on the launch stream, on the most frequent heavy shape of the
+    step — the 3x3 convolution 320->320 at 64x64 for the UNet batch of 5 (M=20480, N=320, K=2880).
+    Algorithmic flops per launch = 2*M*N*K."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    B, hw, cin, cout = 5, 64, 320, 320
+    x = torch.randn(B, hw, hw, cin, device="cuda").half()
+    w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * 0.02)
+    for _ in range(5):
+        H.conv3x3(x, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        H.conv3x3(x, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * B * hw * hw * cout * cin * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_f16_kernel<256,64,conv> (3x3 conv 320->320 @64x64, batch 5)", "bound": "mfma",
+            "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
+            "traffic": None, "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+
+
 def roofline_field_kernel(system, batch, reps: int = 20):
     """Average duration (HIP events on the launch stream) of the dominant hand-written renderer kernel,
     field_fwd_kernel, on the live samples of one step; algorithmic bytes per DESIGN.md / SURVEY.md §8d."""
@@ -201,7 +227,8 @@ def main():
                        "diffusion_backend": args.backend, "diffusion_weights": "seeded random init"},
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
         }
-        out["roofline"] = roofline_field_kernel(system, batch)
+        out["roofline"] = roofline_gemm_kernel()
+        out["roofline_renderer"] = roofline_field_kernel(system, batch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, batch, seed=10)
         print(json.dumps(out), flush=True)

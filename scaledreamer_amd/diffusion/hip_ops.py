@@ -32,7 +32,8 @@ def pick_split_k(M: int, N: int, K: int) -> int:
     tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     if tiles >= 256 or K < 1024:
         return 1
-    s = min(16, max(1, 640 // tiles), K // 512)
+    target = 512 if tiles <= 128 else 640
+    s = min(16, max(1, target // tiles), K // 512)
     return max(1, s)
 
 
