@@ -153,4 +153,67 @@ __device__ __forceinline__ void asd_scatter(const asd_grid_meta& m, float* __res
         }
     }
 }
+// Scatter with wave-level run aggregation.  Samples are packed ray-major / t-ascending, so on the coarse
+// levels consecutive lanes of a wave fall into the same grid cell (run length ~ cell size / march step: ~18 on
+// level 0, ~1.4 on level 7) and would hit the same 8 table entries with 16 atomics each.  gfx950 sustains only
+// ~21 G fp32 atomics/s (3.6 G/s on a hot address set, tools/atomic_probe.hip), so for levels < NAGG the per-corner
+// contributions of a run are first summed across its lanes (segmented shuffle reduction on the run id) and only
+// the run's first lane issues the atomics.  Must be called by all 64 lanes (inactive lanes pass active=false).
+template <int L, int NAGG>
+__device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* __restrict__ dparams, float x, float y,
+                                                 float z, const float (&denc)[2 * L], bool active) {
+    x = asd_unit(x); y = asd_unit(y); z = asd_unit(z);
+    const int lane = asd_lane();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float g0 = active ? denc[2 * l] : 0.f, g1 = active ? denc[2 * l + 1] : 0.f;
+        const float s = m.scale[l];
+        const float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f), pz = fmaf(s, z, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l];
+        if (l < NAGG) {
+            const uint32_t res = m.resolution[l];
+            const uint32_t key = active ? cx + (cy + cz * res) * res : 0xFFFFFFFFu - (uint32_t)lane;
+            const uint32_t prev = __shfl_up(key, 1, 64);
+            const bool head = lane == 0 || prev != key;
+            const unsigned long long hm = __ballot(head);
+            const int rid = __popcll(hm & (~0ull >> (63 - lane)));   // heads at or below this lane = run id
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+                v[2 * c] = wt * g0;
+                v[2 * c + 1] = wt * g1;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int prid = __shfl_down(rid, o, 64);
+                const bool ok = (lane + o < 64) && prid == rid;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float u = __shfl_down(v[q], o, 64);
+                    v[q] += ok ? u : 0.f;
+                }
+            }
+            if (head && active) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
+                    if (v[2 * c] != 0.f) atomicAdd(tab + 2u * (size_t)idx, v[2 * c]);
+                    if (v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
+                }
+            }
+        } else if (active && (g0 != 0.f || g1 != 0.f)) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+                const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
+                atomicAdd(tab + 2u * (size_t)idx, wt * g0);
+                atomicAdd(tab + 2u * (size_t)idx + 1, wt * g1);
+            }
+        }
+    }
+}
 #endif  // __HIPCC__

@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                 if (active) *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
-        if (active)
-            asd_scatter<L>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, denc);
+        asd_scatter_runs<L, 8>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, denc,
+                               active);
     }
     __syncthreads();
     for (int q = tid; q < H; q += 256) atomicAdd(&dw2d[q], w2_acc[q]);
