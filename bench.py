@@ -181,6 +181,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    # the host side of a step is ~60 tiny CPU tensor ops (camera sampling): with torch's default of one OpenMP
+    # thread per core (256 on the GPU box) every one of them pays a fork/join; keep the host path single-threaded
+    torch.set_num_threads(1)
     if world > 1:
         asd_dist.init_from_env("nccl")
     dev = torch.device("cuda", local_rank)
@@ -212,6 +215,28 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    phases = None
+    if args.phases and rank == 0:
+        # untimed extra steps with events around the phases of train_one_step (adds host syncs: not part of `value`)
+        def ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        acc = {}
+        for _ in range(5):
+            b = to_device(data.collate(), dev)
+            e0 = ev(); system.on_train_batch_start(); system.optimizer.zero_grad(set_to_none=True)
+            e1 = ev(); out_r = system(b)
+            e2 = ev(); g_out = system.guidance(out_r["comp_rgb"], system.prompt_utils, **b)
+            loss_p = g_out["loss_asd"] + 30.0 * (out_r["opacity"] ** 2 + 0.01).sqrt().mean()
+            e3 = ev(); loss_p.backward()
+            e4 = ev(); asd_dist.allreduce_mean_grads(system.optimizer); system.optimizer.step(); system.true_global_step += 1
+            e5 = ev(); torch.cuda.synchronize()
+            for k, (a, b_) in {"update_hooks": (e0, e1), "render_fwd": (e1, e2), "vae_fwd+unet_x5+asd": (e2, e3),
+                               "backward(vae+render)": (e3, e4), "allreduce+adamw": (e4, e5)}.items():
+                acc[k] = acc.get(k, 0.0) + a.elapsed_time(b_) / 5
+        phases = {k: round(v, 3) for k, v in acc.items()}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         steps_per_s = world * args.steps / dt
@@ -227,6 +252,8 @@ def main():
                        "diffusion_backend": args.backend, "diffusion_weights": "seeded random init"},
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
         }
+        if phases:
+            out["phases_ms"] = phases
         out["roofline"] = roofline_gemm_kernel()
         out["roofline_renderer"] = roofline_field_kernel(system, batch)
         if world == 1 and not args.no_cpu_baseline:

@@ -77,10 +77,12 @@ class _LinearFn(torch.autograd.Function):
 
 
 class HipVAEEncoder:
-    def __init__(self, params: P, cfg: Optional[W.VAEConfig] = None, device="cuda"):
+    def __init__(self, params: P, cfg: Optional[W.VAEConfig] = None, device="cuda", use_graph: bool = False):
         self.cfg = cfg or W.VAEConfig()
         self.device = torch.device(device)
         self.shapes, self.plan = W.vae_encoder_layout(self.cfg)
+        self.use_graph = use_graph
+        self._graphed = {}
         self._pack(params)
 
     def _pack(self, p: P):
@@ -130,7 +132,18 @@ class HipVAEEncoder:
         self.w = w
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
-        """images [B,3,H,W] in [-1,1] (any float dtype, may require grad) -> moments [B, 2*embed_dim, H/8, W/8] fp32."""
+        """images [B,3,H,W] in [-1,1] (may require grad) -> moments [B, 2*embed_dim, H/8, W/8] fp32.
+        use_graph (off by default: measured 9.14 vs 9.17 ms per fwd+bwd at 512^2, the encoder is GPU-bound) captures the
+        forward and the input-gradient pass into two HIP graphs (torch.cuda.make_graphed_callables)."""
+        if self.use_graph and images.is_cuda and images.requires_grad and images.dtype == torch.float32 and torch.is_grad_enabled():
+            key = tuple(images.shape)
+            if key not in self._graphed:
+                sample = torch.zeros(key, device=images.device, dtype=torch.float32).uniform_(-1, 1).requires_grad_(True)
+                self._graphed[key] = torch.cuda.make_graphed_callables(self._forward, (sample,))
+            return self._graphed[key](images.contiguous())
+        return self._forward(images)
+
+    def _forward(self, images: torch.Tensor) -> torch.Tensor:
         w = self.w
         B, Cin, Hh, Ww = images.shape
         x = F.pad(images.permute(0, 2, 3, 1), (0, 32 - Cin)).to(torch.float16).contiguous()   # NHWC, channels padded to 32

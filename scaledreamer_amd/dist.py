@@ -70,4 +70,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     if not is_distributed():
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+        if t.numel() == 0:
+            continue
+        if t.dtype == torch.bool:  # e.g. the occupancy grid's `binaries`
+            u = t.data.to(torch.uint8)
+            dist.broadcast(u, src=src)
+            t.data.copy_(u.bool())
+        else:
+            dist.broadcast(t.data, src=src)
