@@ -27,14 +27,13 @@ P = Dict[str, torch.Tensor]
 class HipUNet:
     def __init__(self, params: P, cfg: Optional[W.UNetConfig] = None, device="cuda", use_graph: bool = True):
         self.cfg = cfg or W.UNetConfig()
-        if self.cfg.camera_dim is not None:
-            raise NotImplementedError("MVDream (camera-conditioned, cross-view attention) UNet: next round")
         if self.cfg.num_head_channels != 64:
             raise NotImplementedError("the attention kernel is built for head_dim 64")
         self.device = torch.device(device)
         self.shapes, self.inputs, self.middle, self.outputs = W.unet_layout(self.cfg)
         self.use_graph = use_graph
         self._graphs: Dict[Tuple, Tuple] = {}
+        self._num_frames = 1
         self._pack(params)
 
     # ---- weight packing ---------------------------------------------------------------------------
@@ -92,6 +91,7 @@ class HipUNet:
     def _transformer(self, name, x, ctx_pad, B, hw, n_ctx, ctx_stride):
         w = self.w
         L = hw[0] * hw[1]
+        F_ = self._num_frames  # MVDream: self-attention spans the F views of a group (attention.py:348-354)
         C = x.shape[-1]
         heads = C // 64
         h = H.groupnorm(x.view(B, L, C), w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-6, False).view(B * L, C)
@@ -101,7 +101,7 @@ class HipUNet:
             y = H.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
             qk = H.gemm(y, w[b + ".attn1.to_qk.weight"])                       # [M, 2C]
             vT = H.gemm(w[b + ".attn1.to_v.weight"], y)                         # [C, M] = V^T (operands swapped)
-            o = H.attention(qk[:, :C], qk[:, C:], vT, B, heads, L, L)
+            o = H.attention(qk[:, :C], qk[:, C:], vT, B // F_, heads, F_ * L, F_ * L)
             h = H.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], residual=h)
             y = H.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
             q = H.gemm(y, w[b + ".attn2.to_q.weight"])
@@ -134,12 +134,16 @@ class HipUNet:
         return h, hw
 
     # ---- forward ------------------------------------------------------------------------------------------
-    def _forward_impl(self, x_nhwc32: torch.Tensor, t: torch.Tensor, ctx_pad: torch.Tensor, n_ctx: int, ctx_stride: int):
+    def _forward_impl(self, x_nhwc32: torch.Tensor, t: torch.Tensor, ctx_pad: torch.Tensor, n_ctx: int, ctx_stride: int,
+                      camera: Optional[torch.Tensor] = None):
         cfg, w = self.cfg, self.w
         B, Hh, Ww, _ = x_nhwc32.shape
         t_emb = H.timestep_embedding(t, cfg.model_channels)
         e = H.gemm(t_emb, w["time_embed.0.weight"], bias=w["time_embed.0.bias"], act=1)
         e = H.gemm(e, w["time_embed.2.weight"], bias=w["time_embed.2.bias"])
+        if camera is not None:  # MultiViewUNetModel: emb += camera_embed(camera)  (openaimodel.py:1197-1200)
+            c = H.gemm(camera, w["camera_embed.0.weight"], bias=w["camera_embed.0.bias"], act=1)
+            e = H.gemm(c, w["camera_embed.2.weight"], bias=w["camera_embed.2.bias"], residual=e)
         emb_all = H.gemm(H.silu(e), w["emb_all.weight"], bias=w["emb_all.bias"])     # every ResBlock's emb_layers at once
         hs: List[Tuple[torch.Tensor, Tuple[int, int]]] = []
         h, hw = x_nhwc32.reshape(B * Hh * Ww, 32), (Hh, Ww)
@@ -157,31 +161,34 @@ class HipUNet:
         return out  # [B, H, W, out_channels] fp32
 
     @torch.no_grad()
-    def __call__(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
-        """x [N,4,H,W], t [N], context [N,n_ctx,1024] -> eps [N,4,H,W] (dtype of x)."""
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, camera: Optional[torch.Tensor] = None,
+                 num_frames: int = 1) -> torch.Tensor:
+        """x [N,4,H,W], t [N], context [N,n_ctx,ctx_dim] (+ camera [N,16], num_frames for MVDream) -> eps [N,4,H,W]."""
         N, Cin, Hh, Ww = x.shape
+        assert N % num_frames == 0, "[UNet] input batch size must be dividable by num_frames!"
+        assert (camera is not None) == (self.cfg.camera_dim is not None), "camera is given iff the UNet is camera-conditioned"
+        self._num_frames = num_frames if self.cfg.camera_dim is not None else 1
         n_ctx = context.shape[1]
         ctx_stride = (n_ctx + 7) // 8 * 8
-        key = (N, Hh, Ww, n_ctx)
+        key = (N, Hh, Ww, n_ctx, self._num_frames)
         if not self.use_graph:
-            xin, tin, cin = self._stage_inputs(x, t, context, ctx_stride)
-            return self._forward_impl(xin, tin, cin, n_ctx, ctx_stride).permute(0, 3, 1, 2).to(x.dtype)
+            xin, tin, cin, cam = self._stage_inputs(x, t, context, ctx_stride, camera)
+            return self._forward_impl(xin, tin, cin, n_ctx, ctx_stride, cam).permute(0, 3, 1, 2).to(x.dtype)
         if key not in self._graphs:
-            xin = torch.zeros((N, Hh, Ww, 32), device=self.device, dtype=torch.float16)
-            tin = torch.zeros(N, device=self.device, dtype=torch.float32)
-            cin = torch.zeros((N * ctx_stride, context.shape[2]), device=self.device, dtype=torch.float16)
-            self._write_inputs(xin, tin, cin, x, t, context, ctx_stride)
+            xin, tin, cin, cam = self._stage_inputs(x, t, context, ctx_stride, camera)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):            # warm-up outside the capture (allocator, lazy module load)
-                self._forward_impl(xin, tin, cin, n_ctx, ctx_stride)
+                self._forward_impl(xin, tin, cin, n_ctx, ctx_stride, cam)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._forward_impl(xin, tin, cin, n_ctx, ctx_stride)
-            self._graphs[key] = (g, xin, tin, cin, out)
-        g, xin, tin, cin, out = self._graphs[key]
+                out = self._forward_impl(xin, tin, cin, n_ctx, ctx_stride, cam)
+            self._graphs[key] = (g, xin, tin, cin, cam, out)
+        g, xin, tin, cin, cam, out = self._graphs[key]
         self._write_inputs(xin, tin, cin, x, t, context, ctx_stride)
+        if cam is not None:
+            cam.copy_(camera)
         g.replay()
         return out.permute(0, 3, 1, 2).to(x.dtype)
 
@@ -191,13 +198,14 @@ class HipUNet:
         tin.copy_(t)
         cin.view(N, ctx_stride, -1)[:, :context.shape[1]].copy_(context)
 
-    def _stage_inputs(self, x, t, context, ctx_stride):
+    def _stage_inputs(self, x, t, context, ctx_stride, camera=None):
         N, _, Hh, Ww = x.shape
         xin = torch.zeros((N, Hh, Ww, 32), device=self.device, dtype=torch.float16)
         tin = torch.zeros(N, device=self.device, dtype=torch.float32)
         cin = torch.zeros((N * ctx_stride, context.shape[2]), device=self.device, dtype=torch.float16)
         self._write_inputs(xin, tin, cin, x, t, context, ctx_stride)
-        return xin, tin, cin
+        cam = None if camera is None else camera.to(device=self.device, dtype=torch.float16).contiguous().clone()
+        return xin, tin, cin, cam
 
 
 class HipBackend(DiffusionBackend):

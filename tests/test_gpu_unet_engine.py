@@ -72,3 +72,29 @@ def test_full_sd21_unet_matches_reference_golden():
     for i in range(5):
         l2, mx = _rel(got5[i:i + 1], torch.from_numpy(g["eps"]))
         assert l2 < 1e-2 and mx < 1e-2, (i, l2, mx)
+
+
+def test_mvdream_unet_matches_oracle():
+    """MultiViewUNetModel (openaimodel.py:811-1213): camera embedding + self-attention across the 4 views of a group
+    (BasicTransformerBlock3D, attention.py:343-354); the oracle is pinned by tests/golden/diffusion_mvunet_small.npz."""
+    from oracle import diffusion_ref as D
+    from scaledreamer_amd.diffusion import weights as W
+    from scaledreamer_amd.diffusion.engine import HipUNet
+
+    cfg = W.UNetConfig(model_channels=128, num_head_channels=64, context_dim=128, camera_dim=16)
+    layout = W.unet_layout(cfg)
+    p = W.gen_params(layout[0], seed=31)
+    B, F_ = 8, 4
+    x, ctx, cam = rnd("in.x", (B, 4, 16, 16), 31), rnd("in.context", (B, 77, 128), 31), rnd("in.camera", (B, 16), 31)
+    t = torch.tensor([700.0] * 4 + [910.0] * 4)                     # one shared t per 4-view group
+    with torch.no_grad():
+        ref = D.unet_forward(p, layout, cfg, x, t, ctx, camera=cam, num_frames=F_)
+    eng = HipUNet(p, cfg, "cuda", use_graph=True)
+    for _ in range(2):
+        got = eng(x.cuda(), t.cuda(), ctx.cuda(), camera=cam.cuda(), num_frames=F_)
+        l2, mx = _rel(got, ref)
+        assert l2 < 1e-2 and mx < 1e-2, (l2, mx)
+    # the views must really be coupled: permuting frames inside a group changes the result of frame 0
+    perm = torch.tensor([1, 0, 2, 3, 4, 5, 6, 7])
+    got_p = eng(x[perm].cuda(), t.cuda(), ctx[perm].cuda(), camera=cam[perm].cuda(), num_frames=F_)
+    assert _rel(got_p[1:2], ref[0:1])[0] < 1e-2
