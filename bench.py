@@ -29,14 +29,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F16_PEAK_TF = 2500.0  # dense bf16/f16 MFMA
 
 
-def build_system(backend: str, seed: int):
+def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     from scaledreamer_amd import presets
-    from scaledreamer_amd.data import RandomCameraIterableDataset
+    from scaledreamer_amd.data import RandomCameraIterableDataset, RandomMultiviewCameraIterableDataset
     from scaledreamer_amd.guidance import PromptUtils
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
 
-    cfg = presets.asd_sd_nerf(guidance_backend=backend)
+    mv = workload == "asd_mv_nerf"
+    cfg = presets.asd_mv_nerf() if mv else presets.asd_sd_nerf(guidance_backend=backend)
     torch.manual_seed(seed)
     random.seed(seed)
     pp = cfg["system"]["prompt_processor"]
@@ -45,7 +46,7 @@ def build_system(backend: str, seed: int):
                                          back_threshold=pp["back_threshold"])
     system = find(cfg["system_type"])(cfg["system"], prompt_utils=prompt_utils)
     system.train()
-    data = RandomCameraIterableDataset(cfg["data"])
+    data = (RandomMultiviewCameraIterableDataset if mv else RandomCameraIterableDataset)(cfg["data"])
     return cfg, system, data
 
 
@@ -170,6 +171,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default=os.environ.get("ASD_BACKEND", "hip"), choices=["hip", "eager"])
+    ap.add_argument("--workload", default="asd_sd_nerf", choices=["asd_sd_nerf", "asd_mv_nerf"],
+                    help="asd_sd_nerf = BASELINE configs[1] (the headline metric); asd_mv_nerf = SURVEY C3 (MVDream, 4 views), secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also report per-phase milliseconds (adds syncs; untimed extra steps)")
     args = ap.parse_args()
@@ -189,7 +192,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # per-rank seed = cfg.seed + rank (launch.py:171): different cameras / noise / t per rank
-    cfg, system, data = build_system(args.backend, seed=10 + rank)
+    cfg, system, data = build_system(args.backend, seed=10 + rank, workload=args.workload)
     asd_dist.broadcast_parameters(system)  # identical initial parameters (DDP wrap-time broadcast)
 
     def step():
@@ -252,11 +255,16 @@ def main():
                        "diffusion_backend": args.backend, "diffusion_weights": "seeded random init"},
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
         }
+        if args.workload == "asd_mv_nerf":  # secondary line (not BASELINE's metric): 4 views / step / GPU
+            out.update({"metric": "ASD train steps/sec (4 views x 64x64 render, MVDream)", "rays_per_sec": round(steps_per_s * 16384, 1)})
+            out["config"].update({"workload": "asd_mv_nerf: 4 views/GPU, 4x64x64 rays, 256 spp occgrid march, implicit-volume iNGP, MVDream "
+                                              "UNet batch 12 @32x32 latents (CFG + shifted t, cross-view attention), VAE 4x256^2 fwd+bwd, AdamW",
+                                  "views_per_gpu": 4})
         if phases:
             out["phases_ms"] = phases
         out["roofline"] = roofline_gemm_kernel()
         out["roofline_renderer"] = roofline_field_kernel(system, batch)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":
             out["cpu_baseline"] = cpu_baseline(system, batch, seed=10)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -171,3 +171,85 @@ class RandomCameraIterableDataset(Updateable):
                 "camera_positions": camera_positions, "c2w": c2w, "light_positions": light_positions,
                 "elevation": elevation_deg, "azimuth": azimuth_deg, "camera_distances": camera_distances,
                 "height": self.height, "width": self.width, "fovy": fovy, "proj_mtx": proj_mtx}
+
+
+@dataclass
+class RandomMultiviewCameraDataModuleConfig(RandomCameraDataModuleConfig):
+    relative_radius: bool = True
+    n_view: int = 1
+    zoom_range: Tuple[float, float] = (1.0, 1.0)
+
+
+@register("mvdream-random-multiview-camera-datamodule")
+class RandomMultiviewCameraIterableDataset(RandomCameraIterableDataset):
+    """threestudio/data/uncond_multiview.py:29-255: groups of `n_view` cameras sharing elevation / fovy / distance /
+    perturbations / light, azimuths spread evenly over the range; distance relative to 1/tan(fovy/2).  The order of
+    the RNG draws is the reference's (elevation, azimuth, fovy, distance, zoom, perturbs, light)."""
+
+    def __init__(self, cfg: Any) -> None:
+        cfg_mv = parse_structured(RandomMultiviewCameraDataModuleConfig, cfg)
+        super().__init__({k: getattr(cfg_mv, k) for k in RandomCameraDataModuleConfig.__dataclass_fields__})
+        self.cfg = cfg_mv
+        self.zoom_range = list(self.cfg.zoom_range)
+
+    def collate(self, batch=None) -> Dict[str, Any]:
+        c, V = self.cfg, self.cfg.n_view
+        assert self.batch_size % V == 0, f"batch_size ({self.batch_size}) must be dividable by n_view ({V})!"
+        R, B = self.batch_size // V, self.batch_size
+        rep = lambda v: v.repeat_interleave(V, dim=0)
+        if random.random() < 0.5:
+            elevation_deg = rep(torch.rand(R) * (self.elevation_range[1] - self.elevation_range[0]) + self.elevation_range[0])
+            elevation = elevation_deg * math.pi / 180
+        else:
+            lo, hi = ((v + 90.0) / 180.0 for v in self.elevation_range)
+            elevation = rep(torch.asin(2 * (torch.rand(R) * (hi - lo) + lo) - 1.0))
+            elevation_deg = elevation / math.pi * 180.0
+        azimuth_deg = (torch.rand(R).reshape(-1, 1) + torch.arange(V).reshape(1, -1)).reshape(-1) / V * (
+            self.azimuth_range[1] - self.azimuth_range[0]) + self.azimuth_range[0]
+        azimuth = azimuth_deg * math.pi / 180
+        fovy_deg = rep(torch.rand(R) * (self.fovy_range[1] - self.fovy_range[0]) + self.fovy_range[0])
+        fovy = fovy_deg * math.pi / 180
+        camera_distances = rep(torch.rand(R) * (self.camera_distance_range[1] - self.camera_distance_range[0]) + self.camera_distance_range[0])
+        if c.relative_radius:
+            camera_distances = 1 / torch.tan(0.5 * fovy) * camera_distances
+        zoom = rep(torch.rand(R) * (self.zoom_range[1] - self.zoom_range[0]) + self.zoom_range[0])
+        fovy, fovy_deg = fovy * zoom, fovy_deg * zoom
+        camera_positions = torch.stack([camera_distances * torch.cos(elevation) * torch.cos(azimuth),
+                                        camera_distances * torch.cos(elevation) * torch.sin(azimuth),
+                                        camera_distances * torch.sin(elevation)], dim=-1)
+        center = torch.zeros_like(camera_positions)
+        up = torch.as_tensor([0, 0, 1], dtype=torch.float32)[None, :].repeat(B, 1)
+        camera_positions = camera_positions + rep(torch.rand(R, 3) * 2 * c.camera_perturb - c.camera_perturb)
+        center = center + rep(torch.randn(R, 3) * c.center_perturb)
+        up = up + rep(torch.randn(R, 3) * c.up_perturb)
+        light_distances = rep(torch.rand(R) * (c.light_distance_range[1] - c.light_distance_range[0]) + c.light_distance_range[0])
+        if c.light_sample_strategy == "dreamfusion":
+            light_direction = F.normalize(camera_positions + rep(torch.randn(R, 3)) * c.light_position_perturb, dim=-1)
+            light_positions = light_direction * light_distances[:, None]
+        elif c.light_sample_strategy == "magic3d":
+            local_z = F.normalize(camera_positions, dim=-1)
+            local_x = F.normalize(torch.stack([local_z[:, 1], -local_z[:, 0], torch.zeros_like(local_z[:, 0])], dim=-1), dim=-1)
+            local_y = F.normalize(torch.cross(local_z, local_x, dim=-1), dim=-1)
+            rot = torch.stack([local_x, local_y, local_z], dim=-1)
+            la = rep(torch.rand(R) * math.pi - 2 * math.pi)      # (sic) uncond_multiview.py:190-191
+            le = rep(torch.rand(R) * math.pi / 3 + math.pi / 6)
+            local = torch.stack([light_distances * torch.cos(le) * torch.cos(la), light_distances * torch.cos(le) * torch.sin(la),
+                                 light_distances * torch.sin(le)], dim=-1)
+            light_positions = (rot @ local[:, :, None])[:, :, 0]
+        else:
+            raise ValueError(f"Unknown light sample strategy: {c.light_sample_strategy}")
+        lookat = F.normalize(center - camera_positions, dim=-1)
+        right = F.normalize(torch.cross(lookat, up, dim=-1), dim=-1)
+        up = F.normalize(torch.cross(right, lookat, dim=-1), dim=-1)
+        c2w3x4 = torch.cat([torch.stack([right, up, -lookat], dim=-1), camera_positions[:, :, None]], dim=-1)
+        c2w = torch.cat([c2w3x4, torch.zeros_like(c2w3x4[:, :1])], dim=1)
+        c2w[:, 3, 3] = 1.0
+        focal_length = 0.5 * self.height / torch.tan(0.5 * fovy)
+        directions = self.directions_unit_focal[None].repeat(B, 1, 1, 1)
+        directions[:, :, :, :2] = directions[:, :, :, :2] / focal_length[:, None, None, None]
+        rays_o, rays_d = get_rays(directions, c2w, normalize=True)
+        proj_mtx = get_projection_matrix(fovy, self.width / self.height, 0.1, 1000.0)
+        return {"rays_o": rays_o, "rays_d": rays_d, "mvp_mtx": get_mvp_matrix(c2w, proj_mtx),
+                "camera_positions": camera_positions, "c2w": c2w, "light_positions": light_positions,
+                "elevation": elevation_deg, "azimuth": azimuth_deg, "camera_distances": camera_distances,
+                "height": self.height, "width": self.width, "fovy": fovy_deg}

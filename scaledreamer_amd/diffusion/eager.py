@@ -157,7 +157,9 @@ class EagerBackend(DiffusionBackend):
         self.dtype = dtype
 
     @torch.no_grad()
-    def unet(self, latents, t, context):
+    def unet(self, latents, t, context, camera=None, num_frames: int = 1):
+        if camera is not None:
+            raise NotImplementedError("the library-op backend covers the SD-2.1 UNet only")
         return unet_forward(self.up, self.unet_layout, self.unet_cfg, latents, t, context)
 
     def encode(self, images):

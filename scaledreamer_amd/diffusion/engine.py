@@ -228,8 +228,8 @@ class HipBackend(DiffusionBackend):
         self.hip_vae = HipVAEEncoder(vp, self.vae_cfg, device)
 
     @torch.no_grad()
-    def unet(self, latents, t, context):
-        return self.hip_unet(latents, t, context)
+    def unet(self, latents, t, context, camera=None, num_frames: int = 1):
+        return self.hip_unet(latents, t, context, camera=camera, num_frames=num_frames)
 
     def encode(self, images):
         return self.hip_vae(images)
@@ -238,3 +238,9 @@ class HipBackend(DiffusionBackend):
 @register_backend("hip")
 def _make_hip(cfg, device, dtype):
     return HipBackend(device, dtype, seed=getattr(cfg, "weights_seed", 1))
+
+
+@register_backend("hip-mvdream")
+def _make_hip_mvdream(cfg, device, dtype):
+    """MVDream: the SD-2.1 UNet with camera_dim = 16 (extern/mvdream/configs/sd-v2-base.yaml:13-27)."""
+    return HipBackend(device, dtype, seed=getattr(cfg, "weights_seed", 1), unet_cfg=W.UNetConfig(camera_dim=16))

@@ -116,7 +116,8 @@ class DiffusionBackend:
     """Frozen SD-2.1 prior. Implementations: scaledreamer_amd.diffusion.engine (HIP) and .eager (library ops)."""
     scaling_factor: float = 0.18215
 
-    def unet(self, latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+    def unet(self, latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, camera: Optional[torch.Tensor] = None,
+             num_frames: int = 1) -> torch.Tensor:
         raise NotImplementedError
 
     def encode(self, images: torch.Tensor) -> torch.Tensor:
@@ -291,3 +292,132 @@ class SDTimestepShiftedScoreDistillationGuidance(BaseObject):
             self.grad_clip_val = C(self.cfg.grad_clip, epoch, global_step)
         self.set_min_max_steps(min_step_percent=C(self.cfg.min_step_percent, epoch, global_step),
                                max_step_percent=C(self.cfg.max_step_percent, epoch, global_step))
+
+
+def normalize_camera(camera_matrix: torch.Tensor) -> torch.Tensor:
+    """extern/mvdream/camera_utils.py:45-57: camera location projected onto the unit sphere, flattened to [B,16]."""
+    cam = camera_matrix.reshape(-1, 4, 4).clone()
+    tr = cam[:, :3, 3]
+    cam[:, :3, 3] = tr / (torch.norm(tr, dim=1, keepdim=True) + 1e-8)
+    return cam.reshape(-1, 16)
+
+
+@register("mvdream-asynchronous-score-distillation-guidance")
+class MVDreamTimestepShiftedScoreDistillationGuidance(BaseObject):
+    """threestudio/models/guidance/mvdream_asd_guidance.py:26-304: 4-view groups share one timestep, the UNet batch is
+    [x_t | x_t | x_t+] with contexts [cond | uncond | cond], camera-conditioned with cross-view self-attention, plain CFG
+    (no Perp-Neg), VAE at 256x256 -> 32x32 latents."""
+
+    @dataclass
+    class Config(BaseObject.Config):
+        model_name: str = "sd-v2.1-base-4view"
+        ckpt_path: Optional[str] = None
+        grad_clip: Optional[Any] = None
+        half_precision_weights: bool = True
+        guidance_scale: float = 7.5
+        n_view: int = 4
+        min_step_percent: Any = 0.02
+        max_step_percent: Any = 0.98
+        weighting_strategy: str = "sds"
+        plus_ratio: float = 0.1
+        plus_random: bool = False
+        camera_condition_type: str = "rotation"
+        view_dependent_prompting: bool = False
+        backend: str = "hip-mvdream"
+        weights_seed: int = 1
+
+    cfg: Config
+
+    def configure(self, backend: Optional[DiffusionBackend] = None) -> None:
+        info("Loading Multiview Diffusion ...")
+        if backend is None:
+            if self.cfg.backend not in _BACKEND_FACTORY:
+                from .diffusion import backends  # noqa: F401
+            backend = _BACKEND_FACTORY[self.cfg.backend](self.cfg, self.device, torch.float16)
+        self.backend = backend
+        self.num_train_timesteps = 1000
+        self.alphas = ddpm_alphas_cumprod(self.num_train_timesteps).to(self.device)
+        min_p = self.cfg.min_step_percent if isinstance(self.cfg.min_step_percent, (int, float)) else 0.02
+        max_p = self.cfg.max_step_percent if isinstance(self.cfg.max_step_percent, (int, float)) else 0.98
+        self.min_step, self.max_step = int(self.num_train_timesteps * min_p), int(self.num_train_timesteps * max_p)
+        self.grad_clip_val: Optional[float] = None
+        self.noise_fn = torch.randn_like
+        self.timestep_fn = lambda lo, hi, n, device: torch.randint(lo, hi, [n], dtype=torch.long, device=device)
+        self.rand_fn = lambda shape, device: torch.rand(*shape, device=device)
+        self.posterior_noise_fn = torch.randn_like
+
+    def get_camera_cond(self, camera: torch.Tensor, fovy=None) -> torch.Tensor:
+        if self.cfg.camera_condition_type != "rotation":
+            raise NotImplementedError(f"Unknown camera_condition_type={self.cfg.camera_condition_type}")
+        return normalize_camera(camera).flatten(start_dim=1)
+
+    def encode_images(self, imgs: torch.Tensor) -> torch.Tensor:
+        imgs = imgs * 2.0 - 1.0
+        moments = self.backend.encode(imgs)
+        mean, logvar = torch.chunk(moments.float(), 2, dim=1)
+        logvar = torch.clamp(logvar, -30.0, 20.0)
+        return (mean + torch.exp(0.5 * logvar) * self.posterior_noise_fn(mean)) * self.backend.scaling_factor
+
+    def get_latents(self, rgb_BCHW: torch.Tensor, rgb_as_latents: bool = False) -> torch.Tensor:
+        if rgb_as_latents:
+            return F.interpolate(rgb_BCHW, size=(32, 32), mode="bilinear", align_corners=False)
+        return self.encode_images(F.interpolate(rgb_BCHW, size=(256, 256), mode="bilinear", align_corners=False))
+
+    def q_sample(self, x, t, noise):
+        a = self.alphas.to(x.device)[t].view(-1, 1, 1, 1)
+        return a.sqrt() * x + (1 - a).sqrt() * noise
+
+    def get_t_plus(self, t: torch.Tensor) -> torch.Tensor:
+        assert self.cfg.plus_ratio >= 0.0
+        t_plus = self.cfg.plus_ratio * (t - self.min_step)
+        t_plus = t_plus.clamp(torch.zeros_like(t), self.num_train_timesteps - t - 1)
+        if self.cfg.plus_random:
+            t_plus = t_plus * self.rand_fn(t.shape, t.device)
+        return torch.clamp(t + t_plus.to(torch.long), 1, max=self.num_train_timesteps - 1)
+
+    def __call__(self, rgb: torch.Tensor, prompt_utils, elevation, azimuth, camera_distances, c2w, rgb_as_latents: bool = False,
+                 fovy=None, input_is_latent=False, **kwargs) -> Dict[str, Any]:
+        camera = c2w
+        batch_size = rgb.shape[0]
+        latents = self.get_latents(rgb.permute(0, 3, 1, 2), rgb_as_latents=rgb_as_latents)
+        noise = self.noise_fn(latents)
+        text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+        tb = text_embeddings.shape[0] // 2
+        vd = text_embeddings[0:tb].repeat(batch_size // tb, 1, 1)
+        uncond = text_embeddings[tb:2 * tb].repeat(batch_size // tb, 1, 1)
+        text_embeddings = torch.cat([vd, uncond, vd], dim=0)
+        with torch.no_grad():
+            _t = self.timestep_fn(self.min_step, self.max_step + 1, 1, latents.device)   # one t shared by the group
+            t = _t.repeat(batch_size)
+            latents_noisy = self.q_sample(latents, t, noise)
+            t_plus = self.get_t_plus(_t).repeat(batch_size)
+            latents_noisy_second = self.q_sample(latents, t_plus, noise)
+            x_in = torch.cat([latents_noisy, latents_noisy, latents_noisy_second], dim=0)
+            t_in = torch.cat([t, t, t_plus], dim=0)
+            if camera is not None:
+                cam = self.get_camera_cond(camera, fovy).repeat(3, 1).to(text_embeddings)
+                noise_pred = self.backend.unet(x_in, t_in, text_embeddings, camera=cam, num_frames=self.cfg.n_view)
+            else:
+                noise_pred = self.backend.unet(x_in, t_in, text_embeddings)
+            noise_pred = noise_pred.to(latents.dtype)
+        text, unc, second = noise_pred.chunk(3)
+        first = unc + self.cfg.guidance_scale * (text - unc)
+        alphas = self.alphas.to(latents.device)
+        if self.cfg.weighting_strategy == "sds":
+            w = (1 - alphas[t]).view(-1, 1, 1, 1)
+        elif self.cfg.weighting_strategy == "uniform":
+            w = 1
+        elif self.cfg.weighting_strategy == "fantasia3d":
+            w = (alphas[t] ** 0.5 * (1 - alphas[t])).view(-1, 1, 1, 1)
+        else:
+            raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
+        grad = torch.nan_to_num((first - second) * w)
+        if self.grad_clip_val is not None:
+            grad = torch.clamp(grad, -self.grad_clip_val, self.grad_clip_val)
+        target = (latents - grad).detach()
+        loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / batch_size
+        return {"loss_asd": loss, "grad_norm": grad.norm(), "min_step": self.min_step, "max_step": self.max_step}
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        self.min_step = int(self.num_train_timesteps * C(self.cfg.min_step_percent, epoch, global_step))
+        self.max_step = int(self.num_train_timesteps * C(self.cfg.max_step_percent, epoch, global_step))

@@ -53,6 +53,30 @@ def asd_sd_nerf(prompt: str = "synthetic", guidance_backend: str = "hip") -> dic
     })
 
 
+def asd_mv_nerf(prompt: str = "synthetic", guidance_backend: str = "hip-mvdream") -> dict:
+    """configs/single-prompt_benchmark/asd_mv_nerf.yaml: 4 views of one prompt, 256 spp, MVDream guidance
+    (shared t, batch 12 at 32x32 latents, no Perp-Neg), one optimizer group for the whole background."""
+    cfg = asd_sd_nerf(prompt)
+    cfg["name"] = "asd_mv_nerf"
+    cfg["data_type"] = "mvdream-random-multiview-camera-datamodule"
+    cfg["data"] = {"batch_size": [4, 4], "n_view": 4, "width": [64, 256], "height": [64, 256], "resolution_milestones": [10000],
+                   "camera_distance_range": [0.8, 1.0], "fovy_range": [15, 60], "elevation_range": [0, 30], "camera_perturb": 0.0,
+                   "center_perturb": 0.0, "up_perturb": 0.0, "eval_camera_distance": 3.0, "eval_fovy_deg": 40.0, "n_val_views": 30}
+    s = cfg["system"]
+    s["renderer"]["num_samples_per_ray"] = 256
+    s["prompt_processor"] = {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "prompt": prompt,
+                             "front_threshold": 30.0, "back_threshold": 30.0}
+    s["guidance_type"] = "mvdream-asynchronous-score-distillation-guidance"
+    s["guidance"] = {"model_name": "sd-v2.1-base-4view", "ckpt_path": "pretrained/sd-v2.1-base-4view.pt", "guidance_scale": 7.5,
+                     "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 25000],
+                     "max_step_percent": [0, 0.98, 0.5, 25000], "backend": guidance_backend}
+    s["loss"] = {"lambda_asd": 1.0, "lambda_orient": [10000, 0.0, 100.0, 10001], "lambda_sparsity": 20,
+                 "lambda_opaque": [10000, 0.0, 100.0, 10001], "lambda_z_variance": 0.0}
+    s["optimizer"]["params"] = {"geometry.encoding": {"lr": 0.003}, "geometry.density_network": {"lr": 0.003},
+                                "geometry.feature_network": {"lr": 0.003}, "background": {"lr": 0.003}}
+    return cfg
+
+
 def nerf_only_c1() -> dict:
     """BASELINE config 1: single prompt, 32x32 rays, 16 samples per ray, NeRF-only render (no diffusion)."""
     cfg = asd_sd_nerf()

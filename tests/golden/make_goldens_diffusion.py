@@ -201,10 +201,89 @@ def make_asd_glue_golden(seed=5):
           f"unet t={calls['t'].tolist()}")
 
 
+def make_mvdream_glue_golden(seed=8):
+    """MVDreamTimestepShiftedScoreDistillationGuidance.__call__ (mvdream_asd_guidance.py:167-304) with a stand-in
+    LatentDiffusionInterface (q_sample / apply_model / encode_first_stage / get_first_stage_encoding)."""
+    import types
+    H._mod("extern.mvdream.model_zoo", build_model=None)
+    from threestudio.models.guidance.mvdream_asd_guidance import MVDreamTimestepShiftedScoreDistillationGuidance as G
+    from threestudio.models.prompt_processors.base import DirectionConfig, PromptProcessorOutput
+
+    B = 4
+    guid = object.__new__(G)
+    guid.cfg = G.Config(guidance_scale=7.5, plus_ratio=0.1, plus_random=True, n_view=4)
+    guid.device = torch.device("cpu")
+    guid.num_train_timesteps = 1000
+    guid.min_step, guid.max_step = 20, 980
+    guid.grad_clip_val = None
+    ac = torch.from_numpy(np.load(os.path.join(HERE, "diffusion_schedule.npz"))["alphas_cumprod"]).float()
+    guid.alphas = ac
+    calls = {}
+
+    class Model:
+        alphas_cumprod = ac
+
+        def q_sample(self, x, t, noise=None):
+            a = ac[t].view(-1, 1, 1, 1)
+            return a.sqrt() * x + (1 - a).sqrt() * noise
+
+        def apply_model(self, x, t, cond):
+            calls.update(x=x.clone(), t=t.clone(), ctx=cond["context"].clone(), camera=cond["camera"].clone(), nf=cond["num_frames"])
+            s = cond["context"].mean(dim=(1, 2)).view(-1, 1, 1, 1) + cond["camera"].mean(dim=1).view(-1, 1, 1, 1)
+            return torch.tanh(0.7 * x + 3.0 * s) * (1.0 + t.view(-1, 1, 1, 1) / 1000.0) + 0.1 * x.flip(-1)
+
+        def encode_first_stage(self, imgs):
+            pooled = torch.nn.functional.avg_pool2d(imgs, 8)
+            return torch.cat([pooled, pooled.mean(1, keepdim=True) ** 2], dim=1)
+
+        def get_first_stage_encoding(self, z):
+            return 0.18215 * z
+    guid.model = Model()
+    emb = rnd("mv.prompt", (1, 77, 1024), seed)
+    unc = rnd("mv.uncond", (1, 77, 1024), seed)
+    side = DirectionConfig("side", lambda s: s, lambda s: s, lambda ele, azi, dis: torch.ones_like(ele, dtype=torch.bool))
+    pu = PromptProcessorOutput(text_embeddings=emb, uncond_text_embeddings=unc, text_embeddings_vd=emb.expand(4, -1, -1),
+                               uncond_text_embeddings_vd=unc.expand(4, -1, -1), directions=[side], direction2idx={"side": 0},
+                               use_perp_neg=False, perp_neg_f_sb=(1, 0.5, -0.606), perp_neg_f_fsb=(1, 0.5, 0.967),
+                               perp_neg_f_fs=(4, 0.5, -2.426), perp_neg_f_sf=(4, 0.5, -2.426), prompt="", prompts_vd=[""] * 4)
+    elevation = torch.tensor([10.0, 10.0, 10.0, 10.0])
+    azimuth = torch.tensor([12.0, 102.0, -168.0, -78.0])
+    distances = torch.full((4,), 1.2)
+    c2w = torch.eye(4).repeat(4, 1, 1)
+    c2w[:, :3, :3] = torch.linalg.qr(rnd("mv.rot", (4, 3, 3), seed))[0]
+    c2w[:, :3, 3] = rnd("mv.pos", (4, 3), seed) * 1.3
+    rgb = torch.sigmoid(rnd("mv.rgb", (B, 64, 64, 3), seed)).requires_grad_(True)
+    rec = {}
+    real = dict(randn_like=torch.randn_like, randint=torch.randint, rand=torch.rand)
+
+    def wrap(name):
+        def f(*a, **k):
+            out = real[name](*a, **k)
+            rec[name] = out.clone()
+            return out
+        return f
+    torch.manual_seed(seed)
+    torch.randn_like, torch.randint, torch.rand = wrap("randn_like"), wrap("randint"), wrap("rand")
+    try:
+        out = guid(rgb, pu, elevation, azimuth, distances, c2w.clone())
+    finally:
+        torch.randn_like, torch.randint, torch.rand = real["randn_like"], real["randint"], real["rand"]
+    out["loss_asd"].backward()
+    np.savez_compressed(os.path.join(HERE, "diffusion_mvdream_glue.npz"), seed=seed, elevation=elevation.numpy(), azimuth=azimuth.numpy(),
+                        camera_distances=distances.numpy(), c2w=c2w.numpy(), noise=rec["randn_like"].numpy(), t=rec["randint"].numpy(),
+                        rand=rec["rand"].numpy(), loss_asd=np.float64(out["loss_asd"].item()), grad_norm=np.float64(out["grad_norm"].item()),
+                        grad_rgb=rgb.grad.numpy(), unet_in_t=calls["t"].numpy(), unet_in_x=calls["x"].numpy(),
+                        unet_in_camera=calls["camera"].numpy(), unet_in_ctx_mean=calls["ctx"].mean(dim=2).numpy(), num_frames=calls["nf"])
+    print(f"mvdream glue: loss={out['loss_asd'].item():.5f} t={calls['t'].tolist()}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     make_schedule_golden()
     make_asd_glue_golden()
+    make_mvdream_glue_golden()
+    if "--glue-only" in sys.argv:
+        sys.exit(0)
     small = W.UNetConfig(model_channels=64, num_head_channels=32, context_dim=96)
     make_unet_golden("diffusion_unet_small", small, batch=3, hw=16, n_ctx=7, seed=3)
     small_mv = W.UNetConfig(model_channels=64, num_head_channels=32, context_dim=96, camera_dim=16)

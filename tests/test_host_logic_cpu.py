@@ -2,6 +2,8 @@
 module / state-dict layout.  No GPU."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -101,3 +103,36 @@ def test_hip_path_fails_loudly_without_a_gpu():
     m = _lib.make_grid_meta(16, 2, 19, 16, 1.447269237440378)
     with pytest.raises(_lib.AsdError):
         ops.hashgrid_fwd(m, torch.zeros(m.n_params), torch.zeros(4, 3))
+
+
+@pytest.mark.parametrize("golden,name,extra", [
+    ("camera_sv", "random-camera-datamodule", {}),
+    ("camera_mv", "mvdream-random-multiview-camera-datamodule", {}),
+    ("camera_mv_magic3d", "mvdream-random-multiview-camera-datamodule",
+     dict(light_sample_strategy="magic3d", camera_perturb=0.1, center_perturb=0.2, up_perturb=0.02, zoom_range=[0.8, 1.0])),
+])
+def test_camera_batches_match_reference_collate(golden, name, extra):
+    """a1: the product datamodules draw from torch / random in the reference's order (tests/golden/make_goldens_camera.py)."""
+    import os
+    import random
+
+    import scaledreamer_amd.data  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", golden + ".npz"))
+    sv = dict(batch_size=[2, 1], width=[16, 32], height=[16, 32], resolution_milestones=[10000], camera_distance_range=[1.0, 1.5],
+              fovy_range=[40, 70], elevation_range=[-10, 45], camera_perturb=0.0, center_perturb=0.0, up_perturb=0.0,
+              eval_camera_distance=1.2, eval_fovy_deg=70.0, n_val_views=30)
+    mv = dict(batch_size=[8, 4], n_view=4, width=[16, 32], height=[16, 32], resolution_milestones=[10000],
+              camera_distance_range=[0.8, 1.0], fovy_range=[15, 60], elevation_range=[0, 30], camera_perturb=0.0,
+              center_perturb=0.0, up_perturb=0.0, eval_camera_distance=3.0, eval_fovy_deg=40.0, n_val_views=30)
+    cfg = dict(sv if golden == "camera_sv" else mv)
+    cfg.update(extra)
+    for s in g["seeds"].tolist():
+        ds = find(name)(cfg)
+        torch.manual_seed(s)
+        random.seed(s)
+        b = ds.collate(None)
+        for k in ["rays_o", "rays_d", "mvp_mtx", "camera_positions", "c2w", "light_positions", "elevation", "azimuth",
+                  "camera_distances", "fovy"]:
+            np.testing.assert_allclose(b[k].numpy(), g[f"s{s}.{k}"], rtol=2e-6, atol=2e-6, err_msg=f"{golden} seed {s} key {k}")
