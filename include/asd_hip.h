@@ -237,6 +237,13 @@ int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, vo
 /* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */
 int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma, const void* beta, float eps,
                       void* y, void* stream);
+/* Row softmax y = softmax(scale * x) and its input gradient ds = scale * p o (dp - rowsum(dp o p)), fp16 in/out with
+ * fp32 statistics: the single-head 512-wide attention of the VAE encoder's mid block (AttnBlock,
+ * extern/mvdream/ldm/modules/diffusionmodules/model.py:170-227: bmm(q,k) * c^-0.5 -> softmax -> bmm(v, w)) runs as
+ * asd_gemm_f16 -> asd_softmax_f16 -> asd_gemm_f16, and likewise backwards. */
+int asd_softmax_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, float scale, void* y, int32_t ldy, void* stream);
+int asd_softmax_bwd_f16(const void* p, const void* dp, int32_t ld, int32_t rows, int32_t cols, float scale, void* ds,
+                        void* stream);
 /* GEGLU (attention.py:49-56): y[r, j] = h[r, j] * gelu(h[r, c + j]), h = [rows, 2c]. */
 int asd_geglu_f16(const void* h, int32_t rows, int32_t c, void* y, void* stream);
 /* y = silu(x) elementwise (emb_layers, openaimodel.py:213-219). */

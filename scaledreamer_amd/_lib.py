@@ -86,7 +86,7 @@ SYMBOLS = [
     "asd_envmap_fwd", "asd_envmap_bwd",
     "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
-    "asd_gemm_f16", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_geglu_f16", "asd_silu_f16",
+    "asd_gemm_f16", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
     "asd_version", "asd_last_error",
 ]

@@ -248,6 +248,92 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
+
+// ---- row softmax (single-head attention of the VAE mid block, executed as GEMM -> softmax -> GEMM) -----------
+// One 256-thread block per row, the row lives in registers (NV half8 vectors per thread), fp32 statistics.
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = is_max ? fmaxf(v, o) : v + o;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    const float a = red[0], b = red[1], c = red[2], d = red[3];
+    return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_kernel(const half_t* __restrict__ x, int ldx, int cols, float scale,
+                                                      half_t* __restrict__ y, int ldy) {
+    __shared__ float red[4];
+    const half_t* xr = x + (size_t)blockIdx.x * ldx;
+    half8 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x * 8 + j * 2048;
+        if (c < cols) {
+            v[j] = *(const half8*)(xr + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = fmaxf(m, (float)v[j][k]);
+        }
+    }
+    m = block_reduce(m, red, true) * scale;
+    float e[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (threadIdx.x * 8 + j * 2048 < cols) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { e[j][k] = __expf(fmaf((float)v[j][k], scale, -m)); s += e[j][k]; }
+        }
+    const float inv = 1.f / block_reduce(s, red, false);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x * 8 + j * 2048;
+        if (c < cols) {
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (half_t)(e[j][k] * inv);
+            *(half8*)(y + (size_t)blockIdx.x * ldy + c) = o;
+        }
+    }
+}
+
+// dS = scale * P o (dP - rowsum(dP o P))
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const half_t* __restrict__ p, const half_t* __restrict__ dp, int ld,
+                                                          int cols, float scale, half_t* __restrict__ ds) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * ld;
+    half8 pv[NV], dv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x * 8 + j * 2048;
+        if (c < cols) {
+            pv[j] = *(const half8*)(p + base + c);
+            dv[j] = *(const half8*)(dp + base + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = fmaf((float)pv[j][k], (float)dv[j][k], s);
+        }
+    }
+    s = block_reduce(s, red, false);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = threadIdx.x * 8 + j * 2048;
+        if (c < cols) {
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (half_t)(scale * (float)pv[j][k] * ((float)dv[j][k] - s));
+            *(half8*)(ds + base + c) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void geglu_kernel(const half_t* __restrict__ h, int rows, int C, half_t* __restrict__ y) {
     const int slots = C / 8;
     const size_t total = (size_t)rows * slots;
@@ -366,6 +452,35 @@ int asd_layernorm_f16(const void* x, int32_t rows, int32_t c, const void* gamma,
     else if (c <= 1536) LN_LAUNCH(3);
     else LN_LAUNCH(4);
 #undef LN_LAUNCH
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_softmax_f16(const void* x, int32_t ldx, int32_t rows, int32_t cols, float scale, void* y, int32_t ldy, void* stream) {
+    ASD_CHECK_ARG(x && y && rows > 0 && cols > 0, "null argument");
+    ASD_CHECK_ARG(cols % 8 == 0 && cols <= 8192 && ldx % 8 == 0 && ldy % 8 == 0, "cols must be a multiple of 8 and <= 8192");
+    const dim3 g(rows), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SM_LAUNCH(NV) hipLaunchKernelGGL((softmax_kernel<NV>), g, blk, 0, s, (const half_t*)x, ldx, cols, scale, (half_t*)y, ldy)
+    if (cols <= 2048) SM_LAUNCH(1);
+    else if (cols <= 4096) SM_LAUNCH(2);
+    else SM_LAUNCH(4);
+#undef SM_LAUNCH
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_softmax_bwd_f16(const void* p, const void* dp, int32_t ld, int32_t rows, int32_t cols, float scale, void* ds,
+                        void* stream) {
+    ASD_CHECK_ARG(p && dp && ds && rows > 0 && cols > 0, "null argument");
+    ASD_CHECK_ARG(cols % 8 == 0 && cols <= 8192 && ld % 8 == 0, "cols must be a multiple of 8 and <= 8192");
+    const dim3 g(rows), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SMB_LAUNCH(NV) hipLaunchKernelGGL((softmax_bwd_kernel<NV>), g, blk, 0, s, (const half_t*)p, (const half_t*)dp, ld, cols, scale, (half_t*)ds)
+    if (cols <= 2048) SMB_LAUNCH(1);
+    else if (cols <= 4096) SMB_LAUNCH(2);
+    else SMB_LAUNCH(4);
+#undef SMB_LAUNCH
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -42,7 +42,8 @@ class HipUNet:
         f16 = lambda t: t.to(device=dev, dtype=torch.float16).contiguous()
         w: Dict[str, torch.Tensor] = {}
         emb_w, emb_b, self.emb_slices = [], [], {}
-        off = 0
+        ck_w, cv_w, self.ctx_slices = [], [], {}
+        off = coff = 0
         for name, t in p.items():
             if name.endswith(".weight") and t.ndim == 4:
                 if t.shape[-1] == 3:
@@ -51,7 +52,7 @@ class HipUNet:
                     w[name] = f16(t.reshape(t.shape[0], t.shape[1]))  # 1x1 conv == Linear on NHWC
             elif ".emb_layers.1." in name:
                 continue
-            elif ".attn1.to_q." in name or ".attn1.to_k." in name:
+            elif ".attn1.to_q." in name or ".attn1.to_k." in name or ".attn2.to_k." in name or ".attn2.to_v." in name:
                 continue
             else:
                 w[name] = f16(t)
@@ -66,8 +67,16 @@ class HipUNet:
                     for d in range(self.cfg.transformer_depth):
                         b = f"{name}.transformer_blocks.{d}.attn1"
                         w[b + ".to_qk.weight"] = f16(torch.cat([p[b + ".to_q.weight"], p[b + ".to_k.weight"]], 0))
+                        b2 = f"{name}.transformer_blocks.{d}.attn2"
+                        ck_w.append(p[b2 + ".to_k.weight"])
+                        cv_w.append(p[b2 + ".to_v.weight"])
+                        self.ctx_slices[b2] = (coff, cout)
+                        coff += cout
         w["emb_all.weight"] = f16(torch.cat(emb_w, 0))
         w["emb_all.bias"] = f16(torch.cat(emb_b, 0))
+        # the context is the same for every cross-attention: all 16 K and V^T projections are two GEMMs per forward
+        w["ctx_k_all.weight"] = f16(torch.cat(ck_w, 0))
+        w["ctx_v_all.weight"] = f16(torch.cat(cv_w, 0))
         self.w = w
 
     # ---- layers -----------------------------------------------------------------------------------------
@@ -105,9 +114,9 @@ class HipUNet:
             h = H.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], residual=h)
             y = H.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
             q = H.gemm(y, w[b + ".attn2.to_q.weight"])
-            kc = H.gemm(ctx_pad, w[b + ".attn2.to_k.weight"])                    # [B*ctx_stride, C]
-            vT = H.gemm(w[b + ".attn2.to_v.weight"], ctx_pad)                    # [C, B*ctx_stride]
-            o = H.attention(q, kc, vT, B, heads, L, n_ctx, ctx_stride)
+            coff, _ = self.ctx_slices[b + ".attn2"]
+            kc_all, vT_all = self._ctx_kv
+            o = H.attention(q, kc_all[:, coff:coff + C], vT_all[coff:coff + C], B, heads, L, n_ctx, ctx_stride)
             h = H.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], residual=h)
             y = H.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
             g = H.geglu(H.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"]))
@@ -145,6 +154,8 @@ class HipUNet:
             c = H.gemm(camera, w["camera_embed.0.weight"], bias=w["camera_embed.0.bias"], act=1)
             e = H.gemm(c, w["camera_embed.2.weight"], bias=w["camera_embed.2.bias"], residual=e)
         emb_all = H.gemm(H.silu(e), w["emb_all.weight"], bias=w["emb_all.bias"])     # every ResBlock's emb_layers at once
+        self._ctx_kv = (H.gemm(ctx_pad, w["ctx_k_all.weight"]),       # [B*ctx_stride, sum C]
+                        H.gemm(w["ctx_v_all.weight"], ctx_pad))       # [sum C, B*ctx_stride] = every V^T
         hs: List[Tuple[torch.Tensor, Tuple[int, int]]] = []
         h, hw = x_nhwc32.reshape(B * Hh * Ww, 32), (Hh, Ww)
         for blk in self.inputs:

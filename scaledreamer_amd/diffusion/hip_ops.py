@@ -1,5 +1,5 @@
 """Tensor-level wrappers of the diffusion kernels of the C ABI (include/asd_hip.h: asd_gemm_f16, asd_groupnorm_f16,
-asd_layernorm_f16, asd_geglu_f16, asd_silu_f16, asd_timestep_embedding_f16, asd_concat_f16, asd_attention_f16).
+asd_layernorm_f16, asd_softmax_f16, asd_softmax_bwd_f16, asd_geglu_f16, asd_silu_f16, asd_timestep_embedding_f16, asd_concat_f16, asd_attention_f16).
 Activations are NHWC / token-major fp16 tensors; outputs are allocated with torch on the current stream."""
 from __future__ import annotations
 
@@ -133,6 +133,23 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((cols, rows), device=x.device, dtype=torch.float16)
     check(lib().asd_transpose_f16(C.c_void_p(x.data_ptr()), i32(rows), i32(cols), i32(x.stride(0)), ptr(y), i32(rows), stream()))
     return y
+
+
+def softmax(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """row softmax of scale * x, x [rows, cols] fp16 (row stride = x.stride(0))."""
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), device=x.device, dtype=torch.float16)
+    check(lib().asd_softmax_f16(C.c_void_p(x.data_ptr()), i32(x.stride(0)), i32(rows), i32(cols), f32(scale), ptr(y), i32(cols), stream()))
+    return y
+
+
+def softmax_bwd(p: torch.Tensor, dp: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """ds = scale * p o (dp - rowsum(dp o p)) for contiguous [rows, cols] fp16 tensors."""
+    rows, cols = p.shape
+    assert p.is_contiguous() and dp.is_contiguous()
+    ds = torch.empty_like(p)
+    check(lib().asd_softmax_bwd_f16(ptr(p), ptr(dp), i32(cols), i32(rows), i32(cols), f32(scale), ptr(ds), stream()))
+    return ds
 
 
 def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:

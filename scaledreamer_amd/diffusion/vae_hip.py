@@ -76,6 +76,43 @@ class _LinearFn(torch.autograd.Function):
         return H.gemm(dy.contiguous(), ctx.w_t), None, None, None
 
 
+class _AttnFn(torch.autograd.Function):
+    """Single-head attention over [B, L, C] rows (AttnBlock, model.py:195-224): per image S = Q K^T -> P = softmax(S / sqrt(C))
+    -> O = P V as two MFMA GEMMs around a row-softmax kernel; the input gradients are four more GEMMs around the
+    softmax-gradient kernel.  P (L x L fp16) is kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B):
+        L, C_ = q.shape[0] // B, q.shape[1]
+        scale = float(C_) ** -0.5
+        o = torch.empty_like(q)
+        ps = []
+        for b in range(B):
+            r = slice(b * L, (b + 1) * L)
+            p = H.softmax(H.gemm(q[r], k[r]), scale)                  # [L, L]
+            H.gemm(p, H.transpose(v[r]), out=o[r])                    # P V  (W operand = V^T [C, L])
+            ps.append(p)
+        ctx.save_for_backward(q, k, v, *ps)
+        ctx.B, ctx.scale = B, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, *ps = ctx.saved_tensors
+        B, scale = ctx.B, ctx.scale
+        L = q.shape[0] // B
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for b in range(B):
+            r = slice(b * L, (b + 1) * L)
+            p = ps[b]
+            H.gemm(H.transpose(p), H.transpose(do[r]), out=dv[r])      # dV = P^T dO
+            ds = H.softmax_bwd(p, H.gemm(do[r], v[r]), scale)          # dP = dO V^T ; dS = scale P o (dP - sum)
+            H.gemm(ds, H.transpose(k[r]), out=dq[r])                   # dQ = dS K
+            H.gemm(H.transpose(ds), H.transpose(q[r]), out=dk[r])      # dK = dS^T Q
+        return dq, dk, dv, None
+
+
 class HipVAEEncoder:
     def __init__(self, params: P, cfg: Optional[W.VAEConfig] = None, device="cuda", use_graph: bool = False):
         self.cfg = cfg or W.VAEConfig()
@@ -166,9 +203,8 @@ class HipVAEEncoder:
             elif kind == "attn":
                 Bh, Hc, Wc, C_ = h.shape
                 t = _GroupNormFn.apply(h, w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-6, False).reshape(-1, C_)
-                q, k, v = (_LinearFn.apply(t, w[f"{name}.{n}.w"], w[f"{name}.{n}.b"], w[f"{name}.{n}.wt"]).view(Bh, 1, Hc * Wc, C_)
-                           for n in ("q", "k", "v"))
-                o = F.scaled_dot_product_attention(q, k, v).reshape(-1, C_)
+                q, k, v = (_LinearFn.apply(t, w[f"{name}.{n}.w"], w[f"{name}.{n}.b"], w[f"{name}.{n}.wt"]) for n in ("q", "k", "v"))
+                o = _AttnFn.apply(q, k, v, Bh)
                 o = _LinearFn.apply(o, w[name + ".proj_out.w"], w[name + ".proj_out.b"], w[name + ".proj_out.wt"])
                 h = h + o.view(Bh, Hc, Wc, C_)
             elif kind == "out":

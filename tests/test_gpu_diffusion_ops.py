@@ -127,3 +127,42 @@ def test_attention(B, heads, lq, lk, lk_stride):
     vf = v.float().view(B, lk_stride, heads, 64)[:, :lk].transpose(1, 2)
     ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(B * lq, C_)
     _close(got, ref, tol=3e-3)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 4096), (33, 1024), (7, 8192), (5, 264)])
+def test_softmax_and_its_gradient(rows, cols):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(rows, cols, scale=6.0, seed=1)
+    scale = 512 ** -0.5
+    ref = torch.softmax(x.float() * scale, dim=-1)
+    p = H.softmax(x, scale)
+    _close(p, ref, tol=1e-3)
+    assert abs(p.float().sum(-1) - 1).max().item() < 5e-3
+    # row-strided input (a column slice of a wider matrix)
+    wide = _rand(rows, cols + 16, scale=6.0, seed=2)
+    _close(H.softmax(wide[:, 8:8 + cols], scale), torch.softmax(wide[:, 8:8 + cols].float() * scale, -1), tol=1e-3)
+    dp = _rand(rows, cols, seed=3)
+    pf = p.float()
+    ref_ds = scale * pf * (dp.float() - (dp.float() * pf).sum(-1, keepdim=True))
+    ds = H.softmax_bwd(p, dp, scale)
+    err = (ds.float() - ref_ds).abs().max().item()
+    assert err <= 2e-3 * ref_ds.abs().max().item() + 1e-6
+
+
+def test_vae_single_head_attention_matches_sdpa_forward_and_backward():
+    from scaledreamer_amd.diffusion.vae_hip import _AttnFn
+
+    B, L, C_ = 2, 1024, 512
+    q, k, v = (_rand(B * L, C_, seed=s).requires_grad_(True) for s in (1, 2, 3))
+    o = _AttnFn.apply(q, k, v, B)
+    go = _rand(B * L, C_, seed=4)
+    o.backward(go)
+    qf, kf, vf = (t.detach().float().view(B, 1, L, C_).requires_grad_(True) for t in (q, k, v))
+    of = F.scaled_dot_product_attention(qf, kf, vf)
+    of.backward(go.float().view(B, 1, L, C_))
+    _close(o, of.reshape(B * L, C_), tol=4e-3)
+    for got, want in ((q.grad, qf.grad), (k.grad, kf.grad), (v.grad, vf.grad)):
+        want = want.reshape(B * L, C_)
+        err = (got.float() - want).abs().max().item()
+        assert err <= 1e-2 * want.abs().max().item(), f"{err} vs {want.abs().max().item()}"
