@@ -63,7 +63,12 @@ int asd_hashgrid_bwd(const asd_grid_meta* meta, const float* x, const float* dou
  * Replaces ImplicitVolume.forward / forward_density (threestudio/models/geometry/implicit_volume.py:
  * 109-207) = TCNNEncoding + 2x VanillaMLP (networks.py:214-251) + get_activated_density (:80-107).
  * ---------------------------------------------------------------------------------------------- */
-enum { ASD_BIAS_CONST = 0, ASD_BIAS_BLOB_MAGIC3D = 1, ASD_BIAS_BLOB_DREAMFUSION = 2 };
+enum { ASD_BIAS_CONST = 0, ASD_BIAS_BLOB_MAGIC3D = 1, ASD_BIAS_BLOB_DREAMFUSION = 2,
+       ASD_BIAS_SPHERE = 3 /* |p| - bias_value: sdf_bias "sphere", custom/amortized/models/geometry/hyper_iNGP.py:222-225 */ };
+/* field_mode: DENSITY = ImplicitVolume (normal = -grad sigma / |.|); SDF = the amortized geometries' signed-distance
+ * head (Hyper-iNGP, hyper_iNGP.py:263-330): raw MLP output + bias, no activation, sdf_grad = +(sdf(x+eps e_k) - sdf(x))/eps,
+ * normal = sdf_grad / |sdf_grad|.  In SDF mode the per-prompt weights of the hypernetwork are passed as the MLP weights. */
+enum { ASD_FIELD_DENSITY = 0, ASD_FIELD_SDF = 1 };
 enum { ASD_ACT_SOFTPLUS = 0, ASD_ACT_EXP = 1, ASD_ACT_TRUNC_EXP = 2, ASD_ACT_NONE = 3 };
 
 typedef struct asd_field_cfg {
@@ -76,6 +81,7 @@ typedef struct asd_field_cfg {
     float   fd_eps;                     /* finite_difference_normal_eps */
     int32_t n_hidden;                   /* 64 */
     int32_t n_feature_dims;             /* 3 (0: no feature network) */
+    int32_t field_mode;                 /* ASD_FIELD_* */
 } asd_field_cfg;
 
 /* sigma[n] only (no_grad): geometry.forward_density — used by the marcher's sigma_fn
@@ -87,15 +93,16 @@ int asd_field_density(const asd_grid_meta* meta, const asd_field_cfg* cfg, const
                       float* sigma /*[n]*/, void* stream);
 
 /* Training forward at kept samples: geometry(points, output_normal) (nerf_volume_renderer.py:282-284).
- * Outputs: sigma[n], features[n,C] (pre-activation), normal[n,3] (NULL: skip the 3 offset evaluations).
+ * Outputs: sigma[n] (the sdf in SDF mode), features[n,C] (pre-activation), normal[n,3] (NULL: skip the 3 offset
+ * evaluations), fd_grad[n,3] (NULL or the un-normalised finite-difference gradient: `sdf_grad`, hyper_iNGP.py:305-318).
  * enc_save[n, L*F] keeps the centre encoding for the backward pass. */
 int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
                   const float* w1_density, const float* w2_density,
                   const float* w1_feature /*[H,32]*/, const float* w2_feature /*[C,H]*/,
                   const float* points, int32_t n, const int32_t* n_dev,
-                  float* sigma, float* features, float* normal, float* enc_save, void* stream);
+                  float* sigma, float* features, float* normal, float* fd_grad, float* enc_save, void* stream);
 
-/* Backward: given dL/dsigma[n], dL/dfeatures[n,C], dL/dnormal[n,3] (any may be NULL) accumulate (+=)
+/* Backward: given dL/dsigma[n], dL/dfeatures[n,C], dL/dnormal[n,3], dL/dfd_grad[n,3] (any may be NULL) accumulate (+=)
  * d_grid_params (atomic scatter) and the MLP weight gradients dw1_density[H,32], dw2_density[1,H],
  * dw1_feature[H,32], dw2_feature[C,H].  `workspace` holds asd_field_bwd_workspace() floats
  * (hidden-layer gradients per sample + per-chunk partial sums, reduced in a fixed order). */
@@ -105,7 +112,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* w1_feature, const float* w2_feature,
                   const float* points, const float* enc_save, const float* sigma /* forward output */,
                   int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
-                  float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
+                  const float* d_fd_grad, float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
                   float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

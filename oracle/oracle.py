@@ -26,7 +26,7 @@ class FieldCfg(C.Structure):
     _fields_ = [("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("radius", C.c_float),
                 ("bias_mode", C.c_int32), ("bias_value", C.c_float), ("blob_scale", C.c_float),
                 ("blob_std", C.c_float), ("activation", C.c_int32), ("fd_eps", C.c_float),
-                ("n_hidden", C.c_int32), ("n_feature_dims", C.c_int32)]
+                ("n_hidden", C.c_int32), ("n_feature_dims", C.c_int32), ("field_mode", C.c_int32)]
 
 
 class MarchCfg(C.Structure):
@@ -75,14 +75,14 @@ def grid_meta(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=1
 
 
 def field_cfg(radius=1.0, bias_mode=1, bias_value=0.0, blob_scale=10.0, blob_std=0.5, activation=0, fd_eps=0.01,
-              n_hidden=64, n_feature_dims=3) -> FieldCfg:
+              n_hidden=64, n_feature_dims=3, field_mode=0) -> FieldCfg:
     c = FieldCfg()
     for d in range(3):
         c.bbox_min[d] = -radius
         c.bbox_max[d] = radius
     c.radius, c.bias_mode, c.bias_value = radius, bias_mode, bias_value
     c.blob_scale, c.blob_std, c.activation, c.fd_eps = blob_scale, blob_std, activation, fd_eps
-    c.n_hidden, c.n_feature_dims = n_hidden, n_feature_dims
+    c.n_hidden, c.n_feature_dims, c.field_mode = n_hidden, n_feature_dims, field_mode
     return c
 
 
@@ -121,28 +121,98 @@ def field_density(m, c, grid, w1d, w2d, points):
     return sigma
 
 
-def field_fwd(m, c, grid, w1d, w2d, w1f, w2f, points, want_normal=True):
+def field_fwd(m, c, grid, w1d, w2d, w1f, w2f, points, want_normal=True, want_fd_grad=False):
     grid, w1d, w2d, w1f, w2f, points = map(_f, (grid, w1d, w2d, w1f, w2f, points))
     n = points.shape[0]
     sigma = np.empty(n, np.float32)
     feats = np.empty((n, c.n_feature_dims), np.float32)
     normal = np.empty((n, 3), np.float32) if want_normal else None
+    fd_grad = np.empty((n, 3), np.float32) if want_fd_grad else None
     enc = np.empty((n, m.n_levels * 2), np.float32)
     lib().orc_field_fwd(C.byref(m), C.byref(c), _p(grid), _p(w1d), _p(w2d), _p(w1f), _p(w2f), _p(points),
-                        C.c_int32(n), _p(sigma), _p(feats), _p(normal), _p(enc))
+                        C.c_int32(n), _p(sigma), _p(feats), _p(normal), _p(fd_grad), _p(enc))
+    if want_fd_grad:
+        return sigma, feats, normal, fd_grad, enc
     return sigma, feats, normal, enc
 
 
-def field_bwd(m, c, grid, w1d, w2d, w1f, w2f, points, d_sigma=None, d_features=None, d_normal=None):
+def field_bwd(m, c, grid, w1d, w2d, w1f, w2f, points, d_sigma=None, d_features=None, d_normal=None, d_fd_grad=None):
     grid, w1d, w2d, w1f, w2f, points = map(_f, (grid, w1d, w2d, w1f, w2f, points))
-    d_sigma, d_features, d_normal = _f(d_sigma), _f(d_features), _f(d_normal)
+    d_sigma, d_features, d_normal, d_fd_grad = _f(d_sigma), _f(d_features), _f(d_normal), _f(d_fd_grad)
     dgrid = np.zeros(m.n_params, np.float32)
     dw1d, dw2d = np.zeros_like(w1d), np.zeros_like(w2d)
     dw1f, dw2f = np.zeros_like(w1f), np.zeros_like(w2f)
     lib().orc_field_bwd(C.byref(m), C.byref(c), _p(grid), _p(w1d), _p(w2d), _p(w1f), _p(w2f), _p(points),
-                        C.c_int32(points.shape[0]), _p(d_sigma), _p(d_features), _p(d_normal), _p(dgrid),
+                        C.c_int32(points.shape[0]), _p(d_sigma), _p(d_features), _p(d_normal), _p(d_fd_grad), _p(dgrid),
                         _p(dw1d), _p(dw2d), _p(dw1f), _p(dw2f))
     return dgrid, dw1d, dw2d, dw1f, dw2f
+
+
+# ---- amortized path: importance sampling, VolSDF density, voxel / tri-plane samplers ----------------------------
+def importance_resample(vals, cdfs, n_out, jitter=None):
+    vals, cdfs, jitter = _f(vals), _f(cdfs), _f(jitter)
+    n_rays, e_in = vals.shape
+    out = np.empty((n_rays, n_out + 1), np.float32)
+    lib().orc_importance_resample(_p(vals), _p(cdfs), C.c_int32(n_rays), C.c_int32(e_in), C.c_int32(n_out), _p(jitter), _p(out))
+    return out
+
+
+def transmittance_cdf(t_edges, sigma):
+    t_edges, sigma = _f(t_edges), _f(sigma)
+    n_rays, S = sigma.shape
+    cdf = np.empty((n_rays, S + 1), np.float32)
+    lib().orc_transmittance_cdf(_p(t_edges), _p(sigma), C.c_int32(n_rays), C.c_int32(S), _p(cdf))
+    return cdf
+
+
+def merge_sorted(a, b):
+    a, b = _f(a), _f(b)
+    out = np.empty((a.shape[0], a.shape[1] + b.shape[1]), np.float32)
+    lib().orc_merge_sorted(_p(a), C.c_int32(a.shape[1]), _p(b), C.c_int32(b.shape[1]), C.c_int32(a.shape[0]), _p(out))
+    return out
+
+
+def volsdf_density(sdf, inv_std):
+    sdf = _f(sdf)
+    out = np.empty_like(sdf)
+    lib().orc_volsdf_density(_p(sdf), C.c_int64(sdf.size), C.c_float(inv_std), _p(out))
+    return out
+
+
+def voxel_sample_fwd(voxel_cl, points):
+    voxel_cl, points = _f(voxel_cl), _f(points)
+    B, D, H, W, Cc = voxel_cl.shape
+    M = points.shape[1]
+    out = np.empty((B, M, Cc), np.float32)
+    lib().orc_voxel_sample_fwd(_p(voxel_cl), *(C.c_int32(v) for v in (B, D, H, W, Cc)), _p(points), C.c_int32(M), _p(out))
+    return out
+
+
+def voxel_sample_bwd(d_out, points, shape):
+    d_out, points = _f(d_out), _f(points)
+    B, D, H, W, Cc = shape
+    dv = np.zeros(shape, np.float32)
+    lib().orc_voxel_sample_bwd(_p(d_out), *(C.c_int32(v) for v in (B, D, H, W, Cc)), _p(points), C.c_int32(points.shape[1]), _p(dv))
+    return dv
+
+
+def triplane_sample_fwd(planes_cl, points, coord_scale=1.0):
+    planes_cl, points = _f(planes_cl), _f(points)
+    B, _, H, W, Cc = planes_cl.shape
+    M = points.shape[1]
+    out = np.empty((B, M, 3 * Cc), np.float32)
+    lib().orc_triplane_sample_fwd(_p(planes_cl), *(C.c_int32(v) for v in (B, H, W, Cc)), _p(points), C.c_int32(M),
+                                  C.c_float(coord_scale), _p(out))
+    return out
+
+
+def triplane_sample_bwd(d_out, points, shape, coord_scale=1.0):
+    d_out, points = _f(d_out), _f(points)
+    B, _, H, W, Cc = shape
+    dp = np.zeros(shape, np.float32)
+    lib().orc_triplane_sample_bwd(_p(d_out), *(C.c_int32(v) for v in (B, H, W, Cc)), _p(points), C.c_int32(points.shape[1]),
+                                  C.c_float(coord_scale), _p(dp))
+    return dp
 
 
 def envmap_fwd(m, grid, w0, w1, w2, dirs):

@@ -50,6 +50,7 @@ class FieldCfg(C.Structure):
         ("fd_eps", C.c_float),
         ("n_hidden", C.c_int32),
         ("n_feature_dims", C.c_int32),
+        ("field_mode", C.c_int32),
     ]
 
 

@@ -89,6 +89,7 @@ __device__ __forceinline__ float field_bias(const asd_field_cfg& c, float px, fl
     const float r2 = px * px + py * py + pz * pz;
     if (c.bias_mode == ASD_BIAS_BLOB_MAGIC3D) return c.blob_scale * (1.f - sqrtf(r2) / c.blob_std);
     if (c.bias_mode == ASD_BIAS_BLOB_DREAMFUSION) return c.blob_scale * expf(-0.5f * r2 / (c.blob_std * c.blob_std));
+    if (c.bias_mode == ASD_BIAS_SPHERE) return sqrtf(r2) - c.bias_value;
     return c.bias_value;
 }
 __device__ __forceinline__ float field_act(const asd_field_cfg& c, float raw) {
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
                                                         const float* __restrict__ points, int n,
                                                         const int* __restrict__ n_dev, float* __restrict__ sigma,
                                                         float* __restrict__ features, float* __restrict__ normal,
-                                                        float* __restrict__ enc_save) {
+                                                        float* __restrict__ fd_grad, float* __restrict__ enc_save) {
+    const float fd_sign = c.field_mode == ASD_FIELD_SDF ? 1.f : -1.f;
     const int nn = n_dev ? min(*n_dev, n) : n;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nn; i += gridDim.x * 256) {
         const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #pragma unroll
             for (int o = 0; o < C; ++o) features[(size_t)i * C + o] = f[o];
         }
-        if (normal) {
+        if (normal || fd_grad) {
             float nr[3];
 #pragma unroll 1
             for (int k = 0; k < 3; ++k) {
@@ -208,13 +210,20 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
                 const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
                 float e2[2 * L];
                 const float sk = field_act(c, field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2));
-                nr[k] = -(sk - s) / c.fd_eps;
+                nr[k] = fd_sign * (sk - s) / c.fd_eps;
             }
-            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
-            const float inv = 1.f / fmaxf(len, 1e-12f);
-            normal[3 * (size_t)i] = nr[0] * inv;
-            normal[3 * (size_t)i + 1] = nr[1] * inv;
-            normal[3 * (size_t)i + 2] = nr[2] * inv;
+            if (fd_grad) {
+                fd_grad[3 * (size_t)i] = nr[0];
+                fd_grad[3 * (size_t)i + 1] = nr[1];
+                fd_grad[3 * (size_t)i + 2] = nr[2];
+            }
+            if (normal) {
+                const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+                const float inv = 1.f / fmaxf(len, 1e-12f);
+                normal[3 * (size_t)i] = nr[0] * inv;
+                normal[3 * (size_t)i + 1] = nr[1] * inv;
+                normal[3 * (size_t)i + 2] = nr[2] * inv;
+            }
         }
     }
 }
@@ -241,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
     const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
     const float* __restrict__ points, const float* __restrict__ enc_save, const float* __restrict__ sigma, int n,
     const int* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_features,
-    const float* __restrict__ d_normal, float* __restrict__ d_grid, float* __restrict__ da_out /*[rows,2H]*/,
+    const float* __restrict__ d_normal, const float* __restrict__ d_fd_grad, float* __restrict__ d_grid,
+    float* __restrict__ da_out /*[rows,2H]*/,
     float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f) {
     constexpr int NIN = 2 * L;
     __shared__ float w2_acc[(C > 0 ? C : 1) * H + H];
@@ -271,7 +281,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
 
     // gradient through the finite-difference normal: d sigma_k and an extra term on d sigma
     float dsk[3] = {0.f, 0.f, 0.f}, rawk[3] = {0.f, 0.f, 0.f};
-    if (d_normal && active) {
+    const bool with_fd = d_normal || d_fd_grad;
+    const float fd_sign = c.field_mode == ASD_FIELD_SDF ? 1.f : -1.f;
+    if (with_fd && active) {
         float nr[3];
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
@@ -280,27 +292,32 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
             const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
             float e2[NIN];
             rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
-            nr[k] = -(field_act(c, rawk[k]) - s) / c.fd_eps;
+            nr[k] = fd_sign * (field_act(c, rawk[k]) - s) / c.fd_eps;
         }
-        const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
-        const float g0 = d_normal[3 * (size_t)i], g1 = d_normal[3 * (size_t)i + 1], g2 = d_normal[3 * (size_t)i + 2];
-        float dnr[3];
-        if (len > 1e-12f) {
-            const float inv = 1.f / len;
-            const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
-            const float dot = n0 * g0 + n1 * g1 + n2 * g2;
-            dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
-        } else {
-            dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
+        float dnr[3] = {0.f, 0.f, 0.f};
+        if (d_normal) {
+            const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+            const float g0 = d_normal[3 * (size_t)i], g1 = d_normal[3 * (size_t)i + 1], g2 = d_normal[3 * (size_t)i + 2];
+            if (len > 1e-12f) {
+                const float inv = 1.f / len;
+                const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
+                const float dot = n0 * g0 + n1 * g1 + n2 * g2;
+                dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
+            } else {
+                dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
+            }
+        }
+        if (d_fd_grad) {
+            dnr[0] += d_fd_grad[3 * (size_t)i]; dnr[1] += d_fd_grad[3 * (size_t)i + 1]; dnr[2] += d_fd_grad[3 * (size_t)i + 2];
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            dsk[k] = -dnr[k] / c.fd_eps;
-            ds += dnr[k] / c.fd_eps;
+            dsk[k] = fd_sign * dnr[k] / c.fd_eps;
+            ds -= fd_sign * dnr[k] / c.fd_eps;
         }
     }
 
-    const int n_pts = d_normal ? 4 : 1;
+    const int n_pts = with_fd ? 4 : 1;
 #pragma unroll 1
     for (int pt = 0; pt < n_pts; ++pt) {
         float qx = px, qy = py, qz = pz, draw;
@@ -671,14 +688,14 @@ int asd_field_density(const asd_grid_meta* meta, const asd_field_cfg* cfg, const
 int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const float* grid_params,
                   const float* w1_density, const float* w2_density, const float* w1_feature,
                   const float* w2_feature, const float* points, int32_t n, const int32_t* n_dev, float* sigma,
-                  float* features, float* normal, float* enc_save, void* stream) {
+                  float* features, float* normal, float* fd_grad, float* enc_save, void* stream) {
     if (n == 0) return ASD_OK;
     ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && sigma && n > 0, "null argument");
     if (!field_supported(meta, cfg)) return ASD_ERR_UNSUPPORTED;
     ASD_CHECK_ARG(cfg->n_feature_dims == 0 || !features || (w1_feature && w2_feature), "feature weights missing");
     hipLaunchKernelGGL((field_fwd_kernel<16, 64, 3>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        *meta, *cfg, grid_params, w1_density, w2_density, w1_feature, w2_feature, points, n, n_dev,
-                       sigma, cfg->n_feature_dims == 3 ? features : nullptr, normal, enc_save);
+                       sigma, cfg->n_feature_dims == 3 ? features : nullptr, normal, fd_grad, enc_save);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -696,7 +713,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* w1_density, const float* w2_density, const float* w1_feature,
                   const float* w2_feature, const float* points, const float* enc_save, const float* sigma, int32_t n,
                   const int32_t* n_dev, const float* d_sigma, const float* d_features, const float* d_normal,
-                  float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
+                  const float* d_fd_grad, float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
                   float* workspace, void* stream) {
     if (n == 0) return ASD_OK;
     ASD_CHECK_ARG(meta && cfg && grid_params && w1_density && w2_density && points && enc_save && sigma &&
@@ -706,7 +723,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     ASD_CHECK_ARG(cfg->n_feature_dims == 3 || !d_features, "d_features given but no feature network");
     ASD_CHECK_ARG(cfg->n_feature_dims == 0 || (dw1_feature && dw2_feature && w1_feature && w2_feature), "feature gradients missing");
     hipStream_t s = (hipStream_t)stream;
-    const int with_normal = d_normal != nullptr;
+    const int with_normal = d_normal != nullptr || d_fd_grad != nullptr;
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
     const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
     float* da = workspace;
@@ -716,11 +733,11 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     if (cfg->n_feature_dims == 3)
         hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
                            w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
-                           d_normal, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+                           d_normal, d_fd_grad, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
     else
         hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 0>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
                            w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
-                           d_normal, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+                           d_normal, d_fd_grad, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);
     // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks

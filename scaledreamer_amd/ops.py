@@ -58,27 +58,31 @@ def field_density(meta, cfg: FieldCfg, grid, w1d, w2d, points, n_dev: Optional[t
 
 
 def field_fwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, want_normal: bool,
-              n_dev: Optional[torch.Tensor] = None):
+              n_dev: Optional[torch.Tensor] = None, want_fd_grad: bool = False):
+    """-> (sigma|sdf, features, normal, enc)   or, with want_fd_grad, (sdf, features, normal, fd_grad, enc)."""
     _need_cuda(grid, points)
     points = _c(points)
     n, dev = points.shape[0], points.device
     sigma = torch.empty(n, device=dev, dtype=torch.float32)
     feats = torch.empty((n, cfg.n_feature_dims), device=dev, dtype=torch.float32) if cfg.n_feature_dims > 0 else None
     normal = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    fd_grad = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_fd_grad else None
     enc = torch.empty((n, meta.n_levels * 2), device=dev, dtype=torch.float32)
     check(lib().asd_field_fwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
-                              ptr(points), i32(n), ptr(n_dev), ptr(sigma), ptr(feats), ptr(normal), ptr(enc),
+                              ptr(points), i32(n), ptr(n_dev), ptr(sigma), ptr(feats), ptr(normal), ptr(fd_grad), ptr(enc),
                               stream()))
+    if want_fd_grad:
+        return sigma, feats, normal, fd_grad, enc
     return sigma, feats, normal, enc
 
 
 def field_bwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma, d_sigma, d_features, d_normal,
-              d_grid: torch.Tensor, n_dev: Optional[torch.Tensor] = None):
+              d_grid: torch.Tensor, n_dev: Optional[torch.Tensor] = None, d_fd_grad=None):
     """Accumulates into d_grid (atomics); returns (dw1d, dw2d, dw1f, dw2f)."""
     points = _c(points)
     n, dev = points.shape[0], points.device
     nf = C.c_int64(0)
-    check(lib().asd_field_bwd_workspace(C.byref(cfg), i32(n), i32(int(d_normal is not None)), C.byref(nf)))
+    check(lib().asd_field_bwd_workspace(C.byref(cfg), i32(n), i32(int(d_normal is not None or d_fd_grad is not None)), C.byref(nf)))
     ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
     H, Cf = cfg.n_hidden, cfg.n_feature_dims
     dw1d = torch.zeros((H, 32), device=dev, dtype=torch.float32)
@@ -87,7 +91,7 @@ def field_bwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma,
     dw2f = torch.zeros((Cf, H), device=dev, dtype=torch.float32) if Cf > 0 else None
     check(lib().asd_field_bwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
                               ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), ptr(_c(d_sigma)),
-                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(d_grid), ptr(dw1d), ptr(dw2d), ptr(dw1f),
+                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(_c(d_fd_grad)), ptr(d_grid), ptr(dw1d), ptr(dw2d), ptr(dw1f),
                               ptr(dw2f), ptr(ws), stream()))
     return dw1d, dw2d, dw1f, dw2f
 

@@ -244,3 +244,84 @@ def install():
 
     tnet.config_to_primitive = lambda c, resolve=True: c
     tnet.get_rank = lambda: 0
+
+
+# ---- amortized path (custom/amortized): oracle-backed nerfacc.pdf / volrend / render_weight_from_alpha ----------
+class _OracleAlphaWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alphas, offset, count):
+        n, nr = alphas.shape[0], count.shape[0]
+        z, z3, bg = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((nr, 3), np.float32)
+        out = O.composite_fwd(alphas.detach().numpy(), z, z, z3, offset, count, bg, mode=1)
+        ctx.stuff = (alphas.detach().numpy(), z, z3, offset, count, bg, out)
+        return torch.from_numpy(out["weights"])
+
+    @staticmethod
+    def backward(ctx, dw):
+        a, z, z3, offset, count, bg, out = ctx.stuff
+        d_alpha, _, _ = O.composite_bwd(a, z, z, z3, offset, count, bg, out, d_weights=dw.contiguous().numpy(), mode=1)
+        return torch.from_numpy(d_alpha), None, None
+
+
+def render_weight_from_alpha(alphas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+    offset, count = _packed(ray_indices, n_rays)
+    w = _OracleAlphaWeights.apply(alphas, offset, count)
+    with torch.no_grad():
+        trans = w / alphas.clamp_min(1e-10)
+    return w, trans
+
+
+@dataclasses.dataclass
+class RayIntervals:
+    vals: torch.Tensor
+
+
+IMPORTANCE_JITTER = []   # golden scripts push one [n_rays] jitter array per importance_sampling call (stratified)
+IMPORTANCE_LOG = []
+
+
+def importance_sampling(intervals, cdfs, n_intervals_per_ray, stratified=False):
+    jit = IMPORTANCE_JITTER.pop(0) if stratified else None
+    out = O.importance_resample(intervals.vals.numpy(), cdfs.detach().numpy(), int(n_intervals_per_ray), jit)
+    IMPORTANCE_LOG.append(dict(vals=intervals.vals.numpy().copy(), cdfs=cdfs.detach().numpy().copy(), n=int(n_intervals_per_ray),
+                               jitter=None if jit is None else jit.copy(), out=out.copy()))
+    t = torch.from_numpy(out)
+    return RayIntervals(vals=t), RayIntervals(vals=0.5 * (t[:, 1:] + t[:, :-1]))
+
+
+def render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+    sd = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sd)
+    trans = torch.exp(-(torch.cumsum(sd, dim=-1) - sd))   # exclusive cumulative sum
+    return trans, alphas
+
+
+def install_amortized():
+    """extra stubs for custom/amortized (Hyper-iNGP, VolSDF renderer, importance estimator, hyper background)."""
+    install()
+    sys.modules["omegaconf"].ListConfig = list
+    _mod("omegaconf.dictconfig", DictConfig=dict)
+    na = sys.modules["nerfacc"]
+    na.render_weight_from_alpha = render_weight_from_alpha
+    sys.modules["nerfacc.data_specs"].RayIntervals = RayIntervals
+
+    class AbstractEstimator(nn.Module):
+        @property
+        def device(self):
+            return torch.device("cpu")
+    sys.modules["nerfacc.estimators.base"].AbstractEstimator = AbstractEstimator
+    sys.modules["nerfacc.pdf"].importance_sampling = importance_sampling
+    sys.modules["nerfacc.pdf"].searchsorted = None
+    sys.modules["nerfacc.volrend"].render_transmittance_from_density = render_transmittance_from_density
+    cu = _mod("custom")
+    cu.__path__ = [os.path.join(REFERENCE, "custom")]
+    for pkg in ["amortized", "amortized.models", "amortized.models.geometry", "amortized.models.renderers",
+                "amortized.models.background", "amortized.extern"]:
+        m = _mod("custom." + pkg)
+        m.__path__ = [os.path.join(REFERENCE, "custom", *pkg.split("."))]
+    import threestudio.utils.misc as tmisc
+
+    tmisc.broadcast = lambda t, src=0: t
+    import threestudio as ts
+
+    ts.error = print
