@@ -131,6 +131,40 @@ int asd_envmap_bwd(const asd_grid_meta* meta, const float* grid_params,
                    float* d_grid_params, float* dw0, float* dw1, float* dw2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Amortized (multi-prompt) render path: importance sampling on dense [n_rays, edges] tensors, replacing the
+ * nerfacc v0.5.2 calls of ImportanceEstimator.sampling (threestudio/models/estimators.py:72-74,84-88,93-94).
+ * Placement convention (nerfacc's jitter stream is unpinned): output edge j of a ray sits at cdf value
+ * u_j = (j + jitter[r]) / (n_out + 1) when jitter != NULL (stratified: one jitter per ray) else j / n_out; the edge is
+ * linearly interpolated inside the cdf segment [p, p+1], p = last index with cdf[p] <= u.
+ * ---------------------------------------------------------------------------------------------- */
+int asd_importance_resample(const float* vals /*[n_rays,e_in] sorted*/, const float* cdfs /*[n_rays,e_in]*/, int32_t n_rays,
+                            int32_t e_in, int32_t n_out, const float* jitter /*[n_rays] or NULL*/,
+                            float* out /*[n_rays,n_out+1]*/, void* stream);
+/* cdf[r,j] = 1 - exp(-sum_{k<j} sigma[r,k] (t[r,k+1] - t[r,k])), cdf[r,S] = 1: render_transmittance_from_density +
+ * `1 - cat([trans, 0])` (estimators.py:84-86). */
+int asd_transmittance_cdf(const float* t_edges /*[n_rays,S+1]*/, const float* sigma /*[n_rays,S]*/, int32_t n_rays,
+                          int32_t n_samples, float* cdf /*[n_rays,S+1]*/, void* stream);
+/* per-ray merge of two sorted edge lists = sort(cat([a, b], -1)) (estimators.py:93-94); ties keep a first. */
+int asd_merge_sorted(const float* a, int32_t na, const float* b, int32_t nb, int32_t n_rays, float* out /*[n_rays,na+nb]*/,
+                     void* stream);
+
+/* Feature samplers of the generator-backed geometries (custom/amortized/models/geometry/utils.py):
+ * get_trilinear_feature (:95-110) = F.grid_sample(voxel[B,C,D,H,W], points, bilinear, zeros, align_corners=False) and
+ * sample_from_planes (:81-93) = 3 bilinear grid_samples on planes[B,3,C,H,W] with the projections (x,y), (x,z), (z,y).
+ * Features are stored channel-LAST ([B,D,H,W,C] / [B,3,H,W,C], C in {4,8,16,32,64}); asd_relayout_f32 converts
+ * [batch, rows, cols] -> [batch, cols, rows] (NCDHW <-> NDHWC with rows = C, cols = D*H*W).  points [B,M,3] in [-1,1]:
+ * x -> W, y -> H, z -> D.  Backward accumulates (+=, atomics) into the zero-initialised feature gradient. */
+int asd_voxel_sample_fwd(const float* voxel_cl, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, const float* points,
+                         int32_t M, float* out /*[B,M,C]*/, void* stream);
+int asd_voxel_sample_bwd(const float* d_out, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, const float* points,
+                         int32_t M, float* d_voxel_cl, void* stream);
+int asd_triplane_sample_fwd(const float* planes_cl, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
+                            float coord_scale /* 2 / box_warp */, float* out /*[B,M,3C]*/, void* stream);
+int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
+                            float coord_scale, float* d_planes_cl, void* stream);
+int asd_relayout_f32(const float* x, int32_t batch, int32_t rows, int32_t cols, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Occupancy-grid ray marching (replaces nerfacc.OccGridEstimator.sampling -> CUDA traverse_grids /
  * ray_aabb_intersect / render_visibility_from_density; call site nerf_volume_renderer.py:139-180).
  * Sample placement convention (nerfacc's is unpinned): per ray the samples lie on the

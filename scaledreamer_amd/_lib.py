@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasd_hip.so")
 ASD_MAX_LEVELS = 16
 
-ASD_BIAS_CONST, ASD_BIAS_BLOB_MAGIC3D, ASD_BIAS_BLOB_DREAMFUSION = 0, 1, 2
+ASD_BIAS_CONST, ASD_BIAS_BLOB_MAGIC3D, ASD_BIAS_BLOB_DREAMFUSION, ASD_BIAS_SPHERE = 0, 1, 2, 3
+ASD_FIELD_DENSITY, ASD_FIELD_SDF = 0, 1
 ASD_ACT_SOFTPLUS, ASD_ACT_EXP, ASD_ACT_TRUNC_EXP, ASD_ACT_NONE = 0, 1, 2, 3
 
 
@@ -85,6 +86,8 @@ SYMBOLS = [
     "asd_grid_meta_init", "asd_hashgrid_fwd", "asd_hashgrid_bwd",
     "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd",
     "asd_envmap_fwd", "asd_envmap_bwd",
+    "asd_importance_resample", "asd_transmittance_cdf", "asd_merge_sorted", "asd_voxel_sample_fwd", "asd_voxel_sample_bwd",
+    "asd_triplane_sample_fwd", "asd_triplane_sample_bwd", "asd_relayout_f32",
     "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
     "asd_gemm_f16", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",

@@ -211,3 +211,83 @@ def pack_bits(binaries: torch.Tensor) -> torch.Tensor:
     w = (b.view(-1, 32) << torch.arange(32, device=b.device, dtype=torch.int64)).sum(1)
     w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
     return w.to(torch.int32).contiguous()
+
+
+# ---- amortized path: importance sampling, voxel / tri-plane samplers ------------------------------------------
+def importance_resample(vals: torch.Tensor, cdfs: torch.Tensor, n_out: int, jitter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vals, cdfs [n_rays, e_in] -> resampled edges [n_rays, n_out + 1] (include/asd_hip.h: asd_importance_resample)."""
+    _need_cuda(vals, cdfs)
+    vals, cdfs = _c(vals), _c(cdfs)
+    n_rays, e_in = vals.shape
+    out = torch.empty((n_rays, n_out + 1), device=vals.device, dtype=torch.float32)
+    check(lib().asd_importance_resample(ptr(vals), ptr(cdfs), i32(n_rays), i32(e_in), i32(n_out), ptr(_c(jitter)), ptr(out), stream()))
+    return out
+
+
+def transmittance_cdf(t_edges: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    _need_cuda(t_edges, sigma)
+    t_edges, sigma = _c(t_edges), _c(sigma)
+    n_rays, S = sigma.shape
+    assert t_edges.shape == (n_rays, S + 1)
+    cdf = torch.empty((n_rays, S + 1), device=sigma.device, dtype=torch.float32)
+    check(lib().asd_transmittance_cdf(ptr(t_edges), ptr(sigma), i32(n_rays), i32(S), ptr(cdf), stream()))
+    return cdf
+
+
+def merge_sorted(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need_cuda(a, b)
+    a, b = _c(a), _c(b)
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), device=a.device, dtype=torch.float32)
+    check(lib().asd_merge_sorted(ptr(a), i32(a.shape[1]), ptr(b), i32(b.shape[1]), i32(a.shape[0]), ptr(out), stream()))
+    return out
+
+
+def relayout(x: torch.Tensor) -> torch.Tensor:
+    """[batch, rows, cols] -> [batch, cols, rows] (fp32)."""
+    _need_cuda(x)
+    x = _c(x)
+    b, r, c = x.shape
+    y = torch.empty((b, c, r), device=x.device, dtype=torch.float32)
+    check(lib().asd_relayout_f32(ptr(x), i32(b), i32(r), i32(c), ptr(y), stream()))
+    return y
+
+
+def voxel_sample_fwd(voxel_cl: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
+    """voxel_cl [B,D,H,W,C], points [B,M,3] -> [B,M,C]"""
+    _need_cuda(voxel_cl, points)
+    B, D, H, W, Cc = voxel_cl.shape
+    points = _c(points)
+    M = points.shape[1]
+    out = torch.empty((B, M, Cc), device=points.device, dtype=torch.float32)
+    check(lib().asd_voxel_sample_fwd(ptr(voxel_cl), i32(B), i32(D), i32(H), i32(W), i32(Cc), ptr(points), i32(M), ptr(out), stream()))
+    return out
+
+
+def voxel_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape) -> torch.Tensor:
+    B, D, H, W, Cc = shape
+    d_voxel = torch.zeros(shape, device=d_out.device, dtype=torch.float32)
+    points = _c(points)
+    check(lib().asd_voxel_sample_bwd(ptr(_c(d_out)), i32(B), i32(D), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
+                                     ptr(d_voxel), stream()))
+    return d_voxel
+
+
+def triplane_sample_fwd(planes_cl: torch.Tensor, points: torch.Tensor, coord_scale: float) -> torch.Tensor:
+    """planes_cl [B,3,H,W,C], points [B,M,3] -> [B,M,3C]"""
+    _need_cuda(planes_cl, points)
+    B, _, H, W, Cc = planes_cl.shape
+    points = _c(points)
+    M = points.shape[1]
+    out = torch.empty((B, M, 3 * Cc), device=points.device, dtype=torch.float32)
+    check(lib().asd_triplane_sample_fwd(ptr(planes_cl), i32(B), i32(H), i32(W), i32(Cc), ptr(points), i32(M), f32(coord_scale), ptr(out),
+                                        stream()))
+    return out
+
+
+def triplane_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape, coord_scale: float) -> torch.Tensor:
+    B, _, H, W, Cc = shape
+    d_planes = torch.zeros(shape, device=d_out.device, dtype=torch.float32)
+    points = _c(points)
+    check(lib().asd_triplane_sample_bwd(ptr(_c(d_out)), i32(B), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
+                                        f32(coord_scale), ptr(d_planes), stream()))
+    return d_planes

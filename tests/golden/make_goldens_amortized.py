@@ -36,7 +36,7 @@ def seeded(name, shape, seed, scale=1.0):
 def make_samplers_golden(seed=3):
     # get_trilinear_feature's final reshape(df, -1).T (utils.py:108) is only meaningful for B = 1 (the reference runs one
     # prompt per GPU with this geometry), so the voxel golden uses B = 1
-    vox = seeded("voxel", (1, 6, 5, 7, 9), seed).requires_grad_(True)         # [B, C, D, H, W]
+    vox = seeded("voxel", (1, 8, 5, 7, 9), seed).requires_grad_(True)         # [B, C, D, H, W]
     pts = (torch.rand(2, 80, 3, generator=torch.Generator().manual_seed(seed)) * 2.4 - 1.2)   # some fall outside [-1, 1]
     pts[0, :4] = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [0.999, -0.999, 0.5]])
     f = get_trilinear_feature(pts[:1], vox)                                   # [1, M, C]

@@ -1,0 +1,171 @@
+"""GPU parity of the amortized (multi-prompt) render path, through the C ABI: kernels vs the oracle on seeded inputs,
+drop-in sampler functions and the Hyper-iNGP VolSDF renderer vs the goldens produced by the reference's own code."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _load(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("stratified", [True, False])
+def test_importance_resample_cdf_merge_match_oracle(stratified):
+    from oracle import oracle as O
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(5)
+    n_rays, e_in, n_out = 777, 129, 64
+    vals = np.sort(rng.uniform(0.1, 4.0, (n_rays, e_in)).astype(np.float32), axis=1)
+    sig = (rng.uniform(0, 1, (n_rays, e_in - 1)) ** 6 * 60).astype(np.float32)
+    sig[:5] = 0.0
+    cdf_o = O.transmittance_cdf(vals, sig)
+    cdf = ops.transmittance_cdf(_dev(vals), _dev(sig)).cpu().numpy()
+    np.testing.assert_allclose(cdf, cdf_o, rtol=0, atol=3e-7)
+    jit = rng.uniform(0, 1, n_rays).astype(np.float32) if stratified else None
+    out_o = O.importance_resample(vals, cdf_o, n_out, jit)
+    out = ops.importance_resample(_dev(vals), _dev(cdf_o), n_out, None if jit is None else _dev(jit)).cpu().numpy()
+    np.testing.assert_array_equal(out, out_o)                           # same fp32 arithmetic, same search result: bit-exact
+    assert (np.diff(out, axis=1) >= 0).all() and out.min() >= vals.min() and out.max() <= vals.max()
+    merged = ops.merge_sorted(_dev(vals), _dev(out_o)).cpu().numpy()
+    np.testing.assert_array_equal(merged, O.merge_sorted(vals, out_o))
+    np.testing.assert_array_equal(merged, np.sort(np.concatenate([vals, out_o], 1), axis=1))
+
+
+@pytest.mark.parametrize("C_", [32, 8])
+def test_voxel_and_triplane_kernels_match_oracle(C_):
+    from oracle import oracle as O
+    from scaledreamer_amd import ops
+
+    rng = np.random.default_rng(6)
+    B, D, H, W, M = 2, 9, 12, 10, 3000
+    vox = rng.normal(size=(B, D, H, W, C_)).astype(np.float32)
+    pts = rng.uniform(-1.15, 1.15, (B, M, 3)).astype(np.float32)
+    out = ops.voxel_sample_fwd(_dev(vox), _dev(pts)).cpu().numpy()
+    np.testing.assert_array_equal(out, O.voxel_sample_fwd(vox, pts))
+    g = rng.normal(size=out.shape).astype(np.float32)
+    dv = ops.voxel_sample_bwd(_dev(g), _dev(pts), vox.shape).cpu().numpy()
+    np.testing.assert_allclose(dv, O.voxel_sample_bwd(g, pts, vox.shape), rtol=1e-4, atol=1e-4)
+    pl = rng.normal(size=(B, 3, H, W, C_)).astype(np.float32)
+    outp = ops.triplane_sample_fwd(_dev(pl), _dev(pts), 1.0).cpu().numpy()
+    np.testing.assert_array_equal(outp, O.triplane_sample_fwd(pl, pts, 1.0))
+    gp = rng.normal(size=outp.shape).astype(np.float32)
+    dp = ops.triplane_sample_bwd(_dev(gp), _dev(pts), pl.shape, 1.0).cpu().numpy()
+    np.testing.assert_allclose(dp, O.triplane_sample_bwd(gp, pts, pl.shape, 1.0), rtol=1e-4, atol=1e-4)
+    x = rng.normal(size=(3, 37, 1000)).astype(np.float32)
+    np.testing.assert_array_equal(ops.relayout(_dev(x)).cpu().numpy(), x.transpose(0, 2, 1))
+
+
+def test_dropin_samplers_match_reference_goldens():
+    """get_trilinear_feature / sample_from_planes with the reference's argument layout (channel-first) and autograd."""
+    from scaledreamer_amd import samplers as S
+
+    g = _load("amortized_samplers")
+    vox = _dev(g["voxel"]).requires_grad_(True)
+    pts = _dev(g["points"])
+    f = S.get_trilinear_feature(pts[:1], vox)
+    np.testing.assert_allclose(f.detach().cpu().numpy(), g["tri_out"], rtol=1e-5, atol=2e-6)
+    (f * _dev(g["tri_g"])).sum().backward()
+    np.testing.assert_allclose(vox.grad.cpu().numpy(), g["tri_dvoxel"], rtol=1e-4, atol=1e-5)
+    planes = _dev(g["planes"]).requires_grad_(True)
+    fp = S.sample_from_planes(planes, pts)
+    np.testing.assert_allclose(fp.detach().cpu().numpy(), g["plane_out"], rtol=1e-5, atol=2e-6)
+    (fp * _dev(g["plane_g"])).sum().backward()
+    np.testing.assert_allclose(planes.grad.cpu().numpy(), g["plane_dplanes"], rtol=1e-4, atol=1e-5)
+    bbox = torch.tensor([[-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]]).cuda()
+    np.testing.assert_allclose(S.contract_to_unisphere_custom(pts * 2, bbox, False).cpu().numpy(), g["contract"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("with_fd", [True, False])
+def test_sdf_field_mode_matches_oracle(with_fd):
+    from oracle import oracle as O
+    from oracle import ref_amortized as RA
+    from scaledreamer_amd import _lib, ops
+
+    rng = np.random.default_rng(8)
+    n = 5000
+    om = O.grid_meta()
+    oc = RA.sdf_field_cfg(2.0, 0.5, 0.01)
+    hm = _lib.make_grid_meta(16, 2, 19, 16, 1.447269237440378)
+    hc = _lib.FieldCfg()
+    for d in range(3):
+        hc.bbox_min[d], hc.bbox_max[d] = -2.0, 2.0
+    hc.radius, hc.bias_mode, hc.bias_value, hc.blob_scale, hc.blob_std = 2.0, _lib.ASD_BIAS_SPHERE, 0.5, 0.0, 1.0
+    hc.activation, hc.fd_eps, hc.n_hidden, hc.n_feature_dims, hc.field_mode = _lib.ASD_ACT_NONE, 0.01, 64, 3, _lib.ASD_FIELD_SDF
+    grid = rng.uniform(-0.05, 0.05, om.n_params).astype(np.float32)
+    w = [rng.normal(size=s).astype(np.float32) * 0.2 for s in ((64, 32), (1, 64), (64, 32), (3, 64))]
+    pts = rng.uniform(-2.3, 2.3, (n, 3)).astype(np.float32)
+    dg, dw, dp = _dev(grid), [_dev(a) for a in w], _dev(pts)
+    sdf, feat, nrm, fdg, enc = ops.field_fwd(hm, hc, dg, *dw, dp, True, want_fd_grad=True)
+    s2, f2, n2, g2, _ = O.field_fwd(om, oc, grid, *w, pts, want_normal=True, want_fd_grad=True)
+    np.testing.assert_allclose(sdf.cpu().numpy(), s2, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(feat.cpu().numpy(), f2, rtol=0, atol=2e-6)
+    assert np.abs(fdg.cpu().numpy() - g2).max() <= 5e-4 * max(1.0, np.abs(g2).max())      # differences of ~1e-6 divided by eps = 0.01
+    ds, df = rng.normal(size=n).astype(np.float32), rng.normal(size=(n, 3)).astype(np.float32)
+    dn = rng.normal(size=(n, 3)).astype(np.float32) if with_fd else None
+    dgd = rng.normal(size=(n, 3)).astype(np.float32) * 0.1 if with_fd else None
+    d_grid = torch.zeros_like(dg)
+    got = ops.field_bwd(hm, hc, dg, *dw, dp, enc, sdf, _dev(ds), _dev(df), None if dn is None else _dev(dn), d_grid,
+                        d_fd_grad=None if dgd is None else _dev(dgd))
+    want = O.field_bwd(om, oc, grid, *w, pts, ds, df, dn, dgd)
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30)
+    assert rel(d_grid.cpu().numpy(), want[0]) < 2e-3
+    for a, b in zip(got, want[1:]):
+        assert rel(a.cpu().numpy(), b) < 2e-3
+
+
+def test_hyper_ingp_volsdf_renderer_matches_reference_golden():
+    from test_goldens_amortized_cpu import amortized_loss, amortized_problem, check_amortized_against_golden
+
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = _load("amortized_hyper_ingp_2x4x4")
+    P = amortized_problem(g)
+    enc = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16,
+           "per_level_scale": 1.447269237440378}
+    hyper = {"c_dim": 1024, "out_dims": {"sdf_weights": [64, 1], "feature_weights": [64, 3]}, "spectral_norm": False, "n_neurons": 64,
+             "n_hidden_layers": 1}
+    geo = find("Hyper-iNGP")({"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere",
+                              "sdf_bias_params": 0.5, "shape_init": "sphere", "shape_init_params": 0.5, "hypernet_config": hyper,
+                              "pos_encoding_config": enc}).cuda()
+    mat = find("no-material")({"n_output_dims": 3, "color_activation": "sigmoid", "requires_normal": True}).cuda()
+    bg = find("multiprompt-neural-hashgrid-environment-map-background")(
+        {"color_activation": "sigmoid", "random_aug": True, "random_aug_prob": 0.2, "pos_encoding_config": dict(enc, per_level_scale=1.0)}).cuda()
+    ren = find("generative-space-volsdf-volume-renderer")(
+        {"radius": 2.0, "use_volsdf": True, "trainable_variance": False, "learned_variance_init": 0.340119, "estimator": "importance",
+         "num_samples_per_ray": int(g["n_fine"]), "num_samples_per_ray_importance": int(g["n_prop"]), "near_plane": 0.1, "far_plane": 4.0,
+         "train_chunk_size": 0}, geometry=geo, material=mat, background=bg).cuda()
+    geo.do_update_step(0, 0)
+    assert geo._fcfg is not None, "the Hyper-iNGP config of asd_sd_hyper_iNGP_50k.yaml must take the fused SDF kernels"
+    with torch.no_grad():
+        geo.encoding.encoding.encoding.params.copy_(P["grid"].detach())
+        bg.encoding.encoding.encoding.params.copy_(P["bgrid"].detach())
+        for tag, net in (("geo_hyper", geo.hypernet), ("bg_hyper", bg.hypernet)):
+            for k, p in net.named_parameters():
+                p.copy_(P[tag][k].detach())
+    jit = [_dev(g["jitter0"]), _dev(g["jitter1"])]
+    ren.estimator.jitter_fn = lambda n, device: jit.pop(0)
+    real = random.random
+    random.random = lambda: 0.9
+    try:
+        ren.train(); geo.train(); bg.train(); mat.train()
+        out = ren(rays_o=_dev(g["rays_o"]), rays_d=_dev(g["rays_d"]), light_positions=_dev(g["light_positions"]), text_embed=_dev(g["text_embed"]))
+    finally:
+        random.random = real
+    loss, loss_eik = amortized_loss(out, g)
+    loss.backward()
+    Pg = {"grid": geo.encoding.encoding.encoding.params, "bgrid": bg.encoding.encoding.encoding.params,
+          "geo_hyper": dict(geo.hypernet.named_parameters()), "bg_hyper": dict(bg.hypernet.named_parameters())}
+    check_amortized_against_golden(out, Pg, g, loss, loss_eik, tol=2.0)
+    assert abs(float(out["inv_std"]) - 30.0) < 1e-2
