@@ -77,6 +77,53 @@ def asd_mv_nerf(prompt: str = "synthetic", guidance_backend: str = "hip-mvdream"
     return cfg
 
 
+def asd_sd_hyper_ingp(prompts=None, guidance_backend: str = "hip") -> dict:
+    """configs/multi-prompt_benchmark/asd_sd_hyper_iNGP_50k.yaml: multi-prompt amortized training — Hyper-iNGP SDF field
+    (per-prompt MLP weights from a hypernetwork), hypernetwork hash-grid background, importance-sampled VolSDF renderer
+    (128 proposal + 64 resampled edges -> 193 intervals per ray), SD-2.1 ASD guidance, Adam."""
+    prompts = prompts or [f"synthetic prompt {i}" for i in range(16)]
+    enc = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16}
+    return copy.deepcopy({
+        "name": "asd_sd_hyper_iNGP_50k", "seed": 0,
+        "data_type": "multiprompt-camera-datamodule",
+        "data": {"batch_size": 1, "width": 64, "height": 64, "camera_distance_range": [1.0, 1.5], "fovy_range": [40, 70],
+                 "elevation_range": [-10, 45], "camera_perturb": 0.0, "center_perturb": 0.0, "up_perturb": 0.0,
+                 "eval_camera_distance": 1.5, "eval_fovy_deg": 70.0, "n_val_views": 30, "dim_gaussian": 0,
+                 "prompt_library": {"train": prompts, "val": prompts[:1], "test": prompts[:1]}},
+        "system_type": "multiprompt-radience-field-generator-system",
+        "system": {
+            "stage": "coarse", "initialize_shape": False, "visualize_samples": False, "validation_via_video": True,
+            "geometry_type": "Hyper-iNGP",
+            "geometry": {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere",
+                         "sdf_bias_params": 0.5, "shape_init": "sphere", "shape_init_params": 0.5,
+                         "hypernet_config": {"c_dim": 1024, "out_dims": {"sdf_weights": [64, 1], "feature_weights": [64, 3]},
+                                             "spectral_norm": False, "n_neurons": 64, "n_hidden_layers": 1}},
+            "material_type": "no-material",
+            "material": {"n_output_dims": 3, "color_activation": "sigmoid", "requires_normal": True},
+            "background_type": "multiprompt-neural-hashgrid-environment-map-background",
+            "background": {"color_activation": "sigmoid", "random_aug": True, "random_aug_prob": 0.2,
+                           "pos_encoding_config": dict(enc, per_level_scale=1.0)},
+            "renderer_type": "generative-space-volsdf-volume-renderer",
+            "renderer": {"radius": 2.0, "use_volsdf": True, "trainable_variance": False, "learned_variance_init": 0.340119,
+                         "estimator": "importance", "num_samples_per_ray": 64, "num_samples_per_ray_importance": 128,
+                         "near_plane": 0.1, "far_plane": 4.0, "train_chunk_size": 0},
+            "prompt_processor_type": "stable-diffusion-multi-prompt-processor",
+            "prompt_processor": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "use_perp_neg": True,
+                                 "front_threshold": 30.0, "back_threshold": 30.0},
+            "guidance_type": "stable-diffusion-asynchronous-score-distillation-guidance",
+            "guidance": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "guidance_scale": 7.5,
+                         "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 50000],
+                         "max_step_percent": [0, 0.98, 0.5, 50000], "guidance_perp_neg": -0.5, "backend": guidance_backend},
+            "loggers": {"wandb": {"enable": False, "project": "threestudio", "name": "None"}},
+            "loss": {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 20, "lambda_opaque": [40000, 0, 10.0, 50000],
+                     "lambda_z_variance": 0.0, "lambda_eikonal": [1, 100.0, 1.0, 5000]},
+            "optimizer": {"name": "Adam", "args": {"betas": [0.0, 0.99], "eps": 1.0e-8},
+                          "params": {"geometry": {"lr": 0.004}, "background": {"lr": 0.001}}},
+        },
+        "trainer": {"max_steps": 50000, "precision": 32},
+    })
+
+
 def nerf_only_c1() -> dict:
     """BASELINE config 1: single prompt, 32x32 rays, 16 samples per ray, NeRF-only render (no diffusion)."""
     cfg = asd_sd_nerf()

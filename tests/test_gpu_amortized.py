@@ -169,3 +169,36 @@ def test_hyper_ingp_volsdf_renderer_matches_reference_golden():
           "geo_hyper": dict(geo.hypernet.named_parameters()), "bg_hyper": dict(bg.hypernet.named_parameters())}
     check_amortized_against_golden(out, Pg, g, loss, loss_eik, tol=2.0)
     assert abs(float(out["inv_std"]) - 30.0) < 1e-2
+
+
+def test_hyper_ingp_amortized_asd_step_runs():
+    """asd_sd_hyper_iNGP preset end to end: prompt draw -> hypernetworks -> importance-sampled VolSDF render -> SD guidance
+    (reduced-width HIP UNet, full VAE) -> eikonal + sparsity -> backward into hash grids and hypernetworks -> Adam."""
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.diffusion import weights as W
+    from scaledreamer_amd.diffusion.engine import HipBackend
+    from scaledreamer_amd.multiprompt import MultipromptRandomCameraIterableDataset, SyntheticMultiPromptProcessor
+    from scaledreamer_amd.registry import find
+    import scaledreamer_amd.plugins  # noqa: F401
+
+    torch.manual_seed(0)
+    random.seed(0)
+    dev = torch.device("cuda", 0)
+    cfg = presets.asd_sd_hyper_ingp()
+    backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128), vae_cfg=W.VAEConfig(), seed=3)
+    proc = SyntheticMultiPromptProcessor(cfg["data"]["prompt_library"]["train"], seed=2, device=dev, ctx_dim=128, global_dim=1024,
+                                         front_threshold=30.0, back_threshold=30.0)
+    system = find(cfg["system_type"])(cfg["system"], guidance_backend=backend, prompt_processor=proc)
+    system.train()
+    data = MultipromptRandomCameraIterableDataset(cfg["data"], rank=0, n_ranks=1)
+    w_before = system.geometry.hypernet.layers[3].weight.detach().clone()
+    g_before = system.geometry.encoding.encoding.encoding.params.detach().clone()
+    for _ in range(2):
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+        loss = system.train_one_step(batch)
+    assert torch.isfinite(loss).item()
+    assert system.geometry._fcfg is not None
+    for k in ("train/loss_asd", "train/loss_eikonal", "train/loss_sparsity"):
+        assert torch.isfinite(system.logged[k]).item(), k
+    assert (system.geometry.hypernet.layers[3].weight.detach() != w_before).any().item()
+    assert (system.geometry.encoding.encoding.encoding.params.detach() != g_before).any().item()

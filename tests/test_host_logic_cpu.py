@@ -136,3 +136,40 @@ def test_camera_batches_match_reference_collate(golden, name, extra):
         for k in ["rays_o", "rays_d", "mvp_mtx", "camera_positions", "c2w", "light_positions", "elevation", "azimuth",
                   "camera_distances", "fovy"]:
             np.testing.assert_allclose(b[k].numpy(), g[f"s{s}.{k}"], rtol=2e-6, atol=2e-6, err_msg=f"{golden} seed {s} key {k}")
+
+
+def test_multiprompt_utils_reduce_to_single_prompt_utils():
+    """MultiPromptProcessorOutput (custom/.../prompt_processors/base.py:434-560) with the same view-dependent embeddings for
+    every batch element must assemble exactly what the single-prompt PromptProcessorOutput (pinned by its golden) does."""
+    from scaledreamer_amd.guidance import PromptUtils
+    from scaledreamer_amd.multiprompt import MultiPromptUtils, SyntheticMultiPromptProcessor
+
+    g = torch.Generator().manual_seed(3)
+    vd, un = torch.randn(4, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g).expand(4, -1, -1).contiguous()
+    single = PromptUtils(vd, un, vd[0], un[0], front_threshold=30.0, back_threshold=30.0)
+    B = 5
+    multi = MultiPromptUtils([vd[0, 0]] * B, [vd[0]] * B, un[0], [vd] * B, un, front_threshold=30.0, back_threshold=30.0)
+    ele = torch.tensor([5.0, 70.0, 20.0, -5.0, 30.0])
+    azi = torch.tensor([10.0, 50.0, 100.0, -170.0, -60.0])
+    dist = torch.ones(B)
+    t1, w1 = single.get_text_embeddings_perp_neg(ele, azi, dist, True)
+    t2, w2 = multi.get_text_embeddings_perp_neg(ele, azi, dist, True)
+    assert torch.equal(t1, t2) and torch.allclose(w1, w2)
+    assert torch.equal(single.get_text_embeddings(ele, azi, dist, True), multi.get_text_embeddings(ele, azi, dist, True))
+    proc = SyntheticMultiPromptProcessor(["a", "b", "c"], seed=1, ctx_dim=64)
+    pu = proc(prompt=["c", "a"])
+    assert pu.get_global_text_embeddings().shape == (2, 64) and torch.equal(pu.text_embeddings_vd[1], proc.table["a"][2])
+    with pytest.raises(ValueError):
+        proc(prompt="zzz")
+
+
+def test_multiprompt_datamodule_shards_library_by_rank():
+    from scaledreamer_amd.multiprompt import MultipromptRandomCameraIterableDataset as D
+
+    lib = {"train": [f"p{i}" for i in range(10)]}
+    cfg = dict(batch_size=2, width=8, height=8, dim_gaussian=4, prompt_library=lib)
+    d0, d1 = D(cfg, rank=0, n_ranks=4), D(cfg, rank=1, n_ranks=4)
+    assert d0.prompt_library == ["p0", "p4", "p8"] and d1.prompt_library == ["p1", "p5", "p9"]
+    b = d0.collate()
+    assert b["noise"].shape == (2, 4) and len(b["prompt"]) == 2 and set(b["prompt"]) <= set(d0.prompt_library)
+    assert b["rays_o"].shape == (2, 8, 8, 3)
