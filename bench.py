@@ -98,7 +98,10 @@ def roofline_gemm_kernel(reps: int = 30):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * B * hw * hw * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_f16_kernel<256,64,conv> (3x3 conv 320->320 @64x64, batch 5)", "bound": "mfma",
+    plan = H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1))
+    tile = f"{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}" if plan[0] else "model"
+    return {"kernel": f"gemm_f16_kernel<{tile},conv> split_k={plan[1]} (3x3 conv 320->320 @64x64, batch 5; autotuned plan, "
+                      "time includes the split-K epilogue launch)", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
             "traffic": None, "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 

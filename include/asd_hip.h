@@ -260,8 +260,13 @@ typedef struct asd_gemm_args {
     const void* zero_page;  /* >= 16 B of zeros: source of out-of-range rows / taps */
     int32_t split_k;        /* >= 1; > 1 needs workspace[split_k, M, N] fp32 */
     float*  workspace;
+    int32_t tile_cfg;       /* 0: tile chosen by the built-in cost model; 1 + i: tile configuration i (see asd_gemm_force_tile),
+                               as found by the caller's autotuner (scaledreamer_amd/diffusion/hip_ops.py) */
 } asd_gemm_args;
 int asd_gemm_f16(const asd_gemm_args* args, void* stream);
+/* Tuning hook (tools/gemm_sweep.py): force tile configuration `cfg` (index into the table of csrc/gemm.hip: 128x64, 128x128,
+ * 256x64, 256x128, 128x320, 256x256, 256x320, 320x128) for all following asd_gemm_f16 calls; -1 restores the cost model. */
+int asd_gemm_force_tile(int32_t cfg);
 
 /* GroupNorm(32 groups) [+ SiLU] on NHWC fp16 with fp32 statistics (GroupNorm32, diffusionmodules/util.py:229-231);
  * x may be the channel-concatenation of two tensors (skip connections, openaimodel.py:797-799): x2/c2. */

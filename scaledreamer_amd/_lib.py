@@ -76,6 +76,7 @@ class GemmArgs(C.Structure):
         ("conv", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
         ("Wout", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("upsample", C.c_int32),
         ("zero_page", C.c_void_p), ("split_k", C.c_int32), ("workspace", C.c_void_p),
+        ("tile_cfg", C.c_int32),
     ]
 
 
@@ -90,7 +91,7 @@ SYMBOLS = [
     "asd_triplane_sample_fwd", "asd_triplane_sample_bwd", "asd_relayout_f32",
     "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
-    "asd_gemm_f16", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
+    "asd_gemm_f16", "asd_gemm_force_tile", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
     "asd_version", "asd_last_error",
 ]

@@ -36,30 +36,29 @@ __device__ __forceinline__ void load_slab(const char* src_row_chunk, char* lds_s
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src_row_chunk, (LDS_AS void*)lds_slab_base, 16, 0, 0);
 }
 
-// One pipeline stage holds a 128 x 64 A tile and a BN x 64 W tile with 128-byte LDS rows: a wave-level
-// global_load_lds instruction then covers 8 rows x one full 128-B cache line (64-B rows touch twice as many lines
-// per byte, and the texture-address path, not the MFMA pipe, limits this kernel).  The 16-B chunk index is
-// XOR-swizzled with (row & 7) on the source address and on the ds_read_b128 side (conflict-free).  A k-step
-// issues 2 x TM x TN MFMAs per wave.  NST stages form a ring: with NST = 3 the loads of tile k+2 are issued while
-// tile k is consumed and only tile k+1 is waited for (counted s_waitcnt vmcnt + raw s_barrier; a
-// __syncthreads() would drain the LDS-DMA queue).  K % 64 != 0 (K = 32-multiples) uses the KHALF variant that
-// leaves the second half of the last row chunk to the zero page.
-template <int BM, int BN, bool CONV, int NST>
-__global__ __launch_bounds__(BM * 2) void gemm_f16_kernel(const asd_gemm_args p) {
-    constexpr int NW = BM / 32;               // waves: (BM/64) x 2
-    constexpr int TM = 4;                     // 64 rows per wave in m
-    constexpr int TN = BN / 32;               // BN/2 columns per wave in n
+// One pipeline stage holds a BM x 64 A tile and a BN x 64 W tile with 128-byte LDS rows: a wave-level
+// global_load_lds instruction covers 8 rows x one full 128-B cache line.  The 16-B chunk index is XOR-swizzled with
+// (row & 7) on the source address and on the ds_read_b128 side (conflict-free).  Two stages (double buffer): the loads
+// of tile k+1 are issued right after the barrier that publishes tile k.
+//
+// Measured on MI355X (tools/gemm_ablate.py): removing the MFMAs or the ds_reads from this loop does not change its time,
+// removing the global->LDS tile loads makes it 1.5-2.6x faster, and every shape lands at ~8 TB/s of aggregate L2->LDS
+// traffic.  The kernel is bound by bytes loaded per flop = (1/BM + 1/BN) / 128 B, so the tile is chosen as large as the
+// problem allows (WM x WN waves, each owning a (BM/WM) x (BN/WN) register tile), up to 256 x 320.
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_args p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int RB = 128;                   // LDS row bytes (64 halfs)
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int ASLABS = BM / 8, WSLABS = BN / 8;       // 8-row slabs (1 KiB per wave instruction)
-    constexpr int AS = ASLABS / NW;                        // A slabs per wave (4)
-    constexpr int WS = (WSLABS + NW - 1) / NW;             // W slabs per wave (upper bound)
-    constexpr int LOADS_PER_TILE = AS + WS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST][A | W]
+    constexpr int ASLABS = BM / 8, TSLABS = (BM + BN) / 8;   // 8-row slabs (1 KiB per wave instruction); A first, then W
+    constexpr int SPW = (TSLABS + NW - 1) / NW;            // slabs per wave (slab id = wave + j * NW)
+    static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tile must be a multiple of 16 x 16");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A | W]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // tile order: consecutive blocks walk down M inside one N panel, so a weight panel stays hot in L2
     const int tiles_m = (p.M + BM - 1) / BM;
     const int bid = blockIdx.x;
@@ -72,74 +71,94 @@ __global__ __launch_bounds__(BM * 2) void gemm_f16_kernel(const asd_gemm_args p)
     // ---- per-lane source descriptors: lane -> (row = lane>>3 of an 8-row slab, physical chunk = lane&7) -------
     const int lrow = lane >> 3, pchunk = lane & 7;
     const char* zero = (const char*)p.zero_page;
-    const char* a_base[AS];
-    int a_y[AS], a_x[AS], a_valid[AS], a_lch[AS];
-    const char* a_img[AS];
+    // fast conv addressing: when every 64-wide k-step lies inside one filter tap (Cin % 64 == 0) and the input is sampled
+    // on a regular lattice (no fused upsample / transposed mode), the tap decode is wave-uniform (scalar) and a lane only
+    // adds a uniform byte offset to the address of its output pixel's centre tap
+    const bool fast_conv = CONV && p.upsample == 0 && (p.Cin & 63) == 0;
+    // Descriptors are kept small (the accumulators need the registers): the swizzled chunk of a lane is the same in every
+    // slab (row & 7 == lane >> 3), plain row-major operands are addressed as base + slab * stride, and only the conv
+    // A slabs carry per-slab state (centre-tap address + packed (y, x)).
+    const int lch = pchunk ^ lrow;               // logical 16-B chunk (8 halfs) that lands in this lane's LDS slot
+    constexpr int ASPW = (ASLABS + NW - 1) / NW; // A slabs a wave can own (slab ids wave, wave + NW, ...)
+    const char* a0 = nullptr;                    // plain A: address of (row m0 + lrow, chunk lch)
+    const char* c_base[CONV ? ASPW : 1];         // conv: image base (generic path) or centre-tap address (fast path)
+    int c_yx[CONV ? ASPW : 1];
+    if (!CONV) {
+        a0 = (const char*)p.A + (size_t)(m0 + lrow) * p.lda * 2 + lch * 16;
+    } else {
 #pragma unroll
-    for (int i = 0; i < AS; ++i) {
-        const int row = (wave * AS + i) * 8 + lrow;       // row inside the block tile
-        const int m = m0 + row;
-        a_lch[i] = pchunk ^ (row & 7);                     // logical 16-B chunk (8 halfs) that lands in this slot
-        a_valid[i] = m < p.M;
-        if (CONV) {
+        for (int j = 0; j < ASPW; ++j) {
+            const int slab = wave + j * NW;
+            const int m = min(m0 + slab * 8 + lrow, p.M - 1);   // clamped: validity is re-derived from the row index
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, r = m - b * hw;
-            a_y[i] = r / p.Wout;
-            a_x[i] = r - a_y[i] * p.Wout;
-            a_img[i] = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-            a_base[i] = nullptr;
-        } else {
-            a_base[i] = (const char*)p.A + (size_t)m * p.lda * 2 + a_lch[i] * 16;
+            int y = r / p.Wout, x = r - y * p.Wout;
+            c_base[j] = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+            if (fast_conv) {
+                y *= p.stride; x *= p.stride;                    // input-lattice coordinates of the centre tap (before -pad)
+                c_base[j] += ((size_t)(y * p.Win + x) * p.Cin) * 2 + lch * 16;
+            }
+            c_yx[j] = (y << 16) | x;
         }
     }
-    const char* w_base[WS];
-    int w_valid[WS], w_lch[WS];
-#pragma unroll
-    for (int i = 0; i < WS; ++i) {
-        const int slab = wave * WS + i;
-        const int row = slab * 8 + lrow;
-        const int n = n0 + row;
-        w_lch[i] = pchunk ^ (row & 7);
-        w_valid[i] = n < p.N && slab < WSLABS;
-        w_base[i] = (const char*)p.W + (size_t)n * p.ldw * 2 + w_lch[i] * 16;
-    }
+    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
+    const size_t a_slab_stride = (size_t)8 * p.lda * 2, w_slab_stride = (size_t)8 * p.ldw * 2;
 
     auto issue = [&](int ks, int stage) {
-        char* As = smem + stage * STAGE_BYTES;
-        char* Bs = As + A_BYTES;
+        char* st = smem + stage * STAGE_BYTES;    // slab s of the stage lives at st + s * 1 KiB (A slabs, then W slabs)
         const int k0 = ks * 64;
-#pragma unroll
-        for (int i = 0; i < AS; ++i) {
-            const char* src;
-            const int kc = k0 + a_lch[i] * 8;               // first k of this lane's chunk
-            if (CONV) {
-                const int tap = kc / p.Cin, c0 = kc - tap * p.Cin;   // chunks never straddle a tap (Cin % 8 == 0)
-                const int ky = tap / 3, kx = tap - ky * 3;
-                int yi = a_y[i] * p.stride + ky - p.pad, xi = a_x[i] * p.stride + kx - p.pad;
-                bool ok = a_valid[i] && kc < p.K;
-                if (p.upsample == 1) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
-                    ok = ok && yi >= 0 && xi >= 0 && yi < 2 * p.Hin && xi < 2 * p.Win;
-                    yi >>= 1; xi >>= 1;
-                } else if (p.upsample == 2) {
-                    // input gradient of a stride-2 convolution: dX[y,x] += dY[(y+pad-ky)/2, (x+pad-kx)/2] W[ky,kx]
-                    // for the taps where both numerators are even (the other taps read the zero page)
-                    yi = a_y[i] + p.pad - ky; xi = a_x[i] + p.pad - kx;
-                    ok = ok && yi >= 0 && xi >= 0 && !(yi & 1) && !(xi & 1) && (yi >> 1) < p.Hin && (xi >> 1) < p.Win;
-                    yi >>= 1; xi >>= 1;
-                } else {
-                    ok = ok && yi >= 0 && xi >= 0 && yi < p.Hin && xi < p.Win;
-                }
-                src = ok ? a_img[i] + ((size_t)(yi * p.Win + xi) * p.Cin + c0) * 2 : zero;
-            } else {
-                src = (a_valid[i] && kc < p.K) ? a_base[i] + (size_t)k0 * 2 : zero;
-            }
-            load_slab(src, As + (wave * AS + i) * 8 * RB);
+        const int kc = k0 + lch * 8;              // first k of this lane's chunk
+        const bool k_ok = kc < p.K;
+        int opaque = 0;                           // defeats loop-invariant hoisting of the per-slab addresses (register budget)
+        asm volatile("" : "+v"(opaque));
+        int tdy = 0, tdx = 0;
+        long long toff = 0;
+        if (fast_conv) {
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;           // wave-uniform
+            const int ky = tap / 3, kx = tap - ky * 3;
+            tdy = ky - p.pad; tdx = kx - p.pad;
+            toff = ((long long)(tdy * p.Win + tdx) * p.Cin + c0) * 2;
         }
 #pragma unroll
-        for (int i = 0; i < WS; ++i) {
-            if (wave * WS + i >= WSLABS) continue;  // wave-uniform: fewer W slabs than waves
-            const char* src = (w_valid[i] && k0 + w_lch[i] * 8 < p.K) ? w_base[i] + (size_t)k0 * 2 : zero;
-            load_slab(src, Bs + (wave * WS + i) * 8 * RB);
+        for (int j = 0; j < SPW; ++j) {
+            const int slab = wave + j * NW;
+            if (slab >= TSLABS) continue;      // wave-uniform
+            const char* src;
+            if (slab >= ASLABS) {
+                const int ws = slab - ASLABS;
+                src = (k_ok && n0 + ws * 8 + lrow < p.N) ? w0 + (ws + opaque) * w_slab_stride + (size_t)k0 * 2 : zero;
+            } else if (!CONV) {
+                src = (k_ok && m0 + slab * 8 + lrow < p.M) ? a0 + (slab + opaque) * a_slab_stride + (size_t)k0 * 2 : zero;
+            } else {
+                constexpr int JA = CONV ? ASPW : 1;
+                const int ja = j < JA ? j : JA - 1;      // A slabs of a wave are its first ones
+                const bool row_ok = m0 + slab * 8 + lrow < p.M;
+                const int sy = c_yx[ja] >> 16, sx = c_yx[ja] & 0xffff;
+                if (fast_conv) {
+                    const int yi = sy + tdy, xi = sx + tdx;
+                    const bool ok = row_ok && (unsigned)yi < (unsigned)p.Hin && (unsigned)xi < (unsigned)p.Win;
+                    src = ok ? c_base[ja] + toff : zero;
+                } else {
+                    const int tap = kc / p.Cin, c0 = kc - tap * p.Cin;   // chunks never straddle a tap (Cin % 8 == 0)
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    int yi = sy * p.stride + ky - p.pad, xi = sx * p.stride + kx - p.pad;
+                    bool ok = row_ok && k_ok;
+                    if (p.upsample == 1) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
+                        ok = ok && yi >= 0 && xi >= 0 && yi < 2 * p.Hin && xi < 2 * p.Win;
+                        yi >>= 1; xi >>= 1;
+                    } else if (p.upsample == 2) {
+                        // input gradient of a stride-2 convolution: dX[y,x] += dY[(y+pad-ky)/2, (x+pad-kx)/2] W[ky,kx]
+                        // for the taps where both numerators are even (the other taps read the zero page)
+                        yi = sy + p.pad - ky; xi = sx + p.pad - kx;
+                        ok = ok && yi >= 0 && xi >= 0 && !(yi & 1) && !(xi & 1) && (yi >> 1) < p.Hin && (xi >> 1) < p.Win;
+                        yi >>= 1; xi >>= 1;
+                    } else {
+                        ok = ok && yi >= 0 && xi >= 0 && yi < p.Hin && xi < p.Win;
+                    }
+                    src = ok ? c_base[ja] + ((size_t)(yi * p.Win + xi) * p.Cin + c0) * 2 : zero;
+                }
+            }
+            load_slab(src, st + slab * 8 * RB);
         }
     };
 
@@ -149,35 +168,30 @@ __global__ __launch_bounds__(BM * 2) void gemm_f16_kernel(const asd_gemm_args p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment reads: lane -> row (lane&15) of a 16-row sub-tile, k-quarter (lane>>4); chunk = kh*4 + quarter
+    // fragment reads: lane -> row (lane&15) of a 16-row sub-tile, k-quarter (lane>>4); chunk = kh*4 + quarter.  Sub-tiles
+    // start at multiples of 16 rows, so the swizzle term (row & 7) is the same for all of them: two lane offsets (kh = 0, 1)
+    // plus compile-time immediates cover every fragment of the wave
     const int frow = lane & 15, fq = lane >> 4;
+    const int fa0 = (wm * (BM / WM) + frow) * RB, fb0 = A_BYTES + (wn * (BN / WN) + frow) * RB;
+    const int fsw[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
 
     const int nk = ks1 - ks0;
     if (nk > 0) {
-#pragma unroll
-        for (int s = 0; s < NST - 1; ++s)
-            if (s < nk) issue(ks0 + s, s);
+        issue(ks0, 0);
         for (int k = 0; k < nk; ++k) {
-            // tile k must have landed; with a 3-stage ring the newest prefetch (tile k+1) may stay in flight
-            if (NST >= 3 && k + 1 < nk && WSLABS % NW == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // tile k visible block-wide; everyone is done reading tile k-1
-            if (k + NST - 1 < nk) issue(ks0 + k + NST - 1, (k + NST - 1) % NST);
-            const char* As = smem + (k % NST) * STAGE_BYTES;
-            const char* Bs = As + A_BYTES;
-#pragma unroll
+            if (k + 1 < nk) issue(ks0 + k + 1, (k + 1) & 1);
+            const char* As = smem + (k & 1) * STAGE_BYTES;
+            // big register tiles: keep ONE set of fragments live (no cross-kh prefetch), the loop is load-bound anyway
+#pragma unroll TM * TN >= 32 ? 1 : 2
             for (int kh = 0; kh < 2; ++kh) {
                 half8 xa[TM], wb[TN];
+                const int fs = TM * TN >= 32 ? (((kh * 4 + fq) ^ (frow & 7)) * 16) : fsw[kh];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wm * 64 + i * 16 + frow;
-                    xa[i] = *(const half8*)(As + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
-                }
+                for (int i = 0; i < TM; ++i) xa[i] = *(const half8*)(As + fa0 + fs + i * 16 * RB);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = wn * (BN / 2) + j * 16 + frow;
-                    wb[j] = *(const half8*)(Bs + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
-                }
+                for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(As + fb0 + fs + j * 16 * RB);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -188,17 +202,17 @@ __global__ __launch_bounds__(BM * 2) void gemm_f16_kernel(const asd_gemm_args p)
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    // acc[i][j][r] = C[m = m0 + wm*64 + i*16 + (lane&15)][n = n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
+    // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
     const int em = lane & 15, en = (lane >> 4) * 4;
     if (gridDim.z > 1) {  // split-K: fp32 partial slabs, finished by splitk_epilogue_kernel
         float* ws = p.workspace + (size_t)kz * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + em;
+            const int m = m0 + wm * (BM / WM) + i * 16 + em;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + en;
+                const int n = n0 + wn * (BN / WN) + j * 16 + en;
                 if (n < p.N) *(floatx4*)(ws + (size_t)m * p.N + n) = acc[i][j];
             }
         }
@@ -206,12 +220,12 @@ __global__ __launch_bounds__(BM * 2) void gemm_f16_kernel(const asd_gemm_args p)
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + em;
+        const int m = m0 + wm * (BM / WM) + i * 16 + em;
         if (m >= p.M) continue;
         const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.N : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + en;
+            const int n = n0 + wn * (BN / WN) + j * 16 + en;
             if (n >= p.N) continue;
             floatx4 v = acc[i][j];
             if (p.bias) {
@@ -275,7 +289,42 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
     }
 }
 
+
+// ---- tile configurations -------------------------------------------------------------------------------------------
+struct asd_gemm_tile { int bm, bn, wm, wn; };
+#define ASD_GEMM_NCFG 8
+static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
+    {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
+    {320, 128, 5, 2}};
+
+// Load-bound cost model (see the kernel comment): a block spends ~ k_steps * (BM + BN) on its tile loads, the chip runs
+// 256 blocks at a time at full aggregate rate (fewer blocks run up to ~1.5x faster each), padding is wasted work, and
+// every block pays a fixed prologue/epilogue.  Returns the cheapest configuration for the given split.
+static int g_force_tile = -1;   // tuning hook (asd_gemm_force_tile, tools/gemm_sweep.py); -1 = cost model
+
+static int asd_gemm_pick_tile(int M, int N, int K, int split) {
+    const int ksteps = asd_div_up(asd_div_up(K, 64), split);
+    double best = 1e300;
+    int best_cfg = 1;
+    for (int c = 0; c < ASD_GEMM_NCFG; ++c) {
+        const int bm = asd_gemm_tiles[c].bm, bn = asd_gemm_tiles[c].bn;
+        if (bn > 64 && N % bn != 0 && !(bn == 128 && N % 128 == 0)) continue;   // wide tiles only without N padding
+        if (bn == 64 && N % 128 == 0) continue;
+        const long long blocks = (long long)asd_div_up(M, bm) * asd_div_up(N, bn) * split;
+        const double per_block = (double)ksteps * (bm + bn) + 6.0 * 64 + 0.02 * bm * bn;   // loads + prologue + epilogue stores
+        const double rounds = blocks >= 256 ? (double)blocks / 256.0 : 0.62 + 0.38 * (double)blocks / 256.0;
+        const double cost = per_block * rounds;
+        if (cost < best) { best = cost; best_cfg = c; }
+    }
+    return best_cfg;
+}
+
 extern "C" {
+
+int asd_gemm_force_tile(int32_t cfg) {
+    g_force_tile = cfg;
+    return ASD_OK;
+}
 
 int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
     ASD_CHECK_ARG(a && a->A && a->W && a->C && a->zero_page, "null argument");
@@ -288,41 +337,42 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         ASD_CHECK_ARG(a->Hout > 0 && a->Wout > 0 && a->M % (a->Hout * a->Wout) == 0, "conv: M must be B*Hout*Wout");
     }
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
-    const int bn = a->N % 128 == 0 ? 128 : 64;
-    static int nst_env = -1;  // ASD_GEMM_NST: ring depth (tuning knob), default 2
-    if (nst_env < 0) { const char* e = getenv("ASD_GEMM_NST"); nst_env = e ? atoi(e) : 2; }
-    const int nst = nst_env == 3 ? 3 : 2;
-    static int bm_env = -1;  // ASD_GEMM_BM: 128 | 256 (tuning knob)
-    if (bm_env < 0) { const char* e = getenv("ASD_GEMM_BM"); bm_env = e ? atoi(e) : 0; }
-    // 256-row tiles (8 waves: 5.3 MFMAs per LDS-DMA instruction instead of 4 / 2.7) when they still fill the chip
-    int bm = (asd_div_up(a->M, 256) * asd_div_up(a->N, bn) >= 200) ? 256 : 128;
-    if (bm_env == 128 || bm_env == 256) bm = bm_env;
+    int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
+    if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
+    if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
+    ASD_CHECK_ARG(asd_gemm_tiles[cfg].bn == 64 || a->N % asd_gemm_tiles[cfg].bn == 0 || (asd_gemm_tiles[cfg].bn == 128 && a->N % 4 == 0),
+                  "tile configuration does not divide N");
+    const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;
     const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
-    const dim3 grid(tiles, 1, a->split_k), block(bm * 2);
-    const size_t lds = (size_t)nst * (bm + bn) * 128;
+    const dim3 grid(tiles, 1, a->split_k), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * 64);
+    const size_t lds = (size_t)2 * (bm + bn) * 128;
     hipStream_t s = (hipStream_t)stream;
-#define GEMM_LAUNCH(BM_, BN_, CONV_, NST_)                                                                               \
+#define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_)                                                                           \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, CONV_, NST_>,                               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, NST_ * (BM_ + BN_) * 128);             \
+            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM_ + BN_) * 128);                \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, CONV_, NST_>), grid, block, lds, s, *a);                           \
+        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_>), grid, block, lds, s, *a);                       \
     } while (0)
-#define GEMM_DISPATCH_NST(BN_, CONV_)                                                            \
-    do {                                                                                          \
-        if (bm == 256) GEMM_LAUNCH(256, BN_, CONV_, 2);                                           \
-        else if (nst == 2) GEMM_LAUNCH(128, BN_, CONV_, 2);                                       \
-        else GEMM_LAUNCH(128, BN_, CONV_, 3);                                                     \
-    } while (0)
-    if (bn == 128) {
-        if (a->conv) GEMM_DISPATCH_NST(128, true); else GEMM_DISPATCH_NST(128, false);
-    } else {
-        if (a->conv) GEMM_DISPATCH_NST(64, true); else GEMM_DISPATCH_NST(64, false);
+#define GEMM_CASE(IDX_, BM_, BN_, WM_, WN_)                                                                              \
+    case IDX_:                                                                                                           \
+        if (a->conv) GEMM_LAUNCH(BM_, BN_, WM_, WN_, true); else GEMM_LAUNCH(BM_, BN_, WM_, WN_, false);                 \
+        break
+    switch (cfg) {
+        GEMM_CASE(0, 128, 64, 2, 2);
+        GEMM_CASE(1, 128, 128, 2, 2);
+        GEMM_CASE(2, 256, 64, 4, 2);
+        GEMM_CASE(3, 256, 128, 4, 2);
+        GEMM_CASE(4, 128, 320, 2, 4);
+        GEMM_CASE(5, 256, 256, 2, 4);
+        GEMM_CASE(6, 256, 320, 2, 4);
+        GEMM_CASE(7, 320, 128, 5, 2);
+        default: asd_set_error("bad tile configuration %d", cfg); return ASD_ERR_ARG;
     }
-#undef GEMM_DISPATCH_NST
+#undef GEMM_CASE
 #undef GEMM_LAUNCH
     if (a->split_k > 1) {
         const size_t total4 = (size_t)a->M * a->N / 4;

@@ -4,6 +4,7 @@ Activations are NHWC / token-major fp16 tensors; outputs are allocated with torc
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -37,6 +38,48 @@ def pick_split_k(M: int, N: int, K: int) -> int:
     return max(1, s)
 
 
+# ---- GEMM plans: (tile configuration, split-K) per problem shape ---------------------------------------------------
+# The kernel is bound by tile loads, so the best tile / split depends on the shape in ways a closed-form model only roughly
+# captures (tools/gemm_sweep.py).  Like a BLAS library's tuned-kernel table, each new shape is timed once over the valid
+# candidates (a few ms, outside graph capture) and the winner is cached for the process; ASD_GEMM_AUTOTUNE=0 keeps the
+# built-in cost model (csrc/gemm.hip: asd_gemm_pick_tile) + pick_split_k.
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320)
+AUTOTUNE = os.environ.get("ASD_GEMM_AUTOTUNE", "1") != "0"
+_plans = {}
+
+
+def _candidates(M: int, N: int, K: int):
+    for t, (bm, bn) in enumerate(zip(TILE_BM, TILE_BN)):
+        if bn != 64 and N % bn != 0:
+            continue
+        if bn == 64 and N % 128 == 0 and N >= 256:
+            if bm == 128:
+                continue
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        for sk in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sk > 1 and (K // sk < 256 or tiles * sk > 1536):
+                continue
+            yield t, sk
+
+
+def _autotune(key, launch, M, N, K):
+    best, best_t = None, 1e30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for t, sk in _candidates(M, N, K):
+        launch(t + 1, sk)
+        e0.record()
+        for _ in range(3):
+            launch(t + 1, sk)
+        e1.record()
+        e1.synchronize()
+        dt = e0.elapsed_time(e1)
+        if dt < best_t:
+            best, best_t = (t + 1, sk), dt
+    _plans[key] = best
+    return best
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
          M: Optional[int] = None) -> torch.Tensor:
@@ -66,13 +109,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
         for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "pad", "upsample"):
             setattr(g, k, int(conv[k]))
     g.zero_page = zero_page(dev).data_ptr()
-    sk = pick_split_k(M, N, K) if split_k is None else split_k
-    g.split_k = sk
-    ws = None
-    if sk > 1:
-        ws = torch.empty((sk, M, N), device=dev, dtype=torch.float32)
-        g.workspace = ws.data_ptr()
-    check(lib().asd_gemm_f16(C.byref(g), stream()))
+
+    def launch(tile_cfg: int, sk: int):
+        g.tile_cfg, g.split_k = tile_cfg, sk
+        ws = None
+        if sk > 1:
+            ws = torch.empty((sk, M, N), device=dev, dtype=torch.float32)
+            g.workspace = ws.data_ptr()
+        check(lib().asd_gemm_f16(C.byref(g), stream()))
+
+    if split_k is not None:
+        launch(0, split_k)
+        return out
+    key = (M, N, K, lda if conv is None else (conv["Hin"], conv["Cin"], conv["stride"], conv["upsample"], conv["pad"]))
+    plan = _plans.get(key)
+    if plan is None:
+        if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            plan = _autotune(key, launch, M, N, K)
+        else:
+            plan = (0, pick_split_k(M, N, K))
+    launch(*plan)
     return out
 
 
