@@ -99,9 +99,12 @@ def roofline_gemm_kernel(reps: int = 30):
     flops = 2.0 * B * hw * hw * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
     plan = H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1))
-    tile = f"{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}" if plan[0] else "model"
-    return {"kernel": f"gemm_f16_kernel<{tile},conv> split_k={plan[1]} (3x3 conv 320->320 @64x64, batch 5; autotuned plan, "
-                      "time includes the split-K epilogue launch)", "bound": "mfma",
+    if plan[0] - 1 in H.WINDOW_TILES:
+        kern = f"conv3x3_win_kernel<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window)"
+    else:
+        kern = f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]},conv>" if plan[0] else "gemm_f16_kernel<model tile,conv>"
+    return {"kernel": f"{kern} split_k={plan[1]} (3x3 conv 320->320 @64x64, batch 5; autotuned plan, "
+                      "time includes the split-K epilogue launch if any)", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
             "traffic": None, "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 

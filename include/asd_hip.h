@@ -265,7 +265,8 @@ typedef struct asd_gemm_args {
 } asd_gemm_args;
 int asd_gemm_f16(const asd_gemm_args* args, void* stream);
 /* Tuning hook (tools/gemm_sweep.py): force tile configuration `cfg` (index into the table of csrc/gemm.hip: 128x64, 128x128,
- * 256x64, 256x128, 128x320, 256x256, 256x320, 320x128) for all following asd_gemm_f16 calls; -1 restores the cost model. */
+ * 256x64, 256x128, 128x320, 256x256, 256x320, 320x128, and for 3x3 stride-1 convolutions the LDS-window kernel with
+ * 16x16-pixel patches x 64 / x 128 channels) for all following asd_gemm_f16 calls; -1 restores the cost model. */
 int asd_gemm_force_tile(int32_t cfg);
 
 /* GroupNorm(32 groups) [+ SiLU] on NHWC fp16 with fp32 statistics (GroupNorm32, diffusionmodules/util.py:229-231);

@@ -254,6 +254,152 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     }
 }
 
+// bias + row_bias + SiLU + residual + store of 4 consecutive output channels of row m (shared by all GEMM / conv kernels)
+__device__ __forceinline__ void gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
+    if (p.bias) {
+        const half4 b = *(const half4*)((const half_t*)p.bias + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.row_bias) {
+        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.N + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+    }
+    if (p.residual) {
+        const half4 b = *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.out_f32) {
+        *(floatx4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+    } else {
+        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 convolution with an LDS-resident input WINDOW (the implicit GEMM above re-fetches every input pixel
+// once per filter tap; its time is the tile-load time).  A block owns a 16 x 16 patch of output pixels x BN channels.  Per
+// 64-channel chunk it brings the 18 x 18 input window (324 rows x 128 B, zero page outside the image) into LDS ONCE and
+// runs the 9 taps against it by shifting the fragment row (ty + ky) * 18 + tx + kx; only the BN x 64 weight tile of each
+// (tap, chunk) streams per step.  Bytes loaded per flop drop from (1/256 + 1/BN)/128 to (41.5 KB/9 + BN * 128 B) per
+// 256 * BN * 128 flop — 2.3x less at BN = 128.  The next chunk's window is prefetched in ninths, one piece per tap.
+// 8 waves = 4 (M: 4 patch rows of 16 pixels each) x 2 (N).  Split-K slices the channel chunks.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p) {
+    constexpr int WN = 2, TM = 4, TN = BN / WN / 16;
+    constexpr int RB = 128;
+    constexpr int WIN = 18, WIN_ROWS = WIN * WIN, WIN_SLABS = (WIN_ROWS + 7) / 8;      // 324 rows, 41 slabs
+    constexpr int A_BYTES = WIN_SLABS * 8 * RB, W_BYTES = BN * RB;
+    constexpr int WSLABS = BN / 8, WSPW = (WSLABS + 7) / 8;
+    constexpr int APIECE = (WIN_SLABS + 8) / 9;                                        // window slabs prefetched per tap (5)
+    extern __shared__ __attribute__((aligned(16))) char smem[];                        // [A0 | A1 | W0 | W1]
+    char* const a_buf = smem;
+    char* const w_buf = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_x = p.Wout / 16, tiles_y = p.Hout / 16;
+    const int tiles_m = (p.M / (p.Hout * p.Wout)) * tiles_y * tiles_x;
+    const int tm = blockIdx.x % tiles_m, n0 = (blockIdx.x / tiles_m) * BN;
+    const int b = tm / (tiles_y * tiles_x), tr = tm - b * tiles_y * tiles_x;
+    const int y0 = (tr / tiles_x) * 16, x0 = (tr - (tr / tiles_x) * tiles_x) * 16;
+    const int n_chunks = p.Cin / 64;
+    const int c_per = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int c0 = blockIdx.z * c_per, c1 = min(n_chunks, c0 + c_per);
+    const int steps = (c1 - c0) * 9;
+
+    const int lrow = lane >> 3, pchunk = lane & 7, lch = pchunk ^ lrow;
+    const char* zero = (const char*)p.zero_page;
+    const char* img = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
+    const size_t w_slab_stride = (size_t)8 * p.ldw * 2;
+
+    auto load_window_slab = [&](int slab, int chunk, char* dst_buf) {   // slab: wave-uniform, < WIN_SLABS
+        const int wrow = slab * 8 + lrow;
+        const int wy = (wrow * 3641) >> 16, wx = wrow - wy * WIN;        // wrow / 18 for wrow < 328
+        const int yi = y0 - 1 + wy, xi = x0 - 1 + wx;
+        const bool ok = wrow < WIN_ROWS && (unsigned)yi < (unsigned)p.Hin && (unsigned)xi < (unsigned)p.Win;
+        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + lch * 16 : zero;
+        load_slab(src, dst_buf + slab * 8 * RB);
+    };
+    auto load_w_tile = [&](int step, char* dst_buf) {
+        const int chunk = c0 + step / 9, tap = step - (step / 9) * 9;
+        const size_t koff = ((size_t)tap * p.Cin + chunk * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WSPW; ++j) {
+            const int slab = wave + j * 8;
+            if (slab >= WSLABS) continue;
+            const char* src = (n0 + slab * 8 + lrow < p.N) ? w0 + slab * w_slab_stride + koff : zero;
+            load_slab(src, dst_buf + slab * 8 * RB);
+        }
+    };
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fb0 = (wn * (BN / WN) + frow) * RB;
+    const int fswb[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
+
+    if (steps > 0) {
+        for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0, a_buf);
+        load_w_tile(0, w_buf);
+#pragma unroll 1
+        for (int s = 0; s < steps; ++s) {
+            const int cl = s / 9, tap = s - cl * 9;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < steps) load_w_tile(s + 1, w_buf + ((s + 1) & 1) * W_BYTES);
+            if (c0 + cl + 1 < c1) {
+                const int slab = tap * APIECE + wave;
+                if (wave < APIECE && slab < WIN_SLABS) load_window_slab(slab, c0 + cl + 1, a_buf + ((cl + 1) & 1) * A_BYTES);
+            }
+            const char* Aw = a_buf + (cl & 1) * A_BYTES;
+            const char* Wt = w_buf + (s & 1) * W_BYTES;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int wbase = (wm * 4 + ky) * WIN + frow + kx;      // window row of this lane's pixel in patch row wm*4
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                half8 xa[TM], wb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wbase + i * WIN;
+                    xa[i] = *(const half8*)(Aw + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(Wt + fb0 + fswb[kh] + j * 16 * RB);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
+    const int en = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + en;
+            if (n >= p.N) continue;
+            if (gridDim.z > 1) *(floatx4*)(p.workspace + ((size_t)blockIdx.z * p.M + m) * p.N + n) = acc[i][j];
+            else gemm_store4(p, acc[i][j], m, n);
+        }
+    }
+}
+
 // sums the split-K slabs and applies the same epilogue (4 outputs per thread)
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_args p, int splits) {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -292,10 +438,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn; };
-#define ASD_GEMM_NCFG 8
+#define ASD_GEMM_NCFG 10
+#define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN)
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
-    {320, 128, 5, 2}};
+    {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}};
+
+static bool asd_conv_window_ok(const asd_gemm_args* a) {
+    return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Cin % 64 == 0 && a->Hin == a->Hout &&
+           a->Win == a->Wout && a->Hout % 16 == 0 && a->Wout % 16 == 0;
+}
 
 // Load-bound cost model (see the kernel comment): a block spends ~ k_steps * (BM + BN) on its tile loads, the chip runs
 // 256 blocks at a time at full aggregate rate (fewer blocks run up to ~1.5x faster each), padding is wasted work, and
@@ -306,7 +458,7 @@ static int asd_gemm_pick_tile(int M, int N, int K, int split) {
     const int ksteps = asd_div_up(asd_div_up(K, 64), split);
     double best = 1e300;
     int best_cfg = 1;
-    for (int c = 0; c < ASD_GEMM_NCFG; ++c) {
+    for (int c = 0; c < ASD_GEMM_WIN0; ++c) {
         const int bm = asd_gemm_tiles[c].bm, bn = asd_gemm_tiles[c].bn;
         if (bn > 64 && N % bn != 0 && !(bn == 128 && N % 128 == 0)) continue;   // wide tiles only without N padding
         if (bn == 64 && N % 128 == 0) continue;
@@ -343,6 +495,27 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
     ASD_CHECK_ARG(asd_gemm_tiles[cfg].bn == 64 || a->N % asd_gemm_tiles[cfg].bn == 0 || (asd_gemm_tiles[cfg].bn == 128 && a->N % 4 == 0),
                   "tile configuration does not divide N");
     const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;
+    if (cfg >= ASD_GEMM_WIN0) {
+        ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
+        ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
+        const int tiles_w = (a->M / 256) * asd_div_up(a->N, bn);
+        const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)2 * bn * 128;
+        hipStream_t sw = (hipStream_t)stream;
+        static bool attr64 = false, attr128 = false;
+        if (bn == 64) {
+            if (!attr64) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr64 = true; }
+            hipLaunchKernelGGL((conv3x3_win_kernel<64>), dim3(tiles_w, 1, a->split_k), dim3(512), lds_w, sw, *a);
+        } else {
+            if (!attr128) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr128 = true; }
+            hipLaunchKernelGGL((conv3x3_win_kernel<128>), dim3(tiles_w, 1, a->split_k), dim3(512), lds_w, sw, *a);
+        }
+        if (a->split_k > 1) {
+            const size_t total4 = (size_t)a->M * a->N / 4;
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+        }
+        ASD_LAUNCH_CHECK();
+        return ASD_OK;
+    }
     const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
     const dim3 grid(tiles, 1, a->split_k), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * 64);
     const size_t lds = (size_t)2 * (bm + bn) * 128;

@@ -57,30 +57,47 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
+// Apply: same thread -> channel-slot ownership as the statistics kernel (grid (batch, chunks)): the per-channel scale and
+// shift  y = x * a + b  (a = rstd * gamma, b = beta - mean * a) are formed ONCE per thread, the row loop is one 16-byte
+// load, 8 FMAs (+ SiLU) and one 16-byte store — the first version recomputed group index, mean and rsqrt per element and
+// was VALU-bound at a quarter of the HBM rate.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
-                                                       int c2, int batch, int hw, const half_t* __restrict__ gamma,
+                                                       int c2, int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, float eps, int silu,
                                                        const float* __restrict__ stats, half_t* __restrict__ y) {
     const int C = c1 + c2, slots = C / 8, cg = C / 32;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
-    const size_t total = (size_t)batch * hw * slots;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / slots;
-        const int c = (int)(i - row * slots) * 8;
-        const int b = (int)(row / hw);
-        const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
-        const half8 gm = *(const half8*)(gamma + c), bt = *(const half8*)(beta + c);
-        half8 o;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
+    const int rsub = slots >= 256 ? 0 : tid / slots;
+    const int slot0 = slots >= 256 ? tid : tid % slots;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // second pass only when more than 256 slots (C = 2560)
+        const int slot = slot0 + j * 256;
+        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
+        const int c = slot * 8;
+        float sa[8], sb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int g = (c + k) / cg;
             const float mean = stats[(b * 32 + g) * 2] * inv_cnt;
             const float var = fmaxf(stats[(b * 32 + g) * 2 + 1] * inv_cnt - mean * mean, 0.f);
-            float f = ((float)v[k] - mean) * rsqrtf(var + eps) * (float)gm[k] + (float)bt[k];
-            if (silu) f = silu_f(f);
-            o[k] = (half_t)f;
+            sa[k] = rsqrtf(var + eps) * (float)gamma[c + k];
+            sb[k] = (float)beta[c + k] - mean * sa[k];
         }
-        *(half8*)(y + row * C + c) = o;
+        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
+            const size_t row = (size_t)b * hw + r;
+            const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float f = fmaf((float)v[k], sa[k], sb[k]);
+                if (silu) f = silu_f(f);
+                o[k] = (half_t)f;
+            }
+            *(half8*)(y + row * C + c) = o;
+        }
     }
 }
 
@@ -154,32 +171,44 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restr
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
-                                                           int batch, int hw, const half_t* __restrict__ gamma,
+                                                           int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                            const half_t* __restrict__ beta, float eps, int silu,
                                                            const float* __restrict__ fstats, const float* __restrict__ bstats,
                                                            half_t* __restrict__ dx) {
     const int slots = C / 8, cg = C / 32;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
-    const size_t total = (size_t)batch * hw * slots;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / slots;
-        const int c = (int)(i - row * slots) * 8;
-        const int b = (int)(row / hw);
-        const half8 xv = *(const half8*)(x + row * C + c), dv = *(const half8*)(dy + row * C + c);
-        const half8 gmv = *(const half8*)(gamma + c), btv = *(const half8*)(beta + c);
-        half8 o;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
+    const int rsub = slots >= 256 ? 0 : tid / slots;
+    const int slot0 = slots >= 256 ? tid : tid % slots;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = slot0 + j * 256;
+        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
+        const int c = slot * 8;
+        float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int g = (c + k) / cg;
-            const float mean = fstats[(b * 32 + g) * 2] * inv_cnt;
-            const float rstd = rsqrtf(fmaxf(fstats[(b * 32 + g) * 2 + 1] * inv_cnt - mean * mean, 0.f) + eps);
-            const float xh = ((float)xv[k] - mean) * rstd;
-            float gg = (float)dv[k] * (float)gmv[k];
-            if (silu) gg *= silu_grad(xh * (float)gmv[k] + (float)btv[k]);
-            const float m1 = bstats[(b * 32 + g) * 2] * inv_cnt, m2 = bstats[(b * 32 + g) * 2 + 1] * inv_cnt;
-            o[k] = (half_t)(rstd * (gg - m1 - xh * m2));
+            mean[k] = fstats[(b * 32 + g) * 2] * inv_cnt;
+            rstd[k] = rsqrtf(fmaxf(fstats[(b * 32 + g) * 2 + 1] * inv_cnt - mean[k] * mean[k], 0.f) + eps);
+            gm[k] = (float)gamma[c + k]; bt[k] = (float)beta[c + k];
+            m1[k] = bstats[(b * 32 + g) * 2] * inv_cnt; m2[k] = bstats[(b * 32 + g) * 2 + 1] * inv_cnt;
         }
-        *(half8*)(dx + row * C + c) = o;
+        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
+            const size_t off = ((size_t)b * hw + r) * C + c;
+            const half8 xv = *(const half8*)(x + off), dv = *(const half8*)(dy + off);
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = ((float)xv[k] - mean[k]) * rstd[k];
+                float gg = (float)dv[k] * gm[k];
+                if (silu) gg *= silu_grad(fmaf(xh, gm[k], bt[k]));
+                o[k] = (half_t)(rstd[k] * (gg - m1[k] - xh * m2[k]));
+            }
+            *(half8*)(dx + off) = o;
+        }
     }
 }
 
@@ -396,15 +425,15 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     hipStream_t s = (hipStream_t)stream;
     // (a kernel, not hipMemsetAsync: the launch sequence is captured into HIP graphs and replayed)
     hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, stats, 64 * batch);
-    int chunks = asd_div_up(hw, 16);  // >= 16 rows per block; enough blocks to cover the chip at every resolution
-    if (chunks > 128) chunks = 128;
-    const int rows_per_block = asd_div_up(hw, chunks);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
-                       rows_per_block, stats);
-    const size_t total = (size_t)batch * hw * (C / 8);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, s, (const half_t*)x1, c1,
-                       (const half_t*)x2, c2, batch, hw, (const half_t*)gamma, (const half_t*)beta, eps, silu, stats,
-                       (half_t*)y);
+    // statistics: >= 16 rows per block and at most ~512 blocks (each ends with 64 atomics on one hot set of addresses);
+    // apply: no atomics, so up to ~2048 blocks
+    int chunks = asd_div_up(hw, 16);
+    const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
+    const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
+                       asd_div_up(hw, chunks_s), stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, stats, (half_t*)y);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -417,14 +446,13 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, bwd_stats, 64 * batch);
     int chunks = asd_div_up(hw, 16);
-    if (chunks > 128) chunks = 128;
-    const int rows_per_block = asd_div_up(hw, chunks);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
-                       rows_per_block, (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
-    const size_t total = (size_t)batch * hw * (c / 8);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, s, (const half_t*)x,
-                       (const half_t*)dy, c, batch, hw, (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats,
-                       bwd_stats, (half_t*)dx);
+    const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
+    const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                       asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats,
+                       (half_t*)dx);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -43,14 +43,57 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # captures (tools/gemm_sweep.py).  Like a BLAS library's tuned-kernel table, each new shape is timed once over the valid
 # candidates (a few ms, outside graph capture) and the winner is cached for the process; ASD_GEMM_AUTOTUNE=0 keeps the
 # built-in cost model (csrc/gemm.hip: asd_gemm_pick_tile) + pick_split_k.
-TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128)
-TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320)
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256)
+WINDOW_TILES = (8, 9)       # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels)
 AUTOTUNE = os.environ.get("ASD_GEMM_AUTOTUNE", "1") != "0"
+PLAN_FILE = os.environ.get("ASD_GEMM_PLAN_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans.json"))
 _plans = {}
 
 
-def _candidates(M: int, N: int, K: int):
+def _key_str(key) -> str:
+    return repr(key)
+
+
+def load_plans(path: str = PLAN_FILE) -> int:
+    """plans found earlier by the autotuner (tools/gemm_tune.py writes the in-tree table for the shapes of the shipped
+    configs); shapes not in the table are tuned on first use."""
+    import ast
+    import json
+
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        table = json.load(f)
+    for k, v in table.items():
+        _plans[ast.literal_eval(k)] = tuple(v)
+    return len(table)
+
+
+def save_plans(path: str = PLAN_FILE) -> None:
+    import json
+
+    with open(path, "w") as f:
+        json.dump({_key_str(k): list(v) for k, v in sorted(_plans.items(), key=lambda kv: repr(kv[0]))}, f, indent=0)
+
+
+if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none":
+    load_plans()
+
+
+def _candidates(M: int, N: int, K: int, conv: Optional[dict] = None):
+    window_ok = (conv is not None and conv["stride"] == 1 and conv["pad"] == 1 and conv["upsample"] == 0 and conv["Cin"] % 64 == 0
+                 and conv["Hin"] == conv["Hout"] and conv["Win"] == conv["Wout"] and conv["Hout"] % 16 == 0 and conv["Wout"] % 16 == 0)
     for t, (bm, bn) in enumerate(zip(TILE_BM, TILE_BN)):
+        if t in WINDOW_TILES:
+            if not window_ok or (bn != 64 and N % bn != 0):
+                continue
+            tiles = (M // 256) * ((N + bn - 1) // bn)
+            for sk in (1, 2, 3, 4, 5, 6, 8, 10):
+                if sk > 1 and (conv["Cin"] // 64 < 2 * sk or tiles * sk > 1536):
+                    continue
+                yield t, sk
+            continue
         if bn != 64 and N % bn != 0:
             continue
         if bn == 64 and N % 128 == 0 and N >= 256:
@@ -63,10 +106,10 @@ def _candidates(M: int, N: int, K: int):
             yield t, sk
 
 
-def _autotune(key, launch, M, N, K):
+def _autotune(key, launch, M, N, K, conv=None):
     best, best_t = None, 1e30
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for t, sk in _candidates(M, N, K):
+    for t, sk in _candidates(M, N, K, conv):
         launch(t + 1, sk)
         e0.record()
         for _ in range(3):
@@ -125,7 +168,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     plan = _plans.get(key)
     if plan is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-            plan = _autotune(key, launch, M, N, K)
+            plan = _autotune(key, launch, M, N, K, conv)
         else:
             plan = (0, pick_split_k(M, N, K))
     launch(*plan)

@@ -76,6 +76,34 @@ def test_conv3x3_variants(B, H_, W_, Cin, Cout, stride, pad, up):
     _close(got.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1)])
+def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
+    """all GEMM tile shapes (implicit GEMM 128x64 ... 256x320, 320x128) and the LDS-window kernels (16x16-pixel patches x 64 /
+    128 channels) against F.conv2d, with bias + residual, with and without split-K"""
+    import ctypes as C
+
+    from scaledreamer_amd._lib import lib
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    bn = H.TILE_BN[tile]
+    if bn != 64 and Cout % bn != 0:
+        pytest.skip("tile does not divide N")
+    if tile in H.WINDOW_TILES and sk > Cin // 64:
+        pytest.skip("more splits than channel chunks")
+    x = _rand(B, Cin, HW, HW, seed=8)
+    w = _rand(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=9)
+    bias, res = _rand(Cout, seed=10), _rand(B, HW, HW, Cout, seed=11)
+    ref = F.conv2d(x.float(), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1) + res.float()
+    xn, wp = x.permute(0, 2, 3, 1).contiguous(), H.pack_conv3x3_weight(w)
+    lib().asd_gemm_force_tile(C.c_int32(tile))
+    try:
+        got = H.conv3x3(xn, wp, bias=bias, residual=res.view(-1, Cout), split_k=sk)
+    finally:
+        lib().asd_gemm_force_tile(C.c_int32(-1))
+    _close(got, ref)
+
+
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(5, 4096, 320, 0, True), (5, 64, 1280, 1280, True), (2, 1024, 640, 320, False),
                                              (3, 256, 1920, 0, True), (1, 77, 32, 0, False)])
 def test_groupnorm(B, HW, C1, C2, silu):

@@ -7,8 +7,8 @@ import torch
 from scaledreamer_amd._lib import lib
 from scaledreamer_amd.diffusion import hip_ops as H
 
-TILES = ["128x64", "128x128", "256x64", "256x128", "128x320", "256x256", "256x320", "320x128"]
-BN = [64, 128, 64, 128, 320, 256, 320, 128]
+TILES = ["128x64", "128x128", "256x64", "256x128", "128x320", "256x256", "256x320", "320x128", "win64", "win128"]
+BN = [64, 128, 64, 128, 320, 256, 320, 128, 64, 128]
 
 
 def timeit(fn, reps=20):
@@ -30,6 +30,7 @@ def r(*s):
 shapes = [("conv", 5, 64, 320, 320), ("conv", 5, 64, 640, 320), ("conv", 5, 64, 960, 320), ("conv", 5, 32, 640, 640), ("conv", 5, 32, 1280, 640),
           ("conv", 5, 16, 1280, 1280), ("conv", 5, 16, 2560, 1280), ("conv", 5, 8, 1280, 1280), ("conv", 5, 8, 2560, 1280),
           ("conv", 1, 512, 128, 128), ("conv", 1, 256, 256, 256), ("conv", 1, 128, 512, 512), ("conv", 1, 64, 512, 512),
+          ("conv", 1, 64, 128, 128), ("conv", 1, 256, 128, 128), ("conv", 4, 32, 320, 320),
           ("gemm", 20480, 320, 320), ("gemm", 20480, 2560, 320), ("gemm", 20480, 320, 1280), ("gemm", 5120, 640, 640), ("gemm", 5120, 5120, 640),
           ("gemm", 5120, 640, 2560), ("gemm", 1280, 1280, 1280), ("gemm", 1280, 10240, 1280), ("gemm", 1280, 1280, 5120), ("gemm", 320, 1280, 1280),
           ("gemm", 320, 10240, 1280), ("gemm", 320, 1280, 5120), ("gemm", 400, 12480, 1024), ("gemm", 4096, 4096, 512), ("gemm", 4096, 512, 4096)]
@@ -50,9 +51,13 @@ for sh in shapes:
     for t, name in enumerate(TILES):
         if N % BN[t] != 0 and not (BN[t] == 64):
             continue
+        if t >= 8 and (sh[0] != "conv" or sh[2] % 16 != 0 or sh[3] % 64 != 0):
+            continue
         lib().asd_gemm_force_tile(C.c_int32(t))
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
             if sk > 1 and (K // sk < 256):
+                continue
+            if t >= 8 and sk > sh[3] // 64:
                 continue
             res.append((timeit(lambda: run(sk), reps=8), name, sk))
     lib().asd_gemm_force_tile(C.c_int32(-1))
