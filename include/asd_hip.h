@@ -252,7 +252,8 @@ typedef struct asd_gemm_args {
     int32_t rows_per_group;
     const void* residual;   /* fp16 [M,ldr] or NULL, added after the activation */
     int32_t ldr;
-    int32_t act;            /* 0 none, 1 SiLU */
+    int32_t act;            /* 0 none, 1 SiLU, 2 fused GEGLU: W rows (and bias) interleaved in 32-row groups [16 value | 16 gate],
+                               C[M, N/2] = (value + b) * gelu(gate + b)  (attention.py:49-56) */
     int32_t out_f32;
     int32_t conv;           /* 0: GEMM, 1: 3x3 convolution (K = 9*Cin) */
     int32_t Hin, Win, Cin, Hout, Wout, stride, pad;
@@ -269,16 +270,18 @@ int asd_gemm_f16(const asd_gemm_args* args, void* stream);
  * 16x16-pixel patches x 64 / x 128 channels) for all following asd_gemm_f16 calls; -1 restores the cost model. */
 int asd_gemm_force_tile(int32_t cfg);
 
+#define ASD_GN_STATS_FLOATS(batch) (64 * (batch) + 64 * (512 + (batch)))
 /* GroupNorm(32 groups) [+ SiLU] on NHWC fp16 with fp32 statistics (GroupNorm32, diffusionmodules/util.py:229-231);
  * x may be the channel-concatenation of two tensors (skip connections, openaimodel.py:797-799): x2/c2. */
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw,
                       const void* gamma, const void* beta, float eps, int32_t silu, void* y,
-                      float* stats /*[batch*32*2]*/, void* stream);
+                      float* stats /* ASD_GN_STATS_FLOATS(batch): [batch*32*2] sums for the backward pass + per-block partials */,
+                      void* stream);
 /* Input gradient of GroupNorm(+SiLU) with frozen gamma/beta (VAE encoder backward, the reference keeps the
  * VAE in the autograd graph: stable_diffusion_asd_guidance.py:171-178,225): dx from x, dy and the forward stats. */
 int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,
                           const void* beta, float eps, int32_t silu, const float* fwd_stats, void* dx,
-                          float* bwd_stats /*[batch*32*2]*/, void* stream);
+                          float* bwd_stats /* workspace: ASD_GN_STATS_FLOATS(batch) - 64*batch floats */, void* stream);
 /* y[cols, rows] = x[rows, cols]^T, fp16 (operand layout changes for the attention-backward GEMMs). */
 int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream);
 /* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */

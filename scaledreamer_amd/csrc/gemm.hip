@@ -218,6 +218,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
         }
         return;
     }
+    if (p.act == 2) {
+        // fused GEGLU (attention.py:49-56): the weight rows were interleaved in 32-row groups [16 value | 16 gate] at pack
+        // time, so fragments 2j' / 2j'+1 of a lane hold value and gate of the same 4 channels; output has N/2 columns
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + em;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int n = n0 + wn * (BN / WN) + j * 16 + en;      // value columns n..n+3, gate columns n+16..n+19
+                    if (n + 16 >= p.N) continue;
+                    const half4 bx = *(const half4*)((const half_t*)p.bias + n), bg = *(const half4*)((const half_t*)p.bias + n + 16);
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = (half_t)((acc[i][j][r] + (float)bx[r]) * gelu_erf(acc[i][j + 1][r] + (float)bg[r]));
+                    *(half4*)((half_t*)p.C + (size_t)m * p.ldc + (n >> 5) * 16 + (n & 15)) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + em;
@@ -489,9 +512,15 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         ASD_CHECK_ARG(a->Hout > 0 && a->Wout > 0 && a->M % (a->Hout * a->Wout) == 0, "conv: M must be B*Hout*Wout");
     }
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
+    if (a->act == 2)
+        ASD_CHECK_ARG(a->N % 32 == 0 && a->bias && !a->conv && !a->residual && !a->row_bias && !a->out_f32 && a->split_k == 1,
+                      "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");
     int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
+    if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
     if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
     if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
+    ASD_CHECK_ARG(a->act != 2 || (cfg < ASD_GEMM_WIN0 && (asd_gemm_tiles[cfg].bn / asd_gemm_tiles[cfg].wn) % 32 == 0),
+                  "GEGLU epilogue needs a tile whose per-wave width is a multiple of 32 columns");
     ASD_CHECK_ARG(asd_gemm_tiles[cfg].bn == 64 || a->N % asd_gemm_tiles[cfg].bn == 0 || (asd_gemm_tiles[cfg].bn == 128 && a->N % 4 == 0),
                   "tile configuration does not divide N");
     const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;

@@ -51,10 +51,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
         atomicAdd(&gsq[g], qq);
     }
     __syncthreads();
-    if (tid < 32) {
-        atomicAdd(&stats[(b * 32 + tid) * 2], gsum[tid]);
-        atomicAdd(&stats[(b * 32 + tid) * 2 + 1], gsq[tid]);
+    if (tid < 32) {   // per-block partial sums (no global atomics, nothing to zero): reduced by the apply kernel's prologue
+        float* part = stats + ((size_t)b * gridDim.y + blockIdx.y) * 64;
+        part[tid * 2] = gsum[tid];
+        part[tid * 2 + 1] = gsq[tid];
     }
+}
+
+// sum of the statistics partials of batch element b -> st[64] (LDS); 256 threads
+__device__ __forceinline__ void gn_reduce_partials(const float* __restrict__ partials, int b, int n_chunks, float* st /*[64]*/,
+                                                   float (*scratch)[64] /*[4][64]*/) {
+    const int tid = threadIdx.x, v = tid & 63, q = tid >> 6;
+    float acc = 0.f;
+    for (int c = q; c < n_chunks; c += 4) acc += partials[((size_t)b * n_chunks + c) * 64 + v];
+    scratch[q][v] = acc;
+    __syncthreads();
+    if (tid < 64) st[tid] = (scratch[0][tid] + scratch[1][tid]) + (scratch[2][tid] + scratch[3][tid]);
+    __syncthreads();
 }
 
 // Apply: same thread -> channel-slot ownership as the statistics kernel (grid (batch, chunks)): the per-channel scale and
@@ -64,9 +77,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
                                                        int c2, int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, float eps, int silu,
-                                                       const float* __restrict__ stats, half_t* __restrict__ y) {
+                                                       const float* __restrict__ partials, int n_chunks,
+                                                       float* __restrict__ stats_out, half_t* __restrict__ y) {
+    __shared__ float st[64];
+    __shared__ float scratch[4][64];
     const int C = c1 + c2, slots = C / 8, cg = C / 32;
     const int b = blockIdx.x, tid = threadIdx.x;
+    gn_reduce_partials(partials, b, n_chunks, st, scratch);
+    if (blockIdx.y == 0 && tid < 64) stats_out[b * 64 + tid] = st[tid];   // kept for the backward pass
+    const float* stats = st - b * 64;                                        // (indexing below is (b*32 + g)*2)
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
@@ -165,18 +184,23 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restr
     }
     __syncthreads();
     if (tid < 32) {
-        atomicAdd(&bstats[(b * 32 + tid) * 2], gsum[tid]);
-        atomicAdd(&bstats[(b * 32 + tid) * 2 + 1], gsq[tid]);
+        float* part = bstats + ((size_t)b * gridDim.y + blockIdx.y) * 64;
+        part[tid * 2] = gsum[tid];
+        part[tid * 2 + 1] = gsq[tid];
     }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
                                                            int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                            const half_t* __restrict__ beta, float eps, int silu,
-                                                           const float* __restrict__ fstats, const float* __restrict__ bstats,
-                                                           half_t* __restrict__ dx) {
+                                                           const float* __restrict__ fstats, const float* __restrict__ bpartials,
+                                                           int n_chunks, half_t* __restrict__ dx) {
+    __shared__ float st[64];
+    __shared__ float scratch[4][64];
     const int slots = C / 8, cg = C / 32;
     const int b = blockIdx.x, tid = threadIdx.x;
+    gn_reduce_partials(bpartials, b, n_chunks, st, scratch);
+    const float* bstats = st - b * 64;
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
@@ -423,17 +447,17 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     if (!x2) c2 = 0;
     ASD_CHECK_ARG(C % 32 == 0 && C % 8 == 0 && c1 % 8 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
-    // (a kernel, not hipMemsetAsync: the launch sequence is captured into HIP graphs and replayed)
-    hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, stats, 64 * batch);
+    float* partials = stats + 64 * batch;   // [batch, chunks_s, 64] per-block partial sums (plain stores: nothing to zero)
     // statistics: >= 16 rows per block and at most ~512 blocks (each ends with 64 atomics on one hot set of addresses);
     // apply: no atomics, so up to ~2048 blocks
     int chunks = asd_div_up(hw, 16);
     const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
-                       asd_div_up(hw, chunks_s), stats);
+                       asd_div_up(hw, chunks_s), partials);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
-                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, stats, (half_t*)y);
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, partials, chunks_s, stats,
+                       (half_t*)y);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -444,14 +468,13 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && dx && bwd_stats && batch > 0 && hw > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(zero_f32_kernel, dim3(asd_div_up(64 * batch, 256)), dim3(256), 0, s, bwd_stats, 64 * batch);
     int chunks = asd_div_up(hw, 16);
     const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
                        asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
-                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats,
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats, chunks_s,
                        (half_t*)dx);
     ASD_LAUNCH_CHECK();
     return ASD_OK;

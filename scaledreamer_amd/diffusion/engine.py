@@ -72,6 +72,9 @@ class HipUNet:
                         cv_w.append(p[b2 + ".to_v.weight"])
                         self.ctx_slices[b2] = (coff, cout)
                         coff += cout
+        for k in [k for k in w if k.endswith(".ff.net.0.proj.weight")]:
+            kb = k[:-len("weight")] + "bias"
+            w[k], w[kb] = H.pack_geglu_weight(w[k], w[kb])
         w["emb_all.weight"] = f16(torch.cat(emb_w, 0))
         w["emb_all.bias"] = f16(torch.cat(emb_b, 0))
         # the context is the same for every cross-attention: all 16 K and V^T projections are two GEMMs per forward
@@ -119,7 +122,7 @@ class HipUNet:
             o = H.attention(q, kc_all[:, coff:coff + C], vT_all[coff:coff + C], B, heads, L, n_ctx, ctx_stride)
             h = H.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], residual=h)
             y = H.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
-            g = H.geglu(H.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"]))
+            g = H.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act=2)   # GEGLU fused in the epilogue
             h = H.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], residual=h)
         return H.gemm(h, w[name + ".proj_out.weight"], bias=w[name + ".proj_out.bias"], residual=x)
 

@@ -81,7 +81,7 @@ if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none":
     load_plans()
 
 
-def _candidates(M: int, N: int, K: int, conv: Optional[dict] = None):
+def _candidates(M: int, N: int, K: int, conv: Optional[dict] = None, geglu: bool = False):
     window_ok = (conv is not None and conv["stride"] == 1 and conv["pad"] == 1 and conv["upsample"] == 0 and conv["Cin"] % 64 == 0
                  and conv["Hin"] == conv["Hout"] and conv["Win"] == conv["Wout"] and conv["Hout"] % 16 == 0 and conv["Wout"] % 16 == 0)
     for t, (bm, bn) in enumerate(zip(TILE_BM, TILE_BN)):
@@ -96,20 +96,22 @@ def _candidates(M: int, N: int, K: int, conv: Optional[dict] = None):
             continue
         if bn != 64 and N % bn != 0:
             continue
+        if geglu and t in (4, 6):       # the GEGLU epilogue pairs 16-column fragments: per-wave width must be a multiple of 32
+            continue
         if bn == 64 and N % 128 == 0 and N >= 256:
             if bm == 128:
                 continue
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-            if sk > 1 and (K // sk < 256 or tiles * sk > 1536):
+            if sk > 1 and (geglu or K // sk < 256 or tiles * sk > 1536):
                 continue
             yield t, sk
 
 
-def _autotune(key, launch, M, N, K, conv=None):
+def _autotune(key, launch, M, N, K, conv=None, geglu=False):
     best, best_t = None, 1e30
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for t, sk in _candidates(M, N, K, conv):
+    for t, sk in _candidates(M, N, K, conv, geglu):
         launch(t + 1, sk)
         e0.record()
         for _ in range(3):
@@ -136,7 +138,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     else:
         lda = 0
     if out is None:
-        out = torch.empty((M, N), device=dev, dtype=torch.float32 if out_f32 else torch.float16)
+        out = torch.empty((M, N // 2 if act == 2 else N), device=dev, dtype=torch.float32 if out_f32 else torch.float16)
     g = GemmArgs()
     g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     g.M, g.N, g.K = M, N, K
@@ -164,13 +166,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     if split_k is not None:
         launch(0, split_k)
         return out
-    key = (M, N, K, lda if conv is None else (conv["Hin"], conv["Cin"], conv["stride"], conv["upsample"], conv["pad"]))
+    key = (M, N, K, (lda if act != 2 else -lda) if conv is None else (conv["Hin"], conv["Cin"], conv["stride"], conv["upsample"], conv["pad"]))
     plan = _plans.get(key)
     if plan is None:
         if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-            plan = _autotune(key, launch, M, N, K, conv)
+            plan = _autotune(key, launch, M, N, K, conv, act == 2)
         else:
-            plan = (0, pick_split_k(M, N, K))
+            plan = (0, 1 if act == 2 else pick_split_k(M, N, K))
     launch(*plan)
     return out
 
@@ -211,17 +213,17 @@ def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optiona
     c2 = 0 if x2 is None else x2.shape[-1]
     hw = x1.numel() // (B * c1)
     y = torch.empty(tuple(x1.shape[:-1]) + (c1 + c2,), device=x1.device, dtype=torch.float16)
-    stats = torch.empty(B * 64, device=x1.device, dtype=torch.float32)
+    stats = torch.empty(B * 64 + (512 + B) * 64, device=x1.device, dtype=torch.float32)   # ASD_GN_STATS_FLOATS(B)
     check(lib().asd_groupnorm_f16(ptr(x1), i32(c1), _p(x2), i32(c2), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps),
                                   i32(int(silu)), ptr(y), ptr(stats), stream()))
-    return (y, stats) if return_stats else y
+    return (y, stats[:B * 64]) if return_stats else y
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor) -> torch.Tensor:
     B, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c)
     dx = torch.empty_like(x)
-    bstats = torch.empty(B * 64, device=x.device, dtype=torch.float32)
+    bstats = torch.empty((512 + B) * 64, device=x.device, dtype=torch.float32)
     check(lib().asd_groupnorm_bwd_f16(ptr(x), ptr(dy), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)),
                                       ptr(stats), ptr(dx), ptr(bstats), stream()))
     return dx
@@ -256,6 +258,15 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
     y = torch.empty_like(x)
     check(lib().asd_layernorm_f16(ptr(x), i32(x.numel() // c), i32(c), ptr(gamma), ptr(beta), f32(eps), ptr(y), stream()))
     return y
+
+
+def pack_geglu_weight(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU.proj [2C', K] (value rows, then gate rows; attention.py:49-56) -> rows interleaved in 32-row groups
+    [16 value | 16 gate] for the fused epilogue (asd_gemm_args.act = 2); the bias is permuted the same way."""
+    c = w.shape[0] // 2
+    assert c % 16 == 0
+    perm = torch.stack([torch.arange(c).view(-1, 16), torch.arange(c, 2 * c).view(-1, 16)], dim=1).reshape(-1).to(w.device)
+    return w[perm].contiguous(), b[perm].contiguous()
 
 
 def geglu(h: torch.Tensor) -> torch.Tensor:

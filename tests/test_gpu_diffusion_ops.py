@@ -194,3 +194,15 @@ def test_vae_single_head_attention_matches_sdpa_forward_and_backward():
         want = want.reshape(B * L, C_)
         err = (got.float() - want).abs().max().item()
         assert err <= 1e-2 * want.abs().max().item(), f"{err} vs {want.abs().max().item()}"
+
+
+@pytest.mark.parametrize("M,C_,K", [(5120, 2560, 640), (333, 1280, 320), (1280, 5120, 1280)])
+def test_gemm_with_fused_geglu_epilogue(M, C_, K):
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    a, w, b = _rand(M, K, seed=1), _rand(2 * C_, K, scale=K ** -0.5, seed=2), _rand(2 * C_, seed=3)
+    h = a.float() @ w.float().T + b.float()
+    ref = h[:, :C_] * F.gelu(h[:, C_:])
+    wp, bp = H.pack_geglu_weight(w, b)
+    _close(H.gemm(a, wp, bias=bp, act=2), ref)
+    _close(H.geglu(H.gemm(a, w, bias=b)), ref)
