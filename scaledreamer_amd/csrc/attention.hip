@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs p) {
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
     const int n_tiles = (p.lk + KT - 1) / KT;
+    const float sl2 = p.scale * 1.44269504088896340736f;   // softmax in the log2 domain
     issue(0, 0);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -114,45 +115,52 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs p) {
                 s[kt][qs] = a;
             }
         }
-        // ---- online softmax per query column ---------------------------------------------------------------
+        // ---- online softmax per query column -------------------------------------------------------------------
+        // VALU-lean form (the loop is VALU-bound: 32 scores per lane and tile): scores are kept in the log2 domain
+        // (one fma folds scale * log2(e) and the running max, v_exp_f32 is 2^x natively), the key-bound mask runs only on
+        // the last tile, and the accumulator rescale is skipped while no
+        // lane's running max moved.
         const int key_base = t * KT + lg * 4;
         half4 pf[4][2];  // probabilities, fp16: [kt][qs] -> 4 consecutive keys
+        if (t == n_tiles - 1 && (p.lk & (KT - 1)) != 0) {
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + kt * 16 + r >= p.lk) s[kt][qs][r] = -1e30f;
+        }
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            float mx = -1e30f;
+            float mx = fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3]));
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][qs][r] * p.scale;
-                    if (key_base + kt * 16 + r >= p.lk) v = -1e30f;
-                    s[kt][qs][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qs][0], s[kt][qs][1]), fmaxf(s[kt][qs][2], s[kt][qs][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qs], mx);
-            const float alpha = __expf(m_run[qs] - m_new);
+            const float m_new = fmaxf(m_run[qs], mx * sl2);          // running max of scale*log2e*s (scale > 0)
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                half4 ph;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kt][qs][r] - m_new);
-                    sum += e;
-                    ph[r] = (half_t)e;
-                }
-                pf[kt][qs] = ph;
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][0], sl2, -m_new));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][1], sl2, -m_new));
+                const float e2 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][2], sl2, -m_new));
+                const float e3 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][3], sl2, -m_new));
+                sum += (e0 + e1) + (e2 + e3);
+                pf[kt][qs] = half4{(half_t)e0, (half_t)e1, (half_t)e2, (half_t)e3};   // v_cvt_pk_f16_f32 (RNE) x2
             }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             l_run[qs] = l_run[qs] * alpha + sum;
-            m_run[qs] = m_new;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {   // wave-uniform: some query's max moved
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                oacc[qs][dt][0] *= alpha; oacc[qs][dt][1] *= alpha; oacc[qs][dt][2] *= alpha; oacc[qs][dt][3] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) {
+                    oacc[qs][dt][0] *= alpha; oacc[qs][dt][1] *= alpha; oacc[qs][dt][2] *= alpha; oacc[qs][dt][3] *= alpha;
+                }
             }
+            m_run[qs] = m_new;
         }
         // ---- O^T += V^T P^T : k-step j covers keys 32j..32j+31 in the permuted order --------------------------
 #pragma unroll
