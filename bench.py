@@ -103,10 +103,14 @@ def roofline_gemm_kernel(reps: int = 30):
         kern = f"conv3x3_win_kernel<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window)"
     else:
         kern = f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]},conv>" if plan[0] else "gemm_f16_kernel<model tile,conv>"
+    # HBM-side bytes per launch of this op from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under
+    # `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950;
+    # summaries in profiles/r01_final2_pmc_roofline_kernel.txt).  Algorithmic: 13.1 MB in + 1.8 MB weights + 13.1 MB out.
+    traffic = {(3, 1): 45.3e6, (7, 3): 195.3e6}.get(tuple(plan))
     return {"kernel": f"{kern} split_k={plan[1]} (3x3 conv 320->320 @64x64, batch 5; autotuned plan, "
                       "time includes the split-K epilogue launch if any)", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": None, "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)", "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 
 
 def roofline_field_kernel(system, batch, reps: int = 20):
