@@ -77,14 +77,22 @@ def to_device(batch, dev):
     return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-def roofline_gemm_kernel(reps: int = 30):
-    """The dominant kernel of the step (rocprofv3: gemm_f16_kernel, conv mode, ~25 % of the step time): average
-    duration of one launch measured with HIP events on the launch stream, on the most frequent heavy shape of the
-    step — the 3x3 convolution 320->320 at 64x64 for the UNet batch of 5 (M=20480, N=320, K=2880).
+# HBM-side bytes per launch from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under `--pmc FETCH_SIZE` and
+# `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; summaries in
+# profiles/r01_final2_pmc_roofline_kernel.txt), keyed by (op, autotuned plan).
+PMC_TRAFFIC = {("vae512", (10, 1)): 145.5e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
+
+
+def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
+    """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final2_kernel_stats_top70.csv:
+    conv3x3_win_kernel<128> 14 % + gemm_f16_kernel variants 30 % of the kernel time).  Average duration of one launch, HIP events on
+    the launch stream, on its heaviest single shape:
+      vae512: 3x3 conv 128->128 at 512x512 (VAE encoder level 0, forward and input-gradient: 8 launches per step) M=262144 N=128 K=1152
+      unet64: 3x3 conv 320->320 at 64x64 for the UNet batch of 5 (7 launches per UNet forward)                 M=20480  N=320 K=2880
     Algorithmic flops per launch = 2*M*N*K."""
     from scaledreamer_amd.diffusion import hip_ops as H
 
-    B, hw, cin, cout = 5, 64, 320, 320
+    B, hw, cin, cout = (1, 512, 128, 128) if which == "vae512" else (5, 64, 320, 320)
     x = torch.randn(B, hw, hw, cin, device="cuda").half()
     w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * 0.02)
     for _ in range(5):
@@ -98,19 +106,16 @@ def roofline_gemm_kernel(reps: int = 30):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * B * hw * hw * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    plan = H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1))
+    plan = tuple(H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
     if plan[0] - 1 in H.WINDOW_TILES:
         kern = f"conv3x3_win_kernel<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window)"
     else:
         kern = f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]},conv>" if plan[0] else "gemm_f16_kernel<model tile,conv>"
-    # HBM-side bytes per launch of this op from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under
-    # `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950;
-    # summaries in profiles/r01_final2_pmc_roofline_kernel.txt).  Algorithmic: 13.1 MB in + 1.8 MB weights + 13.1 MB out.
-    traffic = {(3, 1): 45.3e6, (7, 3): 195.3e6}.get(tuple(plan))
-    return {"kernel": f"{kern} split_k={plan[1]} (3x3 conv 320->320 @64x64, batch 5; autotuned plan, "
-                      "time includes the split-K epilogue launch if any)", "bound": "mfma",
+    shape = "3x3 conv 128->128 @512x512 (VAE encoder)" if which == "vae512" else "3x3 conv 320->320 @64x64, UNet batch 5"
+    return {"kernel": f"{kern} split_k={plan[1]} on {shape}; autotuned plan", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)", "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+            "traffic": PMC_TRAFFIC.get((which, plan)), "traffic_unit": "bytes/launch (PMC, profiles/)", "flops_per_launch": flops,
+            "avg_launch_ms": round(ms, 4)}
 
 
 def roofline_field_kernel(system, batch, reps: int = 20):
@@ -301,7 +306,8 @@ def main():
             out.pop("kept_samples_last_step", None)
         if phases:
             out["phases_ms"] = phases
-        out["roofline"] = roofline_gemm_kernel()
+        out["roofline"] = roofline_conv_kernel("vae512")
+        out["roofline_unet_conv"] = roofline_conv_kernel("unet64")
         if args.workload != "asd_sd_hyper_ingp":
             out["roofline_renderer"] = roofline_field_kernel(system, batch)
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":
