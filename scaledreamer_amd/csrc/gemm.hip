@@ -8,13 +8,13 @@
 // diffusers' UNet2DConditionModel in the reference (stable_diffusion_asd_guidance.py:319-331; layer
 // inventory SURVEY.md Appendix A.1).
 //
-// CDNA4 mapping: 256 threads = 4 waves (2x2), block tile 128 x BN (BN = 128 | 64), BK = 32 = one
-// v_mfma_f32_16x16x32_f16 step, fp32 accumulation.  Both operands stream HBM/L2 -> LDS with
-// global_load_lds (16 B per lane, no VGPR round trip), double buffered, one barrier per k-step.  LDS rows are
-// 64 B; the 16-B chunk index is XOR-swizzled with bit 3 of the row (st_16x32) on the SOURCE address and on
-// the ds_read_b128 side, which makes the fragment reads bank-conflict free.  The MFMA is issued with the
-// weight fragment as the A operand, so each lane ends up with 4 consecutive output channels of one row
-// -> 8-byte stores.  Out-of-range rows / taps read a zero page instead of branching.
+// CDNA4 mapping: WM x WN waves per block, each owning a (BM/WM) x (BN/WN) register tile of v_mfma_f32_16x16x32_f16
+// fragments (fp32 accumulation); k-step 64.  Both operands stream HBM/L2 -> LDS with global_load_lds (16 B per lane, no
+// VGPR round trip), double buffered, one barrier per k-step.  LDS rows are 128 B; the 16-B chunk index is XOR-swizzled
+// with (row & 7) on the SOURCE address and on the ds_read_b128 side (bank-conflict free).  The MFMA is issued with the
+// weight fragment as the A operand, so each lane ends up with 4 consecutive output channels of one row -> 8-byte stores.
+// Out-of-range rows / taps read a zero page instead of branching.  The second kernel of this file, conv3x3_win_kernel,
+// keeps the input window of a 16x16-pixel patch LDS-resident across the 9 taps of a stride-1 3x3 convolution.
 #include <stdlib.h>
 
 #include "asd_common.h"
@@ -26,8 +26,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
-
-#define BK 32
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
@@ -41,7 +39,7 @@ __device__ __forceinline__ void load_slab(const char* src_row_chunk, char* lds_s
 // (row & 7) on the source address and on the ds_read_b128 side (conflict-free).  Two stages (double buffer): the loads
 // of tile k+1 are issued right after the barrier that publishes tile k.
 //
-// Measured on MI355X (tools/gemm_ablate.py): removing the MFMAs or the ds_reads from this loop does not change its time,
+// Measured on MI355X (main-loop ablation builds; numbers in DESIGN.md section 4): removing the MFMAs or the ds_reads from this loop does not change its time,
 // removing the global->LDS tile loads makes it 1.5-2.6x faster, and every shape lands at ~8 TB/s of aggregate L2->LDS
 // traffic.  The kernel is bound by bytes loaded per flop = (1/BM + 1/BN) / 128 B, so the tile is chosen as large as the
 // problem allows (WM x WN waves, each owning a (BM/WM) x (BN/WN) register tile), up to 256 x 320.

@@ -33,9 +33,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
         const int c = slot * 8;
-        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
-            const size_t row = (size_t)b * hw + r;
-            const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+        // 4 rows per trip: four independent 16-byte loads in flight per thread (a single dependent load per trip left the
+        // kernel latency-bound at a third of the HBM rate on the 67 MB VAE tensors)
+        const half_t* base = c < c1 ? x1 + (size_t)b * hw * c1 + c : x2 + (size_t)b * hw * c2 + (c - c1);
+        const size_t rstride = c < c1 ? c1 : c2;
+        int r = r0 + rsub;
+        for (; r + 3 * rows_in_flight < r1; r += 4 * rows_in_flight) {
+            half8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float f = (float)v[u][k]; s[k] += f; q[k] = fmaf(f, f, q[k]); }
+        }
+        for (; r < r1; r += rows_in_flight) {
+            const half8 v = *(const half8*)(base + (size_t)r * rstride);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; q[k] = fmaf(f, f, q[k]); }
         }
@@ -105,9 +118,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
             sa[k] = rsqrtf(var + eps) * (float)gamma[c + k];
             sb[k] = (float)beta[c + k] - mean * sa[k];
         }
-        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
-            const size_t row = (size_t)b * hw + r;
-            const half8 v = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
+        const half_t* base = c < c1 ? x1 + (size_t)b * hw * c1 + c : x2 + (size_t)b * hw * c2 + (c - c1);
+        const size_t rstride = c < c1 ? c1 : c2;
+        half_t* ybase = y + (size_t)b * hw * C + c;
+        int r = r0 + rsub;
+        for (; r + 3 * rows_in_flight < r1; r += 4 * rows_in_flight) {
+            half8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                half8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float f = fmaf((float)v[u][k], sa[k], sb[k]);
+                    if (silu) f = silu_f(f);
+                    o[k] = (half_t)f;
+                }
+                *(half8*)(ybase + (size_t)(r + u * rows_in_flight) * C) = o;
+            }
+        }
+        for (; r < r1; r += rows_in_flight) {
+            const half8 v = *(const half8*)(base + (size_t)r * rstride);
             half8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -115,7 +147,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                 if (silu) f = silu_f(f);
                 o[k] = (half_t)f;
             }
-            *(half8*)(y + row * C + c) = o;
+            *(half8*)(ybase + (size_t)r * C) = o;
         }
     }
 }
@@ -159,14 +191,28 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restr
             gm[k] = (float)gamma[c + k]; bt[k] = (float)beta[c + k];
             s[k] = 0.f; q[k] = 0.f;
         }
-        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
+        int r = r0 + rsub;
+        for (; r + rows_in_flight < r1; r += 2 * rows_in_flight) {   // two rows (4 loads) in flight per thread
+            const size_t off0 = ((size_t)b * hw + r) * C + c, off1 = off0 + (size_t)rows_in_flight * C;
+            const half8 xv0 = *(const half8*)(x + off0), dv0 = *(const half8*)(dy + off0);
+            const half8 xv1 = *(const half8*)(x + off1), dv1 = *(const half8*)(dy + off1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh0 = ((float)xv0[k] - mean[k]) * rstd[k], xh1 = ((float)xv1[k] - mean[k]) * rstd[k];
+                float g0 = (float)dv0[k] * gm[k], g1 = (float)dv1[k] * gm[k];
+                if (silu) { g0 *= silu_grad(fmaf(xh0, gm[k], bt[k])); g1 *= silu_grad(fmaf(xh1, gm[k], bt[k])); }
+                s[k] += g0 + g1;
+                q[k] = fmaf(g0, xh0, fmaf(g1, xh1, q[k]));
+            }
+        }
+        for (; r < r1; r += rows_in_flight) {
             const size_t off = ((size_t)b * hw + r) * C + c;
             const half8 xv = *(const half8*)(x + off), dv = *(const half8*)(dy + off);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float xh = ((float)xv[k] - mean[k]) * rstd[k];
                 float g = (float)dv[k] * gm[k];
-                if (silu) g *= silu_grad(xh * gm[k] + bt[k]);
+                if (silu) g *= silu_grad(fmaf(xh, gm[k], bt[k]));
                 s[k] += g;
                 q[k] = fmaf(g, xh, q[k]);
             }
@@ -431,11 +477,6 @@ __global__ __launch_bounds__(256) void concat_kernel(const half_t* __restrict__ 
         const int c = (int)(i - row * slots) * 8;
         *(half8*)(y + row * C + c) = c < c1 ? *(const half8*)(x1 + row * c1 + c) : *(const half8*)(x2 + row * c2 + (c - c1));
     }
-}
-
-__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.f;
 }
 
 extern "C" {
