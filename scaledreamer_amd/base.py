@@ -27,28 +27,43 @@ def get_device() -> torch.device:
 
 
 class Updateable:
-    def do_update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
-        for attr in self.__dir__():
-            if attr.startswith("_"):
-                continue
+    def _updateable_children(self):
+        """threestudio/utils/base.py:21-52 walks self.__dir__() on every call (hundreds of nn.Module attributes, each a
+        getattr); the set of Updateable attributes is found the same way but cached by attribute name and re-scanned only when
+        the instance's attribute names change."""
+        names = self.__dict__.get("_upd_names")
+        sig = (len(self.__dict__), len(getattr(self, "_modules", ())))
+        if names is None or self.__dict__.get("_upd_sig") != sig:
+            names = []
+            for attr in self.__dir__():
+                if attr.startswith("_"):
+                    continue
+                try:
+                    module = getattr(self, attr)
+                except Exception:
+                    continue
+                if isinstance(module, Updateable):
+                    names.append(attr)
+            object.__setattr__(self, "_upd_names", names)
+            object.__setattr__(self, "_upd_sig", (len(self.__dict__), len(getattr(self, "_modules", ()))))
+        out = []
+        for attr in names:
             try:
                 module = getattr(self, attr)
             except Exception:
                 continue
             if isinstance(module, Updateable):
-                module.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
+                out.append(module)
+        return out
+
+    def do_update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        for module in self._updateable_children():
+            module.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
         self.update_step(epoch, global_step, on_load_weights=on_load_weights)
 
     def do_update_step_end(self, epoch: int, global_step: int):
-        for attr in self.__dir__():
-            if attr.startswith("_"):
-                continue
-            try:
-                module = getattr(self, attr)
-            except Exception:
-                continue
-            if isinstance(module, Updateable):
-                module.do_update_step_end(epoch, global_step)
+        for module in self._updateable_children():
+            module.do_update_step_end(epoch, global_step)
         self.update_step_end(epoch, global_step)
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
