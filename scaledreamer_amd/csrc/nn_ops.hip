@@ -492,7 +492,9 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     // statistics: >= 16 rows per block and at most ~512 blocks (each ends with 64 atomics on one hot set of addresses);
     // apply: no atomics, so up to ~2048 blocks
     int chunks = asd_div_up(hw, 16);
-    const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
+    // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
+    // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
+    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(512, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
                        asd_div_up(hw, chunks_s), partials);
@@ -510,7 +512,9 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
     int chunks = asd_div_up(hw, 16);
-    const int cap_s = asd_div_up(512, batch), cap_a = asd_div_up(2048, batch);
+    // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
+    // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
+    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(512, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
                        asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
