@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 BUCKET_BYTES = 256 << 20
+IN_PLACE_BYTES = 4 << 20   # gradients at least this large are all-reduced in place
 
 
 def is_distributed() -> bool:
@@ -46,23 +47,35 @@ def _buckets(grads: List[torch.Tensor]):
 
 
 def allreduce_mean_grads(optimizer: torch.optim.Optimizer) -> None:
+    """mean of every gradient over the ranks.  Large contiguous gradients (the 50 MB hash table) are reduced in place — no
+    flatten / scatter copies —, the small ones travel together in flat buckets; all calls are issued asynchronously and
+    waited for once, so RCCL can pipeline them over the xGMI links."""
     if not is_distributed():
         return
     world = dist.get_world_size()
     grads = [p.grad for grp in optimizer.param_groups for p in grp["params"] if p.grad is not None]
-    for bucket in _buckets(grads):
-        if len(bucket) == 1:
-            flat = bucket[0].view(-1)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    big = [g for g in grads if g.is_contiguous() and g.numel() * g.element_size() >= IN_PLACE_BYTES]
+    small = [g for g in grads if not any(g is b for b in big)]
+    avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+    works, flats = [], []
+    for g in big:
+        works.append(dist.all_reduce(g.view(-1), op=avg, async_op=True))
+    for bucket in _buckets(small):
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        flats.append((flat, bucket))
+        works.append(dist.all_reduce(flat, op=avg, async_op=True))
+    for w in works:
+        w.wait()
+    if avg == dist.ReduceOp.SUM:
+        for g in big:
+            g.div_(world)
+    for flat, bucket in flats:
+        if avg == dist.ReduceOp.SUM:
             flat.div_(world)
-        else:
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(world)
-            off = 0
-            for g in bucket:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

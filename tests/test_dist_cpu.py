@@ -30,6 +30,7 @@ def _worker(rank, world, port, out_dir):
     local = [p.grad.clone() for p in model.parameters()]
     old_bucket = asd_dist.BUCKET_BYTES
     asd_dist.BUCKET_BYTES = 4096                     # force several buckets incl. multi-tensor ones
+    asd_dist.IN_PLACE_BYTES = 1 << 20                # the 1.2 MB "table" takes the in-place path of the hash-grid gradient
     asd_dist.allreduce_mean_grads(opt)
     asd_dist.BUCKET_BYTES = old_bucket
     torch.save({"init": ref, "local": local, "avg": [p.grad.clone() for p in model.parameters()]}, os.path.join(out_dir, f"r{rank}.pt"))
