@@ -180,3 +180,57 @@ def render(P: dict) -> dict:
                 z_variance=v(z_var, 1), comp_normal=v(cn, 3), weights=w, t_points=t_pos, t_intervals=t_int, t_dirs=t_dirs,
                 ray_indices=ray_idx, points=positions, inv_std=torch.tensor(np.exp(np.float32(P["variance_param"]) * 10.0)) if "variance_param" in P else torch.tensor(inv_std),
                 _debug=dbg, **geo)
+
+
+# ---- generator-backed geometries (3DConv-net / Triplane-transformer-sdf) -----------------------------------------------
+class _VoxelSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, voxel_cl, points):
+        ctx.shape, ctx.pts = tuple(voxel_cl.shape), points.detach().numpy()
+        return torch.from_numpy(O.voxel_sample_fwd(voxel_cl.detach().numpy(), ctx.pts))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return torch.from_numpy(O.voxel_sample_bwd(d_out.contiguous().numpy(), ctx.pts, ctx.shape)), None
+
+
+class _TriplaneSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, planes_cl, points):
+        ctx.shape, ctx.pts = tuple(planes_cl.shape), points.detach().numpy()
+        return torch.from_numpy(O.triplane_sample_fwd(planes_cl.detach().numpy(), ctx.pts, 1.0))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return torch.from_numpy(O.triplane_sample_bwd(d_out.contiguous().numpy(), ctx.pts, ctx.shape, 1.0)), None
+
+
+def sampled_sdf_geometry(points, cache, kind, sdf_w, feat_w, radius=2.0, sphere_r=0.8, eps=0.01):
+    """stylegan_3dconv_net.py:259-346 / triplane_transformer.py:156-240: points [B,Np,3], cache channel-first as the generators
+    emit it ([B,C,D,H,W] voxel | [B,3,C,H,W] planes), sdf_w / feat_w = lists of VanillaMLP weight matrices (no bias, ReLU)."""
+    B = points.shape[0]
+
+    def mlp(x, ws):
+        for w in ws[:-1]:
+            x = torch.relu(x @ w.t())
+        return x @ ws[-1].t()
+
+    def encode(pw):   # pw: world points [B, M, 3]
+        p = pw / radius                                       # contract_to_unisphere_custom: bbox [-r, r] -> [-1, 1]
+        if kind == "voxel":
+            return _VoxelSample.apply(cache.permute(0, 2, 3, 4, 1).contiguous(), p)
+        return _TriplaneSample.apply(cache.permute(0, 1, 3, 4, 2).contiguous(), p)
+
+    def sdf_of(pw):
+        return mlp(encode(pw), sdf_w) + pw.norm(dim=-1, keepdim=True) - sphere_r
+
+    enc = encode(points)
+    sdf = mlp(enc, sdf_w) + points.norm(dim=-1, keepdim=True) - sphere_r
+    feats = mlp(enc, feat_w)
+    offs = torch.eye(3) * eps
+    po = (points[..., None, :] + offs).clamp(-radius, radius)                     # [B, Np, 3, 3]
+    sdf_off = sdf_of(po.reshape(B, -1, 3)).reshape(B, -1, 3)
+    sdf_grad = (sdf_off - sdf) / eps
+    normal = F.normalize(sdf_grad, dim=-1)
+    return {"sdf": sdf.reshape(-1, 1), "features": feats.reshape(-1, feats.shape[-1]), "normal": normal.reshape(-1, 3),
+            "sdf_grad": sdf_grad.reshape(-1, 3)}

@@ -63,9 +63,9 @@ class NeuralEnvironmentMapBackground(BaseBackground):
         self.encoding = get_encoding(3, self.cfg.dir_encoding_config)
         self.network = get_mlp(self.encoding.n_output_dims, self.cfg.n_output_dims, self.cfg.mlp_network_config)
         m = self.cfg.mlp_network_config
-        self._meta = self.encoding.encoding.encoding.meta
+        self._meta = getattr(self.encoding.encoding.encoding, "meta", None)   # None: parameter-free encodings (SphericalHarmonics)
         self._fused = (
-            self._meta.n_levels == 4 and not self.encoding.include_xyz and isinstance(self.network, VanillaMLP)
+            self._meta is not None and self._meta.n_levels == 4 and not self.encoding.include_xyz and isinstance(self.network, VanillaMLP)
             and m.get("n_neurons") == 16 and m.get("n_hidden_layers") == 2 and self.cfg.n_output_dims == 3
             and self.cfg.color_activation == "sigmoid" and m.get("output_activation", "none") in (None, "none")
         )

@@ -1,0 +1,275 @@
+"""Generator backbones of the multi-prompt configs, stated with library tensor ops — they are dense fp32
+training graphs (forward + weight gradients) whose GEMM / conv3d work belongs to rocBLAS / MIOpen; what this repository
+hand-writes is what CONSUMES their output every sample (samplers.py, the SDF field, the VolSDF renderer).
+
+  Generator3D            custom/amortized/extern/stylegan_3dconv_modules.py:85-344   (StyleGAN2-style 3-D synthesis: mapping
+                         network -> modulated 3x3x3 convolutions 4^3 ... 128^3, trilinear upsampling, skip "toRGB" volumes)
+  TriplaneTransformer    custom/amortized/extern/triplane_transformer_modules.py:9-187 (LRM-style transformer over 3 x 32^2
+                         learned tokens with text cross-attention -> ConvTranspose2d -> [N, 3, 32, 64, 64] planes)
+Parameter names and shapes are the reference's, so its checkpoints load with load_state_dict.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ---- StyleGAN-3D --------------------------------------------------------------------------------------------------------
+class FullyConnectedLayer(nn.Module):
+    """equalised-learning-rate linear layer (:36-53): y = act(x (W g_w)^T + b g_b) * act_gain"""
+
+    def __init__(self, in_features, out_features, bias=True, activation="linear", lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.lrelu = activation == "lrelu"
+        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = nn.Parameter(torch.full([out_features], float(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / math.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        b = self.bias * self.bias_gain if self.bias_gain != 1 else self.bias
+        y = torch.addmm(b.unsqueeze(0), x, (self.weight * self.weight_gain).t())
+        return F.leaky_relu(y, 0.2) * math.sqrt(2) if self.lrelu else y
+
+
+def modulated_conv3d(x, weight, styles, padding=0, demodulate=True):
+    """per-sample modulated (and demodulated) convolution as ONE grouped conv3d (:64-82)"""
+    n = x.shape[0]
+    cout, cin = weight.shape[:2]
+    w = weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1, 1)
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4, 5]) + 1e-8).rsqrt().reshape(n, cout, 1, 1, 1, 1)
+    y = F.conv3d(x.reshape(1, n * cin, *x.shape[2:]), w.reshape(n * cout, cin, *weight.shape[2:]), padding=padding, groups=n)
+    return y.reshape(n, cout, *y.shape[2:])
+
+
+def _upsample2(x):
+    return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
+
+
+class SynthesisLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, upsample=False):
+        super().__init__()
+        self.resolution, self.upsample, self.padding = resolution, upsample, kernel_size // 2
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size, kernel_size]))
+        self.register_buffer("noise_const", torch.randn([resolution, resolution, resolution]))
+        self.noise_strength = nn.Parameter(torch.zeros([1]))
+        self.bias = nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode, gain=1):
+        x = modulated_conv3d(x, self.weight, self.affine(w), padding=self.padding)
+        if self.upsample:
+            x = _upsample2(x)
+        if noise_mode == "random":
+            r = self.resolution
+            x = x + torch.randn([x.shape[0], 1, r, r, r], device=x.device) * self.noise_strength
+        elif noise_mode == "const":
+            x = x + self.noise_const * self.noise_strength
+        else:
+            raise TypeError(f"noise_mode {noise_mode!r}: the reference adds `None` here; only 'random' and 'const' are usable")
+        act_gain = math.sqrt(2) * gain
+        return torch.clamp(F.leaky_relu(x + self.bias[None, :, None, None, None], 0.2) * act_gain, -256 * gain, 256 * gain)
+
+
+class ToRGBLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1):
+        super().__init__()
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size, kernel_size]))
+        self.bias = nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / math.sqrt(in_channels) * (kernel_size ** 3)
+
+    def forward(self, x, w):
+        return modulated_conv3d(x, self.weight, self.affine(w) * self.weight_gain, demodulate=False) + self.bias[None, :, None, None, None]
+
+
+class SynthesisPrologue(nn.Module):
+    def __init__(self, out_channels, w_dim, resolution, img_channels):
+        super().__init__()
+        self.const = nn.Parameter(torch.randn([out_channels, resolution, resolution, resolution]))
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution)
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim)
+        self.num_ws = 2
+
+    def forward(self, ws, noise_mode="random"):
+        x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1, 1])
+        x = self.conv1(x, ws[:, 0], noise_mode=noise_mode)
+        return x, self.torgb(x, ws[:, 1])
+
+
+class SynthesisBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, use_const_bias=False):
+        super().__init__()
+        self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, upsample=True)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution)
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim)
+        self.num_ws = 3
+        self.const_bias = (nn.Parameter(torch.randn([out_channels, resolution, resolution, resolution]) / math.sqrt(out_channels))
+                           if use_const_bias else None)
+
+    def forward(self, x, img, ws, noise_mode="random"):
+        x = self.conv0(x, ws[:, 0], noise_mode=noise_mode)
+        if self.const_bias is not None:
+            x = x + self.const_bias
+        x = self.conv1(x, ws[:, 1], noise_mode=noise_mode)
+        return x, _upsample2(img) + self.torgb(x, ws[:, 2])
+
+
+class SynthesisNetwork3D(nn.Module):
+    CHANNELS = {4: 512, 8: 512, 16: 512, 32: 256, 64: 128, 128: 64, 256: 32}
+
+    def __init__(self, w_dim, img_resolution, img_channels, channel_multiplier=1, bias_resolution=64):
+        super().__init__()
+        log2 = int(math.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(2, log2 + 1)]
+        ch = {r: (c if r <= 16 else c * channel_multiplier) for r, c in self.CHANNELS.items()}
+        self.blocks = nn.ModuleList()          # (registration order = the reference's state-dict key order)
+        self.biases = nn.ParameterList()
+        self.first_block = SynthesisPrologue(ch[4], w_dim=w_dim, resolution=4, img_channels=img_channels)
+        for r in self.block_resolutions[1:]:
+            self.blocks.append(SynthesisBlock(ch[r // 2], ch[r], w_dim=w_dim, resolution=r, img_channels=img_channels,
+                                              use_const_bias=r <= bias_resolution))
+        self.num_ws = self.first_block.num_ws + sum(b.num_ws for b in self.blocks)
+
+    def forward(self, ws, noise_mode="random"):
+        # style slices overlap by one (the toRGB style of a block is the first conv style of the next), as in StyleGAN2 (:161)
+        x, img = self.first_block(ws[:, 0:2], noise_mode=noise_mode)
+        for i, blk in enumerate(self.blocks):
+            x, img = blk(x, img, ws[:, 2 * (i + 1) + 1: 2 * (i + 1) + 4], noise_mode)
+        return img
+
+
+class MappingNetwork(nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, lr_multiplier=0.01, w_avg_beta=0.995):
+        super().__init__()
+        self.c_dim, self.num_ws, self.num_layers = c_dim, num_ws, num_layers
+        feats = [z_dim] + [w_dim] * num_layers
+        self.layers = nn.ModuleList([FullyConnectedLayer(feats[i], feats[i + 1], activation="lrelu",
+                                                         lr_multiplier=lr_multiplier if c_dim == 0 else 1) for i in range(num_layers)])
+        self.embed = FullyConnectedLayer(c_dim + feats[-1], w_dim) if c_dim > 0 else None
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer("w_avg", torch.zeros([w_dim]))
+
+    def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None):
+        x = z * (z.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+        for layer in self.layers:
+            x = layer(x)
+        if self.c_dim > 0:
+            x = self.embed(torch.cat((x, c), dim=1))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            raise NotImplementedError("Truncation is not implemented")
+        return x
+
+
+class Generator3D(nn.Module):
+    def __init__(self, z_dim, w_dim, num_layers, img_resolution, img_channels, c_dim=0, channel_multiplier=1, bias_resolution=64, **unused):
+        super().__init__()
+        self.z_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, w_dim, img_resolution, img_channels
+        self.synthesis = SynthesisNetwork3D(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
+                                            channel_multiplier=channel_multiplier, bias_resolution=bias_resolution)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, num_layers=num_layers)
+
+    def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, noise_mode="random", report_stats=False):
+        if report_stats:
+            blocks = [self.synthesis.first_block.conv1] + [b.conv0 for b in self.synthesis.blocks]
+            return {f"res_{4 * 2 ** i}": torch.norm(l.affine.weight, p=2).item() for i, l in enumerate(blocks)}
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return {"image": self.synthesis(ws, noise_mode=noise_mode)}
+
+
+# ---- Triplane transformer ---------------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    """diffusers.models.attention_processor.Attention as constructed at triplane_transformer_modules.py:45-53 (un-vendored,
+    diffusers < 0.20): to_q / to_k / to_v without bias, to_out = [Linear(+bias), Dropout], softmax(q k^T / sqrt(d)) v."""
+
+    def __init__(self, query_dim, heads, dim_head, cross_attention_dim=None, dropout=0.0, bias=False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(ctx, inner, bias=bias)
+        self.to_v = nn.Linear(ctx, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+    def forward(self, hidden_states, encoder_hidden_states=None):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        n, lq, _ = hidden_states.shape
+        split = lambda t: t.view(n, -1, self.heads, t.shape[-1] // self.heads).transpose(1, 2)
+        o = F.scaled_dot_product_attention(split(self.to_q(hidden_states)), split(self.to_k(ctx)), split(self.to_v(ctx)))
+        return self.to_out[1](self.to_out[0](o.transpose(1, 2).reshape(n, lq, -1)))
+
+
+class ConditionModulationBlock(nn.Module):
+    """cross-attention to the text tokens, self-attention, MLP (pre-LayerNorm residual blocks; :34-72)"""
+
+    def __init__(self, inner_dim, cond_dim, num_heads, eps, mlp_ratio=4.0, attn_drop=0.0, attn_bias=False, mlp_drop=0.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(inner_dim, eps)
+        self.cross_attn = Attention(inner_dim, num_heads, inner_dim // num_heads, cross_attention_dim=cond_dim, dropout=attn_drop, bias=attn_bias)
+        self.norm2 = nn.LayerNorm(inner_dim, eps)
+        self.self_attn = Attention(inner_dim, num_heads, inner_dim // num_heads, cross_attention_dim=inner_dim, dropout=attn_drop, bias=attn_bias)
+        self.norm3 = nn.LayerNorm(inner_dim, eps)
+        hid = int(inner_dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Linear(inner_dim, hid), nn.GELU(), nn.Dropout(mlp_drop), nn.Linear(hid, inner_dim), nn.Dropout(mlp_drop))
+
+    def forward(self, x, cond):
+        x = x + self.cross_attn(self.norm1(x), cond)
+        x = x + self.self_attn(self.norm2(x))
+        return x + self.mlp(self.norm3(x))
+
+
+class ConditionModulationBlockwoCrossAttn(nn.Module):
+    """the condition is one extra token in front of the sequence (:74-112)"""
+
+    def __init__(self, inner_dim, cond_dim, num_heads, eps, mlp_ratio=4.0, attn_drop=0.0, attn_bias=False, mlp_drop=0.0):
+        super().__init__()
+        self.norm2 = nn.LayerNorm(inner_dim, eps)
+        self.self_attn = Attention(inner_dim, num_heads, inner_dim // num_heads, cross_attention_dim=inner_dim, dropout=attn_drop, bias=attn_bias)
+        self.norm3 = nn.LayerNorm(inner_dim, eps)
+        hid = int(inner_dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.GELU(), nn.Linear(inner_dim, hid), nn.GELU(), nn.Linear(hid, inner_dim), nn.Dropout(mlp_drop))
+
+    def forward(self, x, cond):
+        x = torch.cat([cond, x], dim=1)
+        x = x + self.self_attn(self.norm2(x))
+        x = x + self.mlp(self.norm3(x))
+        return x[:, 1:, :]
+
+
+class TriplaneTransformer(nn.Module):
+    def __init__(self, inner_dim, condition_dim, triplane_low_res, triplane_high_res, triplane_dim, num_layers, num_heads, local_text,
+                 mlp_ratio=4.0, eps=1e-6, **unused):
+        super().__init__()
+        self.triplane_low_res, self.triplane_high_res, self.triplane_dim = triplane_low_res, triplane_high_res, triplane_dim
+        self.pos_embed = nn.Parameter(torch.randn(1, 3 * triplane_low_res ** 2, inner_dim) * (1.0 / inner_dim) ** 0.5)
+        self.needs_local_text = local_text
+        blk = ConditionModulationBlock if local_text else ConditionModulationBlockwoCrossAttn
+        self.layers = nn.ModuleList([blk(inner_dim=inner_dim, cond_dim=condition_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, eps=eps)
+                                     for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(inner_dim, eps=eps)
+        self.deconv = nn.ConvTranspose2d(inner_dim, triplane_dim, kernel_size=2, stride=2, padding=0, bias=False)
+        if not local_text:
+            self.proj = nn.Linear(condition_dim, inner_dim)
+
+    def forward(self, text_embed):
+        N, Hh = text_embed.shape[0], self.triplane_low_res
+        if not self.needs_local_text:
+            text_embed = self.proj(text_embed).unsqueeze(1)
+        x = self.pos_embed.repeat(N, 1, 1)
+        for layer in self.layers:
+            x = layer(x, text_embed)
+        x = self.norm(x).view(N, 3, Hh, Hh, -1).permute(1, 0, 4, 2, 3).contiguous().view(3 * N, -1, Hh, Hh)   # [3N, D, H, W]
+        x = self.deconv(x)
+        x = x.view(3, N, *x.shape[-3:]).permute(1, 0, 2, 3, 4).contiguous()                                       # [N, 3, D', H', W']
+        assert self.triplane_high_res == x.shape[-2], f"Output triplane resolution does not match with expected: {x.shape[-2]} vs {self.triplane_high_res}"
+        assert self.triplane_dim == x.shape[-3], f"Output triplane dimension does not match with expected: {x.shape[-3]} vs {self.triplane_dim}"
+        return x

@@ -19,7 +19,7 @@ import torch
 
 from .base import get_rank
 from .config import parse_structured
-from .data import RandomCameraDataModuleConfig, RandomCameraIterableDataset
+from .data import RandomCameraDataModuleConfig, RandomCameraIterableDataset, RandomMultiviewCameraIterableDataset
 from .guidance import shift_azimuth_deg, shifted_expotional_decay
 from .registry import find, register
 from .system import StableDreamer, binary_cross_entropy, dot
@@ -153,6 +153,54 @@ class MultipromptRandomCameraIterableDataset(RandomCameraIterableDataset):
             out["prompt"] = random.choices(self.prompt_library, k=self.batch_size)
         else:
             out["prompt"] = random.sample(self.prompt_library, k=self.batch_size)
+        return out
+
+
+@dataclass
+class MultiviewMultipromptRandomCameraDataModuleConfig(RandomCameraDataModuleConfig):
+    dim_gaussian: int = 512
+    prompt_library: Any = "magic3d_prompt_library"
+    prompt_library_dir: str = "load"
+    prompt_library_format: str = "json"
+    eval_prompt: Optional[str] = None
+    target_prompt: Optional[str] = None
+    eval_fix_camera: Optional[int] = None
+    relative_radius: bool = True
+    n_view: int = 1
+    zoom_range: Tuple[float, float] = (1.0, 1.0)
+
+
+@register("multiprompt-multiview-camera-datamodule")
+class MultiviewMultipromptRandomCameraIterableDataset(RandomMultiviewCameraIterableDataset):
+    """custom/amortized/data/multiview_multiprompt.py:36-75: groups of n_view cameras, one prompt (and noise vector) per group."""
+
+    def __init__(self, cfg: Any, prompt_library: Optional[Dict[str, List[str]]] = None, rank: Optional[int] = None,
+                 n_ranks: Optional[int] = None) -> None:
+        cfg_mp = parse_structured(MultiviewMultipromptRandomCameraDataModuleConfig, cfg)
+        from .data import RandomMultiviewCameraDataModuleConfig
+        super().__init__({k: getattr(cfg_mp, k) for k in RandomMultiviewCameraDataModuleConfig.__dataclass_fields__})
+        self.mp_cfg = cfg_mp
+        self.n_view = cfg_mp.n_view
+        if prompt_library is None:
+            if isinstance(cfg_mp.prompt_library, dict):
+                prompt_library = cfg_mp.prompt_library
+            else:
+                path = os.path.join(cfg_mp.prompt_library_dir, cfg_mp.prompt_library) + "." + cfg_mp.prompt_library_format
+                with open(path, "r") as f:
+                    prompt_library = json.load(f)
+        rank = get_rank() if rank is None else rank
+        n_ranks = int(os.environ.get("WORLD_SIZE", max(1, torch.cuda.device_count()))) if n_ranks is None else n_ranks
+        assert "train" in prompt_library, "prompt library must contain train split"
+        self.prompt_library = list(prompt_library["train"])[rank::n_ranks]
+
+    def collate(self, batch=None) -> Dict[str, Any]:
+        groups = self.batch_size // self.n_view
+        out = super().collate(batch)
+        out["noise"] = torch.randn(groups, self.mp_cfg.dim_gaussian)
+        if len(self.prompt_library) < groups:
+            out["prompt"] = random.choices(self.prompt_library, k=groups)
+        else:
+            out["prompt"] = random.sample(self.prompt_library, k=groups)
         return out
 
 

@@ -93,11 +93,41 @@ class Encoding(nn.Module):
         return _HashGridFn.apply(x.contiguous().float(), self.params, self.meta)
 
 
+class SphericalHarmonics(nn.Module):
+    """tcnn `SphericalHarmonics` encoding (the default `dir_encoding_config` of neural-environment-map-background,
+    neural_environment_map_background.py:21-23, reached by the 3DConv-net / triplane configs): the input in [0,1]^3 is mapped to
+    [-1,1]^3 and expanded in the real SH basis of Instant-NGP up to `degree` (degree^2 outputs, no parameters).  Un-vendored
+    third-party arithmetic restated from its published form; a few thousand ray directions per step: plain tensor ops."""
+
+    def __init__(self, n_input_dims: int, encoding_config: dict, dtype=torch.float32):
+        super().__init__()
+        self.degree = int(encoding_config.get("degree", 4))
+        if n_input_dims != 3 or not 1 <= self.degree <= 4:
+            raise NotImplementedError("SphericalHarmonics: 3-D input, degree 1..4")
+        self.n_input_dims, self.n_output_dims = 3, self.degree ** 2
+        self.register_parameter("params", nn.Parameter(torch.zeros(0)))   # tcnn modules expose an (empty) params tensor
+
+    def forward(self, v: torch.Tensor) -> torch.Tensor:
+        x, y, z = (v.float() * 2.0 - 1.0).unbind(-1)
+        xy, yz, xz, x2, y2, z2 = x * y, y * z, x * z, x * x, y * y, z * z
+        out = [torch.full_like(x, 0.28209479177387814)]
+        if self.degree > 1:
+            out += [-0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x]
+        if self.degree > 2:
+            out += [1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+                    -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2]
+        if self.degree > 3:
+            out += [0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+                    0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+                    1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2)]
+        return torch.stack(out, dim=-1)
+
+
 class TCNNEncoding(nn.Module):
     def __init__(self, in_channels, config, dtype=torch.float32) -> None:
         super().__init__()
         self.n_input_dims = in_channels
-        self.encoding = Encoding(in_channels, config, dtype=dtype)
+        self.encoding = (SphericalHarmonics if config.get("otype") == "SphericalHarmonics" else Encoding)(in_channels, config, dtype=dtype)
         self.n_output_dims = self.encoding.n_output_dims
 
     def forward(self, x):

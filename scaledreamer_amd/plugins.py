@@ -1,6 +1,6 @@
 """Importing this module registers every plugin class under the reference's registry names
 (the counterpart of `from . import data, models, systems` in threestudio/__init__.py:55)."""
-from . import background, geometry, hyper, materials, renderer, volsdf_renderer  # noqa: F401
+from . import background, geometry, hyper, materials, renderer, sampled_geometry, volsdf_renderer  # noqa: F401
 
 for _opt in ("guidance", "data", "system", "multiprompt"):
     try:

@@ -124,6 +124,56 @@ def asd_sd_hyper_ingp(prompts=None, guidance_backend: str = "hip") -> dict:
     })
 
 
+def asd_sd_3dconv_net(prompts=None, guidance_backend: str = "hip") -> dict:
+    """configs/multi-prompt_benchmark/asd_sd_3dconv_net_*.yaml: the StyleGAN-3D generator emits a [32, 128^3] feature
+    volume per prompt, sampled trilinearly; otherwise the amortized renderer / guidance of asd_sd_hyper_ingp."""
+    cfg = asd_sd_hyper_ingp(prompts, guidance_backend)
+    cfg["name"] = "asd_sd_3dconv_net"
+    cfg["data"]["dim_gaussian"] = 64
+    s = cfg["system"]
+    s["geometry_type"] = "3DConv-net"
+    s["geometry"] = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "activation": "none",
+                     "sdf_bias": "sphere", "sdf_bias_params": 0.8,
+                     "space_generator_config": {"z_dim": 64, "w_dim": 256, "c_dim": 1024, "num_layers": 2, "img_resolution": 128,
+                                                "img_channels": 32, "channel_multiplier": 1}}
+    s["background_type"] = "neural-environment-map-background"
+    s["background"] = {"color_activation": "sigmoid", "random_aug": True}
+    s["optimizer"] = {"name": "Adam", "args": {"betas": [0.0, 0.99], "eps": 1.0e-8},
+                      "params": {"geometry": {"lr": 0.004}, "background": {"lr": 0.001}}}
+    return cfg
+
+
+def asd_mv_triplane_transformer(prompts=None) -> dict:
+    """configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml: text-conditioned transformer -> three
+    [32, 64, 64] planes per prompt, 4 views per prompt, MVDream guidance, Adan."""
+    cfg = asd_sd_hyper_ingp(prompts, "hip-mvdream")
+    cfg["name"] = "asd_mv_triplane_100k"
+    lib = cfg["data"]["prompt_library"]
+    cfg["data_type"] = "multiprompt-multiview-camera-datamodule"
+    cfg["data"] = {"batch_size": 4, "n_view": 4, "width": 64, "height": 64, "camera_distance_range": [0.8, 1.0], "fovy_range": [15, 60],
+                   "elevation_range": [0, 30], "camera_perturb": 0.0, "center_perturb": 0.0, "up_perturb": 0.0,
+                   "eval_camera_distance": 3.0, "eval_fovy_deg": 40.0, "n_val_views": 40, "prompt_library": lib, "dim_gaussian": 1}
+    s = cfg["system"]
+    s["geometry_type"] = "Triplane-transformer-sdf"
+    s["geometry"] = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere",
+                     "sdf_bias_params": 0.8,
+                     "space_generator_config": {"inner_dim": 768, "condition_dim": 1024, "triplane_low_res": 32, "triplane_high_res": 64,
+                                                "triplane_dim": 32, "num_layers": 12, "num_heads": 16, "mlp_ratio": 4, "local_text": True}}
+    s["material"] = {"n_output_dims": 3, "color_activation": "sigmoid-mipnerf", "requires_normal": True}
+    s["background_type"] = "neural-environment-map-background"
+    s["background"] = {"color_activation": "sigmoid-mipnerf", "random_aug": False}
+    s["prompt_processor"] = {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "use_local_text_embeddings": True}
+    s["guidance_type"] = "mvdream-asynchronous-score-distillation-guidance"
+    s["guidance"] = {"model_name": "sd-v2.1-base-4view", "ckpt_path": "pretrained/sd-v2.1-base-4view.pt", "guidance_scale": 7.5,
+                     "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 100000],
+                     "max_step_percent": [0, 0.98, 0.5, 100000], "backend": "hip-mvdream"}
+    s["loss"] = {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 20, "lambda_opaque": [80000, 0, 1.0, 100000],
+                 "lambda_z_variance": 0.0, "lambda_eikonal": 0.01}
+    s["optimizer"] = {"name": "Adan", "args": {"betas": [0.98, 0.92, 0.99], "eps": 1.0e-15},
+                      "params": {"geometry": {"lr": 0.0002}, "background": {"lr": 0.0002}}}
+    return cfg
+
+
 def nerf_only_c1() -> dict:
     """BASELINE config 1: single prompt, 32x32 rays, 16 samples per ray, NeRF-only render (no diffusion)."""
     cfg = asd_sd_nerf()

@@ -1,0 +1,205 @@
+"""Generator-backed SDF geometries of the multi-prompt configs on the HIP samplers:
+  `3DConv-net`               custom/amortized/models/geometry/stylegan_3dconv_net.py:21-422  (feature volume [B,32,128^3] from the
+                             StyleGAN-3D generator, trilinear lookups)
+  `Triplane-transformer-sdf` custom/amortized/models/geometry/triplane_transformer.py:20-315 (three [32,64,64] planes from the
+                             transformer, 3 bilinear lookups concatenated)
+Both: contract to [-1,1] -> sample features -> VanillaMLP sdf / feature heads -> sdf + sphere bias -> finite-difference
+sdf_grad / normal from 3 offset lookups.  The lookups and their scatter backward are the channel-last HIP kernels of
+samplers.py; the generators (generators.py) and the small MLP heads are library ops.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional, Union
+
+import torch
+import torch.nn.functional as F
+
+from .config import C
+from .generators import Generator3D, TriplaneTransformer
+from .geometry import BaseImplicitGeometry
+from .networks import get_activation, get_mlp
+from .registry import register
+from .samplers import contract_to_unisphere_custom, get_trilinear_feature, sample_from_planes
+
+_MLP1 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 1}
+_MLP2 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 2}
+
+
+class _SampledSdfGeometry(BaseImplicitGeometry):
+    """shared forward of the two classes (their bodies are the same code in the reference, stylegan_3dconv_net.py:259-346 and
+    triplane_transformer.py:156-240)"""
+
+    def _heads(self, input_dim: int) -> None:
+        self.sdf_network = get_mlp(input_dim, 1, self.cfg.mlp_network_config)
+        if self.cfg.n_feature_dims > 0:
+            self.feature_network = get_mlp(input_dim, self.cfg.n_feature_dims, self.cfg.mlp_network_config)
+        if self.cfg.normal_type == "pred":
+            raise NotImplementedError("normal_type == pred is not implemented yet.")
+        if self.cfg.isosurface_deformable_grid:
+            assert self.cfg.isosurface_method == "mt", "isosurface_deformable_grid only works with mt"
+            self.deformation_network = get_mlp(input_dim, 3, self.cfg.mlp_network_config)
+        self.finite_difference_normal_eps: Optional[float] = None
+
+    def interpolate_encodings(self, points: torch.Tensor, space_cache: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_shifted_sdf(self, points, sdf):
+        c = self.cfg
+        if c.sdf_bias == "ellipsoid":
+            assert len(c.sdf_bias_params) == 3
+            size = torch.as_tensor(c.sdf_bias_params).to(points)
+            bias = ((points / size) ** 2).sum(dim=-1, keepdim=True).sqrt() - 1.0
+        elif c.sdf_bias == "sphere":
+            assert isinstance(c.sdf_bias_params, float)
+            bias = (points ** 2).sum(dim=-1, keepdim=True).sqrt() - c.sdf_bias_params
+        elif isinstance(c.sdf_bias, float):
+            bias = c.sdf_bias
+        else:
+            raise ValueError(f"Unknown sdf bias {c.sdf_bias}")
+        return sdf + bias
+
+    def forward(self, points: torch.Tensor, space_cache: Any, output_normal: bool = False) -> Dict[str, torch.Tensor]:
+        batch_size, n_points, _ = points.shape
+        points_unscaled = points
+        pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
+        if output_normal and self.cfg.normal_type == "analytic":
+            raise NotImplementedError("analytic normal is not implemented yet.")
+        enc = self.interpolate_encodings(pts, space_cache)
+        sdf = self.get_shifted_sdf(points_unscaled, self.sdf_network(enc).view(*pts.shape[:-1], 1))
+        out = {"sdf": sdf.view(batch_size * n_points, 1)}
+        if self.cfg.n_feature_dims > 0:
+            out["features"] = self.feature_network(enc).view(batch_size * n_points, self.cfg.n_feature_dims)
+        if output_normal:
+            if self.cfg.normal_type != "finite_difference":
+                raise NotImplementedError(f"normal_type == {self.cfg.normal_type} is not implemented yet.")
+            assert self.finite_difference_normal_eps is not None
+            eps = self.finite_difference_normal_eps
+            offsets = torch.as_tensor([[eps, 0.0, 0.0], [0.0, eps, 0.0], [0.0, 0.0, eps]]).to(points_unscaled)
+            po = (points_unscaled[..., None, :] + offsets).clamp(-self.cfg.radius, self.cfg.radius)
+            sdf_offset = self.forward_sdf(po, space_cache)
+            sdf_grad = (sdf_offset[..., 0::1, 0] - sdf) / eps
+            normal = F.normalize(sdf_grad, dim=-1)
+            out.update({"normal": normal.view(-1, 3), "shading_normal": normal.view(-1, 3), "sdf_grad": sdf_grad.view(-1, 3)})
+        return out
+
+    def forward_sdf(self, points: torch.Tensor, space_cache: Any) -> torch.Tensor:
+        batch_size = points.shape[0]
+        pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
+        enc = self.interpolate_encodings(pts.reshape(batch_size, -1, 3), space_cache).reshape(*pts.shape[:-1], -1)
+        return self.get_shifted_sdf(points, self.sdf_network(enc).reshape(*pts.shape[:-1], 1))
+
+    def forward_field(self, points, space_cache):
+        pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
+        enc = self.interpolate_encodings(pts, space_cache)
+        sdf = self.get_shifted_sdf(points, self.sdf_network(enc).reshape(*pts.shape[:-1], 1))
+        deformation = self.deformation_network(enc).reshape(*pts.shape[:-1], 3) if self.cfg.isosurface_deformable_grid else None
+        return sdf, deformation
+
+    def forward_level(self, field, threshold):
+        return field - threshold
+
+    def export(self, points, space_cache, **kwargs) -> Dict[str, Any]:
+        if self.cfg.n_feature_dims == 0:
+            return {}
+        pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
+        enc = self.interpolate_encodings(pts, space_cache)
+        return {"features": self.feature_network(enc).view(*pts.shape[:-1], self.cfg.n_feature_dims)}
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        if self.cfg.normal_type != "finite_difference":
+            raise NotImplementedError(f"normal_type == {self.cfg.normal_type} is not implemented yet.")
+        if isinstance(self.cfg.finite_difference_normal_eps, float):
+            self.finite_difference_normal_eps = self.cfg.finite_difference_normal_eps
+
+
+@register("3DConv-net")
+class Voxel_3d_Sdf(_SampledSdfGeometry):
+    @dataclass
+    class Config(BaseImplicitGeometry.Config):
+        n_input_dims: int = 3
+        n_feature_dims: int = 3
+        space_generator_config: dict = field(default_factory=lambda: {
+            "z_dim": 512, "w_dim": 512, "num_layers": 2, "img_resolution": 128, "img_channels": 32, "channel_multiplier": 1})
+        mlp_network_config: dict = field(default_factory=lambda: dict(_MLP1))
+        pos_encoding_config: dict = field(default_factory=lambda: {
+            "otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16,
+            "per_level_scale": 1.447269237440378})
+        backbone: str = "3dconv_net"
+        truncation_psi: Any = 1.0
+        activation: str = "none"
+        normal_type: Optional[str] = "finite_difference"
+        finite_difference_normal_eps: Union[float, str] = 0.01
+        shape_init: Optional[str] = None
+        shape_init_params: Optional[Any] = None
+        shape_init_mesh_up: str = "+z"
+        shape_init_mesh_front: str = "+x"
+        force_shape_init: bool = False
+        sdf_bias: Union[float, str] = 0.0
+        sdf_bias_params: Optional[Any] = None
+        isosurface_remove_outliers: bool = False
+
+    cfg: Config
+
+    def configure(self) -> None:
+        super().configure()
+        if self.cfg.backbone != "3dconv_net":
+            raise ValueError(f"Unknown backbone {self.cfg.backbone}")
+        self.space_generator = Generator3D(**self.cfg.space_generator_config)
+        self._heads(self.cfg.space_generator_config["img_channels"])
+        self.noise_dim = self.cfg.space_generator_config["z_dim"]
+        self.truncation_psi = 1.0
+
+    def initialize_shape(self) -> None:
+        if self.cfg.shape_init is None and not self.cfg.force_shape_init:
+            return
+        if self.cfg.weights is not None and not self.cfg.force_shape_init:
+            return
+        raise NotImplementedError("SDF pre-fitting (stylegan_3dconv_net.py:139-223) is a one-off initialisation outside the step path")
+
+    def generate_space_cache(self, styles: torch.Tensor, text_embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self.space_generator(z=styles, c=text_embed, truncation_psi=self.truncation_psi)["image"]
+        return get_activation(self.cfg.activation)(out)
+
+    def interpolate_encodings(self, points, space_cache):
+        return get_trilinear_feature(points=points, voxel=space_cache).reshape(*points.shape[:-1], -1)
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        super().update_step(epoch, global_step, on_load_weights)
+        self.truncation_psi = C(self.cfg.truncation_psi, epoch, global_step)
+
+
+@register("Triplane-transformer-sdf")
+class TriplaneTransformerSDF(_SampledSdfGeometry):
+    @dataclass
+    class Config(BaseImplicitGeometry.Config):
+        n_feature_dims: int = 3
+        space_generator_config: dict = field(default_factory=lambda: {
+            "inner_dim": 768, "condition_dim": 1024, "triplane_low_res": 32, "triplane_high_res": 64, "triplane_dim": 32,
+            "num_layers": 12, "num_heads": 16, "flash_attention": False, "local_text": False})
+        mlp_network_config: dict = field(default_factory=lambda: dict(_MLP2))
+        backbone: str = "triplane_transformer"
+        normal_type: Optional[str] = "finite_difference"
+        finite_difference_normal_eps: Union[float, str] = 0.01
+        sdf_bias: Union[float, str] = 0.0
+        sdf_bias_params: Optional[Any] = None
+        isosurface_remove_outliers: bool = False
+
+    cfg: Config
+
+    def configure(self) -> None:
+        super().configure()
+        if self.cfg.backbone != "triplane_transformer":
+            raise ValueError(f"Unknown backbone {self.cfg.backbone}")
+        self.space_generator = TriplaneTransformer(**self.cfg.space_generator_config)
+        self._heads(self.cfg.space_generator_config["triplane_dim"] * 3)
+        self.noise_dim = None
+
+    def initialize_shape(self) -> None:
+        pass
+
+    def generate_space_cache(self, styles: Optional[torch.Tensor], text_embed: torch.Tensor) -> torch.Tensor:
+        return self.space_generator(text_embed=text_embed)
+
+    def interpolate_encodings(self, points, space_cache):
+        return sample_from_planes(plane_features=space_cache, coordinates=points).view(*points.shape[:-1], -1)

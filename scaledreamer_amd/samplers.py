@@ -40,27 +40,32 @@ class _ChannelsLast(torch.autograd.Function):
         return ops.relayout(dy.reshape(B, -1, Cc)).view(ctx.shape)
 
 
-_cl_cache = weakref.WeakKeyDictionary()
+_cl_cache = {}   # id(tensor) -> (weakref to it, its version, channel-last copy); tensors compare element-wise, so no tensor keys
+
+
+def _cached(x: torch.Tensor, make):
+    hit = _cl_cache.get(id(x))
+    need_graph = torch.is_grad_enabled() and x.requires_grad
+    if hit is not None and hit[0]() is x and hit[1] == x._version and (hit[2].requires_grad or not need_graph):
+        return hit[2]      # (a copy made under no_grad — the proposal pass — must not serve the differentiable pass)
+    y = make(x)
+    for k in [k for k, v in _cl_cache.items() if v[0]() is None]:   # drop entries of freed tensors
+        del _cl_cache[k]
+    _cl_cache[id(x)] = (weakref.ref(x), x._version, y)
+    return y
 
 
 def channels_last(x: torch.Tensor) -> torch.Tensor:
-    """[B, C, *S] -> [B, *S, C]; 5-D plane stacks [N, 3, C, H, W] -> [N, 3, H, W, C].  Cached per tensor version."""
-    hit = _cl_cache.get(x)
-    if hit is not None and hit[0] == x._version:
-        return hit[1]
-    y = _ChannelsLast.apply(x)
-    _cl_cache[x] = (x._version, y)
-    return y
+    """[B, C, *S] -> [B, *S, C], cached per tensor version (one step samples the same volume several times)."""
+    return _cached(x, _ChannelsLast.apply)
 
 
 def planes_channels_last(planes: torch.Tensor) -> torch.Tensor:
-    hit = _cl_cache.get(planes)
-    if hit is not None and hit[0] == planes._version:
-        return hit[1]
-    N, _, Cc, H, W = planes.shape
-    y = _ChannelsLast.apply(planes.reshape(N * 3, Cc, H, W)).view(N, 3, H, W, Cc)
-    _cl_cache[planes] = (planes._version, y)
-    return y
+    """[N, 3, C, H, W] -> [N, 3, H, W, C], cached per tensor version."""
+    def make(p):
+        N, _, Cc, H, W = p.shape
+        return _ChannelsLast.apply(p.reshape(N * 3, Cc, H, W)).view(N, 3, H, W, Cc)
+    return _cached(planes, make)
 
 
 class _VoxelSample(torch.autograd.Function):

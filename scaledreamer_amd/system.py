@@ -44,8 +44,12 @@ def parse_optimizer(config, model) -> torch.optim.Optimizer:
             params.append({"params": ps, "name": name, **args})
     else:
         params = model.parameters()
-    if config["name"] in ("FusedAdam", "Adan"):
-        raise NotImplementedError(f"optimizer {config['name']} (used only by the amortized configs)")
+    if config["name"] == "FusedAdam":
+        raise NotImplementedError("optimizer FusedAdam needs apex (systems/utils.py:42-45); use Adam, which runs fused here")
+    if config["name"] == "Adan":
+        from .optimizers import Adan
+
+        return Adan(params, **dict(config.get("args", {})))
     args = dict(config.get("args", {}))
     if config["name"] in ("Adam", "AdamW") and "fused" not in args and "foreach" not in args and next(model.parameters()).is_cuda:
         # same update rule as the reference's torch.optim call, executed as one multi-tensor kernel per parameter group

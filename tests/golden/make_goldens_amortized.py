@@ -163,7 +163,124 @@ def make_hyper_renderer_golden(name="amortized_hyper_ingp_2x4x4", B=2, h=4, w=4,
           f"inv_std={float(out['inv_std']):.3f} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def _seed_params(module, tag, seed, scale=1.0):
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(seeded(f"{tag}.{k}", tuple(p.shape), seed, scale))
+
+
+def make_generator_goldens(seed=12):
+    """the reference's own generator backbones (in-tree torch code): StyleGAN-3D `Generator` at 16^3 and `TriplaneTransformer`
+    (its diffusers `Attention` dependency is un-vendored: the harness injects scaledreamer_amd.generators.Attention there)."""
+    from scaledreamer_amd import generators as G
+    H._mod("diffusers")
+    H._mod("diffusers.models")
+    H._mod("diffusers.models.attention_processor", Attention=G.Attention)
+    from custom.amortized.extern.stylegan_3dconv_modules import Generator
+    from custom.amortized.extern.triplane_transformer_modules import TriplaneTransformer
+
+    kw = dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
+    gen = Generator(**kw)
+    _seed_params(gen, "gen3d", seed, 0.3)
+    with torch.no_grad():
+        for m in gen.modules():
+            if hasattr(m, "noise_const"):
+                m.noise_const.copy_(seeded("gen3d.noise." + str(tuple(m.noise_const.shape)), tuple(m.noise_const.shape), seed))
+    z, c = seeded("gen3d.z", (2, 64), seed), seeded("gen3d.c", (2, 1024), seed)
+    img = gen(z, c, noise_mode="const")["image"]
+    g = seeded("gen3d.g", tuple(img.shape), seed)
+    (img * g).sum().backward()
+    grads = {k: p.grad for k, p in gen.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "amortized_generator3d_16.npz"), seed=seed, keys=np.array(list(gen.state_dict().keys())),
+                        image_sub=img.detach()[:, ::4, ::2, ::2, ::2].numpy(), image_l2=np.float64(img.double().norm().item()),
+                        g_affine=grads["synthesis.blocks.1.conv0.affine.weight"].numpy(),
+                        g_conv_l2=np.float64(grads["synthesis.blocks.0.conv1.weight"].double().norm().item()),
+                        g_embed_l2=np.float64(grads["mapping.embed.weight"].double().norm().item()),
+                        g_const_l2=np.float64(grads["synthesis.first_block.const"].double().norm().item()))
+    for local in (True, False):
+        tkw = dict(inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
+                   local_text=local, mlp_ratio=4)
+        tt = TriplaneTransformer(**tkw)
+        _seed_params(tt, f"tri{int(local)}", seed, 0.2)
+        te = seeded("tri.text", (2, 77, 128) if local else (2, 128), seed)
+        planes = tt(te)
+        gp = seeded("tri.g", tuple(planes.shape), seed)
+        (planes * gp).sum().backward()
+        tg = {k: p.grad for k, p in tt.named_parameters()}
+        np.savez_compressed(os.path.join(HERE, f"amortized_triplane_transformer_local{int(local)}.npz"), seed=seed,
+                            keys=np.array(list(tt.state_dict().keys())), planes=planes.detach().numpy(),
+                            g_pos_embed=tg["pos_embed"].numpy(), g_deconv=tg["deconv.weight"].numpy(),
+                            g_q_l2=np.float64(tg["layers.0.self_attn.to_q.weight"].double().norm().item()))
+    print("generator goldens written")
+
+
+GEN3D_SMALL = dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
+TRI_SMALL = dict(inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
+                 local_text=True, mlp_ratio=4)
+
+
+def make_sampled_geometry_goldens(seed=14):
+    """Voxel_3d_Sdf.forward / TriplaneTransformerSDF.forward of the reference on a given space cache: contraction, grid_sample
+    lookups, MLP heads, sphere bias, finite-difference sdf_grad / normal, and the gradients w.r.t. the cache and the heads."""
+    from scaledreamer_amd import generators as G
+    H._mod("diffusers")
+    H._mod("diffusers.models")
+    H._mod("diffusers.models.attention_processor", Attention=G.Attention)
+    from custom.amortized.models.geometry.stylegan_3dconv_net import Voxel_3d_Sdf
+    from custom.amortized.models.geometry.triplane_transformer import TriplaneTransformerSDF
+
+    common = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere", "sdf_bias_params": 0.8}
+    cases = [("voxel", Voxel_3d_Sdf, dict(common, space_generator_config=GEN3D_SMALL), (1, 32, 16, 16, 16)),
+             ("triplane", TriplaneTransformerSDF, dict(common, space_generator_config=TRI_SMALL), (2, 3, 32, 16, 16))]
+    for name, cls, cfg, cache_shape in cases:
+        geo = cls(cfg)
+        geo.update_step(0, 0)
+        heads = [("sdf_network", geo.sdf_network), ("feature_network", geo.feature_network)]
+        for tag, net in heads:
+            _seed_params(net, f"{name}.{tag}", seed, 0.25)
+        cache = seeded(f"{name}.cache", cache_shape, seed).requires_grad_(True)
+        B = cache_shape[0]
+        pts = (torch.rand(B, 700, 3, generator=torch.Generator().manual_seed(seed)) * 4.4 - 2.2)   # some outside the radius-2 box
+        out = geo(pts, cache, output_normal=True)
+        gs = {k: seeded(f"{name}.g_{k}", tuple(out[k].shape), seed) for k in ("sdf", "features", "normal", "sdf_grad")}
+        sum((out[k] * gs[k]).sum() for k in gs).backward()
+        save = dict(seed=seed, points=pts.numpy(), d_cache_sub=cache.grad.reshape(-1)[::5].numpy().copy(),
+                    d_cache_l2=np.float64(cache.grad.double().norm().item()))
+        for k in gs:
+            save["out_" + k] = out[k].detach().numpy()
+        for tag, net in heads:
+            for k, p_ in net.named_parameters():
+                save[f"g_{tag}.{k}"] = p_.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"amortized_geometry_{name}.npz"), **save)
+    print("sampled-geometry goldens written")
+
+
+def make_adan_golden(seed=5):
+    """threestudio/systems/optimizers.py Adan (pure torch, in-tree): 4 steps on two parameter groups, with and without clipping."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_optimizers", os.path.join(H.REFERENCE, "threestudio", "systems", "optimizers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    save = {}
+    for tag, kw in (("plain", {}), ("clip_wd", dict(max_grad_norm=0.5, weight_decay=0.02)), ("noprox", dict(weight_decay=0.02, no_prox=True))):
+        p1 = torch.nn.Parameter(seeded("adan.p1", (7, 5), seed))
+        p2 = torch.nn.Parameter(seeded("adan.p2", (11,), seed))
+        opt = mod.Adan([{"params": [p1], "lr": 0.01}, {"params": [p2], "lr": 0.003}], betas=(0.98, 0.92, 0.99), eps=1e-15, **kw)
+        for step in range(4):
+            p1.grad = seeded(f"adan.g1.{step}", (7, 5), seed)
+            p2.grad = seeded(f"adan.g2.{step}", (11,), seed)
+            opt.step()
+        save[f"{tag}.p1"], save[f"{tag}.p2"] = p1.detach().numpy().copy(), p2.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "adan_steps.npz"), seed=seed, **save)
+    print("adan golden written")
+
+
 if __name__ == "__main__":
+    if "--generators" in sys.argv:
+        make_generator_goldens()
+        make_sampled_geometry_goldens()
+        make_adan_golden()
+        sys.exit(0)
     make_samplers_golden()
     make_importance_golden()
     make_hyper_renderer_golden()

@@ -131,3 +131,99 @@ def test_oracle_hyper_ingp_volsdf_renderer_matches_reference():
     loss, loss_eik = amortized_loss(out, g)
     loss.backward()
     check_amortized_against_golden(out, P, g, loss, loss_eik)
+
+
+def _seed_params(module, tag, seed, scale=1.0):
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(seeded(f"{tag}.{k}", tuple(p.shape), seed, scale))
+
+
+def test_generator3d_matches_reference_stylegan3d():
+    """scaledreamer_amd.generators.Generator3D vs the reference's in-tree `Generator` (same state-dict keys, forward, gradients)"""
+    from scaledreamer_amd.generators import Generator3D
+
+    g = _load("amortized_generator3d_16")
+    seed = int(g["seed"])
+    gen = Generator3D(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
+    assert list(gen.state_dict().keys()) == g["keys"].tolist()
+    _seed_params(gen, "gen3d", seed, 0.3)
+    with torch.no_grad():
+        for m in gen.modules():
+            if hasattr(m, "noise_const"):
+                m.noise_const.copy_(seeded("gen3d.noise." + str(tuple(m.noise_const.shape)), tuple(m.noise_const.shape), seed))
+    img = gen(seeded("gen3d.z", (2, 64), seed), seeded("gen3d.c", (2, 1024), seed), noise_mode="const")["image"]
+    np.testing.assert_allclose(img.detach()[:, ::4, ::2, ::2, ::2].numpy(), g["image_sub"], rtol=1e-4, atol=1e-4 * np.abs(g["image_sub"]).max())
+    assert abs(img.double().norm().item() / float(g["image_l2"]) - 1) < 1e-5
+    (img * seeded("gen3d.g", tuple(img.shape), seed)).sum().backward()
+    gr = {k: p.grad for k, p in gen.named_parameters()}
+    ref = g["g_affine"]
+    np.testing.assert_allclose(gr["synthesis.blocks.1.conv0.affine.weight"].numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max())
+    for key, name in (("g_conv_l2", "synthesis.blocks.0.conv1.weight"), ("g_embed_l2", "mapping.embed.weight"), ("g_const_l2", "synthesis.first_block.const")):
+        assert abs(gr[name].double().norm().item() / float(g[key]) - 1) < 1e-4, name
+
+
+@pytest.mark.parametrize("local", [1, 0])
+def test_triplane_transformer_matches_reference(local):
+    from scaledreamer_amd.generators import TriplaneTransformer
+
+    g = _load(f"amortized_triplane_transformer_local{local}")
+    seed = int(g["seed"])
+    tt = TriplaneTransformer(inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2,
+                             num_heads=4, local_text=bool(local), mlp_ratio=4)
+    assert list(tt.state_dict().keys()) == g["keys"].tolist()
+    _seed_params(tt, f"tri{local}", seed, 0.2)
+    planes = tt(seeded("tri.text", (2, 77, 128) if local else (2, 128), seed))
+    np.testing.assert_allclose(planes.detach().numpy(), g["planes"], rtol=1e-4, atol=1e-5 * np.abs(g["planes"]).max())
+    (planes * seeded("tri.g", tuple(planes.shape), seed)).sum().backward()
+    tg = {k: p.grad for k, p in tt.named_parameters()}
+    for key, name in (("g_pos_embed", "pos_embed"), ("g_deconv", "deconv.weight")):
+        np.testing.assert_allclose(tg[name].numpy(), g[key], rtol=1e-3, atol=1e-4 * np.abs(g[key]).max())
+    assert abs(tg["layers.0.self_attn.to_q.weight"].double().norm().item() / float(g["g_q_l2"]) - 1) < 1e-4
+
+
+def sampled_geometry_problem(name, g):
+    seed = int(g["seed"])
+    nh = 1 if name == "voxel" else 2
+    din = 32 if name == "voxel" else 96
+    shapes = [(64, din)] + [(64, 64)] * (nh - 1)
+    heads = {}
+    for tag, dout in (("sdf_network", 1), ("feature_network", 3)):
+        ws = [seeded(f"{name}.{tag}.layers.{2 * i}.weight", s, seed, 0.25) for i, s in enumerate(shapes)]
+        ws.append(seeded(f"{name}.{tag}.layers.{2 * len(shapes)}.weight", (dout, 64), seed, 0.25))
+        heads[tag] = [w.requires_grad_(True) for w in ws]
+    cache_shape = (1, 32, 16, 16, 16) if name == "voxel" else (2, 3, 32, 16, 16)
+    cache = seeded(f"{name}.cache", cache_shape, seed).requires_grad_(True)
+    return heads, cache, torch.from_numpy(g["points"])
+
+
+def check_sampled_geometry(out, heads_grads, cache_grad, name, g, tol=1.0):
+    seed = int(g["seed"])
+    f = lambda t: t.detach().float().cpu().numpy()
+    np.testing.assert_allclose(f(out["sdf"]), g["out_sdf"], rtol=0, atol=2e-5 * tol)
+    np.testing.assert_allclose(f(out["features"]), g["out_features"], rtol=0, atol=2e-5 * tol)
+    ref = g["out_sdf_grad"]
+    assert np.abs(f(out["sdf_grad"]) - ref).max() <= 2e-3 * tol * max(1.0, np.abs(ref).max())   # differences / eps = 0.01
+    assert np.abs(f(out["normal"]) - g["out_normal"]).max() <= 5e-3 * tol
+    assert abs(np.linalg.norm(f(cache_grad).astype(np.float64)) / float(g["d_cache_l2"]) - 1) < 2e-3 * tol
+    sub = g["d_cache_sub"]
+    assert np.abs(f(cache_grad).reshape(-1)[::5] - sub).max() <= 3e-3 * tol * np.abs(sub).max()
+    for key, got in heads_grads.items():
+        ref = g["g_" + key]
+        assert np.abs(f(got) - ref).max() <= 3e-3 * tol * np.abs(ref).max(), key
+
+
+def sampled_geometry_loss(out, name, seed, device="cpu"):
+    return sum((out[k] * seeded(f"{name}.g_{k}", tuple(out[k].shape), seed).to(device)).sum() for k in ("sdf", "features", "normal", "sdf_grad"))
+
+
+@pytest.mark.parametrize("name", ["voxel", "triplane"])
+def test_oracle_sampled_geometry_matches_reference(name):
+    from oracle import ref_amortized as RA
+
+    g = _load("amortized_geometry_" + name)
+    heads, cache, pts = sampled_geometry_problem(name, g)
+    out = RA.sampled_sdf_geometry(pts, cache, name, heads["sdf_network"], heads["feature_network"])
+    sampled_geometry_loss(out, name, int(g["seed"])).backward()
+    hg = {f"{tag}.layers.{2 * i}.weight": w.grad for tag, ws in heads.items() for i, w in enumerate(ws)}
+    check_sampled_geometry(out, hg, cache.grad, name, g)

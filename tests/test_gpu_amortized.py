@@ -202,3 +202,75 @@ def test_hyper_ingp_amortized_asd_step_runs():
         assert torch.isfinite(system.logged[k]).item(), k
     assert (system.geometry.hypernet.layers[3].weight.detach() != w_before).any().item()
     assert (system.geometry.encoding.encoding.encoding.params.detach() != g_before).any().item()
+
+
+@pytest.mark.parametrize("name", ["voxel", "triplane"])
+def test_sampled_geometry_classes_match_reference_golden(name):
+    """`3DConv-net` / `Triplane-transformer-sdf` forward(points, space_cache, output_normal=True) and its gradients w.r.t. the
+    space cache and the MLP heads, against the reference's own classes (tests/golden/make_goldens_amortized.py)."""
+    from test_goldens_amortized_cpu import check_sampled_geometry, sampled_geometry_loss, sampled_geometry_problem
+
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = _load("amortized_geometry_" + name)
+    heads, cache, pts = sampled_geometry_problem(name, g)
+    common = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere", "sdf_bias_params": 0.8}
+    if name == "voxel":
+        geo = find("3DConv-net")(dict(common, space_generator_config=dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16,
+                                                                         img_channels=32, channel_multiplier=1)))
+    else:
+        geo = find("Triplane-transformer-sdf")(dict(common, space_generator_config=dict(
+            inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
+            local_text=True, mlp_ratio=4)))
+    geo = geo.cuda()
+    geo.do_update_step(0, 0)
+    with torch.no_grad():
+        for tag, net in (("sdf_network", geo.sdf_network), ("feature_network", geo.feature_network)):
+            for (k, p), w in zip(net.named_parameters(), heads[tag]):
+                p.copy_(w.detach())
+    cache_d = cache.detach().cuda().requires_grad_(True)
+    out = geo(pts.cuda(), cache_d, output_normal=True)
+    sampled_geometry_loss(out, name, int(g["seed"]), device="cuda").backward()
+    hg = {f"{tag}.{k}": p.grad for tag, net in (("sdf_network", geo.sdf_network), ("feature_network", geo.feature_network))
+          for k, p in net.named_parameters()}
+    check_sampled_geometry(out, hg, cache_d.grad, name, g, tol=2.0)
+
+
+@pytest.mark.parametrize("kind", ["3dconv", "triplane"])
+def test_generator_backed_amortized_step_runs(kind):
+    """asd_sd_3dconv_net / asd_mv_triplane_transformer presets (generator resolution reduced for test time): generator ->
+    feature volume / planes -> HIP samplers -> importance-sampled VolSDF render -> guidance -> backward into the generator."""
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.diffusion import weights as W
+    from scaledreamer_amd.diffusion.engine import HipBackend
+    from scaledreamer_amd.multiprompt import MultipromptRandomCameraIterableDataset, SyntheticMultiPromptProcessor
+    from scaledreamer_amd.registry import find
+    import scaledreamer_amd.plugins  # noqa: F401
+
+    torch.manual_seed(0)
+    random.seed(0)
+    dev = torch.device("cuda", 0)
+    if kind == "3dconv":
+        cfg = presets.asd_sd_3dconv_net()
+        cfg["system"]["geometry"]["space_generator_config"]["img_resolution"] = 32
+        backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128), vae_cfg=W.VAEConfig(), seed=3)
+        local = False
+    else:
+        cfg = presets.asd_mv_triplane_transformer()
+        cfg["system"]["geometry"]["space_generator_config"].update(num_layers=2, inner_dim=256, num_heads=4, condition_dim=128)
+        backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128, camera_dim=16), vae_cfg=W.VAEConfig(), seed=3)
+        local = True
+    proc = SyntheticMultiPromptProcessor(cfg["data"]["prompt_library"]["train"], seed=2, device=dev, ctx_dim=128, global_dim=1024,
+                                         front_threshold=30.0, back_threshold=30.0, use_local_text_embeddings=local,
+                                         use_perp_neg=kind == "3dconv")
+    system = find(cfg["system_type"])(cfg["system"], guidance_backend=backend, prompt_processor=proc)
+    system.train()
+    data = find(cfg["data_type"])(cfg["data"], rank=0, n_ranks=1)
+    gen_w = next(p for n, p in system.geometry.space_generator.named_parameters() if p.ndim >= 2)
+    before = gen_w.detach().clone()
+    for _ in range(2):
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+        loss = system.train_one_step(batch)
+    assert torch.isfinite(loss).item()
+    assert (gen_w.detach() != before).any().item(), "no gradient reached the generator"
