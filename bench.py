@@ -37,8 +37,8 @@ def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     import scaledreamer_amd.plugins  # noqa: F401
 
     mv = workload == "asd_mv_nerf"
-    if workload == "asd_sd_hyper_ingp":
-        return build_hyper_system(backend, seed)
+    if workload in ("asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"):
+        return build_hyper_system(backend, seed, workload)
     cfg = presets.asd_mv_nerf() if mv else presets.asd_sd_nerf(guidance_backend=backend)
     torch.manual_seed(seed)
     random.seed(seed)
@@ -52,22 +52,26 @@ def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     return cfg, system, data
 
 
-def build_hyper_system(backend: str, seed: int):
-    """asd_sd_hyper_iNGP_50k.yaml: multi-prompt amortized training with the Hyper-iNGP field (secondary workload)."""
+def build_hyper_system(backend: str, seed: int, workload: str = "asd_sd_hyper_ingp"):
+    """the multi-prompt amortized configs (secondary workloads): Hyper-iNGP, 3DConv-net (StyleGAN-3D volume), triplane transformer"""
     from scaledreamer_amd import presets
-    from scaledreamer_amd.multiprompt import MultipromptRandomCameraIterableDataset, SyntheticMultiPromptProcessor
+    from scaledreamer_amd.multiprompt import SyntheticMultiPromptProcessor
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
 
-    cfg = presets.asd_sd_hyper_ingp(guidance_backend=backend)
+    cfg = {"asd_sd_hyper_ingp": lambda: presets.asd_sd_hyper_ingp(guidance_backend=backend),
+           "asd_sd_3dconv_net": lambda: presets.asd_sd_3dconv_net(guidance_backend=backend),
+           "asd_mv_triplane": presets.asd_mv_triplane_transformer}[workload]()
     torch.manual_seed(seed)
     random.seed(seed)
     dev = torch.device("cuda", torch.cuda.current_device())
     pp = cfg["system"]["prompt_processor"]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    data = MultipromptRandomCameraIterableDataset(cfg["data"], rank=rank, n_ranks=world)
+    data = find(cfg["data_type"])(cfg["data"], rank=rank, n_ranks=world)
     proc = SyntheticMultiPromptProcessor(cfg["data"]["prompt_library"]["train"], seed=1234, device=dev,
-                                         front_threshold=pp["front_threshold"], back_threshold=pp["back_threshold"])
+                                         front_threshold=pp.get("front_threshold", 45.0), back_threshold=pp.get("back_threshold", 45.0),
+                                         use_local_text_embeddings=pp.get("use_local_text_embeddings", False),
+                                         use_perp_neg=pp.get("use_perp_neg", False))
     system = find(cfg["system_type"])(cfg["system"], prompt_processor=proc)
     system.train()
     return cfg, system, data
@@ -209,7 +213,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backend", default=os.environ.get("ASD_BACKEND", "hip"), choices=["hip", "eager"])
-    ap.add_argument("--workload", default="asd_sd_nerf", choices=["asd_sd_nerf", "asd_mv_nerf", "asd_sd_hyper_ingp"],
+    ap.add_argument("--workload", default="asd_sd_nerf", choices=["asd_sd_nerf", "asd_mv_nerf", "asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"],
                     help="asd_sd_nerf = BASELINE configs[1] (the headline metric); asd_mv_nerf = SURVEY C3 (MVDream, 4 views), secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also report per-phase milliseconds (adds syncs; untimed extra steps)")
@@ -304,6 +308,13 @@ def main():
             out["config"].update({"workload": "asd_mv_nerf: 4 views/GPU, 4x64x64 rays, 256 spp occgrid march, implicit-volume iNGP, MVDream "
                                               "UNet batch 12 @32x32 latents (CFG + shifted t, cross-view attention), VAE 4x256^2 fwd+bwd, AdamW",
                                   "views_per_gpu": 4})
+        if args.workload in ("asd_sd_3dconv_net", "asd_mv_triplane"):
+            out.update({"metric": f"ASD train steps/sec ({args.workload}, amortized)"})
+            out["config"].update({"workload": {"asd_sd_3dconv_net": "asd_sd_3dconv_net: StyleGAN-3D generator (fp32 library conv3d) -> [32,128^3] volume, "
+                                                                       "HIP trilinear samplers, VolSDF renderer, SD-2.1 guidance, 1 prompt+view/GPU",
+                                               "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer (fp32 library ops) -> 3x[32,64,64] "
+                                                                  "planes, HIP tri-plane samplers, VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
+            out.pop("kept_samples_last_step", None)
         if args.workload == "asd_sd_hyper_ingp":  # secondary line: amortized multi-prompt training
             out.update({"metric": "ASD train steps/sec (64x64 render, SD2.1, Hyper-iNGP amortized)"})
             out["config"].update({"workload": "asd_sd_hyper_iNGP: 1 prompt+view/GPU, 64x64 rays, importance-sampled VolSDF renderer (128 proposal + "
@@ -314,7 +325,7 @@ def main():
             out["phases_ms"] = phases
         out["roofline"] = roofline_conv_kernel("vae512")
         out["roofline_unet_conv"] = roofline_conv_kernel("unet64")
-        if args.workload != "asd_sd_hyper_ingp":
+        if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
             out["roofline_renderer"] = roofline_field_kernel(system, batch)
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":
             out["cpu_baseline"] = cpu_baseline(system, batch, seed=10)
