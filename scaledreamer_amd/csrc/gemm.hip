@@ -514,6 +514,8 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         ASD_CHECK_ARG(a->N % 32 == 0 && a->bias && !a->conv && !a->residual && !a->row_bias && !a->out_f32 && a->split_k == 1,
                       "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");
     int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
+    // without a tuned plan: the LDS-window kernel wins on every stride-1 3x3 layer with at least 16 patches (tools/gemm_sweep.py)
+    if (asd_conv_window_ok(a) && a->M >= 4096 && a->split_k <= a->Cin / 64) cfg = a->N % 128 == 0 ? 9 : 8;
     if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
     if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
     if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
