@@ -109,3 +109,34 @@ def test_full_size_unet_batch_items_are_independent():
         single = be.unet(x[i:i + 1], t[i:i + 1], ctx[i:i + 1]).float()
         rel = float((single[0] - full[i]).norm() / full[i].norm())
         assert rel < 1e-2, rel   # different tile / split-K plans per batch size: fp16 rounding only
+
+
+def test_second_resolution_phase_and_eval_rendering():
+    """the 256x256 training phase after `resolution_milestones: [10000]` (65 536 rays per view) and eval-mode
+    rendering at 512x512 (chunked geometry / material / background calls, `comp_normal` in the outputs) run on the same kernels."""
+    system, batch = _system()
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.data import RandomCameraIterableDataset
+
+    data = RandomCameraIterableDataset(presets.asd_sd_nerf()["data"])
+    data.update_step(0, 10_000)
+    assert (data.height, data.width) == (256, 256)
+    b256 = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+    out = system(b256)
+    assert out["comp_rgb"].shape == (1, 256, 256, 3) and out["weights"].shape[0] > 500_000
+    (out["comp_rgb"].sum() + out["opacity"].sum()).backward()
+    g = system.geometry.encoding.encoding.encoding.params.grad
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # eval: 512 x 512, no jitter, chunked calls
+    from scaledreamer_amd.data import get_ray_directions, get_rays
+    c2w = b256["c2w"].cpu()
+    d = get_ray_directions(512, 512, focal=0.5 * 512 / 0.7).unsqueeze(0)
+    ro, rd = get_rays(d, c2w)
+    system.eval()
+    with torch.no_grad():
+        ev = system({"rays_o": ro.cuda(), "rays_d": rd.cuda(), "light_positions": b256["light_positions"]})
+    assert ev["comp_rgb"].shape == (1, 512, 512, 3) and "comp_normal" in ev and "weights" not in ev
+    assert torch.isfinite(ev["comp_rgb"]).all() and float(ev["opacity"].max()) <= 1 + 1e-5
+    with torch.no_grad():
+        ev2 = system({"rays_o": ro.cuda(), "rays_d": rd.cuda(), "light_positions": b256["light_positions"]})
+    assert torch.equal(ev["comp_rgb"], ev2["comp_rgb"]), "eval rendering must be deterministic"
