@@ -195,3 +195,74 @@ def test_adan_matches_reference_optimizer():
             opt.step()
         np.testing.assert_allclose(p1.detach().numpy(), g[f"{tag}.p1"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(p2.detach().numpy(), g[f"{tag}.p2"], rtol=1e-6, atol=1e-7)
+
+
+def test_prompt_processor_reads_the_reference_cache_format(tmp_path):
+    """md5(f"{model}-{prompt}").pt files of [77, 1024] tensors (prompt_processors/base.py:19-23, 411-420), view-dependent prompt
+    strings (base.py:266-297), FileNotFoundError for a missing entry."""
+    import hashlib
+
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    model, prompt, neg = "pretrained/stable-diffusion-2-1-base", "a DSLR photo of a hamburger", "ugly, blurry"
+    strings = [prompt, neg] + [f"{prompt}, {d} view" for d in ("side", "front", "back", "overhead")]
+    g = torch.Generator().manual_seed(0)
+    table = {s: torch.randn(77, 16, generator=g) for s in strings}
+    for s, e in table.items():
+        torch.save(e, tmp_path / (hashlib.md5(f"{model}-{s}".encode()).hexdigest() + ".pt"))
+    cfg = {"pretrained_model_name_or_path": model, "prompt": prompt, "negative_prompt": neg, "use_perp_neg": True,
+           "front_threshold": 30.0, "back_threshold": 30.0}
+    pp = find("stable-diffusion-prompt-processor")(cfg, cache_dir=str(tmp_path))
+    pu = pp()
+    assert pp.prompts_vd == strings[2:] and pu.use_perp_neg and pu.front_threshold == 30.0
+    assert torch.equal(pu.text_embeddings_vd.cpu(), torch.stack([table[s] for s in strings[2:]]))
+    assert torch.equal(pu.uncond_text_embeddings_vd.cpu(), torch.stack([table[neg]] * 4))
+    assert torch.equal(pu.text_embeddings.cpu(), table[prompt][None])
+    with pytest.raises(FileNotFoundError):
+        find("stable-diffusion-prompt-processor")(dict(cfg, prompt="something never cached"), cache_dir=str(tmp_path))
+    # an encoder hook fills the cache in the reference's format
+    calls = []
+    def enc(prompts):
+        calls.append(list(prompts))
+        return torch.zeros(len(prompts), 77, 16)
+    pp2 = find("stable-diffusion-prompt-processor")(dict(cfg, prompt="a new prompt"), cache_dir=str(tmp_path), encode_fn=enc)
+    assert calls and "a new prompt" in calls[0] and neg not in calls[0] and pp2().text_embeddings_vd.shape == (4, 77, 16)
+
+
+def test_state_dict_keys_match_the_reference_modules():
+    """checkpoint compatibility: same keys and shapes as the reference's own modules
+    (tests/golden/make_goldens_state_dicts.py)"""
+    import json
+    import os
+
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    enc = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16,
+           "per_level_scale": 1.447269237440378}
+    bg4 = {"otype": "HashGrid", "n_features_per_level": 2, "log2_hashmap_size": 19, "n_levels": 4, "base_resolution": 4, "per_level_scale": 4.0}
+    hyper = {"c_dim": 1024, "out_dims": {"sdf_weights": [64, 1], "feature_weights": [64, 3]}, "spectral_norm": False, "n_neurons": 64,
+             "n_hidden_layers": 1}
+    gen3d = dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
+    tri = dict(inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
+               local_text=True, mlp_ratio=4)
+    hg = find("Hyper-iNGP")({"radius": 2.0, "sdf_bias": "sphere", "sdf_bias_params": 0.5, "hypernet_config": hyper, "pos_encoding_config": enc})
+    hb = find("multiprompt-neural-hashgrid-environment-map-background")({"color_activation": "sigmoid", "pos_encoding_config": dict(enc, per_level_scale=1.0)})
+    mods = {
+        "implicit-volume": find("implicit-volume")({"radius": 1.0, "normal_type": "finite_difference", "pos_encoding_config": enc}),
+        "neural-environment-map-background": find("neural-environment-map-background")({"color_activation": "sigmoid", "random_aug": True, "dir_encoding_config": bg4}),
+        "no-material": find("no-material")({"n_output_dims": 3, "color_activation": "sigmoid", "requires_normal": True}),
+        "Hyper-iNGP": hg,
+        "multiprompt-neural-hashgrid-environment-map-background": hb,
+        "generative-space-volsdf-volume-renderer": find("generative-space-volsdf-volume-renderer")(
+            {"radius": 2.0, "use_volsdf": True, "trainable_variance": False, "learned_variance_init": 0.340119, "estimator": "importance",
+             "num_samples_per_ray": 64, "num_samples_per_ray_importance": 128}, geometry=hg, material=None, background=hb),
+        "3DConv-net": find("3DConv-net")({"radius": 2.0, "sdf_bias": "sphere", "sdf_bias_params": 0.8, "space_generator_config": gen3d}),
+        "Triplane-transformer-sdf": find("Triplane-transformer-sdf")({"radius": 2.0, "sdf_bias": "sphere", "sdf_bias_params": 0.8, "space_generator_config": tri}),
+    }
+    for name, m in mods.items():
+        got = {k: list(v.shape) for k, v in m.state_dict().items() if not k.startswith("estimator.")}
+        assert got == ref[name], (name, sorted(set(got) ^ set(ref[name])))
