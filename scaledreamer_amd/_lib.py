@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasd_hip.so")
+LIB_PATH = os.environ.get("ASD_HIP_LIB") or os.path.join(_HERE, "libasd_hip.so")   # ASD_HIP_LIB: A/B builds of the same C ABI (tools/)
 ASD_MAX_LEVELS = 16
 
 ASD_BIAS_CONST, ASD_BIAS_BLOB_MAGIC3D, ASD_BIAS_BLOB_DREAMFUSION, ASD_BIAS_SPHERE = 0, 1, 2, 3

@@ -307,9 +307,25 @@ __device__ __forceinline__ void gemm_store4(const asd_gemm_args& p, floatx4 v, i
 // 64-channel chunk it brings the 18 x 18 input window (324 rows x 128 B, zero page outside the image) into LDS ONCE and
 // runs the 9 taps against it by shifting the fragment row (ty + ky) * 18 + tx + kx; only the BN x 64 weight tile of each
 // (tap, chunk) streams per step.  Bytes loaded per flop drop from (1/256 + 1/BN)/128 to (41.5 KB/9 + BN * 128 B) per
-// 256 * BN * 128 flop — 2.3x less at BN = 128.  The next chunk's window is prefetched in ninths, one piece per tap.
-// 8 waves = 4 (M: 4 patch rows of 16 pixels each) x 2 (N).  Split-K slices the channel chunks.
+// 256 * BN * 128 flop — 2.3x less at BN = 128.  8 waves = 4 (M: 4 patch rows of 16 pixels each) x 2 (N).  Split-K slices
+// the channel chunks.
+//
+// Main loop (SQ counters of the first version — one barrier per tap, compiler-scheduled just-in-time fragment reads: a third
+// of the wave cycles parked at waitcnt/barrier, a third stalled behind the partner wave's MFMAs, 45 % MFMA busy):
+//  * one barrier per TWO taps: weight tiles s+2, s+3 are issued at even s into a 4-slot ring, the next chunk's window 16
+//    slabs at a time over three even steps;
+//  * the window swizzle is keyed on the window COLUMN (wx & 7), not the row, so the fragment address of patch row i is the
+//    address of row 0 plus an immediate: ~10 address VALU per step instead of ~60 between the MFMAs;
+//  * fragment reads are software-pipelined by hand at half-step (32-channel) granularity through two register sets:
+//    the reads of half-step h+1 fly while the 16 MFMAs of half-step h run.  hipcc only ever emits lgkmcnt(0), so the
+//    ds_read_b128 / s_waitcnt pairs are inline asm (the waits carry the fragment registers as operands, which orders the
+//    MFMAs behind them).
 // ---------------------------------------------------------------------------------------------------------------------
+#define LDS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define LGKM_WAIT(N, F)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                             \
+                 : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.w[2]), "+v"(F.w[3]))
+
 template <int BN>
 __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p) {
     constexpr int WN = 2, TM = 4, TN = BN / WN / 16;
@@ -317,8 +333,7 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     constexpr int WIN = 18, WIN_ROWS = WIN * WIN, WIN_SLABS = (WIN_ROWS + 7) / 8;      // 324 rows, 41 slabs
     constexpr int A_BYTES = WIN_SLABS * 8 * RB, W_BYTES = BN * RB;
     constexpr int WSLABS = BN / 8, WSPW = (WSLABS + 7) / 8;
-    constexpr int APIECE = (WIN_SLABS + 8) / 9;                                        // window slabs prefetched per tap (5)
-    extern __shared__ __attribute__((aligned(16))) char smem[];                        // [A0 | A1 | W0 | W1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];                        // [A0 | A1 | W0 | W1 | W2 | W3]
     char* const a_buf = smem;
     char* const w_buf = smem + 2 * A_BYTES;
 
@@ -334,10 +349,10 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     const int c0 = blockIdx.z * c_per, c1 = min(n_chunks, c0 + c_per);
     const int steps = (c1 - c0) * 9;
 
-    const int lrow = lane >> 3, pchunk = lane & 7, lch = pchunk ^ lrow;
+    const int lrow = lane >> 3, pchunk = lane & 7;
     const char* zero = (const char*)p.zero_page;
     const char* img = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
+    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + (pchunk ^ lrow) * 16;
     const size_t w_slab_stride = (size_t)8 * p.ldw * 2;
 
     auto load_window_slab = [&](int slab, int chunk, char* dst_buf) {   // slab: wave-uniform, < WIN_SLABS
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
         const int wy = (wrow * 3641) >> 16, wx = wrow - wy * WIN;        // wrow / 18 for wrow < 328
         const int yi = y0 - 1 + wy, xi = x0 - 1 + wx;
         const bool ok = wrow < WIN_ROWS && (unsigned)yi < (unsigned)p.Hin && (unsigned)xi < (unsigned)p.Win;
-        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + lch * 16 : zero;
+        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + (pchunk ^ (wx & 7)) * 16 : zero;
         load_slab(src, dst_buf + slab * 8 * RB);
     };
     auto load_w_tile = [&](int step, char* dst_buf) {
@@ -366,43 +381,87 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // fragment addressing (LDS byte offsets).  Window row of patch pixel (wm*4 + i, frow) under tap (ky, kx):
+    // (wm*4 + ky + i) * 18 + frow + kx; its 16-B chunk c sits at c ^ ((frow + kx) & 7) — independent of i and ky.
     const int frow = lane & 15, fq = lane >> 4;
-    const int fb0 = (wn * (BN / WN) + frow) * RB;
-    const int fswb[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
+    const unsigned lds_a = (unsigned)(size_t)a_buf + (unsigned)((wm * 4 * WIN + frow) * RB);
+    const unsigned lds_w = (unsigned)(size_t)w_buf + (unsigned)((wn * (BN / WN) + frow) * RB);
+    const unsigned fsww[2] = {(unsigned)(((fq) ^ (frow & 7)) * 16), (unsigned)(((4 + fq) ^ (frow & 7)) * 16)};
+    struct Frag { half8 a[4], w[4]; };          // w[2], w[3] mirror w[0], w[1] at TN == 2 (operands of the wait only)
+    static_assert(TM == 4 && (TN == 4 || TN == 2), "fragment sets are written for 4 x {2, 4} sub-tiles");
+
+    // issue the 8 (6) fragment reads of half-step (step s, channel half kh)
+    auto read_frags = [&](Frag& f, int s, int kh) {
+        const int cl = s / 9, tap = s - cl * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned aa = lds_a + (unsigned)((cl & 1) * A_BYTES + (ky * WIN + kx) * RB) + (unsigned)(((kh * 4 + fq) ^ ((frow + kx) & 7)) * 16);
+        const unsigned wa = lds_w + (unsigned)((s & 3) * W_BYTES) + fsww[kh];
+        LDS_READ16(f.a[0], aa, 0 * WIN * RB);
+        LDS_READ16(f.a[1], aa, 1 * WIN * RB);
+        LDS_READ16(f.a[2], aa, 2 * WIN * RB);
+        LDS_READ16(f.a[3], aa, 3 * WIN * RB);
+        LDS_READ16(f.w[0], wa, 0 * 16 * RB);
+        LDS_READ16(f.w[1], wa, 1 * 16 * RB);
+        if constexpr (TN == 4) {
+            LDS_READ16(f.w[2], wa, 2 * 16 * RB);
+            LDS_READ16(f.w[3], wa, 3 * 16 * RB);
+        } else {
+            f.w[2] = f.w[0]; f.w[3] = f.w[1];
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[j], f.a[i], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NRD = TM + TN;                                        // reads per half-step
 
     if (steps > 0) {
         for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0, a_buf);
         load_w_tile(0, w_buf);
+        if (steps > 1) load_w_tile(1, w_buf + W_BYTES);
+        Frag f0, f1;
 #pragma unroll 1
-        for (int s = 0; s < steps; ++s) {
-            const int cl = s / 9, tap = s - cl * 9;
+        for (int s = 0; s < steps; s += 2) {
+            const int cl = s / 9;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s + 1 < steps) load_w_tile(s + 1, w_buf + ((s + 1) & 1) * W_BYTES);
-            if (c0 + cl + 1 < c1) {
-                const int slab = tap * APIECE + wave;
-                if (wave < APIECE && slab < WIN_SLABS) load_window_slab(slab, c0 + cl + 1, a_buf + ((cl + 1) & 1) * A_BYTES);
-            }
-            const char* Aw = a_buf + (cl & 1) * A_BYTES;
-            const char* Wt = w_buf + (s & 1) * W_BYTES;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int wbase = (wm * 4 + ky) * WIN + frow + kx;      // window row of this lane's pixel in patch row wm*4
+            __builtin_amdgcn_s_barrier();           // tiles s, s+1 (and a completed window) visible; everyone is past step s-1
+            if (s + 2 < steps) load_w_tile(s + 2, w_buf + ((s + 2) & 3) * W_BYTES);
+            if (s + 3 < steps) load_w_tile(s + 3, w_buf + ((s + 3) & 3) * W_BYTES);
+            // window of chunk cl+1 -> buffer (cl+1)&1, free once every wave is past chunk cl-1 (s >= 9 cl + 1); three even
+            // steps issue it, the barrier two steps later publishes it before step 9 (cl+1)
+            if (c0 + cl + 1 < c1 && s > 9 * cl) {
+                const int base = ((s - 9 * cl - 1) >> 1) * 16;
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                half8 xa[TM], wb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wbase + i * WIN;
-                    xa[i] = *(const half8*)(Aw + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
+                for (int h = 0; h < 2; ++h) {
+                    const int slab = base + h * 8 + wave;
+                    if (slab < WIN_SLABS) load_window_slab(slab, c0 + cl + 1, a_buf + ((cl + 1) & 1) * A_BYTES);
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(Wt + fb0 + fswb[kh] + j * 16 * RB);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
             }
+            const bool two = s + 1 < steps;         // wave-uniform
+            read_frags(f0, s, 0);
+            read_frags(f1, s, 1);
+            if constexpr (NRD == 8) LGKM_WAIT(8, f0); else LGKM_WAIT(6, f0);
+            mma(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+                read_frags(f0, s + 1, 0);
+                if constexpr (NRD == 8) LGKM_WAIT(8, f1); else LGKM_WAIT(6, f1);
+                mma(f1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(f1, s + 1, 1);
+                if constexpr (NRD == 8) LGKM_WAIT(8, f0); else LGKM_WAIT(6, f0);
+                mma(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                LGKM_WAIT(0, f1);
+                mma(f1);
+            } else {
+                LGKM_WAIT(0, f1);
+                mma(f1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -528,7 +587,7 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
         const int tiles_w = (a->M / 256) * asd_div_up(a->N, bn);
-        const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)2 * bn * 128;
+        const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)4 * bn * 128;
         hipStream_t sw = (hipStream_t)stream;
         static bool attr64 = false, attr128 = false;
         if (bn == 64) {
