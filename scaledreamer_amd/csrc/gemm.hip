@@ -55,7 +55,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tile must be a multiple of 16 x 16");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A | W]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: slab ids, LDS destinations (M0) and operand bases stay in SGPRs
     const int wm = wave / WN, wn = wave % WN;
     // tile order: consecutive blocks walk down M inside one N panel, so a weight panel stays hot in L2
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -101,8 +102,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     }
     const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
     const size_t a_slab_stride = (size_t)8 * p.lda * 2, w_slab_stride = (size_t)8 * p.ldw * 2;
+    // Row-major operands (W always, A of a plain GEMM): one 32-bit byte offset per slab against the scalar operand base
+    // (global_load_lds saddr + voffset), advanced by 128 B per k-step — 3 instructions per 1-KiB wave-level load.  Rows past
+    // M / N are clamped to the last row (their outputs are never stored), so every offset is always valid; only a ragged last
+    // k-step (K % 64 != 0) takes the general path below, which substitutes the zero page per lane.
+    unsigned roff[SPW];
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+        const int slab = wave + j * NW;
+        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + (slab - ASLABS) * 8 + lrow, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + ks0 * 128;
+        else roff[j] = CONV ? 0u : (unsigned)min(m0 + slab * 8 + lrow, p.M - 1) * (unsigned)(p.lda * 2) + lch * 16 + ks0 * 128;
+    }
 
-    auto issue = [&](int ks, int stage) {
+    auto issue_rows = [&](int stage) __attribute__((always_inline)) {
+        char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const int slab = wave + j * NW;
+            if (j * NW + NW - 1 >= TSLABS && slab >= TSLABS) continue;    // only the last j can run past the tile (wave-uniform)
+            if (CONV && slab < ASLABS) continue;
+            const char* base = slab >= ASLABS ? (const char*)p.W : (const char*)p.A;
+            load_slab(base + roff[j], st + slab * 8 * RB);
+            roff[j] += 128;
+        }
+    };
+    // general path: conv A slabs (only_conv_a) or every slab with per-lane zero-page substitution
+    auto issue_general = [&](int ks, int stage, bool only_conv_a) __attribute__((always_inline)) {
         char* st = smem + stage * STAGE_BYTES;    // slab s of the stage lives at st + s * 1 KiB (A slabs, then W slabs)
         const int k0 = ks * 64;
         const int kc = k0 + lch * 8;              // first k of this lane's chunk
@@ -121,6 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
         for (int j = 0; j < SPW; ++j) {
             const int slab = wave + j * NW;
             if (slab >= TSLABS) continue;      // wave-uniform
+            if (only_conv_a && slab >= ASLABS) continue;
             const char* src;
             if (slab >= ASLABS) {
                 const int ws = slab - ASLABS;
@@ -157,6 +183,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
                 }
             }
             load_slab(src, st + slab * 8 * RB);
+        }
+    };
+    auto issue = [&](int ks, int stage) __attribute__((always_inline)) {
+        if (ks * 64 + 64 > p.K || (CONV && !fast_conv)) {   // ragged last k-step / generic conv addressing
+            issue_general(ks, stage, false);
+        } else {
+            issue_rows(stage);
+            if (CONV) issue_general(ks, stage, true);
         }
     };
 
@@ -569,6 +603,8 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         ASD_CHECK_ARG(a->Hout > 0 && a->Wout > 0 && a->M % (a->Hout * a->Wout) == 0, "conv: M must be B*Hout*Wout");
     }
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
+    ASD_CHECK_ARG((size_t)a->N * a->ldw * 2 < ((size_t)1 << 32) && (a->conv || (size_t)a->M * a->lda * 2 < ((size_t)1 << 32)),
+                  "row-major operands are addressed with 32-bit byte offsets (< 4 GiB each)");
     if (a->act == 2)
         ASD_CHECK_ARG(a->N % 32 == 0 && a->bias && !a->conv && !a->residual && !a->row_bias && !a->out_f32 && a->split_k == 1,
                       "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");

@@ -20,6 +20,17 @@ __global__ void k_atomic(float* tab, uint32_t mask, int per_thread, int pattern)
     }
 }
 
+__global__ void k_pairs(float* tab, uint32_t mask, int per_thread) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = t * 2654435761u + 12345u;
+    for (int i = 0; i < per_thread; ++i) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t idx = (x >> 8) & mask;
+        atomicAdd(tab + 2 * idx, 1.0f);
+        atomicAdd(tab + 2 * idx + 1, 1.0f);
+    }
+}
+
 int main() {
     const size_t n = 1u << 24;  // 64 MB table
     float* tab;
@@ -45,6 +56,18 @@ int main() {
             printf("%-18s scope=%s : %8.3f ms  %7.2f G atomics/s\n", pn[pattern], scope == 0 ? "atomicAdd " : scope == 1 ? "workgroup " : "agent     ", ms,
                    total / ms / 1e6);
         }
+    // rate vs table size (does a level-sized table that fits the L2s scatter faster?), pairs of adjacent floats as in the hash grid
+    for (int lg = 18; lg <= 24; ++lg) {
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_pairs, dim3(blocks), dim3(threads), 0, 0, tab, (uint32_t)((1u << (lg - 1)) - 1), per);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        printf("random pairs, table %6.2f MB : %8.3f ms  %7.2f G atomics/s\n", (double)(1u << lg) * 4 / 1048576.0, ms, 2 * total / ms / 1e6);
+    }
     // correctness of workgroup-scope atomics across CUs/XCDs on a hot address set
     hipMemset(tab, 0, n * 4);
     hipLaunchKernelGGL(k_atomic<1>, dim3(blocks), dim3(threads), 0, 0, tab, (uint32_t)(n - 1), per, 2);
