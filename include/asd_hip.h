@@ -263,6 +263,8 @@ typedef struct asd_gemm_args {
     float*  workspace;
     int32_t tile_cfg;       /* 0: tile chosen by the built-in cost model; 1 + i: tile configuration i (see asd_gemm_force_tile),
                                as found by the caller's autotuner (scaledreamer_amd/diffusion/hip_ops.py) */
+    int32_t group_m, group_n; /* block order: workgroups of one XCD walk group_m x group_n super-tiles so that they share operand
+                               tiles through that XCD's L2 (csrc/gemm.hip, asd_xcd_item); 0 = chosen by the library */
 } asd_gemm_args;
 int asd_gemm_f16(const asd_gemm_args* args, void* stream);
 /* Tuning hook (tools/gemm_sweep.py): force tile configuration `cfg` (index into the table of csrc/gemm.hip: 128x64, 128x128,

@@ -34,6 +34,26 @@ __device__ __forceinline__ void load_slab(const char* src_row_chunk, char* lds_s
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src_row_chunk, (LDS_AS void*)lds_slab_base, 16, 0, 0);
 }
 
+// XCD-aware block -> work-item mapping.  Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each XCD
+// has its own 4 MB L2, and everything an L2 misses comes over the fabric at ~7.3 TB/s for the whole chip — while tile loads that
+// hit the L2 run at > 24 TB/s (tools/load_probe.hip: 5 co-XCD blocks streaming the same window 24.6 TB/s, 5 blocks with
+// consecutive ids 7.3 TB/s).  So the blocks that share operand tiles must sit on the SAME XCD at the same time: XCD x takes the
+// contiguous range [x * per, (x + 1) * per) of the work-item order, and that order walks compact (group_m x group_n)
+// super-tiles, so the ~32-64 blocks an XCD runs concurrently read few distinct A and W tiles.
+// Items are (split-K slice, tile) with the slice outermost.  Returns false for the padding blocks of the last XCD.
+__device__ __forceinline__ bool asd_xcd_item(int bid, int items, int& item) {
+    const int per = (items + 7) >> 3;
+    item = (bid & 7) * per + (bid >> 3);
+    return (bid >> 3) < per && item < items;
+}
+__device__ __forceinline__ void asd_grouped_tile(int t, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
+    const int band = t / (gm * tiles_n), r = t - band * gm * tiles_n;
+    const int gsz = min(gm, tiles_m - band * gm);            // rows of this band (the last band may be short)
+    const int st = r / (gsz * gn), rr = r - st * gsz * gn;   // super-tile along N, index inside it
+    tm = band * gm + rr % gsz;
+    tn = st * gn + rr / gsz;
+}
+
 // One pipeline stage holds a BM x 64 A tile and a BN x 64 W tile with 128-byte LDS rows: a wave-level
 // global_load_lds instruction covers 8 rows x one full 128-B cache line.  The 16-B chunk index is XOR-swizzled with
 // (row & 7) on the source address and on the ds_read_b128 side (conflict-free).  Two stages (double buffer): the loads
@@ -58,13 +78,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: slab ids, LDS destinations (M0) and operand bases stay in SGPRs
     const int wm = wave / WN, wn = wave % WN;
-    // tile order: consecutive blocks walk down M inside one N panel, so a weight panel stays hot in L2
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int bid = blockIdx.x;
-    const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
-    const int kz = blockIdx.z;  // split-K slice
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int item, tm_, tn_;
+    if (!asd_xcd_item(blockIdx.x, tiles_m * tiles_n * p.split_k, item)) return;
+    const int kz = item / (tiles_m * tiles_n);  // split-K slice
+    asd_grouped_tile(item - kz * tiles_m * tiles_n, tiles_m, tiles_n, p.group_m, p.group_n, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
     const int k_steps_total = (p.K + 63) / 64;
-    const int k_per = (k_steps_total + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int k_per = (k_steps_total + p.split_k - 1) / p.split_k;
     const int ks0 = kz * k_per, ks1 = min(k_steps_total, ks0 + k_per);
 
     // ---- per-lane source descriptors: lane -> (row = lane>>3 of an 8-row slab, physical chunk = lane&7) -------
@@ -209,6 +230,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
 
     const int nk = ks1 - ks0;
     if (nk > 0) {
+        // Two stages.  Measured (tools/map_ab.py): 3- and 4-stage rings with vmcnt(n) waits are 5-40 % SLOWER on every shape of the
+        // step, small K included — the extra LDS costs the second / third co-resident block per CU, and it is the co-resident
+        // blocks (independent barriers, out of phase) that fill each other's load and barrier bubbles.
         issue(ks0, 0);
         for (int k = 0; k < nk; ++k) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
     const int em = lane & 15, en = (lane >> 4) * 4;
-    if (gridDim.z > 1) {  // split-K: fp32 partial slabs, finished by splitk_epilogue_kernel
+    if (p.split_k > 1) {  // split-K: fp32 partial slabs, finished by splitk_epilogue_kernel
         float* ws = p.workspace + (size_t)kz * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -375,12 +399,17 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_x = p.Wout / 16, tiles_y = p.Hout / 16;
     const int tiles_m = (p.M / (p.Hout * p.Wout)) * tiles_y * tiles_x;
-    const int tm = blockIdx.x % tiles_m, n0 = (blockIdx.x / tiles_m) * BN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int item, tm, tn_;
+    if (!asd_xcd_item(blockIdx.x, tiles_m * tiles_n * p.split_k, item)) return;
+    const int kz = item / (tiles_m * tiles_n);
+    asd_grouped_tile(item - kz * tiles_m * tiles_n, tiles_m, tiles_n, p.group_m, p.group_n, tm, tn_);
+    const int n0 = tn_ * BN;
     const int b = tm / (tiles_y * tiles_x), tr = tm - b * tiles_y * tiles_x;
     const int y0 = (tr / tiles_x) * 16, x0 = (tr - (tr / tiles_x) * tiles_x) * 16;
     const int n_chunks = p.Cin / 64;
-    const int c_per = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int c0 = blockIdx.z * c_per, c1 = min(n_chunks, c0 + c_per);
+    const int c_per = (n_chunks + p.split_k - 1) / p.split_k;
+    const int c0 = kz * c_per, c1 = min(n_chunks, c0 + c_per);
     const int steps = (c1 - c0) * 9;
 
     const int lrow = lane >> 3, pchunk = lane & 7;
@@ -508,7 +537,7 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + en;
             if (n >= p.N) continue;
-            if (gridDim.z > 1) *(floatx4*)(p.workspace + ((size_t)blockIdx.z * p.M + m) * p.N + n) = acc[i][j];
+            if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
             else gemm_store4(p, acc[i][j], m, n);
         }
     }
@@ -557,6 +586,7 @@ struct asd_gemm_tile { int bm, bn, wm, wn; };
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
     {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}};
+static bool asd_cfg_is_window(int cfg) { return cfg >= ASD_GEMM_WIN0; }
 
 static bool asd_conv_window_ok(const asd_gemm_args* a) {
     return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Cin % 64 == 0 && a->Hin == a->Hout &&
@@ -592,7 +622,21 @@ int asd_gemm_force_tile(int32_t cfg) {
     return ASD_OK;
 }
 
-int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
+// super-tile of the block order (asd_grouped_tile): about one XCD's worth of concurrent blocks, near-square in bytes
+static void asd_pick_group(int tiles_m, int tiles_n, int bm, int bn, size_t lds, int* gm, int* gn) {
+    const int conc = 32 * (2 * lds <= 160 * 1024 ? 2 : 1);      // blocks an XCD (32 CUs) runs at a time
+    int m = (int)lroundf(sqrtf((float)conc * (float)bn / (float)bm));
+    m = m < 1 ? 1 : (m > tiles_m ? tiles_m : m);
+    int n = conc / m;
+    n = n < 1 ? 1 : (n > tiles_n ? tiles_n : n);
+    if (n == tiles_n) { m = conc / n; m = m < 1 ? 1 : (m > tiles_m ? tiles_m : m); }
+    *gm = m; *gn = n;
+}
+
+int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
+    ASD_CHECK_ARG(a_in, "null argument");
+    asd_gemm_args a_copy = *a_in;           // group_m / group_n are filled in here when the caller left them 0
+    asd_gemm_args* a = &a_copy;
     ASD_CHECK_ARG(a && a->A && a->W && a->C && a->zero_page, "null argument");
     ASD_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
     ASD_CHECK_ARG(a->K % 8 == 0, "K must be a multiple of 8");
@@ -614,24 +658,25 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
     if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
     if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
     if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
-    ASD_CHECK_ARG(a->act != 2 || (cfg < ASD_GEMM_WIN0 && (asd_gemm_tiles[cfg].bn / asd_gemm_tiles[cfg].wn) % 32 == 0),
+    ASD_CHECK_ARG(a->act != 2 || (!asd_cfg_is_window(cfg) && (asd_gemm_tiles[cfg].bn / asd_gemm_tiles[cfg].wn) % 32 == 0),
                   "GEGLU epilogue needs a tile whose per-wave width is a multiple of 32 columns");
     ASD_CHECK_ARG(asd_gemm_tiles[cfg].bn == 64 || a->N % asd_gemm_tiles[cfg].bn == 0 || (asd_gemm_tiles[cfg].bn == 128 && a->N % 4 == 0),
                   "tile configuration does not divide N");
     const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;
-    if (cfg >= ASD_GEMM_WIN0) {
+    if (asd_cfg_is_window(cfg)) {
         ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
-        const int tiles_w = (a->M / 256) * asd_div_up(a->N, bn);
         const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)4 * bn * 128;
+        if (a->group_m < 1 || a->group_n < 1) asd_pick_group(a->M / 256, asd_div_up(a->N, bn), 256, bn, lds_w, &a->group_m, &a->group_n);
+        const int tiles_w = 8 * asd_div_up((a->M / 256) * asd_div_up(a->N, bn) * a->split_k, 8);   // asd_xcd_item
         hipStream_t sw = (hipStream_t)stream;
         static bool attr64 = false, attr128 = false;
         if (bn == 64) {
             if (!attr64) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr64 = true; }
-            hipLaunchKernelGGL((conv3x3_win_kernel<64>), dim3(tiles_w, 1, a->split_k), dim3(512), lds_w, sw, *a);
+            hipLaunchKernelGGL((conv3x3_win_kernel<64>), dim3(tiles_w), dim3(512), lds_w, sw, *a);
         } else {
             if (!attr128) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr128 = true; }
-            hipLaunchKernelGGL((conv3x3_win_kernel<128>), dim3(tiles_w, 1, a->split_k), dim3(512), lds_w, sw, *a);
+            hipLaunchKernelGGL((conv3x3_win_kernel<128>), dim3(tiles_w), dim3(512), lds_w, sw, *a);
         }
         if (a->split_k > 1) {
             const size_t total4 = (size_t)a->M * a->N / 4;
@@ -641,8 +686,9 @@ int asd_gemm_f16(const asd_gemm_args* a, void* stream) {
         return ASD_OK;
     }
     const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
-    const dim3 grid(tiles, 1, a->split_k), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * 64);
     const size_t lds = (size_t)2 * (bm + bn) * 128;
+    if (a->group_m < 1 || a->group_n < 1) asd_pick_group(asd_div_up(a->M, bm), asd_div_up(a->N, bn), bm, bn, lds, &a->group_m, &a->group_n);
+    const dim3 grid(8 * asd_div_up(tiles * a->split_k, 8)), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * 64);   // asd_xcd_item
     hipStream_t s = (hipStream_t)stream;
 #define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_)                                                                           \
     do {                                                                                                                 \
