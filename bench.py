@@ -112,7 +112,8 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     achieved = flops / (ms * 1e-3) / 1e12
     plan = tuple(H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
     if plan[0] - 1 in H.WINDOW_TILES:
-        kern = f"conv3x3_win_kernel<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window)"
+        kname = "conv3x3_win2_kernel" if plan[0] - 1 >= 10 else "conv3x3_win_kernel"
+        kern = f"{kname}<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window{', two blocks per CU' if plan[0] - 1 >= 10 else ''})"
     else:
         kern = f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]},conv>" if plan[0] else "gemm_f16_kernel<model tile,conv>"
     shape = "3x3 conv 128->128 @512x512 (VAE encoder)" if which == "vae512" else "3x3 conv 320->320 @64x64, UNet batch 5"

@@ -543,6 +543,128 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-blocks-per-CU variant of the window convolution.  Co-resident blocks have independent barriers and drift out of phase, so
+// one block's MFMAs run under the other's loads, waits and epilogue — worth 10-22 % wherever a launch has >= 512 blocks (VAE
+// 512^2 / 256^2 layers, UNet 64^2 layers; tools/win_ab.py).  To fit twice into 160 KB of LDS and 128 registers the block keeps
+// ONE window buffer (the reload at a chunk switch is exposed; the neighbour covers it), a two-slot weight ring with a barrier
+// per tap, and the compiler's just-in-time fragment schedule (117 VGPRs).  Row-keyed swizzle as in the implicit-GEMM kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_args p) {
+    constexpr int WN = 2, TM = 4, TN = BN / WN / 16;
+    constexpr int RB = 128;
+    constexpr int WIN = 18, WIN_ROWS = WIN * WIN, WIN_SLABS = (WIN_ROWS + 7) / 8;      // 324 rows, 41 slabs
+    constexpr int A_BYTES = WIN_SLABS * 8 * RB, W_BYTES = BN * RB;
+    constexpr int WSLABS = BN / 8, WSPW = (WSLABS + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];                        // [A0 | A1 | W0 | W1]
+    char* const a_buf = smem;
+    char* const w_buf = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_x = p.Wout / 16, tiles_y = p.Hout / 16;
+    const int tiles_m = (p.M / (p.Hout * p.Wout)) * tiles_y * tiles_x;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int item, tm, tn_;
+    if (!asd_xcd_item(blockIdx.x, tiles_m * tiles_n * p.split_k, item)) return;
+    const int kz = item / (tiles_m * tiles_n);
+    asd_grouped_tile(item - kz * tiles_m * tiles_n, tiles_m, tiles_n, p.group_m, p.group_n, tm, tn_);
+    const int n0 = tn_ * BN;
+    const int b = tm / (tiles_y * tiles_x), tr = tm - b * tiles_y * tiles_x;
+    const int y0 = (tr / tiles_x) * 16, x0 = (tr - (tr / tiles_x) * tiles_x) * 16;
+    const int n_chunks = p.Cin / 64;
+    const int c_per = (n_chunks + p.split_k - 1) / p.split_k;
+    const int c0 = kz * c_per, c1 = min(n_chunks, c0 + c_per);
+    const int steps = (c1 - c0) * 9;
+
+    const int lrow = lane >> 3, pchunk = lane & 7, lch = pchunk ^ lrow;
+    const char* zero = (const char*)p.zero_page;
+    const char* img = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
+    const size_t w_slab_stride = (size_t)8 * p.ldw * 2;
+
+    auto load_window_slab = [&](int slab, int chunk, char* dst_buf) {   // slab: wave-uniform, < WIN_SLABS
+        const int wrow = slab * 8 + lrow;
+        const int wy = (wrow * 3641) >> 16, wx = wrow - wy * WIN;        // wrow / 18 for wrow < 328
+        const int yi = y0 - 1 + wy, xi = x0 - 1 + wx;
+        const bool ok = wrow < WIN_ROWS && (unsigned)yi < (unsigned)p.Hin && (unsigned)xi < (unsigned)p.Win;
+        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + lch * 16 : zero;
+        load_slab(src, dst_buf + slab * 8 * RB);
+    };
+    auto load_w_tile = [&](int step, char* dst_buf) {
+        const int chunk = c0 + step / 9, tap = step - (step / 9) * 9;
+        const size_t koff = ((size_t)tap * p.Cin + chunk * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WSPW; ++j) {
+            const int slab = wave + j * 8;
+            if (slab >= WSLABS) continue;
+            const char* src = (n0 + slab * 8 + lrow < p.N) ? w0 + slab * w_slab_stride + koff : zero;
+            load_slab(src, dst_buf + slab * 8 * RB);
+        }
+    };
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fb0 = (wn * (BN / WN) + frow) * RB;
+    const int fswb[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
+
+    if (steps > 0) {
+        for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0, a_buf);
+        load_w_tile(0, w_buf);
+#pragma unroll 1
+        for (int s = 0; s < steps; ++s) {
+            const int cl = s / 9, tap = s - cl * 9;
+            if (tap == 0 && s > 0) {   // chunk switch: everyone is done with the old window, reload it (exposed; the co-resident block covers)
+                __builtin_amdgcn_s_barrier();
+                for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0 + cl, a_buf);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < steps) load_w_tile(s + 1, w_buf + ((s + 1) & 1) * W_BYTES);
+            const char* Aw = a_buf;
+            const char* Wt = w_buf + (s & 1) * W_BYTES;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int wbase = (wm * 4 + ky) * WIN + frow + kx;      // window row of this lane's pixel in patch row wm*4
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                half8 xa[TM], wb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wbase + i * WIN;
+                    xa[i] = *(const half8*)(Aw + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(Wt + fb0 + fswb[kh] + j * 16 * RB);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
+    const int en = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + en;
+            if (n >= p.N) continue;
+            if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
+            else gemm_store4(p, acc[i][j], m, n);
+        }
+    }
+}
+
 // sums the split-K slabs and applies the same epilogue (4 outputs per thread)
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_args p, int splits) {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -581,11 +703,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn; };
-#define ASD_GEMM_NCFG 10
-#define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN)
+#define ASD_GEMM_NCFG 12
+#define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
+                          // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
-    {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}};
+    {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}};
 static bool asd_cfg_is_window(int cfg) { return cfg >= ASD_GEMM_WIN0; }
 
 static bool asd_conv_window_ok(const asd_gemm_args* a) {
@@ -654,7 +777,10 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
                       "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");
     int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
     // without a tuned plan: the LDS-window kernel wins on every stride-1 3x3 layer with at least 16 patches (tools/gemm_sweep.py)
-    if (asd_conv_window_ok(a) && a->M >= 4096 && a->split_k <= a->Cin / 64) cfg = a->N % 128 == 0 ? 9 : 8;
+    if (asd_conv_window_ok(a) && a->M >= 4096 && a->split_k <= a->Cin / 64) {
+        cfg = a->N % 128 == 0 ? 9 : 8;
+        if ((a->M / 256) * asd_div_up(a->N, asd_gemm_tiles[cfg].bn) * a->split_k >= 512) cfg += 2;   // enough blocks for two per CU
+    }
     if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
     if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
     if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
@@ -667,9 +793,27 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
         const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)4 * bn * 128;
-        if (a->group_m < 1 || a->group_n < 1) asd_pick_group(a->M / 256, asd_div_up(a->N, bn), 256, bn, lds_w, &a->group_m, &a->group_n);
+        if (a->group_m < 1 || a->group_n < 1)
+            asd_pick_group(a->M / 256, asd_div_up(a->N, bn), 256, bn, cfg >= ASD_GEMM_WIN0 + 2 ? (size_t)80 * 1024 : lds_w, &a->group_m, &a->group_n);
         const int tiles_w = 8 * asd_div_up((a->M / 256) * asd_div_up(a->N, bn) * a->split_k, 8);   // asd_xcd_item
         hipStream_t sw = (hipStream_t)stream;
+        if (cfg >= ASD_GEMM_WIN0 + 2) {     // two blocks per CU: single window buffer, two weight slots
+            const size_t lds2 = (size_t)41 * 1024 + (size_t)2 * bn * 128;
+            static bool a64 = false, a128 = false;
+            if (bn == 64) {
+                if (!a64) { (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); a64 = true; }
+                hipLaunchKernelGGL((conv3x3_win2_kernel<64>), dim3(tiles_w), dim3(512), lds2, sw, *a);
+            } else {
+                if (!a128) { (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); a128 = true; }
+                hipLaunchKernelGGL((conv3x3_win2_kernel<128>), dim3(tiles_w), dim3(512), lds2, sw, *a);
+            }
+            if (a->split_k > 1) {
+                const size_t total4 = (size_t)a->M * a->N / 4;
+                hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+            }
+            ASD_LAUNCH_CHECK();
+            return ASD_OK;
+        }
         static bool attr64 = false, attr128 = false;
         if (bn == 64) {
             if (!attr64) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr64 = true; }

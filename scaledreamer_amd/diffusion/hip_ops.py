@@ -43,9 +43,9 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # captures (tools/gemm_sweep.py).  Like a BLAS library's tuned-kernel table, each new shape is timed once over the valid
 # candidates (a few ms, outside graph capture) and the winner is cached for the process; ASD_GEMM_AUTOTUNE=0 keeps the
 # built-in cost model (csrc/gemm.hip: asd_gemm_pick_tile) + pick_split_k.
-TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128)
-TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256)
-WINDOW_TILES = (8, 9)       # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels)
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256)
+WINDOW_TILES = (8, 9, 10, 11)   # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels); 10, 11: two blocks per CU
 AUTOTUNE = os.environ.get("ASD_GEMM_AUTOTUNE", "1") != "0"
 PLAN_FILE = os.environ.get("ASD_GEMM_PLAN_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans.json"))
 _plans = {}

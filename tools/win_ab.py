@@ -31,8 +31,8 @@ for B, hw, cin, cout in shapes:
     lib().asd_gemm_force_tile(C.c_int32(2))
     ref = H.conv3x3(x, w, split_k=1).float()
     out = []
-    for t, name in ((8, "win64"), (9, "win128")):
-        if t == 9 and cout % 128:
+    for t, name in ((8, "win64"), (9, "win128"), (10, "win64x2"), (11, "win128x2")):
+        if t in (9, 11) and cout % 128:
             continue
         lib().asd_gemm_force_tile(C.c_int32(t))
         for sk in (1, 2, 4, 5, 8):
