@@ -41,8 +41,13 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile 8 KB | V^T tile 8 KB]
     constexpr int TILE_BYTES = KT * HD * 2;                         // 8192
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB + wave * QW;
+    // XCD-aware order (block i runs on XCD i % 8, one L2 per XCD): XCD x takes a contiguous range of (batch, head, q-block)
+    // items with the q-block innermost, so the q-blocks of one head stream that head's K / V^T through ONE L2 instead of eight
+    const int qblocks = (p.lq + QB - 1) / QB, items = qblocks * p.heads * p.batch;
+    const int per = (items + 7) >> 3, item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (((int)blockIdx.x >> 3) >= per || item >= items) return;
+    const int b = item / (qblocks * p.heads), h = (item / qblocks) % p.heads;
+    const int q0 = (item % qblocks) * QB + wave * QW;
     const int lq16 = lane & 15, lg = lane >> 4;
 
     // ---- Q fragments (B operand): lane holds Q[q = q0 + 16*qs + (l&15)][d = 32*ks + (l>>4)*8 .. +8] --------
@@ -214,7 +219,7 @@ int asd_attention_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, co
                   "leading dimensions / key stride must keep 16-byte alignment");
     AttnArgs a{(const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vT, ldv, (half_t*)o, ldo,
                batch, heads, lq, lk, lk_stride, scale, (const char*)zero_page};
-    const dim3 grid(asd_div_up(lq, QB), heads, batch);
+    const dim3 grid(8 * asd_div_up(asd_div_up(lq, QB) * heads * batch, 8));
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 4 * KT * HD * 2, (hipStream_t)stream, a);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
