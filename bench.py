@@ -83,13 +83,13 @@ def to_device(batch, dev):
 
 # HBM-side bytes per launch from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under `--pmc FETCH_SIZE` and
 # `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; summaries in
-# profiles/r01_final2_pmc_roofline_kernel.txt), keyed by (op, autotuned plan).
-PMC_TRAFFIC = {("vae512", (10, 1)): 145.5e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
+# profiles/r01_final3_pmc_roofline_kernel.txt, r01_final2_* for the earlier plans), keyed by (op, autotuned plan).
+PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.0e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
-    """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final2_kernel_stats_top70.csv:
-    conv3x3_win_kernel<128> 14 % + gemm_f16_kernel variants 30 % of the kernel time).  Average duration of one launch, HIP events on
+    """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final3_kernel_stats_top70.csv:
+    conv3x3_win2_kernel<128> + conv3x3_win_kernel<128> + conv3x3_win2_kernel<64> 15.6 % of the kernel time, gemm_f16_kernel variants 35 %).  Average duration of one launch, HIP events on
     the launch stream, on its heaviest single shape:
       vae512: 3x3 conv 128->128 at 512x512 (VAE encoder level 0, forward and input-gradient: 8 launches per step) M=262144 N=128 K=1152
       unet64: 3x3 conv 320->320 at 64x64 for the UNet batch of 5 (7 launches per UNet forward)                 M=20480  N=320 K=2880
