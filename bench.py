@@ -123,6 +123,33 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
             "avg_launch_ms": round(ms, 4)}
 
 
+def roofline_gemm_kernel(reps: int = 50):
+    """The single kernel with the largest share in the rocprofv3 summary is the plain GEMM gemm_f16_kernel<256,64,4,2,false>
+    (13.4 %, ~136 launches per step over the K <= 1280 linears of the UNet transformers).  Its most frequent shape, the 320 -> 320
+    linear on the 64x64 tokens of the UNet batch (M=20480, N=320, K=320; 25 launches per step), has 161 FLOP per algorithmic byte,
+    below the machine balance of 2500 / 8 = 312: HBM-bound.  Algorithmic bytes = A + W + C in fp16, each touched once."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    M, N, K = 20480, 320, 320
+    a, w = torch.randn(M, K, device="cuda").half(), torch.randn(N, K, device="cuda").half()
+    for _ in range(5):
+        H.gemm(a, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        H.gemm(a, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 2.0 * (M * K + N * K + M * N)
+    plan = tuple(H._plans.get((M, N, K, K), (0, 1)))   # plan key of a plain GEMM: (M, N, K, lda)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}> split_k={plan[1]} on linear 320->320, M=20480 (UNet 64x64 tokens x batch 5)"
+                      if plan[0] else "gemm_f16_kernel<model tile> on linear 320->320, M=20480",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4)}
+
+
 def roofline_field_kernel(system, batch, reps: int = 20):
     """Average duration (HIP events on the launch stream) of the dominant hand-written renderer kernel,
     field_fwd_kernel, on the live samples of one step; algorithmic bytes per DESIGN.md / SURVEY.md §8d."""
@@ -326,6 +353,7 @@ def main():
             out["phases_ms"] = phases
         out["roofline"] = roofline_conv_kernel("vae512")
         out["roofline_unet_conv"] = roofline_conv_kernel("unet64")
+        out["roofline_gemm"] = roofline_gemm_kernel()
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
             out["roofline_renderer"] = roofline_field_kernel(system, batch)
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":
