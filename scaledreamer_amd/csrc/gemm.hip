@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
 // one block's MFMAs run under the other's loads, waits and epilogue — worth 10-22 % wherever a launch has >= 512 blocks (VAE
 // 512^2 / 256^2 layers, UNet 64^2 layers; tools/win_ab.py).  To fit twice into 160 KB of LDS and 128 registers the block keeps
 // ONE window buffer (the reload at a chunk switch is exposed; the neighbour covers it), a two-slot weight ring with a barrier
-// per tap, and the compiler's just-in-time fragment schedule (117 VGPRs).  Row-keyed swizzle as in the implicit-GEMM kernel.
+// per tap, and the compiler's just-in-time fragment schedule (<= 128 VGPRs).  Column-keyed window swizzle as in conv3x3_win_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BN>
 __global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_args p) {
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_arg
         const int wy = (wrow * 3641) >> 16, wx = wrow - wy * WIN;        // wrow / 18 for wrow < 328
         const int yi = y0 - 1 + wy, xi = x0 - 1 + wx;
         const bool ok = wrow < WIN_ROWS && (unsigned)yi < (unsigned)p.Hin && (unsigned)xi < (unsigned)p.Win;
-        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + lch * 16 : zero;
+        const char* src = ok ? img + ((size_t)(yi * p.Win + xi) * p.Cin + chunk * 64) * 2 + (pchunk ^ (wx & 7)) * 16 : zero;   // column-keyed swizzle
         load_slab(src, dst_buf + slab * 8 * RB);
     };
     auto load_w_tile = [&](int step, char* dst_buf) {
@@ -627,18 +627,18 @@ __global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_arg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (s + 1 < steps) load_w_tile(s + 1, w_buf + ((s + 1) & 1) * W_BYTES);
-            const char* Aw = a_buf;
             const char* Wt = w_buf + (s & 1) * W_BYTES;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int wbase = (wm * 4 + ky) * WIN + frow + kx;      // window row of this lane's pixel in patch row wm*4
+            // window row of patch pixel (wm*4 + i, frow) under tap (ky, kx): (wm*4 + ky + i) * 18 + frow + kx; its chunk c sits at
+            // c ^ ((frow + kx) & 7) — independent of i and ky, so patch row i is an immediate offset from row 0
+            const char* Ar = a_buf + ((wm * 4 + ky) * WIN + frow + kx) * RB;
+            const int csw = (frow + kx) & 7;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
                 half8 xa[TM], wb[TN];
+                const char* Ak = Ar + (((kh * 4 + fq) ^ csw) * 16);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wbase + i * WIN;
-                    xa[i] = *(const half8*)(Aw + row * RB + (((kh * 4 + fq) ^ (row & 7)) * 16));
-                }
+                for (int i = 0; i < TM; ++i) xa[i] = *(const half8*)(Ak + i * WIN * RB);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(Wt + fb0 + fswb[kh] + j * 16 * RB);
 #pragma unroll
