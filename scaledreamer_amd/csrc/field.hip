@@ -527,6 +527,11 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
                                                          float* __restrict__ d_grid, float* __restrict__ dw0,
                                                          float* __restrict__ dw1, float* __restrict__ dw2) {
     constexpr int NIN = 2 * L;
+    // weight gradients: wave sums -> per-block LDS cells -> one global atomic per weight and block (64 wave leaders hammering the
+    // same 432 addresses ran at the hot-address atomic rate)
+    __shared__ float w_acc[3 * H + H * H + H * NIN];
+    for (int q = threadIdx.x; q < 3 * H + H * H + H * NIN; q += 256) w_acc[q] = 0.f;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n;
     const bool lead = (threadIdx.x & 63) == 0;
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float v = asd_wave_sum(dout[o] * fmaxf(a1[k], 0.f));
-            if (lead) atomicAdd(&dw2[o * H + k], v);
+            if (lead) atomicAdd(&w_acc[o * H + k], v);
             acc = fmaf(dout[o], w2[o * H + k], acc);
         }
         dh1[k] = a1[k] > 0.f ? acc : 0.f;
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const float v = asd_wave_sum(dh1[h] * fmaxf(a0[k], 0.f));
-            if (lead) atomicAdd(&dw1[h * H + k], v);
+            if (lead) atomicAdd(&w_acc[3 * H + h * H + k], v);
             acc = fmaf(dh1[h], w1[h * H + k], acc);
         }
         dh0[k] = a0[k] > 0.f ? acc : 0.f;
@@ -589,12 +594,18 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const float v = asd_wave_sum(dh0[h] * enc[k]);
-            if (lead) atomicAdd(&dw0[h * NIN + k], v);
+            if (lead) atomicAdd(&w_acc[3 * H + H * H + h * NIN + k], v);
             acc = fmaf(dh0[h], w0[h * NIN + k], acc);
         }
         denc[k] = acc;
     }
-    if (active) asd_scatter<L>(m, d_grid, x, y, z, denc);
+    // a wave is 64 consecutive pixels of an image row: on the three coarse levels (cells of 1/4 .. 1/64 of the direction cube) its
+    // lanes fall into a handful of cells, so runs are summed across lanes and only run heads issue atomics
+    asd_scatter_runs<L, 3>(m, d_grid, x, y, z, denc, active);
+    __syncthreads();
+    for (int q = threadIdx.x; q < 3 * H; q += 256) atomicAdd(&dw2[q], w_acc[q]);
+    for (int q = threadIdx.x; q < H * H; q += 256) atomicAdd(&dw1[q], w_acc[3 * H + q]);
+    for (int q = threadIdx.x; q < H * NIN; q += 256) atomicAdd(&dw0[q], w_acc[3 * H + H * H + q]);
 }
 
 // ---------------------------------------------------------------------------------------------------
