@@ -41,6 +41,43 @@ def ddpm_alphas_cumprod(n: int = 1000, beta_start: float = 0.00085, beta_end: fl
     return torch.cumprod(1.0 - betas, dim=0).float()
 
 
+_RESIZE_MATS = {}
+
+
+def _resize_matrix(n_in: int, n_out: int, device) -> torch.Tensor:
+    """[n_out, n_in] matrix of F.interpolate(mode='bilinear', align_corners=False) along one axis, taken from torch itself."""
+    key = (n_in, n_out, str(device))
+    if key not in _RESIZE_MATS:
+        eye = torch.eye(n_in, device=device, dtype=torch.float32).view(1, n_in, n_in, 1)
+        _RESIZE_MATS[key] = F.interpolate(eye, (n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].t().contiguous()
+    return _RESIZE_MATS[key]
+
+
+class _BilinearResize(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) with the same forward kernel and a backward written as the two
+    small matmuls  d_x = R_h^T d_y R_w  (bilinear resampling is separable): ATen's upsample_bilinear2d_backward takes 112 us for a
+    64x64 -> 512x512 image on MI355X, the matmuls ~20 us (profiles/r01_final3_kernel_stats_top70.csv)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_hw = (x.shape[-2], x.shape[-1])
+        ctx.size = size
+        return F.interpolate(x, size, mode="bilinear", align_corners=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rh = _resize_matrix(ctx.in_hw[0], ctx.size[0], dy.device)
+        rw = _resize_matrix(ctx.in_hw[1], ctx.size[1], dy.device)
+        dx = torch.matmul(torch.matmul(rh.t(), dy.float()), rw)
+        return dx.to(dy.dtype), None
+
+
+def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    if x.is_cuda and x.requires_grad and x.dtype == torch.float32:
+        return _BilinearResize.apply(x, tuple(size))
+    return F.interpolate(x, size, mode="bilinear", align_corners=False)
+
+
 @dataclass
 class PromptUtils:
     """Output layout of the prompt processors: view-dependent embeddings [4,77,1024] in the order
@@ -204,7 +241,7 @@ class SDTimestepShiftedScoreDistillationGuidance(BaseObject):
     def get_latents(self, rgb_BCHW: torch.Tensor, rgb_as_latents: bool = False) -> torch.Tensor:
         if rgb_as_latents:
             return F.interpolate(rgb_BCHW, (64, 64), mode="bilinear", align_corners=False)
-        rgb_BCHW_512 = F.interpolate(rgb_BCHW, (512, 512), mode="bilinear", align_corners=False)
+        rgb_BCHW_512 = resize_bilinear(rgb_BCHW, (512, 512))
         return self.encode_images(rgb_BCHW_512)
 
     def add_noise(self, latents, noise, t):
@@ -361,7 +398,7 @@ class MVDreamTimestepShiftedScoreDistillationGuidance(BaseObject):
     def get_latents(self, rgb_BCHW: torch.Tensor, rgb_as_latents: bool = False) -> torch.Tensor:
         if rgb_as_latents:
             return F.interpolate(rgb_BCHW, size=(32, 32), mode="bilinear", align_corners=False)
-        return self.encode_images(F.interpolate(rgb_BCHW, size=(256, 256), mode="bilinear", align_corners=False))
+        return self.encode_images(resize_bilinear(rgb_BCHW, (256, 256)))
 
     def q_sample(self, x, t, noise):
         a = self.alphas.to(x.device)[t].view(-1, 1, 1, 1)
