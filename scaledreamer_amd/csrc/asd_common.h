@@ -40,10 +40,21 @@ static inline int asd_grid_for(int64_t n, int block) {
 // ---- wave64 primitives -------------------------------------------------------------------------
 __device__ __forceinline__ int asd_lane() { return (int)(threadIdx.x & 63); }
 
+// sum over the 64 lanes, returned in every lane.  DPP row shifts / row broadcasts (VALU only; the __shfl_xor butterfly is six
+// ds_bpermute round trips through the LDS pipe per call, and the field / background backward kernels make hundreds of calls per wave)
 __device__ __forceinline__ float asd_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int x;
+#define ASD_DPP_ADD(CTRL, ROW_MASK)                                                                                      \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);                                    \
+    v += __int_as_float(x)
+    ASD_DPP_ADD(0x111, 0xf);   // row_shr:1
+    ASD_DPP_ADD(0x112, 0xf);   // row_shr:2
+    ASD_DPP_ADD(0x114, 0xf);   // row_shr:4
+    ASD_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row sum
+    ASD_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    ASD_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef ASD_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // inclusive scan across the 64 lanes of a wave
