@@ -107,10 +107,9 @@ class PromptUtils:
         """later directions override earlier ones: side < front < back < overhead (base.py:262-294)."""
         idx = torch.zeros_like(elevation, dtype=torch.long)
         azi = shift_azimuth_deg(azimuth)
-        idx[(azi > -self.front_threshold) & (azi < self.front_threshold)] = 1
-        idx[(azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold)] = 2
-        idx[elevation > self.overhead_threshold] = 3
-        return idx
+        idx = torch.where((azi > -self.front_threshold) & (azi < self.front_threshold), torch.ones_like(idx), idx)
+        idx = torch.where((azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold), torch.full_like(idx, 2), idx)
+        return torch.where(elevation > self.overhead_threshold, torch.full_like(idx, 3), idx)
 
     def get_text_embeddings(self, elevation, azimuth, camera_distances, view_dependent_prompting: bool = True):
         batch_size = elevation.shape[0]
@@ -123,30 +122,30 @@ class PromptUtils:
         return torch.cat([text, uncond], dim=0)  # (cond, uncond): the reference's order
 
     def get_text_embeddings_perp_neg(self, elevation, azimuth, camera_distances, view_dependent_prompting: bool = True):
+        """prompt_processors/base.py:82-167.  The reference walks the batch in Python and branches on device scalars (one host
+        sync per `if`); here the same selection is written with torch.where so that nothing between the VAE forward and the
+        UNet launch waits for the GPU.  Output order as the reference: [pos (B), uncond (B), neg (2B: n1_0, n2_0, n1_1, ...)]."""
         assert view_dependent_prompting, "Perp-Neg only works with view-dependent prompting"
         batch_size = elevation.shape[0]
         idx = self.direction_idx(elevation, azimuth, camera_distances)
         side, front, back, overhead = (self.text_embeddings_vd[i] for i in range(4))
-        pos, neg, uncond, weights = [], [], [], []
-        for i, ele, azi in zip(idx.tolist(), elevation, azimuth):
-            azi = shift_azimuth_deg(azi)
-            uncond.append(self.uncond_text_embeddings_vd[i])
-            if i == 3:
-                pos.append(overhead)
-                neg += [self.uncond_text_embeddings_vd[i], self.uncond_text_embeddings_vd[i]]
-                weights += [0.0, 0.0]
-            elif torch.abs(azi) < 90:
-                r = 1 - torch.abs(azi) / 90
-                pos.append(r * front + (1 - r) * side)
-                neg += [front, side]
-                weights += [-shifted_expotional_decay(*self.perp_neg_f_fs, r), -shifted_expotional_decay(*self.perp_neg_f_sf, 1 - r)]
-            else:
-                r = 2.0 - torch.abs(azi) / 90
-                pos.append(r * side + (1 - r) * back)
-                neg += [side, front]
-                weights += [-shifted_expotional_decay(*self.perp_neg_f_sb, r), -shifted_expotional_decay(*self.perp_neg_f_fsb, r)]
-        text_embeddings = torch.cat([torch.stack(pos, 0), torch.stack(uncond, 0), torch.stack(neg, 0)], dim=0)
-        return text_embeddings, torch.as_tensor(weights, device=elevation.device).reshape(batch_size, 2)
+        a = torch.abs(shift_azimuth_deg(azimuth)).to(side.dtype)
+        over = (idx == 3).view(-1, 1, 1)
+        is_front = (a < 90).view(-1, 1, 1)
+        r_f = (1 - a / 90).view(-1, 1, 1)             # front <-> side
+        r_b = (2.0 - a / 90).view(-1, 1, 1)           # side <-> back
+        uncond = self.uncond_text_embeddings_vd[idx]
+        pos = torch.where(over, overhead.expand(batch_size, -1, -1),
+                          torch.where(is_front, r_f * front + (1 - r_f) * side, r_b * side + (1 - r_b) * back))
+        neg1 = torch.where(over, uncond, torch.where(is_front, front.expand(batch_size, -1, -1), side.expand(batch_size, -1, -1)))
+        neg2 = torch.where(over, uncond, torch.where(is_front, side.expand(batch_size, -1, -1), front.expand(batch_size, -1, -1)))
+        rf, rb = r_f.view(-1), r_b.view(-1)
+        w1 = torch.where(a < 90, -shifted_expotional_decay(*self.perp_neg_f_fs, rf), -shifted_expotional_decay(*self.perp_neg_f_sb, rb))
+        w2 = torch.where(a < 90, -shifted_expotional_decay(*self.perp_neg_f_sf, 1 - rf), -shifted_expotional_decay(*self.perp_neg_f_fsb, rb))
+        zero = torch.zeros_like(w1)
+        weights = torch.stack([torch.where(idx == 3, zero, w1), torch.where(idx == 3, zero, w2)], dim=1)
+        neg = torch.stack([neg1, neg2], dim=1).reshape(2 * batch_size, *neg1.shape[1:])
+        return torch.cat([pos, uncond, neg], dim=0), weights.to(torch.float32)
 
 
 class DiffusionBackend:
