@@ -7,7 +7,10 @@ one large RCCL call — per-link-bound ring traffic favours few big collectives 
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import os
+import sys
 from typing import List
 
 import torch
@@ -21,6 +24,25 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner with printf to the C stdout of every rank (it surfaces when the buffer is flushed, i.e. at
+    exit, AFTER anything Python printed).  bench.py's contract is one JSON line on stdout, so communicator creation and teardown
+    run with file descriptor 1 pointing at stderr and the C buffers are flushed before it is restored."""
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_from_env(backend: str = None) -> int:
     """Initialise the process group from torchrun's environment (RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -29,8 +51,19 @@ def init_from_env(backend: str = None) -> int:
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+    with stdout_to_stderr():
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+        if backend == "nccl":   # communicators are created lazily: force it (and the banner) now
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
     return world
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        with stdout_to_stderr():
+            dist.destroy_process_group()
 
 
 def _buckets(grads: List[torch.Tensor]):
