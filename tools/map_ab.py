@@ -14,6 +14,7 @@ def timeit(fn, reps=10):
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(3e5 + 2.5e4 * reps))   # park the GPU while the launches are queued: GPU time, not the host's launch rate
     e0.record()
     for _ in range(reps):
         fn()
