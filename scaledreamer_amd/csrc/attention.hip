@@ -37,7 +37,7 @@ struct AttnArgs {
     const char* zero;
 };
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile 8 KB | V^T tile 8 KB]
     constexpr int TILE_BYTES = KT * HD * 2;                         // 8192
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
