@@ -37,7 +37,10 @@ struct AttnArgs {
     const char* zero;
 };
 
-__global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnArgs p) {
+// launch bounds: with plain __launch_bounds__(256) hipcc parked the MFMA results in AGPRs and moved 192 registers per key tile
+// between the two files (v_accvgpr_read / _write around the softmax: 330 VALU instructions per tile instead of ~140); naming
+// 4 waves per SIMD keeps everything in 128 VGPRs.  L = 4096: 265 -> 199 us.
+__global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile 8 KB | V^T tile 8 KB]
     constexpr int TILE_BYTES = KT * HD * 2;                         // 8192
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnArgs p)
         const int key_base = t * KT + lg * 4;
         half4 pf[4][2];  // probabilities, fp16: [kt][qs] -> 4 consecutive keys
         if (t == n_tiles - 1 && (p.lk & (KT - 1)) != 0) {
+            asm volatile("" ::: "memory");   // keep this a (wave-uniform) branch: if-converted it costs 32 selects on every tile
 #pragma unroll
             for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
