@@ -703,13 +703,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn; };
-#define ASD_GEMM_NCFG 12
+#define ASD_GEMM_NCFG 13
 #define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
                           // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
-    {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}};
-static bool asd_cfg_is_window(int cfg) { return cfg >= ASD_GEMM_WIN0; }
+    {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {256, 64, 4, 2}, {256, 128, 4, 2},
+    {64, 64, 2, 2}};   // 12: small tile, 32 KB LDS: five blocks per CU for the latency-bound K <= 1280 linears
+static bool asd_cfg_is_window(int cfg) { return cfg >= ASD_GEMM_WIN0 && cfg < ASD_GEMM_WIN0 + 4; }
 
 static bool asd_conv_window_ok(const asd_gemm_args* a) {
     return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Cin % 64 == 0 && a->Hin == a->Hout &&
@@ -857,6 +858,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         GEMM_CASE(5, 256, 256, 2, 4);
         GEMM_CASE(6, 256, 320, 2, 4);
         GEMM_CASE(7, 320, 128, 5, 2);
+        GEMM_CASE(12, 64, 64, 2, 2);
         default: asd_set_error("bad tile configuration %d", cfg); return ASD_ERR_ARG;
     }
 #undef GEMM_CASE

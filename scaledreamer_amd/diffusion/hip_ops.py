@@ -43,8 +43,8 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # captures (tools/gemm_sweep.py).  Like a BLAS library's tuned-kernel table, each new shape is timed once over the valid
 # candidates (a few ms, outside graph capture) and the winner is cached for the process; ASD_GEMM_AUTOTUNE=0 keeps the
 # built-in cost model (csrc/gemm.hip: asd_gemm_pick_tile) + pick_split_k.
-TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128)
-TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256)
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64)
 WINDOW_TILES = (8, 9, 10, 11)   # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels); 10, 11: two blocks per CU
 AUTOTUNE = os.environ.get("ASD_GEMM_AUTOTUNE", "1") != "0"
 PLAN_FILE = os.environ.get("ASD_GEMM_PLAN_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans.json"))
@@ -113,8 +113,12 @@ def _autotune(key, launch, M, N, K, conv=None, geglu=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for t, sk in _candidates(M, N, K, conv, geglu):
         launch(t + 1, sk)
+        # An eager launch costs the host ~8-10 us: timed back to back, candidates faster than that tie at the host's rate.
+        # Park the GPU on a spin kernel while the launches are queued, so that the events bracket GPU time only — what the
+        # graph-replayed step sees (rocprofv3: tools/trace_by_grid.py).
+        torch.cuda._sleep(300_000)
         e0.record()
-        for _ in range(3):
+        for _ in range(5):
             launch(t + 1, sk)
         e1.record()
         e1.synchronize()

@@ -76,7 +76,7 @@ def test_conv3x3_variants(B, H_, W_, Cin, Cout, stride, pad, up):
     _close(got.permute(0, 3, 1, 2), ref)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1)])
 def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
     """all GEMM tile shapes (implicit GEMM 128x64 ... 256x320, 320x128) and the LDS-window kernels (16x16-pixel patches x 64 /

@@ -7,8 +7,8 @@ import torch
 from scaledreamer_amd._lib import lib
 from scaledreamer_amd.diffusion import hip_ops as H
 
-TILES = ["128x64", "128x128", "256x64", "256x128", "128x320", "256x256", "256x320", "320x128", "win64", "win128"]
-BN = [64, 128, 64, 128, 320, 256, 320, 128, 64, 128]
+TILES = ["128x64", "128x128", "256x64", "256x128", "128x320", "256x256", "256x320", "320x128", "win64", "win128", "win64x2", "win128x2", "64x64"]
+BN = [64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64]
 
 
 def timeit(fn, reps=20):
@@ -54,13 +54,13 @@ for sh in shapes:
     for t, name in enumerate(TILES):
         if N % BN[t] != 0 and not (BN[t] == 64):
             continue
-        if t >= 8 and (sh[0] != "conv" or sh[2] % 16 != 0 or sh[3] % 64 != 0):
+        if 8 <= t <= 11 and (sh[0] != "conv" or sh[2] % 16 != 0 or sh[3] % 64 != 0):
             continue
         lib().asd_gemm_force_tile(C.c_int32(t))
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
             if sk > 1 and (K // sk < 256):
                 continue
-            if t >= 8 and sk > sh[3] // 64:
+            if 8 <= t <= 11 and sk > sh[3] // 64:
                 continue
             res.append((timeit(lambda: run(sk), reps=8), name, sk))
     lib().asd_gemm_force_tile(C.c_int32(-1))
