@@ -14,6 +14,13 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff
 // C > 2048) and walks the rows of its chunk with stride 256/slots, accumulating per-channel sums in registers;
 // only at the end are they folded into 32 per-group LDS cells and from there into global memory (one atomic
 // pair per block and group).
+#ifndef GN_UNR
+#define GN_UNR 4      // rows in flight per thread (16-B loads)
+#endif
+#ifndef GN_CAP_A
+#define GN_CAP_A 512  // apply blocks per launch
+#endif
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
                                                        int c2, int hw, int rows_per_block, float* __restrict__ stats) {
     __shared__ float gsum[32], gsq[32];
@@ -38,12 +45,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
         const half_t* base = c < c1 ? x1 + (size_t)b * hw * c1 + c : x2 + (size_t)b * hw * c2 + (c - c1);
         const size_t rstride = c < c1 ? c1 : c2;
         int r = r0 + rsub;
-        for (; r + 3 * rows_in_flight < r1; r += 4 * rows_in_flight) {
-            half8 v[4];
+        for (; r + (GN_UNR - 1) * rows_in_flight < r1; r += GN_UNR * rows_in_flight) {
+            half8 v[GN_UNR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
+            for (int u = 0; u < GN_UNR; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < GN_UNR; ++u)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float f = (float)v[u][k]; s[k] += f; q[k] = fmaf(f, f, q[k]); }
         }
@@ -122,12 +129,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         const size_t rstride = c < c1 ? c1 : c2;
         half_t* ybase = y + (size_t)b * hw * C + c;
         int r = r0 + rsub;
-        for (; r + 3 * rows_in_flight < r1; r += 4 * rows_in_flight) {
-            half8 v[4];
+        for (; r + (GN_UNR - 1) * rows_in_flight < r1; r += GN_UNR * rows_in_flight) {
+            half8 v[GN_UNR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
+            for (int u = 0; u < GN_UNR; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GN_UNR; ++u) {
                 half8 o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -494,7 +501,7 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     int chunks = asd_div_up(hw, 16);
     // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
     // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
-    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(512, batch);
+    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(GN_CAP_A, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
                        asd_div_up(hw, chunks_s), partials);
@@ -514,7 +521,7 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     int chunks = asd_div_up(hw, 16);
     // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
     // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
-    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(512, batch);
+    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(GN_CAP_A, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
                        asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);

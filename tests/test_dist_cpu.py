@@ -58,3 +58,23 @@ def test_single_process_is_a_noop():
     p.grad = torch.full((3,), 2.0)
     asd_dist.allreduce_mean_grads(torch.optim.SGD([p], lr=0.1))
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def test_stdout_to_stderr_keeps_c_level_prints_off_stdout():
+    """RCCL printf()s a banner to the C stdout; bench.py's stdout must be exactly one JSON line (dist.stdout_to_stderr)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, sys\n"
+        "from scaledreamer_amd import dist as D\n"
+        "libc = ctypes.CDLL(None)\n"
+        "with D.stdout_to_stderr():\n"
+        "    libc.printf(b'BANNER from C\\n')\n"
+        "    print('python print inside')\n"
+        "print('{\"json\": 1}')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == '{"json": 1}'
+    assert "BANNER from C" in r.stderr and "python print inside" in r.stderr

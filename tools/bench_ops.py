@@ -47,10 +47,10 @@ for (rows, c) in [(20480, 320), (5120, 640), (1280, 1280)]:
     x, g, b = r(rows, c), r(c), r(c)
     us = timeit(lambda: H.layernorm(x, g, b))
     print(f"  layernorm {rows}x{c}: {us:7.1f} us  {rows * c * 4 / us / 1e3:7.1f} GB/s")
-for (hw, c) in [(4096, 320), (4096, 960), (1024, 640), (256, 1280), (64, 2560)]:
-    x, g, b = r(B, hw, c), r(c), r(c)
+for (bb, hw, c) in [(B, 4096, 320), (B, 4096, 960), (B, 1024, 640), (B, 256, 1280), (B, 64, 2560), (1, 262144, 128), (1, 65536, 256), (1, 16384, 512)]:
+    x, g, b = r(bb, hw, c), r(c), r(c)
     us = timeit(lambda: H.groupnorm(x, g, b, 1e-5, True))
-    print(f"  groupnorm+silu {B}x{hw}x{c}: {us:7.1f} us  {B * hw * c * 6 / us / 1e3:7.1f} GB/s (read x2, write x1)")
+    print(f"  groupnorm+silu {bb}x{hw}x{c}: {us:7.1f} us  {bb * hw * c * 6 / us / 1e3:7.1f} GB/s (read x2, write x1)")
 h = r(20480, 2560)
 us = timeit(lambda: H.geglu(h))
 print(f"  geglu 20480x1280: {us:7.1f} us  {20480 * 1280 * 6 / us / 1e3:7.1f} GB/s")
