@@ -124,10 +124,10 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
 
 
 def roofline_gemm_kernel(reps: int = 50):
-    """The single kernel with the largest share in the rocprofv3 summary is the plain GEMM gemm_f16_kernel<256,64,4,2,false>
-    (13.4 %, ~136 launches per step over the K <= 1280 linears of the UNet transformers).  Its most frequent shape, the 320 -> 320
-    linear on the 64x64 tokens of the UNet batch (M=20480, N=320, K=320; 25 launches per step), has 161 FLOP per algorithmic byte,
-    below the machine balance of 2500 / 8 = 312: HBM-bound.  Algorithmic bytes = A + W + C in fp16, each touched once."""
+    """The plain GEMMs of the K <= 1280 transformer linears are the largest MFMA family after the window convolutions
+    (profiles/r01_final6_kernel_stats_top70.csv: gemm_f16_kernel<64,64> 7.8 % + <256,64> 6.9 %, ~150 launches per step).  Their most
+    frequent shape, the 320 -> 320 linear on the 64x64 tokens of the UNet batch (M=20480, N=320, K=320; 25 launches per step), has
+    161 FLOP per algorithmic byte, below the machine balance of 2500 / 8 = 312: HBM-bound.  Algorithmic bytes = A + W + C in fp16, each touched once."""
     from scaledreamer_amd.diffusion import hip_ops as H
 
     M, N, K = 20480, 320, 320
