@@ -228,17 +228,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     const int fa0 = (wm * (BM / WM) + frow) * RB, fb0 = A_BYTES + (wn * (BN / WN) + frow) * RB;
     const int fsw[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
 
-    const int nk = ks1 - ks0;
-    if (nk > 0) {
+    // Input gradient of a stride-2 convolution (upsample == 2): tap (ky, kx) reaches output row Y only when Y + pad - ky is even.
+    // When the whole tile lies in ONE image row (always at W >= BM), the k-steps of the other ky parity multiply zero pages for
+    // every row of the tile: skip them (wave-uniform) — 6 or 3 of the 9 taps remain, 2x fewer k-steps on average.
+    int live_ky_parity = -1;    // -1: every k-step is live
+    if (CONV && p.upsample == 2 && (p.Cin & 63) == 0) {
+        const int m_last = min(m0 + BM, p.M) - 1;
+        if (m0 / p.Wout == m_last / p.Wout) live_ky_parity = ((m0 / p.Wout) % p.Hout + p.pad) & 1;
+    }
+    auto live = [&](int ks) -> bool {
+        if (!CONV || live_ky_parity < 0) return true;
+        const int ky = ((ks * 64) / p.Cin) / 3;
+        return (ky & 1) == live_ky_parity;
+    };
+    int k = ks0;
+    while (k < ks1 && !live(k)) ++k;
+    if (k < ks1) {
         // Two stages.  Measured (tools/map_ab.py): 3- and 4-stage rings with vmcnt(n) waits are 5-40 % SLOWER on every shape of the
         // step, small K included — the extra LDS costs the second / third co-resident block per CU, and it is the co-resident
         // blocks (independent barriers, out of phase) that fill each other's load and barrier bubbles.
-        issue(ks0, 0);
-        for (int k = 0; k < nk; ++k) {
+        issue(k, 0);
+        for (int stage = 0;; stage ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // tile k visible block-wide; everyone is done reading tile k-1
-            if (k + 1 < nk) issue(ks0 + k + 1, (k + 1) & 1);
-            const char* As = smem + (k & 1) * STAGE_BYTES;
+            __builtin_amdgcn_s_barrier();  // this tile visible block-wide; everyone is done reading the previous one
+            int kn = k + 1;
+            while (kn < ks1 && !live(kn)) ++kn;
+            if (kn < ks1) issue(kn, stage ^ 1);
+            const char* As = smem + stage * STAGE_BYTES;
             // big register tiles: keep ONE set of fragments live (no cross-kh prefetch), the loop is load-bound anyway
 #pragma unroll TM * TN >= 32 ? 1 : 2
             for (int kh = 0; kh < 2; ++kh) {
@@ -254,6 +270,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
             }
+            if (kn >= ks1) break;
+            k = kn;
         }
     }
 
