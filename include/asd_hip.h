@@ -263,6 +263,8 @@ typedef struct asd_gemm_args {
     float*  workspace;
     int32_t tile_cfg;       /* 0: tile chosen by the built-in cost model; 1 + i: tile configuration i (see asd_gemm_force_tile),
                                as found by the caller's autotuner (scaledreamer_amd/diffusion/hip_ops.py) */
+    int32_t ld_row_bias;    /* row stride (halfs) of row_bias; 0 = N.  Lets a column slice of a wider matrix be used in place
+                               (the UNet keeps every ResBlock's time-embedding projection in one [B, sum Cout] matrix) */
     int32_t group_m, group_n; /* block order: workgroups of one XCD walk group_m x group_n super-tiles so that they share operand
                                tiles through that XCD's L2 (csrc/gemm.hip, asd_xcd_item); 0 = chosen by the library */
 } asd_gemm_args;

@@ -76,7 +76,7 @@ class GemmArgs(C.Structure):
         ("conv", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("Hout", C.c_int32),
         ("Wout", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("upsample", C.c_int32),
         ("zero_page", C.c_void_p), ("split_k", C.c_int32), ("workspace", C.c_void_p),
-        ("tile_cfg", C.c_int32), ("group_m", C.c_int32), ("group_n", C.c_int32),
+        ("tile_cfg", C.c_int32), ("ld_row_bias", C.c_int32), ("group_m", C.c_int32), ("group_n", C.c_int32),
     ]
 
 

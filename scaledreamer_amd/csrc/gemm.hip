@@ -319,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + em;
         if (m >= p.M) continue;
-        const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.N : nullptr;
+        const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + en;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void gemm_store4(const asd_gemm_args& p, floatx4 v, i
         v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
     }
     if (p.row_bias) {
-        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.N + n);
+        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
         v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
     }
     if (p.act == 1) {
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
         v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
     }
     if (p.row_bias) {
-        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.N + n);
+        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
         v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
     }
     if (p.act == 1) {
@@ -777,8 +777,9 @@ static void asd_pick_group(int tiles_m, int tiles_n, int bm, int bn, size_t lds,
 
 int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     ASD_CHECK_ARG(a_in, "null argument");
-    asd_gemm_args a_copy = *a_in;           // group_m / group_n are filled in here when the caller left them 0
+    asd_gemm_args a_copy = *a_in;           // group_m / group_n / ld_row_bias are filled in here when the caller left them 0
     asd_gemm_args* a = &a_copy;
+    if (a->ld_row_bias <= 0) a->ld_row_bias = a->N;
     ASD_CHECK_ARG(a && a->A && a->W && a->C && a->zero_page, "null argument");
     ASD_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
     ASD_CHECK_ARG(a->K % 8 == 0, "K must be a multiple of 8");

@@ -91,7 +91,7 @@ class HipUNet:
         off, cout = self.emb_slices[name]
         h = H.groupnorm(x.view(B, Hh * Ww, cin), w[name + ".in_layers.0.weight"], w[name + ".in_layers.0.bias"], 1e-5, True)
         h = H.conv3x3(h.view(B, Hh, Ww, cin), w[name + ".in_layers.2.weight"], bias=w[name + ".in_layers.2.bias"],
-                      row_bias=emb_all[:, off:off + cout].contiguous(), rows_per_group=Hh * Ww)
+                      row_bias=emb_all[:, off:off + cout], rows_per_group=Hh * Ww)
         h = H.groupnorm(h.view(B, Hh * Ww, cout), w[name + ".out_layers.0.weight"], w[name + ".out_layers.0.bias"], 1e-5, True)
         if name + ".skip_connection.weight" in w:
             skip = H.gemm(x, w[name + ".skip_connection.weight"], bias=w[name + ".skip_connection.bias"])

@@ -151,6 +151,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     g.lda, g.ldw, g.ldc = lda, w.stride(0), out.stride(0)
     g.bias = None if bias is None else bias.data_ptr()
     g.row_bias = None if row_bias is None else row_bias.data_ptr()
+    if row_bias is not None:     # a column slice of a wider matrix is used in place (row stride = its leading dimension)
+        assert row_bias.stride(-1) == 1 and row_bias.shape[-1] == N, "row_bias: [groups, N] with unit column stride"
+        g.ld_row_bias = row_bias.stride(0) if row_bias.dim() == 2 and row_bias.shape[0] > 1 else N
     g.rows_per_group = rows_per_group if row_bias is not None else 1
     g.residual = None if residual is None else residual.data_ptr()
     g.ldr = 0 if residual is None else residual.stride(0)
