@@ -24,18 +24,21 @@ from . import hip_ops as H
 from . import weights as W
 
 P = Dict[str, torch.Tensor]
+_FUSE_SHORTCUT = __import__("os").environ.get("ASD_VAE_FUSE_SHORTCUT", "1") != "0"   # A/B switch (tools)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_fwd, bias, w_bwd, stride, pad):
+    def forward(ctx, x, w_fwd, bias, w_bwd, stride, pad, residual=None):
         B, Hh, Ww, _ = x.shape
         if stride == 2:  # asymmetric (0,1,0,1) zero padding, model.py:80-85
             out_hw = ((Hh + 1 - 3) // 2 + 1, (Ww + 1 - 3) // 2 + 1)
         else:
             out_hw = (Hh, Ww)
         ctx.w_bwd, ctx.stride, ctx.in_hw = w_bwd, stride, (Hh, Ww)
-        return H.conv3x3(x, w_fwd, bias=bias, stride=stride, pad=pad, out_hw=out_hw)
+        ctx.has_res, ctx.n_out = residual is not None, w_fwd.shape[0]
+        # the shortcut of a ResnetBlock (model.py:141-148: x + h) is added in the conv epilogue: no separate add pass
+        return H.conv3x3(x, w_fwd, bias=bias, stride=stride, pad=pad, out_hw=out_hw, residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
@@ -46,7 +49,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             dx = H.conv3x3(dy, ctx.w_bwd, stride=1, pad=1)
         else:
             dx = H.conv3x3(dy, ctx.w_bwd, stride=1, pad=0, upsample=2, out_hw=ctx.in_hw)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, (dy[..., :ctx.n_out].reshape(-1, ctx.n_out) if ctx.has_res else None)
 
 
 class _GroupNormFn(torch.autograd.Function):
@@ -192,12 +195,14 @@ class HipVAEEncoder:
                 t = _GroupNormFn.apply(h, w[name + ".norm1.weight"], w[name + ".norm1.bias"], 1e-6, True)
                 t = _Conv3x3Fn.apply(t, w[name + ".conv1.fwd"], w[name + ".conv1.bias"], w[name + ".conv1.bwd"], 1, 1)
                 t = _GroupNormFn.apply(t, w[name + ".norm2.weight"], w[name + ".norm2.bias"], 1e-6, True)
-                t = _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1)
                 if name + ".nin.w" in w:
-                    s = _LinearFn.apply(h.reshape(-1, cin), w[name + ".nin.w"], w[name + ".nin.b"], w[name + ".nin.wt"]).view(*h.shape[:3], cout)
+                    s = _LinearFn.apply(h.reshape(-1, cin), w[name + ".nin.w"], w[name + ".nin.b"], w[name + ".nin.wt"])
                 else:
-                    s = h
-                h = s + t
+                    s = h.reshape(-1, cout)
+                if _FUSE_SHORTCUT:
+                    h = _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1, s)   # + shortcut
+                else:
+                    h = s.view(*h.shape[:3], cout) + _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1)
             elif kind == "down":
                 h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 2, 0)
             elif kind == "attn":
