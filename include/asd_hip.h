@@ -284,8 +284,10 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
 /* Input gradient of GroupNorm(+SiLU) with frozen gamma/beta (VAE encoder backward, the reference keeps the
  * VAE in the autograd graph: stable_diffusion_asd_guidance.py:171-178,225): dx from x, dy and the forward stats. */
 int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,
-                          const void* beta, float eps, int32_t silu, const float* fwd_stats, void* dx,
-                          float* bwd_stats /* workspace: ASD_GN_STATS_FLOATS(batch) - 64*batch floats */, void* stream);
+                          const void* beta, float eps, int32_t silu, const float* fwd_stats,
+                          const void* dx_add /* optional [batch, hw, c] fp16 added to the result: the gradient reaching x through
+                                                its other consumer (the ResnetBlock shortcut, model.py:141-148) */,
+                          void* dx, float* bwd_stats /* workspace: ASD_GN_STATS_FLOATS(batch) - 64*batch floats */, void* stream);
 /* y[cols, rows] = x[rows, cols]^T, fp16 (operand layout changes for the attention-backward GEMMs). */
 int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream);
 /* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */

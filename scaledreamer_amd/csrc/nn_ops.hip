@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restr
                                                            int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                            const half_t* __restrict__ beta, float eps, int silu,
                                                            const float* __restrict__ fstats, const float* __restrict__ bpartials,
-                                                           int n_chunks, half_t* __restrict__ dx) {
+                                                           int n_chunks, const half_t* __restrict__ dx_add,
+                                                           half_t* __restrict__ dx) {
     __shared__ float st[64];
     __shared__ float scratch[4][64];
     const int slots = C / 8, cg = C / 32;
@@ -283,6 +284,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restr
                 float gg = (float)dv[k] * gm[k];
                 if (silu) gg *= silu_grad(fmaf(xh, gm[k], bt[k]));
                 o[k] = (half_t)(rstd[k] * (gg - m1[k] - xh * m2[k]));
+            }
+            if (dx_add) {   // the gradient of the block's other consumer (ResnetBlock shortcut) is accumulated here
+                const half8 av = *(const half8*)(dx_add + off);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (half_t)((float)o[k] + (float)av[k]);
             }
             *(half8*)(dx + off) = o;
         }
@@ -513,8 +519,8 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
 }
 
 int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,
-                          const void* beta, float eps, int32_t silu, const float* fwd_stats, void* dx, float* bwd_stats,
-                          void* stream) {
+                          const void* beta, float eps, int32_t silu, const float* fwd_stats, const void* dx_add, void* dx,
+                          float* bwd_stats, void* stream) {
     ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && dx && bwd_stats && batch > 0 && hw > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
@@ -527,7 +533,7 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
                        asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
                        asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats, chunks_s,
-                       (half_t*)dx);
+                       (const half_t*)dx_add, (half_t*)dx);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

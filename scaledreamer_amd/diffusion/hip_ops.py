@@ -228,13 +228,17 @@ def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optiona
     return (y, stats[:B * 64]) if return_stats else y
 
 
-def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor) -> torch.Tensor:
+def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor,
+                  dx_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """input gradient of GroupNorm(+SiLU); dx_add (same shape as x) is added to it in the same pass."""
     B, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c)
     dx = torch.empty_like(x)
     bstats = torch.empty((512 + B) * 64, device=x.device, dtype=torch.float32)
+    if dx_add is not None:
+        assert dx_add.is_contiguous() and dx_add.numel() == x.numel() and dx_add.dtype == x.dtype
     check(lib().asd_groupnorm_bwd_f16(ptr(x), ptr(dy), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)),
-                                      ptr(stats), ptr(dx), ptr(bstats), stream()))
+                                      ptr(stats), ptr(dx_add), ptr(dx), ptr(bstats), stream()))
     return dx
 
 

@@ -79,6 +79,42 @@ class _LinearFn(torch.autograd.Function):
         return H.gemm(dy.contiguous(), ctx.w_t), None, None, None
 
 
+class _ResBlockFn(torch.autograd.Function):
+    """ResnetBlock of the VAE encoder (model.py:95-148) as ONE autograd node: x feeds both norm1 and the shortcut, so plain
+    autograd sums two gradients for it with a separate add pass over the activation.  Here the shortcut gradient enters the
+    norm1 backward kernel (`dx_add`) or, with a 1x1 `nin_shortcut`, the residual input of its GEMM: no add pass in either
+    direction.  Frozen weights: only the input gradient exists."""
+
+    @staticmethod
+    def forward(ctx, x, wd):
+        B, Hh, Ww, cin = x.shape
+        cout = wd["conv2.fwd"].shape[0]
+        t1, st1 = H.groupnorm(x, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, return_stats=True)
+        t2 = H.conv3x3(t1, wd["conv1.fwd"], bias=wd["conv1.bias"], stride=1, pad=1)
+        del t1
+        t3, st2 = H.groupnorm(t2, wd["norm2.weight"], wd["norm2.bias"], 1e-6, True, return_stats=True)
+        s = H.gemm(x.reshape(-1, cin), wd["nin.w"], bias=wd["nin.b"]) if "nin.w" in wd else x.reshape(-1, cout)
+        out = H.conv3x3(t3, wd["conv2.fwd"], bias=wd["conv2.bias"], stride=1, pad=1, residual=s)
+        ctx.save_for_backward(x, st1, t2, st2)
+        ctx.wd = wd
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st1, t2, st2 = ctx.saved_tensors
+        wd = ctx.wd
+        dy = dy.contiguous()
+        d3 = H.conv3x3(dy, wd["conv2.bwd"], stride=1, pad=1)
+        d2 = H.groupnorm_bwd(t2, d3, wd["norm2.weight"], wd["norm2.bias"], 1e-6, True, st2)
+        d1 = H.conv3x3(d2, wd["conv1.bwd"], stride=1, pad=1)
+        if "nin.w" in wd:
+            dmain = H.groupnorm_bwd(x, d1, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, st1)
+            dx = H.gemm(dy.reshape(-1, dy.shape[-1]), wd["nin.wt"], residual=dmain.reshape(-1, x.shape[-1])).view_as(x)
+        else:
+            dx = H.groupnorm_bwd(x, d1, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, st1, dx_add=dy)
+        return dx, None
+
+
 class _AttnFn(torch.autograd.Function):
     """Single-head attention over [B, L, C] rows (AttnBlock, model.py:195-224): per image S = Q K^T -> P = softmax(S / sqrt(C))
     -> O = P V as two MFMA GEMMs around a row-softmax kernel; the input gradients are four more GEMMs around the
@@ -183,6 +219,14 @@ class HipVAEEncoder:
             return self._graphed[key](images.contiguous())
         return self._forward(images)
 
+    def _res_weights(self, name: str) -> Dict[str, torch.Tensor]:
+        """the packed tensors of one ResnetBlock under block-local names (cached)"""
+        cache = self.__dict__.setdefault("_res_cache", {})
+        if name not in cache:
+            pre = name + "."
+            cache[name] = {k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}
+        return cache[name]
+
     def _forward(self, images: torch.Tensor) -> torch.Tensor:
         w = self.w
         B, Cin, Hh, Ww = images.shape
@@ -191,6 +235,8 @@ class HipVAEEncoder:
         for kind, name, cin, cout in self.plan:
             if kind == "conv":
                 h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 1, 1)
+            elif kind == "res" and _FUSE_SHORTCUT:
+                h = _ResBlockFn.apply(h, self._res_weights(name))
             elif kind == "res":
                 t = _GroupNormFn.apply(h, w[name + ".norm1.weight"], w[name + ".norm1.bias"], 1e-6, True)
                 t = _Conv3x3Fn.apply(t, w[name + ".conv1.fwd"], w[name + ".conv1.bias"], w[name + ".conv1.bwd"], 1, 1)

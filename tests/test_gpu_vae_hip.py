@@ -63,6 +63,13 @@ def test_conv_dgrad_and_groupnorm_bwd_ops():
         y = _GroupNormFn.apply(xh, g, b, 1e-6, silu)
         y.backward(gy.half())
         assert _rel(xh.grad, xr.grad)[1] < 5e-3, (Cc, silu)
+        # the fused accumulation of a second gradient (ResnetBlock shortcut) is the plain sum
+        _, stats = H.groupnorm(x, g, b, 1e-6, silu, return_stats=True)
+        extra = torch.randn_like(x)
+        gyh = gy.half().contiguous()
+        fused = H.groupnorm_bwd(x, gyh, g, b, 1e-6, silu, stats, dx_add=extra)
+        plain = H.groupnorm_bwd(x, gyh, g, b, 1e-6, silu, stats)
+        assert _rel(fused, plain.float() + extra.float())[1] < 2e-3, (Cc, silu)
 
 
 @pytest.mark.parametrize("name", ["diffusion_vae_small", "diffusion_vae_full_256"])
