@@ -89,7 +89,8 @@ PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("une
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final7_kernel_stats_top70.csv:
-    conv3x3_win2_kernel<128> + conv3x3_win_kernel<128> + conv3x3_win2_kernel<64> 15.6 % of the kernel time, gemm_f16_kernel variants 35 %).  Average duration of one launch, HIP events on
+    conv3x3_win2_kernel<128> + conv3x3_win_kernel<128> + conv3x3_win2_kernel<64> + conv3x3_win_kernel<64> 19.4 % of the kernel
+    time, gemm_f16_kernel variants 27 %).  Average duration of one launch, HIP events on
     the launch stream, on its heaviest single shape:
       vae512: 3x3 conv 128->128 at 512x512 (VAE encoder level 0, forward and input-gradient: 8 launches per step) M=262144 N=128 K=1152
       unet64: 3x3 conv 320->320 at 64x64 for the UNet batch of 5 (7 launches per UNet forward)                 M=20480  N=320 K=2880
@@ -125,7 +126,7 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
 
 def roofline_gemm_kernel(reps: int = 50):
     """The plain GEMMs of the K <= 1280 transformer linears are the largest MFMA family after the window convolutions
-    (profiles/r01_final7_kernel_stats_top70.csv: gemm_f16_kernel<64,64> 7.8 % + <256,64> 6.9 %, ~150 launches per step).  Their most
+    (profiles/r01_final7_kernel_stats_top70.csv: gemm_f16_kernel<64,64> 10.8 % + <256,64> 4.9 %, ~155 launches per step).  Their most
     frequent shape, the 320 -> 320 linear on the 64x64 tokens of the UNet batch (M=20480, N=320, K=320; 25 launches per step), has
     161 FLOP per algorithmic byte, below the machine balance of 2500 / 8 = 312: HBM-bound.  Algorithmic bytes = A + W + C in fp16, each touched once."""
     from scaledreamer_amd.diffusion import hip_ops as H
