@@ -36,6 +36,8 @@ def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
 
+    if backend == "eager":   # A/B tool: the library-op backend is registered only on demand (tools/eager_backend.py)
+        import tools.eager_backend  # noqa: F401
     mv = workload == "asd_mv_nerf"
     if workload in ("asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"):
         return build_hyper_system(backend, seed, workload)

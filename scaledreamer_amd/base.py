@@ -105,7 +105,7 @@ class BaseModule(nn.Module, Updateable):
         if self.cfg.weights is not None:
             # format: path/to/weights:module_name  (utils/base.py:103-112)
             weights_path, module_name = self.cfg.weights.split(":")
-            ckpt = torch.load(weights_path, map_location="cpu")
+            ckpt = torch.load(weights_path, map_location="cpu", weights_only=False)   # Lightning checkpoints carry non-tensor objects; the path comes from the user's own config
             prefix = module_name + "."
             sd = {k[len(prefix):]: v for k, v in ckpt["state_dict"].items() if k.startswith(prefix)}
             self.load_state_dict(sd)

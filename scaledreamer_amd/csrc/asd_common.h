@@ -164,19 +164,28 @@ __device__ __forceinline__ void asd_scatter(const asd_grid_meta& m, float* __res
         }
     }
 }
-// Scatter with wave-level run aggregation.  Samples are packed ray-major / t-ascending, so on the coarse
-// levels consecutive lanes of a wave fall into the same grid cell (run length ~ cell size / march step: ~18 on
-// level 0, ~1.4 on level 7) and would hit the same 8 table entries with 16 atomics each.  gfx950 sustains only
-// ~21 G fp32 atomics/s (3.6 G/s on a hot address set, tools/atomic_probe.hip), so for levels < NAGG the per-corner
-// contributions of a run are first summed across its lanes (segmented shuffle reduction on the run id) and only
-// the run's first lane issues the atomics.  Must be called by all 64 lanes (inactive lanes pass active=false).
+// Scatter with wave-level run aggregation and request coalescing.
+//
+// What gfx950 rate-limits is not the fp32 atomic but the REQUEST: the lanes of one atomic instruction that fall into the same
+// 64-byte block travel as one request, and the chip retires ~21 G requests/s whatever their width, scope or table size
+// (tools/atomic_probe2.hip: 1 dword per block 21 G dword-atomics/s, 2 -> 42, 4 -> 84, 16 -> 311).  A table entry is two adjacent
+// floats, and the x-neighbour corner is the adjacent entry on the dense levels and — when cx is even — on the hashed ones
+// ((cx ^ h) and ((cx + 1) ^ h) differ in bit 0 only).  So:
+//   * levels >= NAGG (no sharing between neighbouring samples): the work of a wave is transposed — lanes 4k..4k+3 of one
+//     instruction carry (corner x0: f0, f1 | corner x1: f0, f1) of ONE source sample, 16 samples per instruction — so the 16
+//     dword updates of a sample and level travel in 4..8 requests instead of 16;
+//   * levels < NAGG: samples are packed ray-major / t-ascending, consecutive lanes fall into the same cell (run length ~ cell
+//     size / march step: ~18 on level 0, ~1.4 on level 7).  The per-corner contributions of a run are first summed across its
+//     lanes (segmented shuffle reduction on the run id); the run head then issues f0 while the run's second lane issues the f1 of
+//     the same entry in the same instruction (one request); single-lane runs fall back to a second instruction.
+// Must be called by all 64 lanes (inactive lanes pass active=false).
 template <int L, int NAGG>
 __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* __restrict__ dparams, float x, float y,
                                                  float z, const float (&denc)[2 * L], bool active) {
     x = asd_unit(x); y = asd_unit(y); z = asd_unit(z);
     const int lane = asd_lane();
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < (NAGG < L ? NAGG : L); ++l) {
         const float g0 = active ? denc[2 * l] : 0.f, g1 = active ? denc[2 * l + 1] : 0.f;
         const float s = m.scale[l];
         const float px = fmaf(s, x, 0.5f), py = fmaf(s, y, 0.5f), pz = fmaf(s, z, 0.5f);
@@ -184,45 +193,70 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
         const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
         const float wx = px - fx, wy = py - fy, wz = pz - fz;
         float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l];
-        if (l < NAGG) {
-            const uint32_t res = m.resolution[l];
-            const uint32_t key = active ? cx + (cy + cz * res) * res : 0xFFFFFFFFu - (uint32_t)lane;
-            const uint32_t prev = __shfl_up(key, 1, 64);
-            const bool head = lane == 0 || prev != key;
-            const unsigned long long hm = __ballot(head);
-            const int rid = __popcll(hm & (~0ull >> (63 - lane)));   // heads at or below this lane = run id
-            float v[16];
+        const uint32_t res = m.resolution[l];
+        const uint32_t key = active ? cx + (cy + cz * res) * res : 0xFFFFFFFFu - (uint32_t)lane;
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool head = lane == 0 || prev != key;
+        const unsigned long long hm = __ballot(head);
+        const int rid = __popcll(hm & (~0ull >> (63 - lane)));   // heads at or below this lane = run id
+        float v[16];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
-                v[2 * c] = wt * g0;
-                v[2 * c + 1] = wt * g1;
+        for (int c = 0; c < 8; ++c) {
+            const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+            v[2 * c] = wt * g0;
+            v[2 * c + 1] = wt * g1;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int prid = __shfl_down(rid, o, 64);
+            const bool ok = (lane + o < 64) && prid == rid;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float u = __shfl_down(v[q], o, 64);
+                v[q] += ok ? u : 0.f;
             }
+        }
+        // a run's second lane (not a head, its predecessor is) carries the head's f1; heads without such a lane issue it themselves
+        const bool issue = head && active;
+        const bool carrier = !head && ((hm >> (lane - 1)) & 1ull);           // lane >= 1 here (lane 0 is always a head)
+        const bool self_f1 = issue && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int prid = __shfl_down(rid, o, 64);
-                const bool ok = (lane + o < 64) && prid == rid;
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
+            const float f1_prev = __shfl_up(v[2 * c + 1], 1, 64);
+            // the carrier sits in the head's cell, so it forms the same idx
+            const float val = issue ? v[2 * c] : f1_prev;
+            float* dst = tab + 2u * (size_t)idx + (issue ? 0 : 1);
+            if ((issue || carrier) && val != 0.f) atomicAdd(dst, val);
+            if (self_f1 && v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
+        }
+    }
+    if (NAGG >= L) return;
+    // ---- fine levels, transposed: lane = (source sample k = lane >> 2 of group q, x corner (lane >> 1) & 1, feature lane & 1)
+    const int xb = (lane >> 1) & 1, ft = lane & 1;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int src = 16 * q + (lane >> 2);
+        const float sx = __shfl(x, src, 64), sy = __shfl(y, src, 64), sz = __shfl(z, src, 64);
+        const bool sact = __shfl((int)active, src, 64) != 0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float u = __shfl_down(v[q], o, 64);
-                    v[q] += ok ? u : 0.f;
-                }
-            }
-            if (head && active) {
+        for (int l = (NAGG < L ? NAGG : L); l < L; ++l) {
+            const float ga = __shfl(denc[2 * l], src, 64), gb = __shfl(denc[2 * l + 1], src, 64);
+            const float g = ft ? gb : ga;
+            if (!sact || g == 0.f) continue;
+            const float s = m.scale[l];
+            const float px = fmaf(s, sx, 0.5f), py = fmaf(s, sy, 0.5f), pz = fmaf(s, sz, 0.5f);
+            const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+            const uint32_t cx = (uint32_t)(int32_t)fx + (uint32_t)xb, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+            const float wx = px - fx, wy = py - fy, wz = pz - fz;
+            const float ax = xb ? wx : 1.f - wx;
+            float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l] + ft;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
-                    if (v[2 * c] != 0.f) atomicAdd(tab + 2u * (size_t)idx, v[2 * c]);
-                    if (v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
-                }
-            }
-        } else if (active && (g0 != 0.f || g1 != 0.f)) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float wt = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
-                const uint32_t idx = asd_grid_index(m, l, cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1));
-                atomicAdd(tab + 2u * (size_t)idx, wt * g0);
-                atomicAdd(tab + 2u * (size_t)idx + 1, wt * g1);
+            for (int c = 0; c < 4; ++c) {
+                // same product order as the one-lane-per-sample form: (ax * ay) * az
+                const float wt = ax * ((c & 1) ? wy : 1.f - wy) * ((c & 2) ? wz : 1.f - wz);
+                const uint32_t idx = asd_grid_index(m, l, cx, cy + (c & 1), cz + ((c >> 1) & 1));
+                atomicAdd(tab + 2u * (size_t)idx, wt * g);
             }
         }
     }

@@ -249,12 +249,25 @@ class HipBackend(DiffusionBackend):
         return self.hip_vae(images)
 
 
+def _backend_from_cfg(cfg, device, dtype, unet_cfg: W.UNetConfig) -> HipBackend:
+    """weights come from `cfg.ckpt_path` / `cfg.pretrained_model_name_or_path` (checkpoint.resolve_params); seeded random
+    weights only when the config says `allow_random_weights` — never silently."""
+    from . import checkpoint
+
+    vae_cfg = W.VAEConfig()
+    up, vp, what = checkpoint.resolve_params(cfg, unet_cfg, vae_cfg)
+    backend = HipBackend(device, dtype, seed=getattr(cfg, "weights_seed", 1), unet_cfg=unet_cfg, vae_cfg=vae_cfg,
+                         unet_params=up, vae_params=vp)
+    backend.weights_source = what
+    return backend
+
+
 @register_backend("hip")
 def _make_hip(cfg, device, dtype):
-    return HipBackend(device, dtype, seed=getattr(cfg, "weights_seed", 1))
+    return _backend_from_cfg(cfg, device, dtype, W.UNetConfig())
 
 
 @register_backend("hip-mvdream")
 def _make_hip_mvdream(cfg, device, dtype):
     """MVDream: the SD-2.1 UNet with camera_dim = 16 (extern/mvdream/configs/sd-v2-base.yaml:13-27)."""
-    return HipBackend(device, dtype, seed=getattr(cfg, "weights_seed", 1), unet_cfg=W.UNetConfig(camera_dim=16))
+    return _backend_from_cfg(cfg, device, dtype, W.UNetConfig(camera_dim=16))

@@ -66,61 +66,210 @@ def shutdown() -> None:
             dist.destroy_process_group()
 
 
-def _buckets(grads: List[torch.Tensor]):
-    cur, size = [], 0
-    for g in grads:
-        nb = g.numel() * g.element_size()
-        if cur and size + nb > BUCKET_BYTES:
-            yield cur
-            cur, size = [], 0
-        cur.append(g)
-        size += nb
-    if cur:
-        yield cur
+class GradientExchange:
+    """The one exchange step of the data-parallel path (launch.py:233-240: Lightning DDP): mean of every trainable gradient.
+
+    Design for one xGMI node (ring traffic is per-link bound, so few, large collectives; everything asynchronous):
+      * the exchange is cut into UNITS in a fixed order that is identical on every rank: each gradient of at least IN_PLACE_BYTES
+        (the 50 MB hash table, the feature volumes' generators) is its own unit and is all-reduced in place; the remaining
+        parameters are grouped into persistent flat buckets and their `.grad`s ARE views of the bucket (autograd accumulates into
+        them in place), so nothing is concatenated or copied back per step;
+      * a post-accumulate hook marks a unit ready the moment its last gradient has been written by the backward pass and launches
+        its all-reduce (async: RCCL orders it after the producing kernel and runs it on its own stream) while the rest of the
+        backward and the optimizer preparation continue.  Units are always launched in the fixed order — a rank that gets no
+        gradient for a parameter (empty-ray step, unused branch) contributes zeros from `finish()` — so the ranks can never issue
+        different collectives;
+      * the fixed order is the order in which rank 0 saw the units become ready in its first step (broadcast once), like DDP's
+        bucket rebuild: what finishes first is sent first.
+    Usage per step:  ex.prepare()  ->  loss.backward()  ->  ex.finish()  ->  optimizer.step()."""
+
+    def __init__(self, params, bucket_bytes: int = None, in_place_bytes: int = None):
+        self.params = [p for p in params if p.requires_grad]
+        bucket_bytes = BUCKET_BYTES if bucket_bytes is None else bucket_bytes
+        in_place_bytes = IN_PLACE_BYTES if in_place_bytes is None else in_place_bytes
+        self.units = []           # each: dict(params=[...], flat=Tensor|None)
+        cur, size = [], 0
+        for p in self.params:
+            nb = p.numel() * p.element_size()
+            if nb >= in_place_bytes:
+                self.units.append(dict(params=[p], flat=None))
+                continue
+            if cur and (size + nb > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self.units.append(self._flat_unit(cur))
+                cur, size = [], 0
+            cur.append(p)
+            size += nb
+        if cur:
+            self.units.append(self._flat_unit(cur))
+        self._unit_of = {}
+        for ui, u in enumerate(self.units):
+            for p in u["params"]:
+                self._unit_of[id(p)] = ui
+        self.order = list(range(len(self.units)))      # launch order (positions into self.units)
+        self._order_learned = False
+        self._seen_order: List[int] = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._armed = False
+        self.exposed_ms_events = None                   # (start, end) CUDA events of the last finish(): un-overlapped exchange time
+        self.prepare_called = 0
+
+    @staticmethod
+    def _flat_unit(ps):
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return dict(params=list(ps), flat=flat, views=views)
+
+    # ---- per step -----------------------------------------------------------------------------------------------------------
+    def prepare(self) -> None:
+        """replaces optimizer.zero_grad(): bucketed gradients are zeroed views of their bucket, large ones start undefined."""
+        for u in self.units:
+            if u["flat"] is None:
+                u["params"][0].grad = None
+            else:
+                u["flat"].zero_()
+                for p, v in zip(u["params"], u["views"]):
+                    if p.grad is not v:
+                        p.grad = v
+        self._pending = [len(u["params"]) for u in self.units]
+        self._ready = [False] * len(self.units)
+        self._launched = 0                              # number of positions of self.order already launched
+        self._works = []
+        self._seen_order = []
+        self._armed = True
+        self.prepare_called += 1
+
+    def _on_grad(self, p) -> None:
+        if not self._armed:
+            return
+        ui = self._unit_of[id(p)]
+        self._pending[ui] -= 1
+        if self._pending[ui] == 0:
+            self._ready[ui] = True
+            self._seen_order.append(ui)
+            if is_distributed() and self._order_learned:
+                self._launch_ready()
+
+    def _launch_ready(self, force: bool = False) -> None:
+        avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+        while self._launched < len(self.order):
+            ui = self.order[self._launched]
+            if not (self._ready[ui] or force):
+                return
+            u = self.units[ui]
+            if u["flat"] is None:
+                p = u["params"][0]
+                if p.grad is None:                      # this rank produced nothing for it: contribute zeros
+                    p.grad = torch.zeros_like(p)
+                buf = p.grad if p.grad.is_contiguous() else None
+                if buf is None:
+                    p.grad = p.grad.contiguous()
+                    buf = p.grad
+                self._works.append(dist.all_reduce(buf.view(-1), op=avg, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(u["flat"], op=avg, async_op=True))
+            self._launched += 1
+
+    def finish(self) -> None:
+        """launch what the hooks could not (units without a gradient on this rank), wait, turn sums into means."""
+        self._armed = False
+        if not is_distributed():
+            return
+        on_gpu = self.params and self.params[0].is_cuda
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._launch_ready(force=True)
+        for w in self._works:
+            w.wait()
+        if dist.get_backend() != "nccl":
+            world = dist.get_world_size()
+            for u in self.units:
+                (u["flat"] if u["flat"] is not None else u["params"][0].grad).div_(world)
+        if on_gpu:
+            e1.record()
+            self.exposed_ms_events = (e0, e1)
+        if not self._order_learned:                     # adopt rank 0's readiness order of this first step
+            seen = self._seen_order + [i for i in range(len(self.units)) if i not in self._seen_order]
+            t = torch.tensor(seen, dtype=torch.int64, device=self.params[0].device if on_gpu else "cpu")
+            dist.broadcast(t, src=0)
+            self.order = [int(v) for v in t.tolist()]
+            self._order_learned = True
+
+    def exposed_ms(self) -> float:
+        """GPU time between the end of this rank's backward and the end of the exchange in the last step (0 if fully hidden)."""
+        if self.exposed_ms_events is None:
+            return 0.0
+        e0, e1 = self.exposed_ms_events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def allreduce_mean_grads(optimizer: torch.optim.Optimizer) -> None:
-    """mean of every gradient over the ranks.  Large contiguous gradients (the 50 MB hash table) are reduced in place — no
-    flatten / scatter copies —, the small ones travel together in flat buckets; all calls are issued asynchronously and
-    waited for once, so RCCL can pipeline them over the xGMI links."""
+    """one-shot form (no overlap): mean of every gradient over the ranks, after the backward has finished.  Every parameter with
+    requires_grad takes part in a fixed order — a missing gradient contributes zeros — so the ranks always issue the same
+    collectives."""
     if not is_distributed():
         return
     world = dist.get_world_size()
-    grads = [p.grad for grp in optimizer.param_groups for p in grp["params"] if p.grad is not None]
-    big = [g for g in grads if g.is_contiguous() and g.numel() * g.element_size() >= IN_PLACE_BYTES]
-    small = [g for g in grads if not any(g is b for b in big)]
+    params = [p for grp in optimizer.param_groups for p in grp["params"] if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        elif not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
     avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
-    works, flats = [], []
-    for g in big:
-        works.append(dist.all_reduce(g.view(-1), op=avg, async_op=True))
-    for bucket in _buckets(small):
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        flats.append((flat, bucket))
-        works.append(dist.all_reduce(flat, op=avg, async_op=True))
+    works, flats, cur, size = [], [], [], 0
+
+    def flush():
+        nonlocal cur, size
+        if cur:
+            flat = torch.cat([q.grad.reshape(-1) for q in cur])
+            flats.append((flat, cur))
+            works.append(dist.all_reduce(flat, op=avg, async_op=True))
+        cur, size = [], 0
+
+    for p in params:
+        nb = p.numel() * p.element_size()
+        if nb >= IN_PLACE_BYTES:
+            works.append(dist.all_reduce(p.grad.view(-1), op=avg, async_op=True))
+            continue
+        if cur and (size + nb > BUCKET_BYTES or cur[0].dtype != p.dtype):
+            flush()
+        cur.append(p)
+        size += nb
+    flush()
     for w in works:
         w.wait()
     if avg == dist.ReduceOp.SUM:
-        for g in big:
-            g.div_(world)
-    for flat, bucket in flats:
+        for p in params:
+            if p.numel() * p.element_size() >= IN_PLACE_BYTES:
+                p.grad.div_(world)
+    for flat, ps in flats:
         if avg == dist.ReduceOp.SUM:
             flat.div_(world)
         off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        for q in ps:
+            q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
+            off += q.numel()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
-    """identical initial parameters on every rank (DDP broadcasts from rank 0 at wrap time)."""
+    """identical initial parameters and buffers on every rank (DDP broadcasts from rank 0 at wrap time).  Written through
+    copy_() so that tensor version counters move and caches keyed on them (the occupancy grid's packed bits) are rebuilt."""
     if not is_distributed():
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        if t.numel() == 0:
-            continue
-        if t.dtype == torch.bool:  # e.g. the occupancy grid's `binaries`
-            u = t.data.to(torch.uint8)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.numel() == 0:
+                continue
+            u = t.detach().to(torch.uint8) if t.dtype == torch.bool else t.detach().clone()   # e.g. the occupancy grid's `binaries`
             dist.broadcast(u, src=src)
-            t.data.copy_(u.bool())
-        else:
-            dist.broadcast(t.data, src=src)
+            t.copy_(u.to(t.dtype))

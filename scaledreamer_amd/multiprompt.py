@@ -232,51 +232,7 @@ class MultipromptRadienceFieldGeneratorSystem(StableDreamer):
             return {**self.renderer(**batch, render_rgb=False)}
         return {**self.renderer(**batch)}
 
-    def training_step(self, batch, batch_idx: int = 0):
-        out = self(batch)
-        guidance_inp = out["comp_normal"] if self.cfg.stage == "geometry" else out["comp_rgb"]
-        guidance_out = self.guidance(guidance_inp, self.prompt_utils, **batch, rgb_as_latents=self.cfg.rgb_as_latents)
-        loss = 0.0
-        for name, value in guidance_out.items():
-            self.log(f"train/{name}", value)
-            if name.startswith("loss_"):
-                loss = loss + value * self.C(self.cfg.loss[name.replace("loss_", "lambda_")])
-        if "coarse" not in self.cfg.stage:
-            raise ValueError(f"Unknown stage {self.cfg.stage}")
-        L = self.cfg.loss
-        if self.C(L.get("lambda_orient", 0.0)) > 0:
-            if "normal" not in out:
-                raise ValueError("Normal is required for orientation loss, no normal is found in the output.")
-            loss_orient = (out["weights"].detach() * dot(out["normal"], out["t_dirs"]).clamp_min(0.0) ** 2).sum() / (out["opacity"] > 0).sum()
-            self.log("train/loss_orient", loss_orient)
-            loss = loss + loss_orient * self.C(L["lambda_orient"])
-        if self.C(L.get("lambda_sparsity", 0.0)) > 0:
-            loss_sparsity = (out["opacity"] ** 2 + 0.01).sqrt().mean()
-            self.log("train/loss_sparsity", loss_sparsity)
-            loss = loss + loss_sparsity * self.C(L["lambda_sparsity"])
-        if self.C(L.get("lambda_opaque", 0.0)) > 0:
-            oc = out["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3)
-            loss_opaque = binary_cross_entropy(oc, oc)
-            self.log("train/loss_opaque", loss_opaque)
-            loss = loss + loss_opaque * self.C(L["lambda_opaque"])
-        if self.C(L.get("lambda_z_variance", 0.0)) > 0:
-            if "z_variance" not in out:
-                raise ValueError("z_variance is required for z_variance loss, no z_variance is found in the output.")
-            loss_z = out["z_variance"][out["opacity"] > 0.5].mean()
-            self.log("train/loss_z_variance", loss_z)
-            loss = loss + loss_z * self.C(L["lambda_z_variance"])
-        if "lambda_eikonal" in L and self.C(L["lambda_eikonal"]) > 0:
-            if "sdf_grad" not in out:
-                raise ValueError("sdf is required for eikonal loss, no sdf is found in the output.")
-            loss_eikonal = ((torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()
-            self.log("train/loss_eikonal", loss_eikonal)
-            loss = loss + loss_eikonal * self.C(L["lambda_eikonal"])
-            self.log("train/inv_std", out["inv_std"])
-        if self.cfg.stage == "coarse+geometry":
-            g_inp = torch.nan_to_num(out["comp_normal"], nan=0.0, posinf=0.0, neginf=0.0)
-            g_out = self.guidance(g_inp, self.prompt_utils, **batch, rgb_as_latents=False)
-            for name, value in g_out.items():
-                self.log(f"train/shape_{name}", value)
-                if name.startswith("loss_"):
-                    loss = loss + 0.2 * value * self.C(self.cfg.loss[name.replace("loss_", "lambda_")])
-        return {"loss": loss}
+    GEOMETRY_PASS_WEIGHT = 0.2       # multiprompt_radience_field_generator.py:203
+
+    def _rgb_as_latents(self) -> bool:
+        return self.cfg.rgb_as_latents

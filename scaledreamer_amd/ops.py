@@ -20,6 +20,21 @@ def _need_cuda(*ts):
             raise L.AsdError("the HIP path needs device tensors (there is no CPU fallback)")
 
 
+class _Keep:
+    """fp32-contiguous view of an argument as a device pointer; the converted tensor is held until this object dies, i.e. until
+    after the launch has been enqueued.  (`ptr(t.contiguous())` alone frees the copy as soon as ptr() returns: the caching
+    allocator then hands the same block to the next conversion in the argument list and two pointers alias.)"""
+
+    def __init__(self):
+        self.held = []
+
+    def __call__(self, t: Optional[torch.Tensor], dtype=torch.float32):
+        t = _c(t, dtype)
+        if t is not None:
+            self.held.append(t)
+        return ptr(t)
+
+
 def _c(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Tensor]:
     if t is None:
         return None
@@ -33,7 +48,8 @@ def hashgrid_fwd(meta: GridMeta, params: torch.Tensor, x: torch.Tensor) -> torch
     _need_cuda(params, x)
     x = _c(x)
     out = torch.empty((x.shape[0], meta.n_levels * meta.n_features), device=x.device, dtype=torch.float32)
-    check(lib().asd_hashgrid_fwd(C.byref(meta), ptr(_c(params)), ptr(x), i32(x.shape[0]), ptr(out), stream()))
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_hashgrid_fwd(C.byref(meta), k(params), ptr(x), i32(x.shape[0]), ptr(out), stream()))
     return out
 
 
@@ -89,9 +105,10 @@ def field_bwd(meta, cfg: FieldCfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma,
     dw2d = torch.zeros((1, H), device=dev, dtype=torch.float32)
     dw1f = torch.zeros((H, 32), device=dev, dtype=torch.float32) if Cf > 0 else None
     dw2f = torch.zeros((Cf, H), device=dev, dtype=torch.float32) if Cf > 0 else None
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
     check(lib().asd_field_bwd(C.byref(meta), C.byref(cfg), ptr(grid), ptr(w1d), ptr(w2d), ptr(w1f), ptr(w2f),
-                              ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), ptr(_c(d_sigma)),
-                              ptr(_c(d_features)), ptr(_c(d_normal)), ptr(_c(d_fd_grad)), ptr(d_grid), ptr(dw1d), ptr(dw2d), ptr(dw1f),
+                              ptr(points), ptr(enc), ptr(sigma), i32(n), ptr(n_dev), k(d_sigma),
+                              k(d_features), k(d_normal), k(d_fd_grad), ptr(d_grid), ptr(dw1d), ptr(dw2d), ptr(dw1f),
                               ptr(dw2f), ptr(ws), stream()))
     return dw1d, dw2d, dw1f, dw2f
 
@@ -161,7 +178,8 @@ def compact(rays_o, rays_d, offset, count, keep, t0, t1, kept_offset, n_out: int
     t1o = torch.empty(n_out, device=dev, dtype=torch.float32)
     pts = torch.empty((n_out, 3), device=dev, dtype=torch.float32)
     dirs = torch.empty((n_out, 3), device=dev, dtype=torch.float32)
-    check(lib().asd_compact(ptr(_c(rays_o)), ptr(_c(rays_d)), i32(nr), ptr(offset), ptr(count), ptr(keep), ptr(t0),
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_compact(k(rays_o), k(rays_d), i32(nr), ptr(offset), ptr(count), ptr(keep), ptr(t0),
                             ptr(t1), ptr(kept_offset), ptr(ray_idx), ptr(t0o), ptr(t1o), ptr(pts), ptr(dirs),
                             stream()))
     return ray_idx, t0o, t1o, pts, dirs
@@ -183,8 +201,9 @@ def composite_fwd(sigma, t0, t1, rgb, offset, count, bg, mode: int = 0):
     zv = torch.empty(nr, device=dev, dtype=torch.float32)
     fg = torch.empty((nr, 3), device=dev, dtype=torch.float32)
     comp = torch.empty((nr, 3), device=dev, dtype=torch.float32)
-    check(lib().asd_composite_fwd(i32(mode), ptr(_c(sigma)), ptr(t0), ptr(t1), ptr(_c(rgb)), ptr(offset), ptr(count),
-                                  i32(nr), ptr(_c(bg)), ptr(w), ptr(op), ptr(dp), ptr(fg), ptr(zv), ptr(comp),
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_composite_fwd(i32(mode), k(sigma), ptr(t0), ptr(t1), k(rgb), ptr(offset), ptr(count),
+                                  i32(nr), k(bg), ptr(w), ptr(op), ptr(dp), ptr(fg), ptr(zv), ptr(comp),
                                   stream()))
     return dict(weights=w, opacity=op, depth=dp, rgb_fg=fg, z_var=zv, comp_rgb=comp)
 
@@ -195,10 +214,11 @@ def composite_bwd(sigma, t0, t1, rgb, offset, count, bg, fwd, d_comp_rgb=None, d
     d_sigma = torch.empty(n, device=dev, dtype=torch.float32)
     d_rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     d_bg = torch.empty((nr, 3), device=dev, dtype=torch.float32)
-    check(lib().asd_composite_bwd(i32(mode), ptr(_c(sigma)), ptr(t0), ptr(t1), ptr(_c(rgb)), ptr(offset), ptr(count),
-                                  i32(nr), ptr(_c(bg)), ptr(fwd["weights"]), ptr(fwd["opacity"]), ptr(fwd["depth"]),
-                                  ptr(_c(d_comp_rgb)), ptr(_c(d_rgb_fg)), ptr(_c(d_opacity)), ptr(_c(d_depth)),
-                                  ptr(_c(d_z_var)), ptr(_c(d_weights)), ptr(d_sigma), ptr(d_rgb), ptr(d_bg), stream()))
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_composite_bwd(i32(mode), k(sigma), ptr(t0), ptr(t1), k(rgb), ptr(offset), ptr(count),
+                                  i32(nr), k(bg), ptr(fwd["weights"]), ptr(fwd["opacity"]), ptr(fwd["depth"]),
+                                  k(d_comp_rgb), k(d_rgb_fg), k(d_opacity), k(d_depth),
+                                  k(d_z_var), k(d_weights), ptr(d_sigma), ptr(d_rgb), ptr(d_bg), stream()))
     return d_sigma, d_rgb, d_bg
 
 
@@ -220,7 +240,8 @@ def importance_resample(vals: torch.Tensor, cdfs: torch.Tensor, n_out: int, jitt
     vals, cdfs = _c(vals), _c(cdfs)
     n_rays, e_in = vals.shape
     out = torch.empty((n_rays, n_out + 1), device=vals.device, dtype=torch.float32)
-    check(lib().asd_importance_resample(ptr(vals), ptr(cdfs), i32(n_rays), i32(e_in), i32(n_out), ptr(_c(jitter)), ptr(out), stream()))
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_importance_resample(ptr(vals), ptr(cdfs), i32(n_rays), i32(e_in), i32(n_out), k(jitter), ptr(out), stream()))
     return out
 
 
@@ -267,7 +288,8 @@ def voxel_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape) -> torch.
     B, D, H, W, Cc = shape
     d_voxel = torch.zeros(shape, device=d_out.device, dtype=torch.float32)
     points = _c(points)
-    check(lib().asd_voxel_sample_bwd(ptr(_c(d_out)), i32(B), i32(D), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_voxel_sample_bwd(k(d_out), i32(B), i32(D), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
                                      ptr(d_voxel), stream()))
     return d_voxel
 
@@ -288,6 +310,7 @@ def triplane_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape, coord_
     B, _, H, W, Cc = shape
     d_planes = torch.zeros(shape, device=d_out.device, dtype=torch.float32)
     points = _c(points)
-    check(lib().asd_triplane_sample_bwd(ptr(_c(d_out)), i32(B), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
+    k = _Keep()   # converted temporaries must outlive the launch (a freed block would be handed to the next conversion)
+    check(lib().asd_triplane_sample_bwd(k(d_out), i32(B), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
                                         f32(coord_scale), ptr(d_planes), stream()))
     return d_planes

@@ -123,52 +123,97 @@ class StableDreamer(nn.Module, Updateable):
         return {**self.renderer(**batch)}
 
     def on_train_batch_start(self, batch_idx: int = 0):
-        """systems/base.py:180-184: per-step update hooks (occupancy grid, timestep annealing, resolution)."""
+        """systems/base.py:180-184: per-step update hooks (occupancy grid, timestep annealing, resolution).  The guidance is a
+        plain attribute of an Updateable, so the recursion of do_update_step already reaches it."""
         self.do_update_step(self.current_epoch, self.true_global_step)
-        if self.guidance is not None:
-            self.guidance.do_update_step(self.current_epoch, self.true_global_step)
+
+    def on_train_batch_end(self, batch_idx: int = 0):
+        """systems/base.py:120-125"""
+        self.do_update_step_end(self.current_epoch, self.true_global_step)
+
+    # ---- loss assembly (scaledreamer.py:62-126; multiprompt_radience_field_generator.py:142-212) ----------------------------------
+    # Every regulariser is an entry of REGULARISERS: name -> (needs, fn(out) -> scalar).  A term is evaluated iff its
+    # `lambda_<name>` is configured and positive at the current step (the lambdas are C() schedules); `needs` is the output key
+    # whose absence is the reference's ValueError.  `lambda_eikonal` is optional in the config (hasattr test in the reference),
+    # the other four are read unconditionally there, so a config without them is a KeyError here as well.
+    GEOMETRY_PASS_WEIGHT = 0.5       # scaledreamer.py:122 ("hard-coded lambda"); 0.2 in the multi-prompt system (:203)
+    REGULARISERS = {
+        "orient": ("normal", "Normal is required for orientation loss, no normal is found in the output.",
+                   lambda o: (o["weights"].detach() * dot(o["normal"], o["t_dirs"]).clamp_min(0.0) ** 2).sum() / (o["opacity"] > 0).sum()),
+        "sparsity": ("opacity", "opacity is required for the sparsity loss.",
+                     lambda o: (o["opacity"] ** 2 + 0.01).sqrt().mean()),
+        "opaque": ("opacity", "opacity is required for the opaque loss.",
+                   lambda o: (lambda oc: binary_cross_entropy(oc, oc))(o["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3))),
+        "z_variance": ("z_variance", "z_variance is required for z_variance loss, no z_variance is found in the output.",
+                       lambda o: o["z_variance"][o["opacity"] > 0.5].mean()),
+        "eikonal": ("sdf_grad", "sdf is required for eikonal loss, no sdf is found in the output.",
+                    lambda o: ((torch.linalg.norm(o["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()),
+    }
+    OPTIONAL_LAMBDAS = ("eikonal",)
+
+    def _guidance_terms(self, image, batch, prefix: str, weight: float, rgb_as_latents: bool = False):
+        total = 0.0
+        for name, value in self.guidance(image, self.prompt_utils, **batch, rgb_as_latents=rgb_as_latents).items():
+            self.log(f"train/{prefix}{name}", value)
+            if name.startswith("loss_"):
+                total = total + weight * value * self.C(self.cfg.loss["lambda_" + name[len("loss_"):]])
+        return total
+
+    def _regulariser_terms(self, out):
+        total = 0.0
+        for name, (needs, message, fn) in self.REGULARISERS.items():
+            key = "lambda_" + name
+            if name in self.OPTIONAL_LAMBDAS and key not in self.cfg.loss:
+                continue
+            lam = self.C(self.cfg.loss[key])
+            if not lam > 0:
+                continue
+            if needs not in out:
+                raise ValueError(message)
+            value = fn(out)
+            self.log(f"train/loss_{name}", value)
+            total = total + value * lam
+            if name == "eikonal":
+                self.log("train/inv_std", out["inv_std"])
+        return total
+
+    def _rgb_as_latents(self) -> bool:
+        return False
 
     def training_step(self, batch, batch_idx: int = 0):
+        stage = self.cfg.stage
+        if stage not in ("coarse", "coarse+geometry"):
+            # 'geometry' / 'texture' (mesh stages: normal consistency, laplacian) are not on the ASD hot path
+            raise ValueError(f"stage {stage!r}: only the NeRF stages 'coarse' and 'coarse+geometry' are implemented")
         out = self(batch)
-        guidance_out = self.guidance(out["comp_rgb"], self.prompt_utils, **batch, rgb_as_latents=False)
-        loss = 0.0
-        for name, value in guidance_out.items():
-            self.log(f"train/{name}", value)
-            if name.startswith("loss_"):
-                loss = loss + value * self.C(self.cfg.loss[name.replace("loss_", "lambda_")])
-        if "coarse" not in self.cfg.stage:
-            raise ValueError(f"stage {self.cfg.stage!r}: only the NeRF ('coarse') stage is on the ASD hot path")
-        L = self.cfg.loss
-        if self.C(L.get("lambda_orient", 0.0)) > 0:
-            if "normal" not in out:
-                raise ValueError("Normal is required for orientation loss, no normal is found in the output.")
-            loss_orient = (out["weights"].detach() * dot(out["normal"], out["t_dirs"]).clamp_min(0.0) ** 2).sum() / (out["opacity"] > 0).sum()
-            self.log("train/loss_orient", loss_orient)
-            loss = loss + loss_orient * self.C(L["lambda_orient"])
-        if self.C(L.get("lambda_sparsity", 0.0)) > 0:
-            loss_sparsity = (out["opacity"] ** 2 + 0.01).sqrt().mean()
-            self.log("train/loss_sparsity", loss_sparsity)
-            loss = loss + loss_sparsity * self.C(L["lambda_sparsity"])
-        if self.C(L.get("lambda_opaque", 0.0)) > 0:
-            oc = out["opacity"].clamp(1.0e-3, 1.0 - 1.0e-3)
-            loss_opaque = binary_cross_entropy(oc, oc)
-            self.log("train/loss_opaque", loss_opaque)
-            loss = loss + loss_opaque * self.C(L["lambda_opaque"])
-        if self.C(L.get("lambda_z_variance", 0.0)) > 0:
-            if "z_variance" not in out:
-                raise ValueError("z_variance is required for z_variance loss, no z_variance is found in the output.")
-            loss_z = out["z_variance"][out["opacity"] > 0.5].mean()
-            self.log("train/loss_z_variance", loss_z)
-            loss = loss + loss_z * self.C(L["lambda_z_variance"])
+        loss = self._guidance_terms(out["comp_rgb"], batch, "", 1.0, self._rgb_as_latents())
+        loss = loss + self._regulariser_terms(out)
+        if stage == "coarse+geometry":   # second guidance pass on the normal image
+            normal_img = torch.nan_to_num(out["comp_normal"], nan=0.0, posinf=0.0, neginf=0.0)
+            loss = loss + self._guidance_terms(normal_img, batch, "shape_", self.GEOMETRY_PASS_WEIGHT)
         return {"loss": loss}
 
+    def gradient_exchange(self):
+        """the DP exchange object of this system (None on a single process): created on first use, after the process group."""
+        if not asd_dist.is_distributed():
+            return None
+        if getattr(self, "_exchange", None) is None:
+            self._exchange = asd_dist.GradientExchange([p for grp in self.optimizer.param_groups for p in grp["params"]])
+        return self._exchange
+
     def train_one_step(self, batch) -> torch.Tensor:
-        """on_train_batch_start -> training_step -> backward -> (all-reduce) -> optimizer.step."""
+        """on_train_batch_start -> training_step -> backward (gradient all-reduces launched from its hooks) -> optimizer.step."""
         self.on_train_batch_start()
-        self.optimizer.zero_grad(set_to_none=True)
+        ex = self.gradient_exchange()
+        if ex is None:
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            ex.prepare()
         loss = self.training_step(batch)["loss"]
         loss.backward()
-        asd_dist.allreduce_mean_grads(self.optimizer)
+        if ex is not None:
+            ex.finish()
         self.optimizer.step()
+        self.on_train_batch_end()
         self.true_global_step += 1
         return loss.detach()

@@ -284,6 +284,10 @@ if __name__ == "__main__":
     make_mvdream_glue_golden()
     if "--glue-only" in sys.argv:
         sys.exit(0)
+    if "--round2" in sys.argv:   # the headline config's own shapes: only these two files are (re)written
+        make_vae_golden("diffusion_vae_full_512", W.VAEConfig(), batch=1, res=512, seed=2, grad_stride=8)
+        make_unet_golden("diffusion_mvunet_full_b12", W.UNetConfig(camera_dim=16), batch=12, hw=32, n_ctx=77, seed=4, num_frames=4)
+        sys.exit(0)
     small = W.UNetConfig(model_channels=64, num_head_channels=32, context_dim=96)
     make_unet_golden("diffusion_unet_small", small, batch=3, hw=16, n_ctx=7, seed=3)
     small_mv = W.UNetConfig(model_channels=64, num_head_channels=32, context_dim=96, camera_dim=16)

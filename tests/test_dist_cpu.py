@@ -50,6 +50,94 @@ def test_two_rank_gradient_mean_allreduce(tmp_path):
         torch.testing.assert_close(a1, a0)
 
 
+def _system_worker(rank, world, port, out_dir):
+    """the REAL StableDreamer.train_one_step wiring (update hooks -> GradientExchange.prepare -> training_step -> backward with
+    the exchange's hooks -> finish -> optimizer.step -> end hooks) with a stub renderer / guidance: per-rank seed, broadcast
+    initial parameters, a parameter that gets no gradient on rank 1, launch order learned in step 1 and reused in step 2."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from scaledreamer_amd import dist as asd_dist
+    from scaledreamer_amd.base import Updateable
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    assert asd_dist.init_from_env("gloo") == world
+    asd_dist.IN_PLACE_BYTES = 1 << 20
+    seed = 10 + rank                                   # launch.py:171: cfg.seed + rank
+    torch.manual_seed(seed)
+
+    class Renderer(torch.nn.Module, Updateable):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(300_000))       # > IN_PLACE_BYTES: its own in-place unit
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+            self.sometimes_unused = torch.nn.Parameter(torch.randn(7))
+            self.register_buffer("grid_bits", torch.rand(64) > 0.5)       # bool buffer (the occupancy grid's `binaries`)
+            self.updates = []
+
+        def update_step(self, epoch, global_step, on_load_weights=False):
+            self.updates.append(global_step)
+
+        def forward(self, rays_d, **kw):
+            rgb = torch.sigmoid(self.mlp(rays_d) + self.table[:3])
+            if rank == 0:                                                # rank 1 produces no gradient for this parameter
+                rgb = rgb + 0.1 * self.sometimes_unused[:3]
+            return {"comp_rgb": rgb, "opacity": rgb.mean(-1, keepdim=True).clamp(0, 1)}
+
+    class Guidance(Updateable):
+        calls = 0
+
+        def update_step(self, epoch, global_step, on_load_weights=False):
+            Guidance.calls += 1
+
+        def __call__(self, rgb, prompt_utils, rgb_as_latents=False, **batch):
+            return {"loss_asd": (rgb ** 2).sum(), "grad_norm": rgb.detach().norm()}
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.cfg = ConfigDict(stage="coarse", loss=ConfigDict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=2.0, lambda_opaque=0.0,
+                                                        lambda_z_variance=0.0))
+    s.current_epoch, s.true_global_step, s.logged = 0, 0, {}
+    s.renderer, s.guidance, s.prompt_utils = Renderer(), Guidance(), None
+    asd_dist.broadcast_parameters(s)
+    init = {k: v.clone() for k, v in s.state_dict().items()}
+    s.optimizer = torch.optim.SGD([{"params": [s.renderer.table]}, {"params": list(s.renderer.mlp.parameters()) + [s.renderer.sometimes_unused]}], lr=0.5)
+    local = []
+    for step in range(2):
+        batch = {"rays_d": torch.randn(1, 4, 4, 3)}    # different data per rank (torch.manual_seed(seed) above)
+        # this rank's own gradient, computed on the side
+        probe = s.training_step(batch)["loss"]
+        gs = torch.autograd.grad(probe, [p for p in s.renderer.parameters()], allow_unused=True)
+        local.append([torch.zeros_like(p) if g is None else g.clone() for p, g in zip(s.renderer.parameters(), gs)])
+        before = [p.detach().clone() for p in s.renderer.parameters()]
+        s.train_one_step(batch)
+        applied = [(b - p.detach()) / 0.5 for b, p in zip(before, s.renderer.parameters())]   # SGD: the averaged gradient
+        local[-1] = (local[-1], applied)
+    ex = s.gradient_exchange()
+    torch.save({"init": init, "steps": local, "order": ex.order, "n_units": len(ex.units), "updates": s.renderer.updates,
+                "guidance_updates": Guidance.calls, "final": [p.detach().clone() for p in s.renderer.parameters()]},
+               os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_real_system_wiring(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_system_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    for k in r0["init"]:
+        assert torch.equal(r0["init"][k], r1["init"][k]), f"{k} was not broadcast from rank 0"
+    assert r0["order"] == r1["order"] and sorted(r0["order"]) == list(range(r0["n_units"])) and r0["n_units"] == 2
+    assert r0["updates"] == [0, 1] and r0["guidance_updates"] == 2          # hooks once per step, guidance not updated twice
+    for (g0, a0), (g1, a1) in zip(r0["steps"], r1["steps"]):
+        for x0, x1, y0, y1 in zip(g0, g1, a0, a1):
+            torch.testing.assert_close(y0, (x0 + x1) / 2, rtol=1e-4, atol=1e-6)   # what the optimizer applied = mean over ranks
+            torch.testing.assert_close(y1, y0)
+        assert g1[1].abs().sum() == 0 and g0[1].abs().sum() > 0              # `sometimes_unused` (parameters(): table, sometimes_unused, mlp...): rank 1 never touched it, it still gets rank 0's half
+    for a, b in zip(r0["final"], r1["final"]):
+        torch.testing.assert_close(a, b)                                      # replicas stay identical
+
+
 def test_single_process_is_a_noop():
     sys.path.insert(0, ROOT)
     from scaledreamer_amd import dist as asd_dist

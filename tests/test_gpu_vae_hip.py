@@ -72,7 +72,7 @@ def test_conv_dgrad_and_groupnorm_bwd_ops():
         assert _rel(fused, plain.float() + extra.float())[1] < 2e-3, (Cc, silu)
 
 
-@pytest.mark.parametrize("name", ["diffusion_vae_small", "diffusion_vae_full_256"])
+@pytest.mark.parametrize("name", ["diffusion_vae_small", "diffusion_vae_full_256", "diffusion_vae_full_512"])
 def test_hip_vae_matches_reference_golden(name):
     from scaledreamer_amd.diffusion import weights as W
     from scaledreamer_amd.diffusion.vae_hip import HipVAEEncoder
@@ -88,4 +88,4 @@ def test_hip_vae_matches_reference_golden(name):
     assert l2 < 1e-2 and mx < 1e-2, (l2, mx)
     (m * rnd("in.gmoments", tuple(m.shape), seed).cuda()).sum().backward()
     l2, mx = _rel(x.grad[:, :, ::st, ::st], torch.from_numpy(g["grad_x_sub"]))
-    assert l2 < 2e-2 and mx < 2e-2, (l2, mx)
+    assert l2 < 1e-2 and mx < 1e-2, (l2, mx)     # north_star: within 1e-2 rel (the 512^2 case is the headline config's own shape)

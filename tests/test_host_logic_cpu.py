@@ -266,3 +266,205 @@ def test_state_dict_keys_match_the_reference_modules():
     for name, m in mods.items():
         got = {k: list(v.shape) for k, v in m.state_dict().items() if not k.startswith("estimator.")}
         assert got == ref[name], (name, sorted(set(got) ^ set(ref[name])))
+
+
+# ---- a10: the product's own training_step loss assembly vs the reference's (tests/golden/make_goldens_system.py) ----------------
+def _a10_out(seed, requires_grad=True):
+    import zlib
+
+    def rnd(name, shape):
+        g = torch.Generator().manual_seed((seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        return torch.randn(shape, generator=g)
+    B, Hh, Ww, n = 1, 8, 8, 300
+    o = {
+        "comp_rgb": torch.sigmoid(rnd("comp_rgb", (B, Hh, Ww, 3))),
+        "comp_normal": rnd("comp_normal", (B, Hh, Ww, 3)) * 0.5,
+        "opacity": torch.sigmoid(2.5 * rnd("opacity", (B, Hh, Ww, 1))),
+        "z_variance": rnd("z_variance", (B, Hh, Ww, 1)).abs() * 0.05,
+        "weights": torch.sigmoid(rnd("weights", (n, 1))) * 0.1,
+        "normal": torch.nn.functional.normalize(rnd("normal", (n, 3)), dim=-1),
+        "t_dirs": torch.nn.functional.normalize(rnd("t_dirs", (n, 3)), dim=-1),
+        "sdf_grad": rnd("sdf_grad", (n, 3)) * 0.7,
+        "inv_std": torch.tensor(30.0),
+    }
+    o["opacity"].view(-1)[:5] = torch.tensor([0.0, 1.0, 0.0004, 0.9997, 0.5])
+    o["comp_normal"].view(-1)[3] = float("nan")
+    return {k: (v.clone().requires_grad_(True) if requires_grad and k not in ("t_dirs", "inv_std") else v) for k, v in o.items()}
+
+
+A10_CASES = {
+    "asd_sd_nerf_step0": ("coarse", dict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=30, lambda_opaque=[10000, 0.0, 100.0, 10001],
+                                         lambda_z_variance=0.0)),
+    "asd_sd_nerf_step10001": ("coarse", dict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=30,
+                                             lambda_opaque=[10000, 0.0, 100.0, 10001], lambda_z_variance=0.0)),
+    "all_terms": ("coarse", dict(lambda_asd=0.5, lambda_orient=[0, 10.0, 1000.0, 1000], lambda_sparsity=3.0, lambda_opaque=2.0,
+                                 lambda_z_variance=4.0, lambda_eikonal=7.0)),
+    "coarse_geometry": ("coarse+geometry", dict(lambda_asd=1.0, lambda_orient=1.0, lambda_sparsity=1.0, lambda_opaque=0.0,
+                                                lambda_z_variance=0.0)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(A10_CASES))
+def test_training_step_loss_terms_match_the_reference(case):
+    """scaledreamer_amd.system.StableDreamer.training_step on the tensors the reference's StableDreamer.training_step
+    (scaledreamer.py:48-170) was run on: scalar loss, every logged value, gradient w.r.t. every renderer output."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    g = dict(np.load(os.path.join(GOLDEN_DIR, "system_training_step.npz")))
+    stage, loss_cfg = A10_CASES[case]
+    out = _a10_out(int(g["seed"]))
+
+    def guidance(rgb, prompt_utils, rgb_as_latents=False, **batch):
+        probe = torch.linspace(-1.0, 2.0, rgb.numel(), dtype=rgb.dtype).view_as(rgb)
+        return {"loss_asd": (rgb * probe).sum() + 0.5 * (rgb ** 2).sum(), "grad_norm": rgb.detach().norm(), "min_step": 20, "max_step": 980}
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.cfg = ConfigDict(stage=stage, loss=ConfigDict(loss_cfg))
+    s.current_epoch, s.true_global_step = 0, int(g[case + ".step"])
+    s.logged = {}
+    s.renderer = lambda **batch: dict(out)
+    s.guidance, s.prompt_utils = guidance, None
+    loss = s.training_step({"elevation": torch.zeros(1)})["loss"]
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[case + ".loss"]), rel=1e-6)
+    want_logged = {k[len(case) + 5:]: float(v) for k, v in g.items() if k.startswith(case + ".log.")}
+    assert sorted(s.logged) == sorted(want_logged)
+    for k, v in want_logged.items():
+        assert float(s.logged[k]) == pytest.approx(v, rel=1e-6), k
+    for k, t in out.items():
+        if t.requires_grad:
+            want = torch.from_numpy(g[f"{case}.grad.{k}"])
+            got = t.grad if t.grad is not None else torch.zeros_like(t)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-7, msg=k)
+
+
+def test_training_step_rejects_mesh_stages_and_missing_outputs():
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.current_epoch, s.true_global_step, s.logged = 0, 0, {}
+    out = _a10_out(3, requires_grad=False)
+    del out["sdf_grad"]
+    s.renderer = lambda **batch: dict(out)
+    s.guidance, s.prompt_utils = (lambda rgb, pu, **kw: {"loss_asd": rgb.sum()}), None
+    s.cfg = ConfigDict(stage="geometry", loss=ConfigDict(lambda_asd=1.0))
+    with pytest.raises(ValueError):
+        s.training_step({})
+    s.cfg = ConfigDict(stage="coarse", loss=ConfigDict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=0.0, lambda_opaque=0.0,
+                                                        lambda_z_variance=0.0, lambda_eikonal=1.0))
+    with pytest.raises(ValueError, match="sdf is required"):
+        s.training_step({})
+
+
+# ---- frozen-prior checkpoints: diffusers / LDM layouts -> the engine's name-keyed layout, never a silent random prior -----------
+def _diffusers_unet_names(cfg):
+    """parameter names of diffusers' UNet2DConditionModel for an SD-2.x topology (CrossAttnDownBlock2D x3 + DownBlock2D,
+    UNetMidBlock2DCrossAttn, UpBlock2D + CrossAttnUpBlock2D x3), written out from the architecture — not from our mapping."""
+    res = ["norm1", "conv1", "time_emb_proj", "norm2", "conv2"]
+    tf = ["norm", "proj_in", "proj_out"] + [f"transformer_blocks.0.{k}" for k in
+         ["norm1", "norm2", "norm3", "attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn2.to_q", "attn2.to_k", "attn2.to_v",
+          "attn2.to_out.0", "ff.net.0.proj", "ff.net.2"]]
+    nobias = ("to_q", "to_k", "to_v")
+    names = []
+
+    def add(prefix, leaves, shortcut=False):
+        for l in leaves + (["conv_shortcut"] if shortcut else []):
+            names.append(f"{prefix}.{l}.weight")
+            if not l.endswith(nobias):
+                names.append(f"{prefix}.{l}.bias")
+    add("time_embedding", ["linear_1", "linear_2"])
+    add("", [])
+    names += ["conv_in.weight", "conv_in.bias", "conv_norm_out.weight", "conv_norm_out.bias", "conv_out.weight", "conv_out.bias"]
+    mult = cfg.channel_mult
+    ch = cfg.model_channels
+    for lvl in range(4):
+        for j in range(2):
+            cout = mult[lvl] * cfg.model_channels
+            add(f"down_blocks.{lvl}.resnets.{j}", res, shortcut=ch != cout)
+            ch = cout
+            if lvl < 3:
+                add(f"down_blocks.{lvl}.attentions.{j}", tf)
+        if lvl < 3:
+            add(f"down_blocks.{lvl}.downsamplers.0", ["conv"])
+    add("mid_block.resnets.0", res)
+    add("mid_block.attentions.0", tf)
+    add("mid_block.resnets.1", res)
+    for lvl in range(4):
+        for j in range(3):
+            add(f"up_blocks.{lvl}.resnets.{j}", res, shortcut=True)     # every up ResBlock sees a concatenated input
+            if lvl > 0:
+                add(f"up_blocks.{lvl}.attentions.{j}", tf)
+        if lvl < 3:
+            add(f"up_blocks.{lvl}.upsamplers.0", ["conv"])
+    return names
+
+
+def test_diffusers_and_ldm_checkpoints_map_onto_the_engine_layout(tmp_path):
+    from safetensors.torch import save_file
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.diffusion import checkpoint as CK, weights as W
+
+    full = W.UNetConfig()
+    shapes = W.unet_layout(full)[0]
+    mapped = [CK.diffusers_unet_key_to_ldm(k, full) for k in _diffusers_unet_names(full)]
+    assert len(set(mapped)) == len(mapped) and set(mapped) == set(shapes)          # a bijection onto the 686-tensor layout
+    assert CK.diffusers_unet_key_to_ldm("up_blocks.0.upsamplers.0.conv.weight", full) == "output_blocks.2.1.conv.weight"
+    assert CK.diffusers_unet_key_to_ldm("up_blocks.1.upsamplers.0.conv.weight", full) == "output_blocks.5.2.conv.weight"
+    assert CK.diffusers_unet_key_to_ldm("down_blocks.2.downsamplers.0.conv.bias", full) == "input_blocks.9.0.op.bias"
+    assert CK.diffusers_unet_key_to_ldm("mid_block.resnets.1.time_emb_proj.weight", full) == "middle_block.2.emb_layers.1.weight"
+    # file round trip on a narrow model: an LDM checkpoint and a diffusers directory give back the very tensors
+    ucfg, vcfg = W.UNetConfig(model_channels=32, num_head_channels=32, context_dim=16), W.VAEConfig(ch=32)
+    up, vp = W.gen_params(W.unet_layout(ucfg)[0], 5), W.gen_params(W.vae_encoder_layout(vcfg)[0], 6)
+    ldm = {"model.diffusion_model." + k: v for k, v in up.items()}
+    ldm.update({"first_stage_model." + k: v for k, v in vp.items()})
+    ldm["first_stage_model.decoder.conv_in.weight"] = torch.zeros(1)                # ignored
+    torch.save({"state_dict": ldm}, tmp_path / "mv.pt")
+    gu, gv, what = CK.resolve_params(ConfigDict(ckpt_path=str(tmp_path / "mv.pt")), ucfg, vcfg)
+    assert all(torch.equal(gu[k], up[k]) for k in up) and all(torch.equal(gv[k], vp[k]) for k in vp) and "LDM" in what
+    inv = {CK.diffusers_unet_key_to_ldm(k, ucfg): k for k in _diffusers_unet_names(ucfg)}
+    (tmp_path / "sd" / "unet").mkdir(parents=True)
+    (tmp_path / "sd" / "vae").mkdir()
+    save_file({inv[k]: v.contiguous() for k, v in up.items()}, str(tmp_path / "sd" / "unet" / "diffusion_pytorch_model.safetensors"))
+    vae_d = {}
+    for k, v in vp.items():
+        d = k
+        if k.startswith("encoder."):
+            d = (k.replace("encoder.down.", "encoder.down_blocks.").replace(".block.", ".resnets.").replace(".downsample.conv", ".downsamplers.0.conv")
+                  .replace("mid.block_1", "mid_block.resnets.0").replace("mid.block_2", "mid_block.resnets.1").replace("nin_shortcut", "conv_shortcut")
+                  .replace("mid.attn_1.norm", "mid_block.attentions.0.group_norm").replace("mid.attn_1.q", "mid_block.attentions.0.to_q")
+                  .replace("mid.attn_1.k", "mid_block.attentions.0.to_k").replace("mid.attn_1.v", "mid_block.attentions.0.to_v")
+                  .replace("mid.attn_1.proj_out", "mid_block.attentions.0.to_out.0").replace("encoder.norm_out", "encoder.conv_norm_out"))
+            if "attentions.0.to_" in d and d.endswith("weight"):
+                v = v.reshape(v.shape[0], v.shape[1])                               # diffusers stores these as Linear
+        vae_d[d] = v.contiguous()
+    vae_d["decoder.conv_in.weight"] = torch.zeros(1)
+    save_file(vae_d, str(tmp_path / "sd" / "vae" / "diffusion_pytorch_model.safetensors"))
+    gu, gv, what = CK.resolve_params(ConfigDict(pretrained_model_name_or_path=str(tmp_path / "sd")), ucfg, vcfg)
+    assert all(torch.equal(gu[k], up[k]) for k in up) and all(torch.equal(gv[k], vp[k]) for k in vp) and "diffusers" in what
+    # nothing on disk: an error unless random weights were asked for explicitly
+    with pytest.raises(CK.MissingWeightsError):
+        CK.resolve_params(ConfigDict(pretrained_model_name_or_path="stabilityai/stable-diffusion-2-1-base"), ucfg, vcfg)
+    assert CK.resolve_params(ConfigDict(pretrained_model_name_or_path="stabilityai/stable-diffusion-2-1-base", allow_random_weights=True),
+                             ucfg, vcfg)[:2] == (None, None)
+    del ldm["model.diffusion_model.out.2.bias"]
+    torch.save(ldm, tmp_path / "broken.pt")
+    with pytest.raises(KeyError):
+        CK.resolve_params(ConfigDict(ckpt_path=str(tmp_path / "broken.pt")), ucfg, vcfg)
+
+
+def test_converted_arguments_outlive_the_launch():
+    """ops._Keep: every converted temporary stays referenced until the call returns, so two conversions can never
+    be handed the same allocator block."""
+    from scaledreamer_amd import ops
+
+    k = ops._Keep()
+    a, b = torch.arange(12.0).view(3, 4).t(), torch.arange(12.0).view(3, 4).t() * 2     # both need a contiguous copy
+    pa, pb = k(a), k(b)
+    assert len(k.held) == 2 and pa.value != pb.value and k.held[0].data_ptr() == pa.value
+    assert k(None).value in (None, 0) and len(k.held) == 2

@@ -2,9 +2,9 @@
 convolutions, hipBLASLt GEMMs, SDPA attention), fp16 weights and activations like the reference's diffusers
 pipeline (stable_diffusion_asd_guidance.py:38,57-59; channels_last :88-89).
 
-This is the bring-up / A-B baseline backend named in SURVEY.md §7 step 5 ("PyTorch-ROCm eager as the
-always-available fallback and A/B baseline"); the hand-written HIP path is diffusion/engine.py.  It is
-selected with guidance.backend = "eager" and never silently: the default backend is "hip".
+A/B measurement tool only (what PyTorch-ROCm's libraries give on the same GPU): it lives in tools/, is not part of the
+product package and is registered as guidance.backend = "eager" only when this module is imported
+(`bench.py --backend eager` does).  The product's only diffusion path is scaledreamer_amd/diffusion/engine.py (HIP).
 """
 from __future__ import annotations
 
@@ -14,8 +14,12 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from ..guidance import DiffusionBackend, register_backend
-from . import weights as W
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scaledreamer_amd.guidance import DiffusionBackend, register_backend  # noqa: E402
+from scaledreamer_amd.diffusion import weights as W  # noqa: E402
 
 P = Dict[str, torch.Tensor]
 
