@@ -113,7 +113,7 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * B * hw * hw * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    plan = tuple(H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
+    plan = tuple(H.plan_table().get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
     if plan[0] - 1 in H.WINDOW_TILES:
         kname = "conv3x3_win2_kernel" if plan[0] - 1 >= 10 else "conv3x3_win_kernel"
         kern = f"{kname}<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window{', two blocks per CU' if plan[0] - 1 >= 10 else ''})"
@@ -145,7 +145,7 @@ def roofline_gemm_kernel(reps: int = 50):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     nbytes = 2.0 * (M * K + N * K + M * N)
-    plan = tuple(H._plans.get((M, N, K, K), (0, 1)))   # plan key of a plain GEMM: (M, N, K, lda)
+    plan = tuple(H.plan_table().get((M, N, K, K), (0, 1)))   # plan key of a plain GEMM: (M, N, K, lda)
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}> split_k={plan[1]} on linear 320->320, M=20480 (UNet 64x64 tokens x batch 5)"
                       if plan[0] else "gemm_f16_kernel<model tile> on linear 320->320, M=20480",

@@ -316,6 +316,80 @@ int asd_attention_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, co
                       void* o, int32_t ldo, int32_t batch, int32_t heads, int32_t lq, int32_t lk,
                       int32_t lk_stride, float scale, const void* zero_page, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GEMM plan table + autotuner (csrc/gemm.hip).  asd_gemm_f16 with split_k == 0 ("auto") uses the tuned (tile, split-K) of the
+ * problem's shape when one is recorded, else the built-in cost model.  Shape signature: conv == 0: s0 = lda (negated for the
+ * GEGLU epilogue), s1..s4 = 0; conv == 1: s0..s4 = Hin, Cin, stride, upsample, pad.
+ * ---------------------------------------------------------------------------------------------- */
+int asd_gemm_plan_set(int32_t M, int32_t N, int32_t K, int32_t conv, int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t s4,
+                      int32_t tile_cfg, int32_t split_k);
+/* plan of args' shape -> (*tile_cfg, *split_k); returns 0 when tuned, 1 when the defaults (cost model, heuristic split) are given */
+int asd_gemm_plan_get(const asd_gemm_args* args, int32_t* tile_cfg, int32_t* split_k);
+int asd_gemm_plan_count(void);
+int asd_gemm_plan_entry(int32_t i, int32_t* out11 /* {M,N,K,conv,s0..s4,tile_cfg,split_k} */);
+/* bytes of split-K workspace asd_gemm_f16 needs for args (split_k == 0: under the current plan) */
+int64_t asd_gemm_workspace_bytes(const asd_gemm_args* args);
+/* time every valid (tile, split-K) candidate for args on `stream` (not capturing) and record the winner */
+int asd_gemm_tune(const asd_gemm_args* args, void* scratch, int64_t scratch_bytes, void* stream);
+/* y[rows, c_pad] fp16 = x[rows, c] fp32, zero padded */
+int asd_pad_cast_f16(const float* x, int32_t rows, int32_t c, void* y, int32_t c_pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frozen-prior networks as C handles: the layer schedule is enqueued from C++ (csrc/net.hip), one chain of launches on the
+ * caller's stream, no host synchronisation => capturable into a HIP graph from any host language.
+ *   asd_unet_fwd     replaces forward_unet  (stable_diffusion_asd_guidance.py:319-331: diffusers UNet2DConditionModel) and
+ *                    model.apply_model       (mvdream_asd_guidance.py:261-265: MultiViewUNetModel, openaimodel.py:1175-1213)
+ *   asd_vae_enc_fwd  replaces encode_images (stable_diffusion_asd_guidance.py:171-178 / mvdream_asd_guidance.py:105-112: the
+ *                    encoder + quant_conv up to the posterior moments; sampling and the 0.18215 scale stay in asd_latents_*)
+ *   asd_vae_enc_bwd  its input gradient: the reference keeps the VAE in the autograd graph (:225), weights frozen (:101-102)
+ * Protocol: create(desc) -> the handle publishes the PACKED weight table it reads (num_weights / weight_info: name, rows, cols
+ * of a row-major fp16 matrix; scaledreamer_amd/diffusion/weights.py packs a name-keyed LDM state dict into it) -> bind_weights
+ * (device pointers in table order; the caller keeps them alive) -> workspace_bytes(shape) -> fwd.  `tune` != 0: GEMM shapes
+ * without a recorded plan are timed first (asd_gemm_tune; needs the larger workspace workspace_bytes(..., tune) reports; must
+ * not be used under stream capture).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_weight_info { const char* name; int32_t rows, cols; } asd_weight_info;
+
+typedef struct asd_unet_desc {          /* extern/mvdream/configs/sd-v2-base.yaml:13-27 */
+    int32_t in_channels, out_channels, model_channels, num_res_blocks;
+    int32_t n_levels, channel_mult[8];
+    int32_t attention_ds_mask;           /* bit k: transformer blocks at downsample factor 2^k (attention_resolutions [4,2,1] -> 0b111) */
+    int32_t num_head_channels;           /* 64 */
+    int32_t transformer_depth, context_dim;
+    int32_t camera_dim;                  /* 0: SD-2.1; 16: MVDream (camera MLP added to the time embedding, self-attention over
+                                            the num_frames views of a group) */
+} asd_unet_desc;
+typedef struct asd_unet asd_unet;
+int asd_unet_create(const asd_unet_desc* desc, asd_unet** out);
+void asd_unet_destroy(asd_unet* h);
+int32_t asd_unet_num_weights(const asd_unet* h);
+int asd_unet_weight_info(const asd_unet* h, int32_t i, asd_weight_info* info);
+int asd_unet_bind_weights(asd_unet* h, const void* const* device_ptrs, int32_t count);
+int64_t asd_unet_workspace_bytes(asd_unet* h, int32_t batch, int32_t H, int32_t W, int32_t n_ctx, int32_t num_frames, int32_t tune);
+/* x_nhwc: fp16 [batch,H,W,32] (latent channels first, rest zero); t: fp32 [batch]; context: fp16 [batch*ctx_stride, context_dim]
+ * with ctx_stride = n_ctx rounded up to 8, padding rows zero; camera: fp16 [batch,16] or NULL; eps_nhwc: fp32 [batch,H,W,out_channels] */
+int asd_unet_fwd(asd_unet* h, const void* x_nhwc, const float* t, const void* context, const void* camera, int32_t batch, int32_t H,
+                 int32_t W, int32_t n_ctx, int32_t num_frames, void* workspace, int64_t workspace_bytes, float* eps_nhwc, int32_t tune,
+                 void* stream);
+
+typedef struct asd_vae_desc {           /* first_stage_config.ddconfig of sd-v2-base.yaml:33-50 */
+    int32_t in_channels, ch, n_levels, ch_mult[8], num_res_blocks, z_channels, embed_dim;
+} asd_vae_desc;
+typedef struct asd_vae_enc asd_vae_enc;
+int asd_vae_enc_create(const asd_vae_desc* desc, asd_vae_enc** out);
+void asd_vae_enc_destroy(asd_vae_enc* h);
+int32_t asd_vae_enc_num_weights(const asd_vae_enc* h);
+int asd_vae_enc_weight_info(const asd_vae_enc* h, int32_t i, asd_weight_info* info);
+int asd_vae_enc_bind_weights(asd_vae_enc* h, const void* const* device_ptrs, int32_t count);
+/* one workspace serves a forward and the backward that follows it (the forward leaves the activations the gradient needs there) */
+int64_t asd_vae_enc_workspace_bytes(asd_vae_enc* h, int32_t batch, int32_t H, int32_t W, int32_t tune);
+/* x_nhwc32: fp16 [batch,H,W,32] image in [-1,1], channels >= in_channels zero; moments_nhwc: fp32 [batch,H/8,W/8,2*embed_dim] */
+int asd_vae_enc_fwd(asd_vae_enc* h, const void* x_nhwc32, int32_t batch, int32_t H, int32_t W, void* workspace, int64_t workspace_bytes,
+                    float* moments_nhwc, int32_t tune, void* stream);
+/* d_moments_nhwc: fp32 like moments; dx_nhwc32: fp16 [batch,H,W,32], channels < in_channels hold the image gradient */
+int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, int32_t H, int32_t W, void* workspace,
+                    int64_t workspace_bytes, void* dx_nhwc32, int32_t tune, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -80,6 +80,21 @@ class GemmArgs(C.Structure):
     ]
 
 
+class WeightInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class UNetDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("model_channels", C.c_int32), ("num_res_blocks", C.c_int32),
+                ("n_levels", C.c_int32), ("channel_mult", C.c_int32 * 8), ("attention_ds_mask", C.c_int32),
+                ("num_head_channels", C.c_int32), ("transformer_depth", C.c_int32), ("context_dim", C.c_int32), ("camera_dim", C.c_int32)]
+
+
+class VaeDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("ch", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * 8),
+                ("num_res_blocks", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/asd_hip.h declares (tests/test_abi.py checks the header against this list)
@@ -93,6 +108,12 @@ SYMBOLS = [
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
     "asd_gemm_f16", "asd_gemm_force_tile", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
+    "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune",
+    "asd_pad_cast_f16",
+    "asd_unet_create", "asd_unet_destroy", "asd_unet_num_weights", "asd_unet_weight_info", "asd_unet_bind_weights",
+    "asd_unet_workspace_bytes", "asd_unet_fwd",
+    "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",
+    "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
     "asd_version", "asd_last_error",
 ]
 
@@ -111,6 +132,12 @@ def lib() -> C.CDLL:
         l.asd_version.restype = C.c_char_p
         l.asd_grid_meta_init.restype = C.c_uint32
         l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+        for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_vae_enc_workspace_bytes"):
+            getattr(l, fn).restype = C.c_int64
+        l.asd_unet_destroy.restype = None
+        l.asd_vae_enc_destroy.restype = None
+        l.asd_unet_destroy.argtypes = [C.c_void_p]
+        l.asd_vae_enc_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib
 

@@ -18,6 +18,10 @@
 #include <stdlib.h>
 
 #include "asd_common.h"
+#include <map>
+#include <mutex>
+#include <cstring>
+#include <iterator>
 
 typedef _Float16 half_t;
 typedef half_t half8 __attribute__((ext_vector_type(8)));
@@ -757,11 +761,89 @@ static int asd_gemm_pick_tile(int M, int N, int K, int split) {
     return best_cfg;
 }
 
+// ---- tuned plans: (tile configuration, split-K) per problem shape ---------------------------------------------------------
+// The kernel is bound by tile loads, so the best tile / split depends on the shape in ways the closed-form model above only
+// roughly captures.  Like a BLAS library's tuned-kernel table: asd_gemm_tune() times every valid candidate once and records
+// the winner; asd_gemm_f16 with split_k == 0 ("auto") looks the shape up (falling back to the cost model).  The table for the
+// shapes of the shipped configs is committed (scaledreamer_amd/diffusion/gemm_plans.json) and pushed with asd_gemm_plan_set.
+struct asd_plan_key {
+    int32_t M, N, K, conv, a, b, c, d, e;
+    bool operator<(const asd_plan_key& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+struct asd_plan_val { int32_t tile, split; };
+static std::map<asd_plan_key, asd_plan_val> g_plans;
+static std::mutex g_plans_mu;
+
+static asd_plan_key asd_plan_key_of(const asd_gemm_args* a) {
+    asd_plan_key k;
+    memset(&k, 0, sizeof(k));
+    k.M = a->M; k.N = a->N; k.K = a->K; k.conv = a->conv ? 1 : 0;
+    if (a->conv) { k.a = a->Hin; k.b = a->Cin; k.c = a->stride; k.d = a->upsample; k.e = a->pad; }
+    else k.a = a->act == 2 ? -a->lda : a->lda;
+    return k;
+}
+static bool asd_plan_lookup(const asd_gemm_args* a, asd_plan_val* out) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_plans.find(asd_plan_key_of(a));
+    if (it == g_plans.end()) return false;
+    *out = it->second;
+    return true;
+}
+// default split when no plan exists: fill the 256 CUs when the output has few 128x128 tiles and the reduction is long
+static int asd_default_split(const asd_gemm_args* a) {
+    if (a->act == 2) return 1;
+    const int bn = a->N % 128 == 0 ? 128 : 64;
+    const int tiles = asd_div_up(a->M, 128) * asd_div_up(a->N, bn);
+    if (tiles >= 256 || a->K < 1024) return 1;
+    const int target = tiles <= 128 ? 512 : 640;
+    int s = target / tiles;
+    if (s > 16) s = 16;
+    if (s > a->K / 512) s = a->K / 512;
+    return s < 1 ? 1 : s;
+}
+
+__global__ void asd_spin_kernel(long long cycles) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) {}
+}
+
 extern "C" {
 
 int asd_gemm_force_tile(int32_t cfg) {
     g_force_tile = cfg;
     return ASD_OK;
+}
+
+int asd_gemm_plan_set(int32_t M, int32_t N, int32_t K, int32_t conv, int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t s4,
+                      int32_t tile_cfg, int32_t split_k) {
+    ASD_CHECK_ARG(tile_cfg >= 0 && tile_cfg <= ASD_GEMM_NCFG && split_k >= 1, "bad plan");
+    asd_plan_key k;
+    memset(&k, 0, sizeof(k));
+    k.M = M; k.N = N; k.K = K; k.conv = conv ? 1 : 0; k.a = s0; k.b = s1; k.c = s2; k.d = s3; k.e = s4;
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    g_plans[k] = asd_plan_val{tile_cfg, split_k};
+    return ASD_OK;
+}
+
+int asd_gemm_plan_get(const asd_gemm_args* a, int32_t* tile_cfg, int32_t* split_k) {
+    ASD_CHECK_ARG(a && tile_cfg && split_k, "null argument");
+    asd_plan_val v;
+    if (asd_plan_lookup(a, &v)) { *tile_cfg = v.tile; *split_k = v.split; return ASD_OK; }
+    *tile_cfg = 0;
+    *split_k = asd_default_split(a);
+    return 1;   // not tuned: cost model + default split
+}
+
+int asd_gemm_plan_count(void) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    return (int)g_plans.size();
+}
+
+int64_t asd_gemm_workspace_bytes(const asd_gemm_args* a) {
+    int32_t t = 0, s = 1;
+    if (!a) return 0;
+    if (a->split_k >= 1) s = a->split_k; else asd_gemm_plan_get(a, &t, &s);
+    return s > 1 ? (int64_t)s * a->M * a->N * 4 : 0;
 }
 
 // super-tile of the block order (asd_grouped_tile): about one XCD's worth of concurrent blocks, near-square in bytes
@@ -780,6 +862,12 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     asd_gemm_args a_copy = *a_in;           // group_m / group_n / ld_row_bias are filled in here when the caller left them 0
     asd_gemm_args* a = &a_copy;
     if (a->ld_row_bias <= 0) a->ld_row_bias = a->N;
+    if (a->split_k == 0) {   // auto: the tuned plan of this shape, else cost model + default split
+        int32_t t = 0, sk = 1;
+        asd_gemm_plan_get(a, &t, &sk);
+        a->split_k = sk;
+        if (a->tile_cfg == 0) a->tile_cfg = t;
+    }
     ASD_CHECK_ARG(a && a->A && a->W && a->C && a->zero_page, "null argument");
     ASD_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
     ASD_CHECK_ARG(a->K % 8 == 0, "K must be a multiple of 8");
@@ -887,6 +975,96 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);
     }
     ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+
+// candidates of one shape: the rules of the first autotuner (hip_ops._candidates, round 1) restated
+static int asd_tune_candidates(const asd_gemm_args* a, int (*out)[2], int max_out) {
+    static const int sk_plain[] = {1, 2, 3, 4, 6, 8, 12, 16}, sk_win[] = {1, 2, 3, 4, 5, 6, 8, 10};
+    const bool geglu = a->act == 2, window_ok = asd_conv_window_ok(a);
+    int n = 0;
+    for (int t = 0; t < ASD_GEMM_NCFG && n < max_out; ++t) {
+        const int bm = asd_gemm_tiles[t].bm, bn = asd_gemm_tiles[t].bn;
+        if (asd_cfg_is_window(t)) {
+            if (!window_ok || (bn != 64 && a->N % bn != 0)) continue;
+            const int tiles = (a->M / 256) * asd_div_up(a->N, bn);
+            for (int sk : sk_win) {
+                if (sk > 1 && (a->Cin / 64 < 2 * sk || tiles * sk > 1536)) continue;
+                if (n < max_out) { out[n][0] = t + 1; out[n][1] = sk; ++n; }
+            }
+            continue;
+        }
+        if (bn != 64 && a->N % bn != 0) continue;
+        if (geglu && (t == 4 || t == 6)) continue;
+        if (bn == 64 && a->N % 128 == 0 && a->N >= 256 && bm == 128) continue;
+        const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
+        for (int sk : sk_plain) {
+            if (sk > 1 && (geglu || a->K / sk < 256 || tiles * sk > 1536)) continue;
+            if (n < max_out) { out[n][0] = t + 1; out[n][1] = sk; ++n; }
+        }
+    }
+    return n;
+}
+
+/* Time every valid (tile, split-K) candidate of this problem on `stream` (which must not be capturing) and record the winner
+ * in the plan table: among the candidates within 4 % of the fastest the smallest split wins (split-K multiplies the HBM
+ * traffic of the output by 2 * split in fp32 partial slabs), then the fastest.  The launches are queued behind a spin kernel
+ * so that the events bracket GPU time only (an eager launch costs the host ~8 us, more than some candidates run).
+ * `scratch` holds the split-K slabs; candidates that need more than scratch_bytes are skipped. */
+int asd_gemm_tune(const asd_gemm_args* a_in, void* scratch, int64_t scratch_bytes, void* stream) {
+    ASD_CHECK_ARG(a_in, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int cand[160][2];
+    const int n = asd_tune_candidates(a_in, cand, 160);
+    ASD_CHECK_ARG(n > 0, "no tile configuration fits this problem");
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { asd_set_error("hipEventCreate failed"); return ASD_ERR_LAUNCH; }
+    float best_ms = 1e30f;
+    float ms_of[160];
+    for (int i = 0; i < n; ++i) {
+        ms_of[i] = 1e30f;
+        asd_gemm_args a = *a_in;
+        a.tile_cfg = cand[i][0];
+        a.split_k = cand[i][1];
+        if (a.split_k > 1) {
+            if ((int64_t)a.split_k * a.M * a.N * 4 > scratch_bytes) continue;
+            a.workspace = (float*)scratch;
+        }
+        if (asd_gemm_f16(&a, stream) != ASD_OK) continue;       // warm-up (also validates the candidate)
+        hipLaunchKernelGGL(asd_spin_kernel, dim3(1), dim3(1), 0, s, 20000LL);   // ~200 us at the 100 MHz wall clock
+        hipEventRecord(e0, s);
+        for (int r = 0; r < 5; ++r) asd_gemm_f16(&a, stream);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms_of[i] = ms;
+        if (ms < best_ms) best_ms = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    int pick = -1;
+    for (int i = 0; i < n; ++i) {
+        if (ms_of[i] > 1.04f * best_ms) continue;
+        if (pick < 0 || cand[i][1] < cand[pick][1] || (cand[i][1] == cand[pick][1] && ms_of[i] < ms_of[pick])) pick = i;
+    }
+    if (pick < 0) { asd_set_error("asd_gemm_tune: no candidate ran"); return ASD_ERR_LAUNCH; }
+    const asd_plan_key k = asd_plan_key_of(a_in);
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    g_plans[k] = asd_plan_val{cand[pick][0], cand[pick][1]};
+    return ASD_OK;
+}
+
+/* enumerate the plan table (persisting what asd_gemm_tune found): entry i -> 11 ints {M,N,K,conv,s0..s4,tile,split} */
+int asd_gemm_plan_entry(int32_t i, int32_t* out11) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    if (i < 0 || i >= (int)g_plans.size() || !out11) return ASD_ERR_ARG;
+    auto it = g_plans.begin();
+    std::advance(it, i);
+    const asd_plan_key& k = it->first;
+    const int32_t v[11] = {k.M, k.N, k.K, k.conv, k.a, k.b, k.c, k.d, k.e, it->second.tile, it->second.split};
+    memcpy(out11, v, sizeof(v));
     return ASD_OK;
 }
 

@@ -492,6 +492,16 @@ __global__ __launch_bounds__(256) void concat_kernel(const half_t* __restrict__ 
     }
 }
 
+// y[r, :c] = (half) x[r, :c], y[r, c:c_pad] = 0: fp32 gradient of the 8 moment channels -> the K granularity of the dgrad GEMM
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ x, size_t rows, int c, half_t* __restrict__ y, int c_pad) {
+    const size_t total = rows * (size_t)c_pad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / c_pad;
+        const int j = (int)(i - r * c_pad);
+        y[i] = j < c ? (half_t)x[r * c + j] : (half_t)0.f;
+    }
+}
+
 extern "C" {
 
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
@@ -622,6 +632,14 @@ int asd_concat_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int64
     ASD_CHECK_ARG(x1 && x2 && y && rows > 0 && c1 % 8 == 0 && c2 % 8 == 0, "bad argument");
     hipLaunchKernelGGL(concat_kernel, dim3(asd_grid_for((size_t)rows * (c1 + c2) / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)x1, c1, (const half_t*)x2, c2, (size_t)rows, (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_pad_cast_f16(const float* x, int32_t rows, int32_t c, void* y, int32_t c_pad, void* stream) {
+    ASD_CHECK_ARG(x && y && rows > 0 && c > 0 && c_pad >= c, "bad argument");
+    const size_t total = (size_t)rows * c_pad;
+    hipLaunchKernelGGL(pad_cast_kernel, dim3(asd_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (size_t)rows, c, (half_t*)y, c_pad);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -27,37 +27,29 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def pick_split_k(M: int, N: int, K: int) -> int:
-    """fill the 256 CUs when the output has few 128x128 tiles and the reduction is long (low-resolution layers)."""
-    bn = 128 if N % 128 == 0 else 64
-    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
-    if tiles >= 256 or K < 1024:
-        return 1
-    target = 512 if tiles <= 128 else 640
-    s = min(16, max(1, target // tiles), K // 512)
-    return max(1, s)
-
-
 # ---- GEMM plans: (tile configuration, split-K) per problem shape ---------------------------------------------------
-# The kernel is bound by tile loads, so the best tile / split depends on the shape in ways a closed-form model only roughly
-# captures (tools/gemm_sweep.py).  Like a BLAS library's tuned-kernel table, each new shape is timed once over the valid
-# candidates (a few ms, outside graph capture) and the winner is cached for the process; ASD_GEMM_AUTOTUNE=0 keeps the
-# built-in cost model (csrc/gemm.hip: asd_gemm_pick_tile) + pick_split_k.
+# The plan table and the autotuner live in the library (csrc/gemm.hip: asd_gemm_plan_*, asd_gemm_tune): asd_gemm_f16 with
+# split_k = 0 uses the recorded plan of the shape, else its cost model.  The winners for the shapes of the shipped configs are
+# committed in gemm_plans.json and pushed into the library when this module is imported; a shape met for the first time is tuned
+# once (a few ms, never under graph capture) unless ASD_GEMM_AUTOTUNE=0.
 TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64)
 TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64)
 WINDOW_TILES = (8, 9, 10, 11)   # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels); 10, 11: two blocks per CU
 AUTOTUNE = os.environ.get("ASD_GEMM_AUTOTUNE", "1") != "0"
 PLAN_FILE = os.environ.get("ASD_GEMM_PLAN_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans.json"))
-_plans = {}
+TUNE_SCRATCH_BYTES = 512 << 20
+_tune_scratch = {}
 
 
-def _key_str(key) -> str:
-    return repr(key)
+def _sig(key):
+    """(M, N, K, lda) | (M, N, K, (Hin, Cin, stride, upsample, pad)) -> the library's (M, N, K, conv, s0..s4)"""
+    M, N, K, tail = key
+    if isinstance(tail, tuple):
+        return (M, N, K, 1) + tuple(int(v) for v in tail)
+    return (M, N, K, 0, int(tail), 0, 0, 0, 0)
 
 
 def load_plans(path: str = PLAN_FILE) -> int:
-    """plans found earlier by the autotuner (tools/gemm_tune.py writes the in-tree table for the shapes of the shipped
-    configs); shapes not in the table are tuned on first use."""
     import ast
     import json
 
@@ -66,74 +58,61 @@ def load_plans(path: str = PLAN_FILE) -> int:
     with open(path) as f:
         table = json.load(f)
     for k, v in table.items():
-        _plans[ast.literal_eval(k)] = tuple(v)
+        check(lib().asd_gemm_plan_set(*[i32(x) for x in _sig(ast.literal_eval(k))], i32(int(v[0])), i32(int(v[1]))))
     return len(table)
+
+
+def plan_table() -> dict:
+    """the library's current plan table in the JSON file's key form"""
+    out = {}
+    buf = (C.c_int32 * 11)()
+    for i in range(lib().asd_gemm_plan_count()):
+        check(lib().asd_gemm_plan_entry(i32(i), buf))
+        M, N, K, conv, s0, s1, s2, s3, s4, tile, sk = list(buf)
+        out[(M, N, K, (s0, s1, s2, s3, s4) if conv else s0)] = (tile, sk)
+    return out
 
 
 def save_plans(path: str = PLAN_FILE) -> None:
     import json
 
     with open(path, "w") as f:
-        json.dump({_key_str(k): list(v) for k, v in sorted(_plans.items(), key=lambda kv: repr(kv[0]))}, f, indent=0)
+        json.dump({repr(k): list(v) for k, v in sorted(plan_table().items(), key=lambda kv: repr(kv[0]))}, f, indent=0)
 
 
-if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none":
+def plan_of(g: GemmArgs):
+    t, sk = C.c_int32(0), C.c_int32(1)
+    tuned = lib().asd_gemm_plan_get(C.byref(g), C.byref(t), C.byref(sk)) == 0
+    return (t.value, sk.value) if tuned else None
+
+
+def default_split(M: int, N: int, K: int) -> int:
+    """split-K of the library for an un-tuned plain GEMM of this shape (tools)"""
+    g = GemmArgs()
+    g.M, g.N, g.K, g.lda = M, N, K, K
+    t, sk = C.c_int32(0), C.c_int32(1)
+    lib().asd_gemm_plan_get(C.byref(g), C.byref(t), C.byref(sk))
+    return sk.value
+
+
+def tune_scratch(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _tune_scratch:
+        _tune_scratch[key] = torch.empty(TUNE_SCRATCH_BYTES, dtype=torch.uint8, device=device)
+    return _tune_scratch[key]
+
+
+def release_tune_scratch() -> None:
+    _tune_scratch.clear()
+
+
+if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none" and os.path.exists(L.LIB_PATH):
     load_plans()
-
-
-def _candidates(M: int, N: int, K: int, conv: Optional[dict] = None, geglu: bool = False):
-    window_ok = (conv is not None and conv["stride"] == 1 and conv["pad"] == 1 and conv["upsample"] == 0 and conv["Cin"] % 64 == 0
-                 and conv["Hin"] == conv["Hout"] and conv["Win"] == conv["Wout"] and conv["Hout"] % 16 == 0 and conv["Wout"] % 16 == 0)
-    for t, (bm, bn) in enumerate(zip(TILE_BM, TILE_BN)):
-        if t in WINDOW_TILES:
-            if not window_ok or (bn != 64 and N % bn != 0):
-                continue
-            tiles = (M // 256) * ((N + bn - 1) // bn)
-            for sk in (1, 2, 3, 4, 5, 6, 8, 10):
-                if sk > 1 and (conv["Cin"] // 64 < 2 * sk or tiles * sk > 1536):
-                    continue
-                yield t, sk
-            continue
-        if bn != 64 and N % bn != 0:
-            continue
-        if geglu and t in (4, 6):       # the GEGLU epilogue pairs 16-column fragments: per-wave width must be a multiple of 32
-            continue
-        if bn == 64 and N % 128 == 0 and N >= 256:
-            if bm == 128:
-                continue
-        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-        for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-            if sk > 1 and (geglu or K // sk < 256 or tiles * sk > 1536):
-                continue
-            yield t, sk
-
-
-def _autotune(key, launch, M, N, K, conv=None, geglu=False):
-    results = []
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for t, sk in _candidates(M, N, K, conv, geglu):
-        launch(t + 1, sk)
-        # An eager launch costs the host ~8-10 us: timed back to back, candidates faster than that tie at the host's rate.
-        # Park the GPU on a spin kernel while the launches are queued, so that the events bracket GPU time only — what the
-        # graph-replayed step sees (rocprofv3: tools/trace_by_grid.py).
-        torch.cuda._sleep(300_000)
-        e0.record()
-        for _ in range(5):
-            launch(t + 1, sk)
-        e1.record()
-        e1.synchronize()
-        results.append((e0.elapsed_time(e1), sk, t + 1))
-    t_min = min(r[0] for r in results)
-    # among the candidates within 4 % of the fastest take the smallest split (split-K multiplies the HBM traffic of the
-    # output by 2 * split in fp32 partial slabs: profiles/r01_final2_pmc_*), then the fastest
-    dt, sk, tile = min((r for r in results if r[0] <= 1.04 * t_min), key=lambda r: (r[1], r[0]))
-    _plans[key] = (tile, sk)
-    return _plans[key]
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
-         M: Optional[int] = None) -> torch.Tensor:
+         M: Optional[int] = None, tile_cfg: int = 0) -> torch.Tensor:
     """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv."""
     dev = a.device
     N, K = w.shape
@@ -163,26 +142,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
         for k in ("Hin", "Win", "Cin", "Hout", "Wout", "stride", "pad", "upsample"):
             setattr(g, k, int(conv[k]))
     g.zero_page = zero_page(dev).data_ptr()
-
-    def launch(tile_cfg: int, sk: int):
-        g.tile_cfg, g.split_k = tile_cfg, sk
-        ws = None
-        if sk > 1:
-            ws = torch.empty((sk, M, N), device=dev, dtype=torch.float32)
-            g.workspace = ws.data_ptr()
-        check(lib().asd_gemm_f16(C.byref(g), stream()))
-
+    g.tile_cfg = tile_cfg
     if split_k is not None:
-        launch(0, split_k)
-        return out
-    key = (M, N, K, (lda if act != 2 else -lda) if conv is None else (conv["Hin"], conv["Cin"], conv["stride"], conv["upsample"], conv["pad"]))
-    plan = _plans.get(key)
-    if plan is None:
-        if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
-            plan = _autotune(key, launch, M, N, K, conv, act == 2)
-        else:
-            plan = (0, 1 if act == 2 else pick_split_k(M, N, K))
-    launch(*plan)
+        g.split_k = split_k
+    else:
+        g.split_k = 0       # auto
+        if AUTOTUNE and plan_of(g) is None and not torch.cuda.is_current_stream_capturing():
+            sc = tune_scratch(dev)
+            check(lib().asd_gemm_tune(C.byref(g), C.c_void_p(sc.data_ptr()), C.c_int64(sc.numel()), stream()))
+    need = lib().asd_gemm_workspace_bytes(C.byref(g))
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        g.workspace = ws.data_ptr()
+    check(lib().asd_gemm_f16(C.byref(g), stream()))
     return out
 
 
@@ -206,12 +179,9 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1,
 
 
 def pack_conv3x3_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
-    """PyTorch [Cout, Cin, 3, 3] -> [Cout, 9*Cin'] with k = (ky, kx, cin), Cin' = Cin padded to a multiple of 32."""
-    cout, cin = w.shape[:2]
-    cp = cin_pad or ((cin + 31) // 32 * 32)
-    wp = torch.zeros((cout, 3, 3, cp), dtype=w.dtype, device=w.device)
-    wp[..., :cin] = w.permute(0, 2, 3, 1)
-    return wp.reshape(cout, 9 * cp).contiguous()
+    from .weights import _pack_conv3x3
+
+    return _pack_conv3x3(w, cin_pad).contiguous()
 
 
 def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optional[torch.Tensor] = None,
@@ -276,9 +246,9 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
 def pack_geglu_weight(w: torch.Tensor, b: torch.Tensor):
     """GEGLU.proj [2C', K] (value rows, then gate rows; attention.py:49-56) -> rows interleaved in 32-row groups
     [16 value | 16 gate] for the fused epilogue (asd_gemm_args.act = 2); the bias is permuted the same way."""
-    c = w.shape[0] // 2
-    assert c % 16 == 0
-    perm = torch.stack([torch.arange(c).view(-1, 16), torch.arange(c, 2 * c).view(-1, 16)], dim=1).reshape(-1).to(w.device)
+    from .weights import _geglu_rows
+
+    perm = _geglu_rows(w.shape[0] // 2).to(w.device)
     return w[perm].contiguous(), b[perm].contiguous()
 
 

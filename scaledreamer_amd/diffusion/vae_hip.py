@@ -6,12 +6,13 @@ every step pays a forward and an input-gradient ("dgrad") pass at 512x512.  Arch
 (extern/mvdream/ldm/modules/diffusionmodules/model.py:452-543), ResnetBlock :88-146, Downsample :66-85,
 AttnBlock :152-203, quant_conv (models/autoencoder.py:32,81-85).
 
-All heavy layers run in the hand-written kernels: 3x3 convolutions forward and dgrad are the same
-implicit-GEMM MFMA kernel (the dgrad uses weights transposed/flipped once at load; the stride-2 dgrad is the
-kernel's "transposed" gather mode), GroupNorm+SiLU forward/backward are the NHWC kernels of nn_ops.hip, 1x1
-convolutions are GEMMs.  torch.autograd only sequences the layers (each layer is a small autograd.Function
-that calls the C ABI); the single-head 512-wide mid-block attention uses torch's SDPA this round.
-conv_out and quant_conv are both linear, so they are folded into one 3x3 convolution at load time.
+The product path is `HipVAEEncoder`: ONE autograd node around the C-ABI network asd_vae_enc_fwd / asd_vae_enc_bwd
+(csrc/net.hip), which enqueues every layer itself — 3x3 convolutions forward and dgrad are the same implicit-GEMM MFMA kernel
+(the dgrad uses weights transposed/flipped once at load; the stride-2 dgrad is the kernel's "transposed" gather mode),
+GroupNorm+SiLU forward/backward are the NHWC kernels of nn_ops.hip, 1x1 convolutions and the single-head mid-block attention are
+GEMMs around row-softmax kernels; conv_out and quant_conv are both linear and are folded into one 3x3 convolution at pack time.
+The per-layer autograd Functions below (_Conv3x3Fn, _GroupNormFn) drive the same leaf kernels one at a time; they are kept as
+the unit-test harness of those kernels' gradients (tests/test_gpu_vae_hip.py), not used by the encoder.
 """
 from __future__ import annotations
 
@@ -20,11 +21,13 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
+import ctypes as C
+
+from .._lib import AsdError, VaeDesc, check, i32, lib, ptr, stream
 from . import hip_ops as H
 from . import weights as W
 
 P = Dict[str, torch.Tensor]
-_FUSE_SHORTCUT = __import__("os").environ.get("ASD_VAE_FUSE_SHORTCUT", "1") != "0"   # A/B switch (tools)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -66,202 +69,68 @@ class _GroupNormFn(torch.autograd.Function):
         return H.groupnorm_bwd(x, dy.contiguous(), gamma, beta, ctx.eps, ctx.silu, stats), None, None, None, None
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b on [M, Cin] rows (1x1 convolution on NHWC)."""
+def vae_desc(cfg: W.VAEConfig) -> VaeDesc:
+    d = VaeDesc()
+    d.in_channels, d.ch, d.n_levels, d.num_res_blocks = cfg.in_channels, cfg.ch, len(cfg.ch_mult), cfg.num_res_blocks
+    for i, m in enumerate(cfg.ch_mult):
+        d.ch_mult[i] = m
+    d.z_channels, d.embed_dim = cfg.z_channels, cfg.embed_dim
+    return d
+
+
+class _EncodeFn(torch.autograd.Function):
+    """moments = Encoder(images) as ONE autograd node: asd_vae_enc_fwd leaves the activations its input gradient needs in the
+    workspace, asd_vae_enc_bwd walks the layers back (frozen weights: dgrad only).  The workspace tensor is what autograd saves."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, w_t):
-        ctx.w_t = w_t
-        return H.gemm(x, w, bias=bias)
+    def forward(ctx, images, enc):
+        B, Cin, Hh, Ww = images.shape
+        x = torch.zeros((B, Hh, Ww, 32), device=images.device, dtype=torch.float16)     # NHWC, channels padded to the K granularity
+        x[..., :Cin] = images.permute(0, 2, 3, 1)
+        tune = enc.needs_tune((B, Hh, Ww))
+        ws = torch.empty(enc.workspace_bytes(B, Hh, Ww, tune), dtype=torch.uint8, device=images.device)
+        m = torch.empty((B, Hh // 8, Ww // 8, 2 * enc.cfg.embed_dim), device=images.device, dtype=torch.float32)
+        check(lib().asd_vae_enc_fwd(enc.net.handle, ptr(x), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(m), i32(int(tune)), stream()))
+        ctx.enc, ctx.shape, ctx.tune, ctx.in_dtype = enc, (B, Cin, Hh, Ww), tune, images.dtype
+        ctx.save_for_backward(ws)
+        return m.permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, dy):
-        return H.gemm(dy.contiguous(), ctx.w_t), None, None, None
-
-
-class _ResBlockFn(torch.autograd.Function):
-    """ResnetBlock of the VAE encoder (model.py:95-148) as ONE autograd node: x feeds both norm1 and the shortcut, so plain
-    autograd sums two gradients for it with a separate add pass over the activation.  Here the shortcut gradient enters the
-    norm1 backward kernel (`dx_add`) or, with a 1x1 `nin_shortcut`, the residual input of its GEMM: no add pass in either
-    direction.  Frozen weights: only the input gradient exists."""
-
-    @staticmethod
-    def forward(ctx, x, wd):
-        B, Hh, Ww, cin = x.shape
-        cout = wd["conv2.fwd"].shape[0]
-        t1, st1 = H.groupnorm(x, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, return_stats=True)
-        t2 = H.conv3x3(t1, wd["conv1.fwd"], bias=wd["conv1.bias"], stride=1, pad=1)
-        del t1
-        t3, st2 = H.groupnorm(t2, wd["norm2.weight"], wd["norm2.bias"], 1e-6, True, return_stats=True)
-        s = H.gemm(x.reshape(-1, cin), wd["nin.w"], bias=wd["nin.b"]) if "nin.w" in wd else x.reshape(-1, cout)
-        out = H.conv3x3(t3, wd["conv2.fwd"], bias=wd["conv2.bias"], stride=1, pad=1, residual=s)
-        ctx.save_for_backward(x, st1, t2, st2)
-        ctx.wd = wd
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, st1, t2, st2 = ctx.saved_tensors
-        wd = ctx.wd
-        dy = dy.contiguous()
-        d3 = H.conv3x3(dy, wd["conv2.bwd"], stride=1, pad=1)
-        d2 = H.groupnorm_bwd(t2, d3, wd["norm2.weight"], wd["norm2.bias"], 1e-6, True, st2)
-        d1 = H.conv3x3(d2, wd["conv1.bwd"], stride=1, pad=1)
-        if "nin.w" in wd:
-            dmain = H.groupnorm_bwd(x, d1, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, st1)
-            dx = H.gemm(dy.reshape(-1, dy.shape[-1]), wd["nin.wt"], residual=dmain.reshape(-1, x.shape[-1])).view_as(x)
-        else:
-            dx = H.groupnorm_bwd(x, d1, wd["norm1.weight"], wd["norm1.bias"], 1e-6, True, st1, dx_add=dy)
-        return dx, None
-
-
-class _AttnFn(torch.autograd.Function):
-    """Single-head attention over [B, L, C] rows (AttnBlock, model.py:195-224): per image S = Q K^T -> P = softmax(S / sqrt(C))
-    -> O = P V as two MFMA GEMMs around a row-softmax kernel; the input gradients are four more GEMMs around the
-    softmax-gradient kernel.  P (L x L fp16) is kept for the backward pass."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, B):
-        L, C_ = q.shape[0] // B, q.shape[1]
-        scale = float(C_) ** -0.5
-        o = torch.empty_like(q)
-        ps = []
-        for b in range(B):
-            r = slice(b * L, (b + 1) * L)
-            p = H.softmax(H.gemm(q[r], k[r]), scale)                  # [L, L]
-            H.gemm(p, H.transpose(v[r]), out=o[r])                    # P V  (W operand = V^T [C, L])
-            ps.append(p)
-        ctx.save_for_backward(q, k, v, *ps)
-        ctx.B, ctx.scale = B, scale
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        q, k, v, *ps = ctx.saved_tensors
-        B, scale = ctx.B, ctx.scale
-        L = q.shape[0] // B
-        do = do.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        for b in range(B):
-            r = slice(b * L, (b + 1) * L)
-            p = ps[b]
-            H.gemm(H.transpose(p), H.transpose(do[r]), out=dv[r])      # dV = P^T dO
-            ds = H.softmax_bwd(p, H.gemm(do[r], v[r]), scale)          # dP = dO V^T ; dS = scale P o (dP - sum)
-            H.gemm(ds, H.transpose(k[r]), out=dq[r])                   # dQ = dS K
-            H.gemm(H.transpose(ds), H.transpose(q[r]), out=dk[r])      # dK = dS^T Q
-        return dq, dk, dv, None
+    def backward(ctx, d_m):
+        (ws,) = ctx.saved_tensors
+        B, Cin, Hh, Ww = ctx.shape
+        enc = ctx.enc
+        dm = d_m.permute(0, 2, 3, 1).contiguous().float()
+        dx = torch.empty((B, Hh, Ww, 32), device=dm.device, dtype=torch.float16)
+        check(lib().asd_vae_enc_bwd(enc.net.handle, ptr(dm), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(dx), i32(int(ctx.tune)),
+                                    stream()))
+        if ctx.tune:
+            enc.tuned.add((B, Hh, Ww))
+        return dx[..., :Cin].permute(0, 3, 1, 2).to(ctx.in_dtype), None
 
 
 class HipVAEEncoder:
+    """images [B,3,H,W] in [-1,1] -> posterior moments [B, 2*embed_dim, H/8, W/8] fp32, differentiable w.r.t. the images, through
+    the C-ABI network asd_vae_enc_* (csrc/net.hip)."""
+
     def __init__(self, params: P, cfg: Optional[W.VAEConfig] = None, device="cuda", use_graph: bool = False):
+        from .engine import CNet
+
         self.cfg = cfg or W.VAEConfig()
         self.device = torch.device(device)
-        self.shapes, self.plan = W.vae_encoder_layout(self.cfg)
-        self.use_graph = use_graph
-        self._graphed = {}
-        self._pack(params)
+        self.net = CNet("vae_enc", vae_desc(self.cfg), W.pack_vae_encoder(params, self.cfg), self.device)
+        self.tuned = set()       # input shapes whose GEMM shapes (forward and backward) have been through the autotuner
 
-    def _pack(self, p: P):
-        dev = self.device
-        f16 = lambda t: t.to(device=dev, dtype=torch.float16).contiguous()
-        w: Dict[str, torch.Tensor] = {}
+    def needs_tune(self, shape) -> bool:
+        return H.AUTOTUNE and shape not in self.tuned and not torch.cuda.is_current_stream_capturing()
 
-        def conv(name, weight, bias, stride=1):
-            wt = weight.float()
-            w[name + ".fwd"] = H.pack_conv3x3_weight(f16(wt))
-            cin = wt.shape[1]
-            cin_p = (cin + 31) // 32 * 32
-            wb = wt.permute(1, 0, 2, 3)                     # [Cin, Cout, 3, 3]: roles swapped for the input gradient
-            if stride == 1:
-                wb = wb.flip(2, 3)
-            if cin_p != cin:                                  # gradient w.r.t. the zero-padded input channels
-                wb = torch.cat([wb, wb.new_zeros(cin_p - cin, *wb.shape[1:])], 0)
-            w[name + ".bwd"] = H.pack_conv3x3_weight(f16(wb))
-            w[name + ".bias"] = f16(bias)
-
-        for kind, name, cin, cout in self.plan:
-            if kind == "conv":
-                conv(name, p[name + ".weight"], p[name + ".bias"])
-            elif kind == "res":
-                for n in ("norm1", "norm2"):
-                    w[f"{name}.{n}.weight"], w[f"{name}.{n}.bias"] = f16(p[f"{name}.{n}.weight"]), f16(p[f"{name}.{n}.bias"])
-                conv(name + ".conv1", p[name + ".conv1.weight"], p[name + ".conv1.bias"])
-                conv(name + ".conv2", p[name + ".conv2.weight"], p[name + ".conv2.bias"])
-                if name + ".nin_shortcut.weight" in p:
-                    ws = p[name + ".nin_shortcut.weight"].reshape(cout, cin)
-                    w[name + ".nin.w"], w[name + ".nin.wt"], w[name + ".nin.b"] = f16(ws), f16(ws.t()), f16(p[name + ".nin_shortcut.bias"])
-            elif kind == "down":
-                conv(name, p[name + ".weight"], p[name + ".bias"], stride=2)
-            elif kind == "attn":
-                w[name + ".norm.weight"], w[name + ".norm.bias"] = f16(p[name + ".norm.weight"]), f16(p[name + ".norm.bias"])
-                for n in ("q", "k", "v", "proj_out"):
-                    wm = p[f"{name}.{n}.weight"].reshape(cout, cin)
-                    w[f"{name}.{n}.w"], w[f"{name}.{n}.wt"], w[f"{name}.{n}.b"] = f16(wm), f16(wm.t()), f16(p[f"{name}.{n}.bias"])
-            elif kind == "out":
-                w[name + ".norm_out.weight"], w[name + ".norm_out.bias"] = f16(p[name + ".norm_out.weight"]), f16(p[name + ".norm_out.bias"])
-                # moments = quant_conv(conv_out(h)): compose the two linear maps (exact)
-                wq = p["quant_conv.weight"].float().reshape(p["quant_conv.weight"].shape[0], -1)     # [8, 8]
-                wc = p[name + ".conv_out.weight"].float()                                              # [8, 512, 3, 3]
-                wcomb = torch.einsum("om,mikl->oikl", wq, wc)
-                bcomb = wq @ p[name + ".conv_out.bias"].float() + p["quant_conv.bias"].float()
-                conv(name + ".conv_out_quant", wcomb, bcomb)
-        self.w = w
+    def workspace_bytes(self, B, Hh, Ww, tune) -> int:
+        nb = lib().asd_vae_enc_workspace_bytes(self.net.handle, i32(B), i32(Hh), i32(Ww), i32(int(tune)))
+        if nb < 0:
+            raise AsdError(lib().asd_last_error().decode())
+        return nb
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
-        """images [B,3,H,W] in [-1,1] (may require grad) -> moments [B, 2*embed_dim, H/8, W/8] fp32.
-        use_graph (off by default: measured 9.14 vs 9.17 ms per fwd+bwd at 512^2, the encoder is GPU-bound) captures the
-        forward and the input-gradient pass into two HIP graphs (torch.cuda.make_graphed_callables)."""
-        if self.use_graph and images.is_cuda and images.requires_grad and images.dtype == torch.float32 and torch.is_grad_enabled():
-            key = tuple(images.shape)
-            if key not in self._graphed:
-                sample = torch.zeros(key, device=images.device, dtype=torch.float32).uniform_(-1, 1).requires_grad_(True)
-                self._graphed[key] = torch.cuda.make_graphed_callables(self._forward, (sample,))
-            return self._graphed[key](images.contiguous())
-        return self._forward(images)
-
-    def _res_weights(self, name: str) -> Dict[str, torch.Tensor]:
-        """the packed tensors of one ResnetBlock under block-local names (cached)"""
-        cache = self.__dict__.setdefault("_res_cache", {})
-        if name not in cache:
-            pre = name + "."
-            cache[name] = {k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}
-        return cache[name]
-
-    def _forward(self, images: torch.Tensor) -> torch.Tensor:
-        w = self.w
-        B, Cin, Hh, Ww = images.shape
-        x = F.pad(images.permute(0, 2, 3, 1), (0, 32 - Cin)).to(torch.float16).contiguous()   # NHWC, channels padded to 32
-        h = x
-        for kind, name, cin, cout in self.plan:
-            if kind == "conv":
-                h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 1, 1)
-            elif kind == "res" and _FUSE_SHORTCUT:
-                h = _ResBlockFn.apply(h, self._res_weights(name))
-            elif kind == "res":
-                t = _GroupNormFn.apply(h, w[name + ".norm1.weight"], w[name + ".norm1.bias"], 1e-6, True)
-                t = _Conv3x3Fn.apply(t, w[name + ".conv1.fwd"], w[name + ".conv1.bias"], w[name + ".conv1.bwd"], 1, 1)
-                t = _GroupNormFn.apply(t, w[name + ".norm2.weight"], w[name + ".norm2.bias"], 1e-6, True)
-                if name + ".nin.w" in w:
-                    s = _LinearFn.apply(h.reshape(-1, cin), w[name + ".nin.w"], w[name + ".nin.b"], w[name + ".nin.wt"])
-                else:
-                    s = h.reshape(-1, cout)
-                if _FUSE_SHORTCUT:
-                    h = _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1, s)   # + shortcut
-                else:
-                    h = s.view(*h.shape[:3], cout) + _Conv3x3Fn.apply(t, w[name + ".conv2.fwd"], w[name + ".conv2.bias"], w[name + ".conv2.bwd"], 1, 1)
-            elif kind == "down":
-                h = _Conv3x3Fn.apply(h, w[name + ".fwd"], w[name + ".bias"], w[name + ".bwd"], 2, 0)
-            elif kind == "attn":
-                Bh, Hc, Wc, C_ = h.shape
-                t = _GroupNormFn.apply(h, w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-6, False).reshape(-1, C_)
-                q, k, v = (_LinearFn.apply(t, w[f"{name}.{n}.w"], w[f"{name}.{n}.b"], w[f"{name}.{n}.wt"]) for n in ("q", "k", "v"))
-                o = _AttnFn.apply(q, k, v, Bh)
-                o = _LinearFn.apply(o, w[name + ".proj_out.w"], w[name + ".proj_out.b"], w[name + ".proj_out.wt"])
-                h = h + o.view(Bh, Hc, Wc, C_)
-            elif kind == "out":
-                t = _GroupNormFn.apply(h, w[name + ".norm_out.weight"], w[name + ".norm_out.bias"], 1e-6, True)
-                n = name + ".conv_out_quant"
-                h = _Conv3x3Fn.apply(t, w[n + ".fwd"], w[n + ".bias"], w[n + ".bwd"], 1, 1)
-            elif kind == "quant":
-                pass  # folded into conv_out above
-        return h.permute(0, 3, 1, 2).float()
+        if not images.is_cuda:
+            raise AsdError("the HIP VAE encoder needs device tensors (there is no CPU fallback)")
+        return _EncodeFn.apply(images, self)

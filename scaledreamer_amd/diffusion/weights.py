@@ -241,3 +241,98 @@ def count_params(shapes: Shapes) -> int:
             n *= d
         total += n
     return total
+
+
+# ---- packing into the weight tables the C schedules publish (include/asd_hip.h: asd_unet_weight_info / asd_vae_enc_weight_info) ----
+def _pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """PyTorch [Cout, Cin, 3, 3] -> [Cout, 9*Cin'] with k = (ky, kx, cin), Cin' = Cin padded to a multiple of 32."""
+    cout, cin = w.shape[:2]
+    cp = cin_pad or ((cin + 31) // 32 * 32)
+    wp = torch.zeros((cout, 3, 3, cp), dtype=w.dtype, device=w.device)
+    wp[..., :cin] = w.permute(0, 2, 3, 1)
+    return wp.reshape(cout, 9 * cp)
+
+
+def _geglu_rows(c: int) -> torch.Tensor:
+    """GEGLU.proj rows [value (c) | gate (c)] (attention.py:49-56) -> interleaved in 32-row groups [16 value | 16 gate]: the layout
+    the fused epilogue of asd_gemm_f16 (act = 2) reads."""
+    assert c % 16 == 0
+    return torch.stack([torch.arange(c).view(-1, 16), torch.arange(c, 2 * c).view(-1, 16)], dim=1).reshape(-1)
+
+
+def pack_unet(p: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
+    """name-keyed LDM UNet state dict -> the packed fp32/fp16-agnostic matrices of the C table (names as csrc/net.hip: unet_build)."""
+    _, inputs, middle, outputs = unet_layout(cfg)
+    out: Dict[str, torch.Tensor] = {}
+    emb_w, emb_b, ck, cv = [], [], [], []
+    for name, t in p.items():
+        if ".emb_layers.1." in name or any(k in name for k in (".attn1.to_q.", ".attn1.to_k.", ".attn2.to_k.", ".attn2.to_v.")):
+            continue
+        if name.endswith(".weight") and t.ndim == 4:
+            out[name] = _pack_conv3x3(t) if t.shape[-1] == 3 else t.reshape(t.shape[0], t.shape[1])   # 1x1 conv == Linear on NHWC
+        else:
+            out[name] = t
+    for blk in list(inputs) + [middle] + list(outputs):            # the order csrc/net.hip assigns the column offsets in
+        for kind, name, cin, cout in blk.layers:
+            if kind == "res":
+                emb_w.append(p[name + ".emb_layers.1.weight"])
+                emb_b.append(p[name + ".emb_layers.1.bias"])
+            elif kind == "attn":
+                for d in range(cfg.transformer_depth):
+                    b = f"{name}.transformer_blocks.{d}"
+                    out[b + ".attn1.to_qk.weight"] = torch.cat([p[b + ".attn1.to_q.weight"], p[b + ".attn1.to_k.weight"]], 0)
+                    ck.append(p[b + ".attn2.to_k.weight"])
+                    cv.append(p[b + ".attn2.to_v.weight"])
+                    perm = _geglu_rows(4 * cout).to(p[b + ".ff.net.0.proj.weight"].device)
+                    out[b + ".ff.net.0.proj.weight"] = p[b + ".ff.net.0.proj.weight"][perm]
+                    out[b + ".ff.net.0.proj.bias"] = p[b + ".ff.net.0.proj.bias"][perm]
+    out["emb_all.weight"], out["emb_all.bias"] = torch.cat(emb_w, 0), torch.cat(emb_b, 0)
+    out["ctx_k_all.weight"], out["ctx_v_all.weight"] = torch.cat(ck, 0), torch.cat(cv, 0)
+    return out
+
+
+def pack_vae_encoder(p: Dict[str, torch.Tensor], cfg: VAEConfig) -> Dict[str, torch.Tensor]:
+    """LDM first-stage encoder state dict -> the C table of csrc/net.hip: vae_build.  Every convolution gets its forward matrix and
+    the matrix of its input gradient (roles of the channel axes swapped, taps flipped for stride 1; the stride-2 gradient uses the
+    kernel's transposed gather); conv_out and quant_conv are both linear and are composed into one convolution (exact)."""
+    _, plan = vae_encoder_layout(cfg)
+    out: Dict[str, torch.Tensor] = {}
+
+    def conv(name, weight, bias, stride=1):
+        wt = weight.float()
+        out[name + ".fwd"] = _pack_conv3x3(wt)
+        cin = wt.shape[1]
+        cin_p = (cin + 31) // 32 * 32
+        wb = wt.permute(1, 0, 2, 3)
+        if stride == 1:
+            wb = wb.flip(2, 3)
+        if cin_p != cin:                                  # gradient w.r.t. the zero-padded input channels
+            wb = torch.cat([wb, wb.new_zeros(cin_p - cin, *wb.shape[1:])], 0)
+        out[name + ".bwd"] = _pack_conv3x3(wb)
+        out[name + ".bias"] = bias.float()
+
+    for kind, name, cin, cout in plan:
+        if kind == "conv":
+            conv(name, p[name + ".weight"], p[name + ".bias"])
+        elif kind == "res":
+            for n in ("norm1", "norm2"):
+                out[f"{name}.{n}.weight"], out[f"{name}.{n}.bias"] = p[f"{name}.{n}.weight"], p[f"{name}.{n}.bias"]
+            conv(name + ".conv1", p[name + ".conv1.weight"], p[name + ".conv1.bias"])
+            conv(name + ".conv2", p[name + ".conv2.weight"], p[name + ".conv2.bias"])
+            if name + ".nin_shortcut.weight" in p:
+                ws = p[name + ".nin_shortcut.weight"].reshape(cout, cin)
+                out[name + ".nin.w"], out[name + ".nin.wt"], out[name + ".nin.b"] = ws, ws.t(), p[name + ".nin_shortcut.bias"]
+        elif kind == "down":
+            conv(name, p[name + ".weight"], p[name + ".bias"], stride=2)
+        elif kind == "attn":
+            out[name + ".norm.weight"], out[name + ".norm.bias"] = p[name + ".norm.weight"], p[name + ".norm.bias"]
+            for n in ("q", "k", "v", "proj_out"):
+                wm = p[f"{name}.{n}.weight"].reshape(cout, cin)
+                out[f"{name}.{n}.w"], out[f"{name}.{n}.wt"], out[f"{name}.{n}.b"] = wm, wm.t(), p[f"{name}.{n}.bias"]
+        elif kind == "out":
+            out[name + ".norm_out.weight"], out[name + ".norm_out.bias"] = p[name + ".norm_out.weight"], p[name + ".norm_out.bias"]
+            wq = p["quant_conv.weight"].float().reshape(p["quant_conv.weight"].shape[0], -1)
+            wc = p[name + ".conv_out.weight"].float()
+            conv(name + ".conv_out_quant", torch.einsum("om,mikl->oikl", wq, wc),
+                 wq @ p[name + ".conv_out.bias"].float() + p["quant_conv.bias"].float())
+    return out

@@ -178,9 +178,47 @@ def test_softmax_and_its_gradient(rows, cols):
     assert err <= 2e-3 * ref_ds.abs().max().item() + 1e-6
 
 
-def test_vae_single_head_attention_matches_sdpa_forward_and_backward():
-    from scaledreamer_amd.diffusion.vae_hip import _AttnFn
+class _AttnFn(torch.autograd.Function):
+    """the leaf-op sequence csrc/net.hip enqueues for the VAE mid-block attention (AttnBlock, model.py:195-224): per image
+    S = Q K^T -> P = softmax(S / sqrt(C)) -> O = P V, and the four GEMMs + softmax-gradient kernel of its input gradients."""
 
+    @staticmethod
+    def forward(ctx, q, k, v, B):
+        from scaledreamer_amd.diffusion import hip_ops as H
+
+        L, C_ = q.shape[0] // B, q.shape[1]
+        scale = float(C_) ** -0.5
+        o = torch.empty_like(q)
+        ps = []
+        for b in range(B):
+            r = slice(b * L, (b + 1) * L)
+            p = H.softmax(H.gemm(q[r], k[r]), scale)
+            H.gemm(p, H.transpose(v[r]), out=o[r])
+            ps.append(p)
+        ctx.save_for_backward(q, k, v, *ps)
+        ctx.B, ctx.scale = B, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        from scaledreamer_amd.diffusion import hip_ops as H
+
+        q, k, v, *ps = ctx.saved_tensors
+        B, scale = ctx.B, ctx.scale
+        L = q.shape[0] // B
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for b in range(B):
+            r = slice(b * L, (b + 1) * L)
+            p = ps[b]
+            H.gemm(H.transpose(p), H.transpose(do[r]), out=dv[r])
+            ds = H.softmax_bwd(p, H.gemm(do[r], v[r]), scale)
+            H.gemm(ds, H.transpose(k[r]), out=dq[r])
+            H.gemm(H.transpose(ds), H.transpose(q[r]), out=dk[r])
+        return dq, dk, dv, None
+
+
+def test_vae_single_head_attention_matches_sdpa_forward_and_backward():
     B, L, C_ = 2, 1024, 512
     q, k, v = (_rand(B * L, C_, seed=s).requires_grad_(True) for s in (1, 2, 3))
     o = _AttnFn.apply(q, k, v, B)

@@ -29,13 +29,13 @@ for (hw, cin, cout) in [(64, 320, 320), (64, 640, 320), (64, 960, 320), (32, 640
     x, w = r(B, hw, hw, cin), H.pack_conv3x3_weight(r(cout, cin, 3, 3))
     us = timeit(lambda: H.conv3x3(x, w))
     fl = 2 * B * hw * hw * cout * cin * 9
-    print(f"  {hw:3d}^2 {cin:5d}->{cout:5d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  split_k={H.pick_split_k(B*hw*hw, cout, 9*cin)}")
+    print(f"  {hw:3d}^2 {cin:5d}->{cout:5d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  split_k={H.default_split(B*hw*hw, cout, 9*cin)}")
 print("== gemm")
 for (M, N, K) in [(20480, 320, 320), (20480, 640, 320), (20480, 2560, 320), (20480, 320, 1280), (5120, 640, 640), (5120, 5120, 640), (5120, 640, 2560),
                   (1280, 1280, 1280), (1280, 10240, 1280), (1280, 1280, 5120), (320, 1280, 1280), (400, 1280, 1024), (5, 21760, 1280)]:
     a, w = r(M, K), r(N, K)
     us = timeit(lambda: H.gemm(a, w))
-    print(f"  M={M:6d} N={N:6d} K={K:5d}  {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  split_k={H.pick_split_k(M, N, K)}")
+    print(f"  M={M:6d} N={N:6d} K={K:5d}  {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  split_k={H.default_split(M, N, K)}")
 print("== attention (self / cross)")
 for (L, heads, lk, lks) in [(4096, 5, 4096, 4096), (1024, 10, 1024, 1024), (256, 20, 256, 256), (64, 20, 64, 64), (4096, 5, 77, 80), (1024, 10, 77, 80)]:
     C_ = heads * 64

@@ -48,7 +48,7 @@ for sh in shapes:
         a, w = r(M, K), r(N, K)
         run = lambda sk: H.gemm(a, w, split_k=sk)
     lib().asd_gemm_force_tile(C.c_int32(-1))
-    sk0 = H.pick_split_k(M, N, K)
+    sk0 = H.default_split(M, N, K)
     base = timeit(lambda: run(sk0))
     res = []
     for t, name in enumerate(TILES):

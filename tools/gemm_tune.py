@@ -17,10 +17,10 @@ for wl in ("asd_sd_nerf", "asd_mv_nerf"):
     for _ in range(3):
         system.train_one_step(bench.to_device(data.collate(), dev))
     torch.cuda.synchronize()
-    print(wl, "plans:", len(H._plans))
+    print(wl, "plans:", len(H.plan_table()))
     del system
     torch.cuda.empty_cache()
 out = os.path.join(ROOT, "gpurun_out", "gemm_plans.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 H.save_plans(out)
-print("wrote", out, len(H._plans))
+print("wrote", out, len(H.plan_table()))

@@ -11,4 +11,4 @@ for (B, hw, cin, cout) in [(1, 512, 128, 128), (5, 64, 320, 320)]:
     for _ in range(20):
         H.conv3x3(x, w)
     torch.cuda.synchronize()
-    print("plan", (B, hw, cin, cout), H._plans.get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1))))
+    print("plan", (B, hw, cin, cout), H.plan_table().get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1))))
