@@ -390,6 +390,34 @@ int asd_vae_enc_fwd(asd_vae_enc* h, const void* x_nhwc32, int32_t batch, int32_t
 int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, int32_t H, int32_t W, void* workspace,
                     int64_t workspace_bytes, void* dx_nhwc32, int32_t tune, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ASD latent-space glue (csrc/asd_glue.hip): everything between the rendered image and the scalar loss that is not a network.
+ * Replaces the torch elementwise code of SDTimestepShiftedScoreDistillationGuidance.__call__ / get_latents / encode_images /
+ * get_eps (threestudio/models/guidance/stable_diffusion_asd_guidance.py:171-178,196-209,242-283,404-428; perpendicular_component
+ * threestudio/utils/ops.py:501-511) and of the MVDream variant (mvdream_asd_guidance.py:105-139,181-304).
+ * ---------------------------------------------------------------------------------------------- */
+/* x[b,Y,X,0:3] = 2 * bilinear(rgb)[b,Y,X,:] - 1 (F.interpolate(mode="bilinear", align_corners=False) semantics), x[...,3:32] = 0.
+ * rgb: fp32 [B,h,w,3]; x_nhwc32: fp16 [B,H,W,32] = the VAE encoder's input layout. */
+int asd_image_prep_fwd(const float* rgb, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, void* x_nhwc32, void* stream);
+/* its adjoint: d_rgb fp32 [B,h,w,3] from dx fp16 [B,H,W,32] (channels 0..2) */
+int asd_image_prep_bwd(const void* dx_nhwc32, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, float* d_rgb, void* stream);
+/* latents = (mean + exp(0.5 clamp(logvar,-30,20)) * post_noise) * scaling (fp32 NCHW [B,C,hl,wl]); x_t = sqrt(a_t) z + sqrt(1-a_t) noise at
+ * t and at t_plus written as fp16 NHWC-32 rows of the UNet input in the order [x_t] * n_rep, then [x_t+]; unet_t = [t] * n_rep + [t_plus].
+ * moments_nhwc: fp32 [B,hl,wl,2C]; post_noise, noise: fp32 NCHW; t, t_plus: int64 [B]; alphas_cumprod: fp32 [>= max t + 1]. */
+int asd_latents_fwd(const float* moments_nhwc, const float* post_noise, const float* noise, const int64_t* t, const int64_t* t_plus,
+                    const float* alphas_cumprod, int32_t B, int32_t C, int32_t hl, int32_t wl, float scaling, int32_t n_rep,
+                    float* latents, void* unet_x, float* unet_t, void* stream);
+/* eps_nhwc: fp32 [(2 + n_neg + 1) * B, hw, C] in the order text | uncond | negatives (n_neg per sample, interleaved) | second.
+ * eps_p = uncond + s * (pos + sum_k w_k perp(neg_k - uncond, pos)), pos = text - uncond; grad = nan_to_num(w(t) (eps_p - second)) clamped
+ * to +-grad_clip when > 0; weighting 0: sds (1 - a_t), 1: uniform, 2: fantasia3d (sqrt(a_t) (1 - a_t)).
+ * grad: fp32 NCHW [B,C,hw]; sumsq: fp32 [B] workspace; loss_and_norm: fp32 [2] = {0.5 * sum(grad^2) / B, ||grad||}. */
+int asd_score_fwd(const float* eps_nhwc, int32_t B, int32_t C, int32_t hw, int32_t n_neg, const float* neg_w, float guidance_scale,
+                  const int64_t* t, const float* alphas_cumprod, int32_t weighting, float grad_clip, float* grad, float* sumsq,
+                  float* loss_and_norm, void* stream);
+/* d loss / d moments (fp32 [B,hl,wl,2C]) given grad: d z = upstream * grad / B (upstream: device scalar or NULL = 1) */
+int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C,
+                    int32_t hl, int32_t wl, float scaling, float* d_moments_nhwc, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -210,3 +210,32 @@ def asd_eps_aggregate(noise_pred, batch_size: int, guidance_scale: float, neg_gu
             accum = accum + neg_guidance_weights[:, i].view(-1, 1, 1, 1) * perpendicular_component(eps_neg, eps_pos)
         return (eps_pos + accum) * guidance_scale + uncond, second
     return eps_pos * guidance_scale + uncond, noise_pred[2 * B:3 * B]
+
+
+def asd_guidance_loss(rgb, encode_fn, unet_fn, context, neg_w, t, t_plus, noise, post_noise, guidance_scale: float, image_size: int,
+                      weighting: str = "sds", scale_factor: float = 0.18215, grad_clip: Optional[float] = None, unet_kw=None):
+    """One ASD guidance evaluation, composed from the primitives above in the order of
+    SDTimestepShiftedScoreDistillationGuidance.__call__ (stable_diffusion_asd_guidance.py:211-292) / the MVDream variant
+    (mvdream_asd_guidance.py:167-304): resize -> encode -> posterior sample -> two noisings -> one batched UNet call ->
+    CFG / Perp-Neg -> w(t) -> nan_to_num -> MSE re-parameterisation.  `context` is already in the UNet's batch order
+    (text | uncond | [negatives] | text); t, t_plus are per sample.  Returns (loss, grad_norm, unet inputs)."""
+    import torch.nn.functional as F
+
+    B = rgb.shape[0]
+    imgs = F.interpolate(rgb.permute(0, 3, 1, 2), (image_size, image_size), mode="bilinear", align_corners=False) * 2.0 - 1.0
+    latents = sample_posterior(encode_fn(imgs), post_noise, scale_factor)
+    alphas = alphas_cumprod()
+    n_rep = context.shape[0] // B - 1
+    with torch.no_grad():
+        x_in = torch.cat([add_noise(alphas, latents, noise, t)] * n_rep + [add_noise(alphas, latents, noise, t_plus)], dim=0)
+        t_in = torch.cat([t] * n_rep + [t_plus], dim=0)
+        eps = unet_fn(x_in, t_in, context, **(unet_kw or {}))
+        first, second = asd_eps_aggregate(eps, B, guidance_scale, neg_w)
+        a = alphas[t].view(-1, 1, 1, 1)
+        w = {"sds": 1 - a, "uniform": torch.ones_like(a), "fantasia3d": a.sqrt() * (1 - a)}[weighting]
+        grad = torch.nan_to_num(w * (first - second))
+        if grad_clip is not None:
+            grad = grad.clamp(-grad_clip, grad_clip)
+    target = (latents - grad).detach()
+    loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / B
+    return loss, grad.norm(), dict(x=x_in, t=t_in)

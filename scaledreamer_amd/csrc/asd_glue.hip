@@ -1,0 +1,272 @@
+// asd_glue.hip — the latent-space arithmetic of the ASD guidance between the renderer's image and the scalar loss, as five small
+// fused kernels (everything here is elementwise or a per-sample reduction over 4*64*64 values: one pass each, no torch glue):
+//   asd_image_prep_fwd/bwd   rgb[B,h,w,3] -> bilinear (align_corners=False) resize to HxW, *2-1, NHWC fp16 padded to 32 channels
+//                            (stable_diffusion_asd_guidance.py:196-209 get_latents, :171-175 encode_images' imgs*2-1) and its adjoint
+//   asd_latents_fwd          posterior sample * 0.18215 (:176-177), add_noise at t and at t+ (:242-246), written straight into the
+//                            UNet's staging buffers in the batch layout of get_eps (:377-394): n_rep copies of x_t, then x_{t+}
+//   asd_score_fwd            CFG + Perp-Neg combine (:404-428, threestudio/utils/ops.py:501-511 perpendicular_component), w(t)
+//                            (:263-271), nan_to_num (:274), optional clamp (:276-277); grad, loss = 0.5*sum(grad^2)/B (:281-283:
+//                            MSE against the detached target), grad_norm
+//   asd_latents_bwd          d loss / d moments through the posterior sample (gradient reaches the VAE encoder, :225)
+// MVDream (mvdream_asd_guidance.py:181-304) is the same with n_rep = 2, n_neg = 0 and one t per 4-view group.
+#include "asd_common.h"
+
+typedef _Float16 half_t;
+
+namespace {
+
+// F.interpolate(mode="bilinear", align_corners=False): src = max(0, scale * (dst + 0.5) - 0.5), scale = in / out in fp32
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int n_in, int* i0, int* i1, float* l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    const int a = (int)s;
+    *i0 = a;
+    *i1 = a + (a < n_in - 1 ? 1 : 0);
+    *l1 = s - (float)a;
+}
+
+__global__ __launch_bounds__(256) void image_prep_fwd_kernel(const float* __restrict__ rgb, int B, int h, int w, int H, int W,
+                                                             half_t* __restrict__ x) {
+    const size_t total = (size_t)B * H * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H), b = (int)(i / ((size_t)W * H));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_src(Y, sy, h, &y0, &y1, &ly);
+        bilinear_src(X, sx, w, &x0, &x1, &lx);
+        const float* p = rgb + (size_t)b * h * w * 3;
+        half_t o[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) o[c] = (half_t)0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = p[((size_t)y0 * w + x0) * 3 + c], v01 = p[((size_t)y0 * w + x1) * 3 + c];
+            const float v10 = p[((size_t)y1 * w + x0) * 3 + c], v11 = p[((size_t)y1 * w + x1) * 3 + c];
+            // ATen's order: (1-ly) * ((1-lx) v00 + lx v01) + ly * ((1-lx) v10 + lx v11)
+            const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            o[c] = (half_t)(v * 2.0f - 1.0f);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(x + i * 32);
+        const uint4* src = reinterpret_cast<const uint4*>(o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = src[q];
+    }
+}
+
+// adjoint as a gather: one thread per source pixel and channel sums the destination pixels whose footprint contains it
+__global__ __launch_bounds__(256) void image_prep_bwd_kernel(const half_t* __restrict__ dx, int B, int h, int w, int H, int W,
+                                                             float* __restrict__ d_rgb) {
+    const int total = B * h * w * 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % 3, xs = (i / 3) % w, ys = (i / (3 * w)) % h, b = i / (3 * w * h);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    // destination rows / columns that can touch source index s: src in (s-1, s+1)  =>  dst in ((s-0.5)/scale-0.5 .. (s+1.5)/scale-0.5)
+    int Y0 = (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1, Y1 = (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1;
+    int X0 = (int)floorf(((float)xs - 0.5f) / sx - 0.5f) - 1, X1 = (int)ceilf(((float)xs + 1.5f) / sx - 0.5f) + 1;
+    Y0 = Y0 < 0 ? 0 : Y0; X0 = X0 < 0 ? 0 : X0; Y1 = Y1 > H - 1 ? H - 1 : Y1; X1 = X1 > W - 1 ? W - 1 : X1;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        int y0, y1;
+        float ly;
+        bilinear_src(Y, sy, h, &y0, &y1, &ly);
+        const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int X = X0; X <= X1; ++X) {
+            int x0, x1;
+            float lx;
+            bilinear_src(X, sx, w, &x0, &x1, &lx);
+            const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+            if (wx != 0.f) row = fmaf(wx, (float)dx[(((size_t)b * H + Y) * W + X) * 32 + c], row);
+        }
+        acc = fmaf(wy, row, acc);
+    }
+    d_rgb[i] = 2.0f * acc;     // d/d rgb of (2 rgb - 1)
+}
+
+// one thread per latent pixel (b, y, x): all C channels
+template <int C>
+__global__ __launch_bounds__(256) void latents_fwd_kernel(const float* __restrict__ moments /*[B,hw,2C]*/, const float* __restrict__ post_noise /*[B,C,hw]*/,
+                                                          const float* __restrict__ noise /*[B,C,hw]*/, const int64_t* __restrict__ t,
+                                                          const int64_t* __restrict__ t_plus, const float* __restrict__ alphas, int B, int hw,
+                                                          float scaling, int n_rep, float* __restrict__ latents /*[B,C,hw]*/,
+                                                          half_t* __restrict__ unet_x /*[(n_rep+1)B,hw,32]*/, float* __restrict__ unet_t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < (n_rep + 1) * B) unet_t[i] = (float)(i < n_rep * B ? t[i % B] : t_plus[i - n_rep * B]);
+    if (i >= B * hw) return;
+    const int b = i / hw, p = i - b * hw;
+    const float a0 = alphas[t[b]], a1 = alphas[t_plus[b]];
+    const float sa0 = sqrtf(a0), sn0 = sqrtf(1.f - a0), sa1 = sqrtf(a1), sn1 = sqrtf(1.f - a1);
+    half_t x0[32], x1[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { x0[c] = (half_t)0.f; x1[c] = (half_t)0.f; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float mean = moments[(size_t)i * 2 * C + c];
+        float lv = moments[(size_t)i * 2 * C + C + c];
+        lv = fminf(fmaxf(lv, -30.f), 20.f);
+        const size_t q = ((size_t)b * C + c) * hw + p;
+        const float z = (mean + expf(0.5f * lv) * post_noise[q]) * scaling;
+        latents[q] = z;
+        const float e = noise[q];
+        x0[c] = (half_t)(sa0 * z + sn0 * e);
+        x1[c] = (half_t)(sa1 * z + sn1 * e);
+    }
+    const uint4* s0 = reinterpret_cast<const uint4*>(x0);
+    const uint4* s1 = reinterpret_cast<const uint4*>(x1);
+    for (int r = 0; r <= n_rep; ++r) {
+        uint4* dst = reinterpret_cast<uint4*>(unet_x + ((size_t)(r * B + b) * hw + p) * 32);
+        const uint4* src = r < n_rep ? s0 : s1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = src[q];
+    }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+    v = asd_wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sh[k];
+    return s;
+}
+
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (v != v) return 0.f;
+    if (v > 3.4028234663852886e38f) return 3.4028234663852886e38f;
+    if (v < -3.4028234663852886e38f) return -3.4028234663852886e38f;
+    return v;
+}
+
+// one block of 1024 threads per sample.  eps [(n_rep+1)B, hw, C] in the batch order text | uncond | neg (2 per sample, interleaved) | second
+template <int C>
+__global__ __launch_bounds__(1024) void score_fwd_kernel(const float* __restrict__ eps, int B, int hw, int n_neg, const float* __restrict__ neg_w,
+                                                         float guidance_scale, const int64_t* __restrict__ t, const float* __restrict__ alphas,
+                                                         int weighting, float grad_clip, float* __restrict__ grad /*[B,C,hw]*/,
+                                                         float* __restrict__ sumsq /*[B]*/) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x, n = hw * C;
+    const float* e_text = eps + (size_t)b * n;
+    const float* e_unc = eps + (size_t)(B + b) * n;
+    const float* e_sec = eps + (size_t)((2 + n_neg) * B + b) * n;
+    float dot_pp = 0.f, dot_np[2] = {0.f, 0.f};
+    if (n_neg > 0) {
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const float u = e_unc[i], p = e_text[i] - u;
+            dot_pp = fmaf(p, p, dot_pp);
+            for (int k = 0; k < n_neg; ++k) dot_np[k] = fmaf(eps[(size_t)(2 * B + b * n_neg + k) * n + i] - u, p, dot_np[k]);
+        }
+        dot_pp = block_sum_1024(dot_pp, sh);
+        for (int k = 0; k < n_neg; ++k) dot_np[k] = block_sum_1024(dot_np[k], sh);
+    }
+    const float a = alphas[t[b]];
+    const float wt = weighting == 0 ? 1.f - a : (weighting == 1 ? 1.f : sqrtf(a) * (1.f - a));
+    float coef[2] = {0.f, 0.f}, wk[2] = {0.f, 0.f};
+    for (int k = 0; k < n_neg; ++k) {
+        coef[k] = dot_np[k] / fmaxf(dot_pp, 1e-6f);
+        wk[k] = neg_w[b * n_neg + k];
+    }
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float u = e_unc[i], p = e_text[i] - u;
+        float acc = 0.f;
+        for (int k = 0; k < n_neg; ++k) {
+            const float en = eps[(size_t)(2 * B + b * n_neg + k) * n + i] - u;
+            acc += wk[k] * (en - coef[k] * p);               // w_k * perpendicular_component(eps_neg_k, eps_pos)
+        }
+        float g = nan_to_num(wt * ((p + acc) * guidance_scale + u - e_sec[i]));
+        if (grad_clip > 0.f) g = fminf(fmaxf(g, -grad_clip), grad_clip);
+        const int pix = i / C, c = i - pix * C;              // eps is NHWC, grad is NCHW like the latents
+        grad[((size_t)b * C + c) * hw + pix] = g;
+        ss = fmaf(g, g, ss);
+    }
+    ss = block_sum_1024(ss, sh);
+    if (threadIdx.x == 0) sumsq[b] = ss;
+}
+
+__global__ void score_reduce_kernel(const float* __restrict__ sumsq, int B, float* __restrict__ out2) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += sumsq[b];
+    out2[0] = 0.5f * s / (float)B;      // 0.5 * mse_loss(latents, (latents - grad).detach(), "sum") / batch_size
+    out2[1] = sqrtf(s);                 // grad.norm()
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void latents_bwd_kernel(const float* __restrict__ grad /*[B,C,hw]*/, const float* __restrict__ moments,
+                                                          const float* __restrict__ post_noise, const float* __restrict__ upstream, int B, int hw,
+                                                          float scaling, float* __restrict__ d_moments /*[B,hw,2C]*/) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * hw) return;
+    const int b = i / hw, p = i - b * hw;
+    const float up = (upstream ? upstream[0] : 1.f) / (float)B * scaling;    // d loss / d z = grad / B
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t q = ((size_t)b * C + c) * hw + p;
+        const float g = grad[q] * up;
+        const float lv = moments[(size_t)i * 2 * C + C + c];
+        d_moments[(size_t)i * 2 * C + c] = g;
+        d_moments[(size_t)i * 2 * C + C + c] = (lv > -30.f && lv < 20.f) ? g * post_noise[q] * 0.5f * expf(0.5f * lv) : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int asd_image_prep_fwd(const float* rgb, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, void* x_nhwc32, void* stream) {
+    ASD_CHECK_ARG(rgb && x_nhwc32 && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad argument");
+    hipLaunchKernelGGL(image_prep_fwd_kernel, dim3(asd_grid_for((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, rgb, B, h, w, H, W,
+                       (half_t*)x_nhwc32);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_image_prep_bwd(const void* dx_nhwc32, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, float* d_rgb, void* stream) {
+    ASD_CHECK_ARG(dx_nhwc32 && d_rgb && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad argument");
+    hipLaunchKernelGGL(image_prep_bwd_kernel, dim3(asd_div_up((int64_t)B * h * w * 3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)dx_nhwc32, B, h, w, H, W, d_rgb);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_latents_fwd(const float* moments_nhwc, const float* post_noise, const float* noise, const int64_t* t, const int64_t* t_plus,
+                    const float* alphas_cumprod, int32_t B, int32_t C, int32_t hl, int32_t wl, float scaling, int32_t n_rep, float* latents,
+                    void* unet_x, float* unet_t, void* stream) {
+    ASD_CHECK_ARG(moments_nhwc && post_noise && noise && t && t_plus && alphas_cumprod && latents && unet_x && unet_t, "null argument");
+    ASD_CHECK_ARG(C == 4 && B > 0 && hl > 0 && wl > 0 && n_rep >= 1, "latents: 4 channels, n_rep >= 1");
+    const int n = B * hl * wl > (n_rep + 1) * B ? B * hl * wl : (n_rep + 1) * B;
+    hipLaunchKernelGGL((latents_fwd_kernel<4>), dim3(asd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, moments_nhwc, post_noise, noise, t,
+                       t_plus, alphas_cumprod, B, hl * wl, scaling, n_rep, latents, (half_t*)unet_x, unet_t);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_score_fwd(const float* eps_nhwc, int32_t B, int32_t C, int32_t hw, int32_t n_neg, const float* neg_w, float guidance_scale,
+                  const int64_t* t, const float* alphas_cumprod, int32_t weighting, float grad_clip, float* grad, float* sumsq,
+                  float* loss_and_norm, void* stream) {
+    ASD_CHECK_ARG(eps_nhwc && t && alphas_cumprod && grad && sumsq && loss_and_norm, "null argument");
+    ASD_CHECK_ARG(C == 4 && B > 0 && hw > 0 && n_neg >= 0 && n_neg <= 2 && (n_neg == 0 || neg_w) && weighting >= 0 && weighting <= 2,
+                  "score: 4 channels, at most 2 negative prompts per sample");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((score_fwd_kernel<4>), dim3(B), dim3(1024), 0, s, eps_nhwc, B, hw, n_neg, neg_w, guidance_scale, t, alphas_cumprod, weighting,
+                       grad_clip, grad, sumsq);
+    hipLaunchKernelGGL(score_reduce_kernel, dim3(1), dim3(1), 0, s, sumsq, B, loss_and_norm);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C, int32_t hl,
+                    int32_t wl, float scaling, float* d_moments_nhwc, void* stream) {
+    ASD_CHECK_ARG(grad && moments_nhwc && post_noise && d_moments_nhwc && C == 4 && B > 0 && hl > 0 && wl > 0, "bad argument");
+    hipLaunchKernelGGL((latents_bwd_kernel<4>), dim3(asd_div_up(B * hl * wl, 256)), dim3(256), 0, (hipStream_t)stream, grad, moments_nhwc, post_noise,
+                       upstream, B, hl * wl, scaling, d_moments_nhwc);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+}  // extern "C"

@@ -155,16 +155,18 @@ class HipUNet:
 
 
 class HipBackend(DiffusionBackend):
-    """UNet eps-prediction and VAE encoder (forward + input gradient) on the hand-written HIP kernels."""
+    """UNet eps-prediction and VAE encoder (forward + input gradient) as C-ABI networks on the hand-written HIP kernels."""
 
     def __init__(self, device, dtype=torch.float16, seed: int = 1, unet_cfg: Optional[W.UNetConfig] = None,
                  vae_cfg: Optional[W.VAEConfig] = None, unet_params: Optional[P] = None, vae_params: Optional[P] = None,
                  use_graph: bool = True):
         from .vae_hip import HipVAEEncoder
 
+        self.device = torch.device(device)
         self.unet_cfg = unet_cfg or W.UNetConfig()
         self.vae_cfg = vae_cfg or W.VAEConfig()
         self.scaling_factor = self.vae_cfg.scale_factor
+        self.context_dim, self.camera_dim = self.unet_cfg.context_dim, self.unet_cfg.camera_dim or 0
         layout = W.unet_layout(self.unet_cfg)
         up = unet_params if unet_params is not None else W.gen_params(layout[0], seed)
         self.hip_unet = HipUNet(up, self.unet_cfg, device, use_graph=use_graph)
@@ -173,12 +175,30 @@ class HipBackend(DiffusionBackend):
         vp = vae_params if vae_params is not None else W.gen_params(vshapes, seed + 1)
         self.hip_vae = HipVAEEncoder(vp, self.vae_cfg, device)
 
+    # tensor-level seams (tests, tools)
     @torch.no_grad()
     def unet(self, latents, t, context, camera=None, num_frames: int = 1):
         return self.hip_unet(latents, t, context, camera=camera, num_frames=num_frames)
 
     def encode(self, images):
         return self.hip_vae(images)
+
+    # buffer protocol of the fused guidance: no re-layout between the ASD kernels and the networks
+    def vae_forward(self, x_nhwc32):
+        return self.hip_vae.forward_nhwc(x_nhwc32)
+
+    def vae_backward(self, saved, d_moments_nhwc):
+        return self.hip_vae.backward_nhwc(saved, d_moments_nhwc)
+
+    def unet_buffers(self, N, hl, wl, n_ctx, frames=1):
+        from ..guidance import UNetIO
+
+        key = (N, hl, wl, n_ctx, frames if self.camera_dim else 1)
+        _, (xin, tin, cin, cam, out, _, _) = self.hip_unet.staging(*key)
+        return UNetIO(key, xin, tin, cin, cam, out)
+
+    def unet_run(self, io):
+        return self.hip_unet.replay(io.key)
 
 
 def _backend_from_cfg(cfg, device, dtype, unet_cfg: W.UNetConfig) -> HipBackend:

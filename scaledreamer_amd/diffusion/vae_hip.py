@@ -79,34 +79,21 @@ def vae_desc(cfg: W.VAEConfig) -> VaeDesc:
 
 
 class _EncodeFn(torch.autograd.Function):
-    """moments = Encoder(images) as ONE autograd node: asd_vae_enc_fwd leaves the activations its input gradient needs in the
-    workspace, asd_vae_enc_bwd walks the layers back (frozen weights: dgrad only).  The workspace tensor is what autograd saves."""
+    """moments = Encoder(images) as ONE autograd node (tensor-level seam: NCHW images in, NCHW moments out)."""
 
     @staticmethod
     def forward(ctx, images, enc):
         B, Cin, Hh, Ww = images.shape
         x = torch.zeros((B, Hh, Ww, 32), device=images.device, dtype=torch.float16)     # NHWC, channels padded to the K granularity
         x[..., :Cin] = images.permute(0, 2, 3, 1)
-        tune = enc.needs_tune((B, Hh, Ww))
-        ws = torch.empty(enc.workspace_bytes(B, Hh, Ww, tune), dtype=torch.uint8, device=images.device)
-        m = torch.empty((B, Hh // 8, Ww // 8, 2 * enc.cfg.embed_dim), device=images.device, dtype=torch.float32)
-        check(lib().asd_vae_enc_fwd(enc.net.handle, ptr(x), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(m), i32(int(tune)), stream()))
-        ctx.enc, ctx.shape, ctx.tune, ctx.in_dtype = enc, (B, Cin, Hh, Ww), tune, images.dtype
-        ctx.save_for_backward(ws)
+        m, saved = enc.forward_nhwc(x)
+        ctx.enc, ctx.saved, ctx.cin, ctx.in_dtype = enc, saved, Cin, images.dtype
         return m.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, d_m):
-        (ws,) = ctx.saved_tensors
-        B, Cin, Hh, Ww = ctx.shape
-        enc = ctx.enc
-        dm = d_m.permute(0, 2, 3, 1).contiguous().float()
-        dx = torch.empty((B, Hh, Ww, 32), device=dm.device, dtype=torch.float16)
-        check(lib().asd_vae_enc_bwd(enc.net.handle, ptr(dm), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(dx), i32(int(ctx.tune)),
-                                    stream()))
-        if ctx.tune:
-            enc.tuned.add((B, Hh, Ww))
-        return dx[..., :Cin].permute(0, 3, 1, 2).to(ctx.in_dtype), None
+        dx = ctx.enc.backward_nhwc(ctx.saved, d_m.permute(0, 2, 3, 1).contiguous().float())
+        return dx[..., :ctx.cin].permute(0, 3, 1, 2).to(ctx.in_dtype), None
 
 
 class HipVAEEncoder:
@@ -129,6 +116,26 @@ class HipVAEEncoder:
         if nb < 0:
             raise AsdError(lib().asd_last_error().decode())
         return nb
+
+    def forward_nhwc(self, x: torch.Tensor):
+        """x fp16 [B,H,W,32] -> (moments fp32 [B,H/8,W/8,2*embed_dim], saved).  asd_vae_enc_fwd leaves the activations its input
+        gradient needs in the workspace; `saved` (workspace + shape) is what a backward pass needs."""
+        B, Hh, Ww, _ = x.shape
+        tune = self.needs_tune((B, Hh, Ww))
+        ws = torch.empty(self.workspace_bytes(B, Hh, Ww, tune), dtype=torch.uint8, device=x.device)
+        m = torch.empty((B, Hh // 8, Ww // 8, 2 * self.cfg.embed_dim), device=x.device, dtype=torch.float32)
+        check(lib().asd_vae_enc_fwd(self.net.handle, ptr(x), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(m), i32(int(tune)), stream()))
+        return m, (ws, (B, Hh, Ww), tune)
+
+    def backward_nhwc(self, saved, d_moments: torch.Tensor) -> torch.Tensor:
+        """d_moments fp32 [B,H/8,W/8,2*embed_dim] -> image gradient fp16 [B,H,W,32] (frozen weights: dgrad only)"""
+        ws, (B, Hh, Ww), tune = saved
+        dx = torch.empty((B, Hh, Ww, 32), device=d_moments.device, dtype=torch.float16)
+        check(lib().asd_vae_enc_bwd(self.net.handle, ptr(d_moments), i32(B), i32(Hh), i32(Ww), ptr(ws), C.c_int64(ws.numel()), ptr(dx),
+                                    i32(int(tune)), stream()))
+        if tune:
+            self.tuned.add((B, Hh, Ww))
+        return dx
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
         if not images.is_cuda:

@@ -3,10 +3,11 @@
 backend interface, plus the prompt-side helper the guidance consumes
 (threestudio/models/prompt_processors/base.py:38-167 `PromptProcessorOutput`).
 
-The reference loads diffusers' StableDiffusionPipeline (fp16).  Here the frozen UNet / VAE encoder are a
-`DiffusionBackend`:  `unet(latents[N,4,h,w], t[N], context[N,77,1024]) -> eps`  (no grad) and
-`encode(images[B,3,H,W] in [-1,1]) -> moments[B,8,H/8,W/8]`  (differentiable w.r.t. the images).  The
-innermost seams are the reference's own: forward_unet (:319-331) and encode_images (:171-178).
+The reference loads diffusers' StableDiffusionPipeline (fp16) and strings ~60 torch elementwise ops around it.  Here the frozen
+UNet / VAE encoder are a `DiffusionBackend` (C-ABI networks) and everything between the rendered image and the scalar loss is one
+autograd node (`_ScoreDistillation`) on five fused HIP kernels (csrc/asd_glue.hip); the latents, both noisings and the UNet's
+batch layout are written straight into the network's input buffers.  The seams are the reference's own: forward_unet (:319-331)
+and encode_images (:171-178).
 """
 from __future__ import annotations
 
@@ -14,17 +15,10 @@ from dataclasses import dataclass, field
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 
 from .base import BaseObject
 from .config import C
 from .registry import info, register
-
-
-def perpendicular_component(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """threestudio/utils/ops.py:501-511"""
-    eps = torch.ones_like(x[:, 0, 0, 0]) * 1e-6
-    return x - (torch.mul(x, y).sum(dim=[1, 2, 3]) / torch.maximum(torch.mul(y, y).sum(dim=[1, 2, 3]), eps)).view(-1, 1, 1, 1) * y
 
 
 def shift_azimuth_deg(azimuth: torch.Tensor) -> torch.Tensor:
@@ -39,43 +33,6 @@ def ddpm_alphas_cumprod(n: int = 1000, beta_start: float = 0.00085, beta_end: fl
     """scaled-linear schedule of SD (in-tree: extern/mvdream/ldm/interface.py:48-76)."""
     betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float64) ** 2
     return torch.cumprod(1.0 - betas, dim=0).float()
-
-
-_RESIZE_MATS = {}
-
-
-def _resize_matrix(n_in: int, n_out: int, device) -> torch.Tensor:
-    """[n_out, n_in] matrix of F.interpolate(mode='bilinear', align_corners=False) along one axis, taken from torch itself."""
-    key = (n_in, n_out, str(device))
-    if key not in _RESIZE_MATS:
-        eye = torch.eye(n_in, device=device, dtype=torch.float32).view(1, n_in, n_in, 1)
-        _RESIZE_MATS[key] = F.interpolate(eye, (n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].t().contiguous()
-    return _RESIZE_MATS[key]
-
-
-class _BilinearResize(torch.autograd.Function):
-    """F.interpolate(x, size, mode='bilinear', align_corners=False) with the same forward kernel and a backward written as the two
-    small matmuls  d_x = R_h^T d_y R_w  (bilinear resampling is separable): ATen's upsample_bilinear2d_backward takes 112 us for a
-    64x64 -> 512x512 image on MI355X, the matmuls ~20 us (profiles/r01_final3_kernel_stats_top70.csv)."""
-
-    @staticmethod
-    def forward(ctx, x, size):
-        ctx.in_hw = (x.shape[-2], x.shape[-1])
-        ctx.size = size
-        return F.interpolate(x, size, mode="bilinear", align_corners=False)
-
-    @staticmethod
-    def backward(ctx, dy):
-        rh = _resize_matrix(ctx.in_hw[0], ctx.size[0], dy.device)
-        rw = _resize_matrix(ctx.in_hw[1], ctx.size[1], dy.device)
-        dx = torch.matmul(torch.matmul(rh.t(), dy.float()), rw)
-        return dx.to(dy.dtype), None
-
-
-def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
-    if x.is_cuda and x.requires_grad and x.dtype == torch.float32:
-        return _BilinearResize.apply(x, tuple(size))
-    return F.interpolate(x, size, mode="bilinear", align_corners=False)
 
 
 @dataclass
@@ -149,9 +106,19 @@ class PromptUtils:
 
 
 class DiffusionBackend:
-    """Frozen SD-2.1 prior.  The product implementation is scaledreamer_amd.diffusion.engine (hand-written HIP); tests inject
-    stand-ins through `configure(backend=...)`."""
+    """The frozen prior behind the guidance, at the two seams of the reference: forward_unet (stable_diffusion_asd_guidance.py:
+    319-331) and encode_images (:171-178).  The guidance talks to it through device buffers in the layouts of the C ABI
+    (include/asd_hip.h: NHWC fp16 padded to 32 channels in, fp32 NHWC out), so that the fused ASD kernels write the UNet's input
+    in place and nothing is re-laid-out between them and the networks:
+        vae_forward(x_nhwc32) -> (moments_nhwc fp32, saved)      vae_backward(saved, d_moments_nhwc) -> dx_nhwc32
+        unet_buffers(N, hl, wl, n_ctx, frames) -> UNetIO          unet_run(io) -> io.eps
+    The product implementation is scaledreamer_amd.diffusion.engine.HipBackend (C-ABI networks).  Subclasses that only define
+    `unet(latents, t, context[, camera, num_frames]) -> eps` and `encode(images[B,3,H,W] in [-1,1]) -> moments[B,8,H/8,W/8]`
+    (differentiable w.r.t. the images) get the buffer protocol from the adaptors below: the stand-ins of the parity tests and the
+    library-op A/B tool (tools/eager_backend.py) use that."""
     scaling_factor: float = 0.18215
+    context_dim: int = 1024
+    camera_dim: int = 0
 
     def unet(self, latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, camera: Optional[torch.Tensor] = None,
              num_frames: int = 1) -> torch.Tensor:
@@ -159,6 +126,56 @@ class DiffusionBackend:
 
     def encode(self, images: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
+
+    # ---- buffer protocol on top of unet() / encode() ---------------------------------------------------------------------------
+    def vae_forward(self, x_nhwc32: torch.Tensor):
+        img = x_nhwc32[..., :3].permute(0, 3, 1, 2).float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            m = self.encode(img)
+        return m.detach().permute(0, 2, 3, 1).float().contiguous(), (img, m)
+
+    def vae_backward(self, saved, d_moments_nhwc: torch.Tensor) -> torch.Tensor:
+        img, m = saved
+        (g,) = torch.autograd.grad(m, img, d_moments_nhwc.permute(0, 3, 1, 2).to(m.dtype))
+        dx = torch.zeros(tuple(img.shape[0:1]) + tuple(img.shape[2:]) + (32,), device=img.device, dtype=torch.float16)
+        dx[..., :3] = g.permute(0, 2, 3, 1)
+        return dx
+
+    def unet_buffers(self, N: int, hl: int, wl: int, n_ctx: int, frames: int = 1) -> "UNetIO":
+        cache = self.__dict__.setdefault("_io", {})
+        key = (N, hl, wl, n_ctx, frames)
+        if key not in cache:
+            dev = self.__dict__.get("device", None) or ("cuda" if torch.cuda.is_available() else "cpu")
+            stride = (n_ctx + 7) // 8 * 8
+            cache[key] = UNetIO(key, torch.zeros((N, hl, wl, 32), device=dev, dtype=torch.float16), torch.zeros(N, device=dev),
+                                torch.zeros((N * stride, self.context_dim), device=dev, dtype=torch.float16),
+                                torch.zeros((N, self.camera_dim), device=dev, dtype=torch.float16) if self.camera_dim else None,
+                                torch.zeros((N, hl, wl, 4), device=dev))
+        return cache[key]
+
+    def unet_run(self, io: "UNetIO") -> torch.Tensor:
+        N, hl, wl, n_ctx, frames = io.key
+        ctx = io.context.view(N, -1, io.context.shape[-1])[:, :n_ctx].float()
+        kw = {} if io.camera is None else dict(camera=io.camera.float(), num_frames=frames)
+        with torch.no_grad():
+            eps = self.unet(io.x[..., :4].permute(0, 3, 1, 2).float(), io.t, ctx, **kw)
+        io.eps.copy_(eps.permute(0, 2, 3, 1))
+        return io.eps
+
+
+@dataclass
+class UNetIO:
+    """persistent input / output buffers of one UNet input shape (asd_unet_fwd's argument layouts)"""
+    key: Tuple[int, int, int, int, int]     # (N, hl, wl, n_ctx, frames)
+    x: torch.Tensor                          # fp16 [N, hl, wl, 32]
+    t: torch.Tensor                          # fp32 [N]
+    context: torch.Tensor                    # fp16 [N * ctx_stride, context_dim], padding rows zero
+    camera: Optional[torch.Tensor]           # fp16 [N, 16] | None
+    eps: torch.Tensor                        # fp32 [N, hl, wl, 4]
+
+    def set_context(self, context: torch.Tensor) -> None:
+        N, n_ctx = self.key[0], self.key[3]
+        self.context.view(N, -1, self.context.shape[-1])[:, :n_ctx].copy_(context)
 
 
 _BACKEND_FACTORY: Dict[str, Callable[..., DiffusionBackend]] = {}
@@ -171,8 +188,134 @@ def register_backend(name: str):
     return deco
 
 
+WEIGHTING = {"sds": 0, "uniform": 1, "fantasia3d": 2}
+
+
+class _ScoreDistillation(torch.autograd.Function):
+    """loss_asd(rgb) as ONE autograd node on the fused HIP kernels of csrc/asd_glue.hip around the two frozen networks:
+         forward : image_prep -> VAE encoder -> latents (+ both noisings, written into the UNet's input) -> UNet -> score (CFG /
+                   Perp-Neg / w(t) / nan_to_num / loss)
+         backward: latents_bwd -> VAE encoder input gradient -> image_prep adjoint
+       The loss is 0.5 * ||z - sg(z - g)||^2 / B, i.e. its value is 0.5 ||g||^2 / B and d loss / d z = g / B: g is computed once in
+       the forward pass and only rescaled here."""
+
+    @staticmethod
+    def forward(ctx, rgb, backend, job):
+        from ._lib import check, f32, i32, lib, ptr, stream
+
+        l = lib()
+        B, h, w, _ = rgb.shape
+        H = job["image_size"]
+        hl = H // 8
+        C_ = 4
+        dev = rgb.device
+        rgb32 = rgb.detach().contiguous().float()
+        x = torch.empty((B, H, H, 32), device=dev, dtype=torch.float16)
+        check(l.asd_image_prep_fwd(ptr(rgb32), i32(B), i32(h), i32(w), i32(H), i32(H), ptr(x), stream()))
+        moments, saved = backend.vae_forward(x)
+        n_rep, n_neg = job["n_rep"], job["n_neg"]
+        io = backend.unet_buffers((n_rep + 1) * B, hl, hl, job["context"].shape[1], job["frames"])
+        io.set_context(job["context"])
+        if io.camera is not None:
+            io.camera.copy_(job["camera"])
+        latents = torch.empty((B, C_, hl, hl), device=dev, dtype=torch.float32)
+        alphas = job["alphas"]
+        check(l.asd_latents_fwd(ptr(moments), ptr(job["post_noise"]), ptr(job["noise"]), ptr(job["t"]), ptr(job["t_plus"]), ptr(alphas), i32(B), i32(C_),
+                                i32(hl), i32(hl), f32(backend.scaling_factor), i32(n_rep), ptr(latents), ptr(io.x), ptr(io.t), stream()))
+        eps = backend.unet_run(io)
+        grad = torch.empty_like(latents)
+        scratch = torch.empty(B + 2, device=dev, dtype=torch.float32)
+        check(l.asd_score_fwd(ptr(eps), i32(B), i32(C_), i32(hl * hl), i32(n_neg), ptr(job["neg_w"]), f32(job["guidance_scale"]), ptr(job["t"]), ptr(alphas),
+                              i32(job["weighting"]), f32(job["grad_clip"] or 0.0), ptr(grad), ptr(scratch), ptr(scratch[B:]), stream()))
+        ctx.backend, ctx.saved_vae, ctx.dims, ctx.in_dtype = backend, saved, (B, h, w, H, hl, C_), rgb.dtype
+        ctx.save_for_backward(grad, moments, job["post_noise"])
+        loss, norm = scratch[B], scratch[B + 1]
+        ctx.mark_non_differentiable(norm)
+        return loss, norm
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_norm):
+        from ._lib import check, f32, i32, lib, ptr, stream
+
+        l = lib()
+        grad, moments, post_noise = ctx.saved_tensors
+        B, h, w, H, hl, C_ = ctx.dims
+        d_m = torch.empty_like(moments)
+        up = d_loss.detach().reshape(1).float().contiguous()
+        check(l.asd_latents_bwd(ptr(grad), ptr(moments), ptr(post_noise), ptr(up), i32(B), i32(C_), i32(hl), i32(hl), f32(ctx.backend.scaling_factor),
+                                ptr(d_m), stream()))
+        dx = ctx.backend.vae_backward(ctx.saved_vae, d_m)
+        d_rgb = torch.empty((B, h, w, 3), device=grad.device, dtype=torch.float32)
+        check(l.asd_image_prep_bwd(ptr(dx), i32(B), i32(h), i32(w), i32(H), i32(H), ptr(d_rgb), stream()))
+        return d_rgb.to(ctx.in_dtype), None, None
+
+
+class _AsdGuidanceBase(BaseObject):
+    """what the SD and the MVDream guidance share: the timestep window and its annealing, the shifted timestep t+, the random
+    draws (injectable: SURVEY.md Appendix C #5/#6) and the fused score-distillation node."""
+
+    image_size = 512
+
+    def _setup(self, backend: DiffusionBackend) -> None:
+        self.backend = backend
+        self.num_train_timesteps = 1000
+        lo = self.cfg.min_step_percent if isinstance(self.cfg.min_step_percent, (int, float)) else 0.02
+        hi = self.cfg.max_step_percent if isinstance(self.cfg.max_step_percent, (int, float)) else 0.98
+        self.set_min_max_steps(lo, hi)
+        self.alphas = ddpm_alphas_cumprod(self.num_train_timesteps).to(self.device)
+        self.grad_clip_val: Optional[float] = None
+        if self.cfg.weighting_strategy not in WEIGHTING:
+            raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
+        # the four random draws of a step, in the reference's order; tests replace them for "identical inputs"
+        self.posterior_noise_fn = torch.randn_like
+        self.noise_fn = torch.randn_like
+        self.timestep_fn = lambda lo, hi, n, device: torch.randint(lo, hi, [n], dtype=torch.long, device=device)
+        self.rand_fn = lambda shape, device: torch.rand(*shape, device=device)
+
+    def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
+        self.min_step = int(self.num_train_timesteps * min_step_percent)
+        self.max_step = int(self.num_train_timesteps * max_step_percent)
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        if self.cfg.grad_clip is not None:
+            self.grad_clip_val = C(self.cfg.grad_clip, epoch, global_step)
+        self.set_min_max_steps(C(self.cfg.min_step_percent, epoch, global_step), C(self.cfg.max_step_percent, epoch, global_step))
+
+    def get_t_plus(self, t: torch.Tensor) -> torch.Tensor:
+        """t+ = clamp(t + floor(u * clamp(plus_ratio * (t - min_step), 0, T - 1 - t)), 1, T - 1), u = 1 or U[0,1) per element
+        (stable_diffusion_asd_guidance.py:294-316)."""
+        if self.cfg.plus_ratio < 0.0:
+            raise AssertionError("plus_ratio must be >= 0")
+        T = self.num_train_timesteps
+        room = (self.cfg.plus_ratio * (t - self.min_step)).clamp(torch.zeros_like(t), T - t - 1)
+        if self.cfg.plus_random:
+            room = room * self.rand_fn(t.shape, t.device)
+        return (t + room.to(torch.long)).clamp(1, T - 1)
+
+    def _distill(self, rgb: torch.Tensor, context: torch.Tensor, neg_w: Optional[torch.Tensor], n_rep: int, shared_t: bool,
+                 camera: Optional[torch.Tensor] = None, frames: int = 1) -> Dict[str, Any]:
+        if not rgb.is_cuda:
+            from ._lib import AsdError
+
+            raise AsdError("the ASD guidance runs on the HIP path only (device tensors; there is no CPU fallback)")
+        B, dev, hl = rgb.shape[0], rgb.device, self.image_size // 8
+        like = torch.empty((B, 4, hl, hl), device=dev, dtype=torch.float32)
+        post_noise = self.posterior_noise_fn(like).float().contiguous()        # VAE posterior sample
+        noise = self.noise_fn(like).float().contiguous()                        # shared by both timesteps
+        t = self.timestep_fn(self.min_step, self.max_step + 1, 1 if shared_t else B, dev).to(dev)
+        t_plus = self.get_t_plus(t)
+        if shared_t:                                                             # one t for the views of a group
+            t, t_plus = t.repeat(B), t_plus.repeat(B)
+        job = dict(image_size=self.image_size, n_rep=n_rep, n_neg=0 if neg_w is None else neg_w.shape[1], frames=frames,
+                   context=context, camera=camera, post_noise=post_noise, noise=noise, t=t.contiguous(), t_plus=t_plus.contiguous(),
+                   alphas=self.alphas.to(dev), neg_w=None if neg_w is None else neg_w.float().contiguous(),
+                   guidance_scale=float(self.cfg.guidance_scale), weighting=WEIGHTING[self.cfg.weighting_strategy], grad_clip=self.grad_clip_val)
+        loss, norm = _ScoreDistillation.apply(rgb, self.backend, job)
+        return {"loss_asd": loss, "grad_norm": norm, "min_step": self.min_step, "max_step": self.max_step}
+
+
 @register("stable-diffusion-asynchronous-score-distillation-guidance")
-class SDTimestepShiftedScoreDistillationGuidance(BaseObject):
+class SDTimestepShiftedScoreDistillationGuidance(_AsdGuidanceBase):
     @dataclass
     class Config(BaseObject.Config):
         pretrained_model_name_or_path: str = "stabilityai/stable-diffusion-2-1-base"
@@ -197,6 +340,7 @@ class SDTimestepShiftedScoreDistillationGuidance(BaseObject):
         allow_random_weights: bool = False     # without it a missing checkpoint is an error, never a silent random prior
 
     cfg: Config
+    image_size = 512                           # get_latents resizes to 512x512 before the VAE (:204)
 
     def configure(self, backend: Optional[DiffusionBackend] = None) -> None:
         info("Loading Stable Diffusion ...")
@@ -205,130 +349,29 @@ class SDTimestepShiftedScoreDistillationGuidance(BaseObject):
             if self.cfg.backend not in _BACKEND_FACTORY:
                 from .diffusion import engine  # noqa: F401  (registers "hip" / "hip-mvdream"; raises if libasd_hip.so is missing)
             backend = _BACKEND_FACTORY[self.cfg.backend](self.cfg, self.device, self.weights_dtype)
-        self.backend = backend
-        self.num_train_timesteps = 1000
-        min_p = self.cfg.min_step_percent if isinstance(self.cfg.min_step_percent, (int, float)) else 0.02
-        max_p = self.cfg.max_step_percent if isinstance(self.cfg.max_step_percent, (int, float)) else 0.98
-        self.set_min_max_steps(min_p, max_p)
-        self.alphas = ddpm_alphas_cumprod(self.num_train_timesteps).to(self.device)
-        self.grad_clip_val: Optional[float] = None
+        self._setup(backend)
         self.use_perp_neg = self.cfg.guidance_perp_neg != 0
-        # RNG injection points: tests replace these for "identical inputs"
-        self.noise_fn = torch.randn_like
-        self.timestep_fn = lambda lo, hi, n, device: torch.randint(lo, hi, [n], dtype=torch.long, device=device)
-        self.rand_fn = lambda shape, device: torch.rand(*shape, device=device)
-        self.posterior_noise_fn = torch.randn_like
         info(f"Loaded Stable Diffusion! ({getattr(self.backend, 'weights_source', 'caller-supplied backend')})")
 
-    def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
-        self.min_step = int(self.num_train_timesteps * min_step_percent)
-        self.max_step = int(self.num_train_timesteps * max_step_percent)
-
-    # -- seams ------------------------------------------------------------------------------------
-    def forward_unet(self, latents, t, encoder_hidden_states):
-        input_dtype = latents.dtype
-        return self.backend.unet(latents, t, encoder_hidden_states).to(input_dtype)
-
-    def encode_images(self, imgs: torch.Tensor) -> torch.Tensor:
-        input_dtype = imgs.dtype
-        imgs = imgs * 2.0 - 1.0
-        moments = self.backend.encode(imgs)
-        mean, logvar = torch.chunk(moments.float(), 2, dim=1)
-        logvar = torch.clamp(logvar, -30.0, 20.0)
-        latents = (mean + torch.exp(0.5 * logvar) * self.posterior_noise_fn(mean)) * self.backend.scaling_factor
-        return latents.to(input_dtype)
-
-    def get_latents(self, rgb_BCHW: torch.Tensor, rgb_as_latents: bool = False) -> torch.Tensor:
-        if rgb_as_latents:
-            return F.interpolate(rgb_BCHW, (64, 64), mode="bilinear", align_corners=False)
-        rgb_BCHW_512 = resize_bilinear(rgb_BCHW, (512, 512))
-        return self.encode_images(rgb_BCHW_512)
-
-    def add_noise(self, latents, noise, t):
-        a = self.alphas.to(latents.device)[t].view(-1, 1, 1, 1)
-        return a.sqrt() * latents + (1 - a).sqrt() * noise
-
-    def get_t_plus(self, t: torch.Tensor) -> torch.Tensor:
-        assert self.cfg.plus_ratio >= 0.0
-        t_plus = self.cfg.plus_ratio * (t - self.min_step)
-        t_plus = t_plus.clamp(torch.zeros_like(t), self.num_train_timesteps - t - 1)
-        if self.cfg.plus_random:
-            t_plus = t_plus * self.rand_fn(t.shape, t.device)
-        t_plus = t + t_plus.to(torch.long)
-        return torch.clamp(t_plus, 1, max=self.num_train_timesteps - 1)
-
-    def get_eps(self, latents_noisy, latents_noisy_second, t, t_plus, prompt_utils, elevation, azimuth, camera_distances):
-        batch_size = latents_noisy.shape[0]
+    def conditioning(self, prompt_utils, elevation, azimuth, camera_distances):
+        """UNet context in the batch order of get_eps (:377-394): text | uncond | (2 negatives per sample) | text (the shifted-t
+        branch), and the Perp-Neg weights scaled by -guidance_perp_neg."""
+        B = elevation.shape[0]
         if self.use_perp_neg:
-            assert prompt_utils.use_perp_neg
-            text_embeddings, neg_w = prompt_utils.get_text_embeddings_perp_neg(
-                elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
-            neg_w = neg_w * -1 * self.cfg.guidance_perp_neg
-            vd, uncond = text_embeddings[0:batch_size], text_embeddings[batch_size:2 * batch_size]
-            vd_neg = text_embeddings[2 * batch_size:4 * batch_size]
-        else:
-            text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
-                                                               self.cfg.view_dependent_prompting)
-            neg_w, vd_neg = None, None
-            vd, uncond = text_embeddings[0:batch_size], text_embeddings[batch_size:2 * batch_size]
-        parts = [vd, uncond] + ([vd_neg] if self.use_perp_neg else []) + [vd]
-        text_embeddings = torch.cat(parts, dim=0).to(latents_noisy.device)
-        num_repeats = text_embeddings.shape[0] // batch_size - 1
-        input_t = torch.cat([t] * num_repeats + [t_plus], dim=0)
-        input_latents = torch.cat([latents_noisy] * num_repeats + [latents_noisy_second], dim=0)
-        with torch.no_grad():
-            noise_pred = self.forward_unet(input_latents, input_t, encoder_hidden_states=text_embeddings)
-        B = batch_size
-        text, unc = noise_pred[0:B], noise_pred[B:2 * B]
-        second = noise_pred[4 * B:5 * B] if self.use_perp_neg else noise_pred[2 * B:3 * B]
-        eps_pos = text - unc
-        if neg_w is not None:
-            neg = noise_pred[2 * B:4 * B]
-            accum = 0
-            n_neg = neg_w.shape[-1]
-            for i in range(n_neg):
-                eps_neg = neg[i::n_neg] - unc
-                accum = accum + neg_w[:, i].view(-1, *[1] * (eps_neg.ndim - 1)).to(eps_neg) * perpendicular_component(eps_neg, eps_pos)
-            noise_pred_p = (eps_pos + accum) * self.cfg.guidance_scale + unc
-        else:
-            noise_pred_p = eps_pos * self.cfg.guidance_scale + unc
-        return noise_pred_p, second
+            if not prompt_utils.use_perp_neg:
+                raise AssertionError("guidance_perp_neg needs a prompt processor with use_perp_neg")
+            emb, w = prompt_utils.get_text_embeddings_perp_neg(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+            return torch.cat([emb, emb[:B]], dim=0), w * (-1.0 * self.cfg.guidance_perp_neg)
+        emb = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+        return torch.cat([emb, emb[:B]], dim=0), None
 
     def __call__(self, rgb: torch.Tensor, prompt_utils, elevation, azimuth, camera_distances, rgb_as_latents=False,
                  guidance_eval=False, **kwargs) -> Dict[str, Any]:
-        batch_size = rgb.shape[0]
-        rgb_BCHW = rgb.permute(0, 3, 1, 2)
-        latents = self.get_latents(rgb_BCHW, rgb_as_latents=rgb_as_latents)
-        noise = self.noise_fn(latents)  # shared by both timesteps
-        assert self.min_step is not None and self.max_step is not None
-        with torch.no_grad():
-            t = self.timestep_fn(self.min_step, self.max_step + 1, batch_size, latents.device)
-            latents_noisy = self.add_noise(latents, noise, t)
-            t_plus = self.get_t_plus(t)
-            latents_noisy_second = self.add_noise(latents, noise, t_plus)
-            noise_pred, noise_pred_second = self.get_eps(latents_noisy, latents_noisy_second, t, t_plus, prompt_utils,
-                                                         elevation, azimuth, camera_distances)
-        alphas = self.alphas.to(latents.device)
-        if self.cfg.weighting_strategy == "sds":
-            w = (1 - alphas[t]).view(-1, 1, 1, 1)
-        elif self.cfg.weighting_strategy == "uniform":
-            w = 1
-        elif self.cfg.weighting_strategy == "fantasia3d":
-            w = (alphas[t] ** 0.5 * (1 - alphas[t])).view(-1, 1, 1, 1)
-        else:
-            raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
-        grad = torch.nan_to_num(w * (noise_pred - noise_pred_second))
-        if self.grad_clip_val is not None:
-            grad = grad.clamp(-self.grad_clip_val, self.grad_clip_val)
-        target = (latents - grad).detach()  # d(loss)/d(latents) = grad
-        loss_sds = 0.5 * F.mse_loss(latents, target, reduction="sum") / batch_size
-        return {"loss_asd": loss_sds, "grad_norm": grad.norm(), "min_step": self.min_step, "max_step": self.max_step}
-
-    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
-        if self.cfg.grad_clip is not None:
-            self.grad_clip_val = C(self.cfg.grad_clip, epoch, global_step)
-        self.set_min_max_steps(min_step_percent=C(self.cfg.min_step_percent, epoch, global_step),
-                               max_step_percent=C(self.cfg.max_step_percent, epoch, global_step))
+        if rgb_as_latents:
+            raise NotImplementedError("rgb_as_latents=True (latent-space rendering) is not on the ASD hot path of any shipped config")
+        context, neg_w = self.conditioning(prompt_utils, elevation, azimuth, camera_distances)
+        n_rep = context.shape[0] // rgb.shape[0] - 1
+        return self._distill(rgb, context.to(rgb.device), None if neg_w is None else neg_w.to(rgb.device), n_rep, shared_t=False)
 
 
 def normalize_camera(camera_matrix: torch.Tensor) -> torch.Tensor:
@@ -340,7 +383,7 @@ def normalize_camera(camera_matrix: torch.Tensor) -> torch.Tensor:
 
 
 @register("mvdream-asynchronous-score-distillation-guidance")
-class MVDreamTimestepShiftedScoreDistillationGuidance(BaseObject):
+class MVDreamTimestepShiftedScoreDistillationGuidance(_AsdGuidanceBase):
     """threestudio/models/guidance/mvdream_asd_guidance.py:26-304: 4-view groups share one timestep, the UNet batch is
     [x_t | x_t | x_t+] with contexts [cond | uncond | cond], camera-conditioned with cross-view self-attention, plain CFG
     (no Perp-Neg), VAE at 256x256 -> 32x32 latents."""
@@ -365,6 +408,7 @@ class MVDreamTimestepShiftedScoreDistillationGuidance(BaseObject):
         allow_random_weights: bool = False
 
     cfg: Config
+    image_size = 256                           # mvdream_asd_guidance.py:133-135
 
     def configure(self, backend: Optional[DiffusionBackend] = None) -> None:
         info("Loading Multiview Diffusion ...")
@@ -376,91 +420,24 @@ class MVDreamTimestepShiftedScoreDistillationGuidance(BaseObject):
             # fp32 reference is bounded at full width by tests/test_gpu_unet_engine.py::test_full_mvdream_unet_b12_matches_reference_golden
             # (< 1e-2, north_star's tolerance) and reported as such by bench.py (`dtype`).
             backend = _BACKEND_FACTORY[self.cfg.backend](self.cfg, self.device, torch.float16)
-        self.backend = backend
         self.weights_dtype = torch.float16
-        self.num_train_timesteps = 1000
-        self.alphas = ddpm_alphas_cumprod(self.num_train_timesteps).to(self.device)
-        min_p = self.cfg.min_step_percent if isinstance(self.cfg.min_step_percent, (int, float)) else 0.02
-        max_p = self.cfg.max_step_percent if isinstance(self.cfg.max_step_percent, (int, float)) else 0.98
-        self.min_step, self.max_step = int(self.num_train_timesteps * min_p), int(self.num_train_timesteps * max_p)
-        self.grad_clip_val: Optional[float] = None
-        self.noise_fn = torch.randn_like
-        self.timestep_fn = lambda lo, hi, n, device: torch.randint(lo, hi, [n], dtype=torch.long, device=device)
-        self.rand_fn = lambda shape, device: torch.rand(*shape, device=device)
-        self.posterior_noise_fn = torch.randn_like
+        self._setup(backend)
 
     def get_camera_cond(self, camera: torch.Tensor, fovy=None) -> torch.Tensor:
         if self.cfg.camera_condition_type != "rotation":
             raise NotImplementedError(f"Unknown camera_condition_type={self.cfg.camera_condition_type}")
         return normalize_camera(camera).flatten(start_dim=1)
 
-    def encode_images(self, imgs: torch.Tensor) -> torch.Tensor:
-        imgs = imgs * 2.0 - 1.0
-        moments = self.backend.encode(imgs)
-        mean, logvar = torch.chunk(moments.float(), 2, dim=1)
-        logvar = torch.clamp(logvar, -30.0, 20.0)
-        return (mean + torch.exp(0.5 * logvar) * self.posterior_noise_fn(mean)) * self.backend.scaling_factor
-
-    def get_latents(self, rgb_BCHW: torch.Tensor, rgb_as_latents: bool = False) -> torch.Tensor:
-        if rgb_as_latents:
-            return F.interpolate(rgb_BCHW, size=(32, 32), mode="bilinear", align_corners=False)
-        return self.encode_images(resize_bilinear(rgb_BCHW, (256, 256)))
-
-    def q_sample(self, x, t, noise):
-        a = self.alphas.to(x.device)[t].view(-1, 1, 1, 1)
-        return a.sqrt() * x + (1 - a).sqrt() * noise
-
-    def get_t_plus(self, t: torch.Tensor) -> torch.Tensor:
-        assert self.cfg.plus_ratio >= 0.0
-        t_plus = self.cfg.plus_ratio * (t - self.min_step)
-        t_plus = t_plus.clamp(torch.zeros_like(t), self.num_train_timesteps - t - 1)
-        if self.cfg.plus_random:
-            t_plus = t_plus * self.rand_fn(t.shape, t.device)
-        return torch.clamp(t + t_plus.to(torch.long), 1, max=self.num_train_timesteps - 1)
-
     def __call__(self, rgb: torch.Tensor, prompt_utils, elevation, azimuth, camera_distances, c2w, rgb_as_latents: bool = False,
                  fovy=None, input_is_latent=False, **kwargs) -> Dict[str, Any]:
-        camera = c2w
-        batch_size = rgb.shape[0]
-        latents = self.get_latents(rgb.permute(0, 3, 1, 2), rgb_as_latents=rgb_as_latents)
-        noise = self.noise_fn(latents)
-        text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
-        tb = text_embeddings.shape[0] // 2
-        vd = text_embeddings[0:tb].repeat(batch_size // tb, 1, 1)
-        uncond = text_embeddings[tb:2 * tb].repeat(batch_size // tb, 1, 1)
-        text_embeddings = torch.cat([vd, uncond, vd], dim=0)
-        with torch.no_grad():
-            _t = self.timestep_fn(self.min_step, self.max_step + 1, 1, latents.device)   # one t shared by the group
-            t = _t.repeat(batch_size)
-            latents_noisy = self.q_sample(latents, t, noise)
-            t_plus = self.get_t_plus(_t).repeat(batch_size)
-            latents_noisy_second = self.q_sample(latents, t_plus, noise)
-            x_in = torch.cat([latents_noisy, latents_noisy, latents_noisy_second], dim=0)
-            t_in = torch.cat([t, t, t_plus], dim=0)
-            if camera is not None:
-                cam = self.get_camera_cond(camera, fovy).repeat(3, 1).to(text_embeddings)
-                noise_pred = self.backend.unet(x_in, t_in, text_embeddings, camera=cam, num_frames=self.cfg.n_view)
-            else:
-                noise_pred = self.backend.unet(x_in, t_in, text_embeddings)
-            noise_pred = noise_pred.to(latents.dtype)
-        text, unc, second = noise_pred.chunk(3)
-        first = unc + self.cfg.guidance_scale * (text - unc)
-        alphas = self.alphas.to(latents.device)
-        if self.cfg.weighting_strategy == "sds":
-            w = (1 - alphas[t]).view(-1, 1, 1, 1)
-        elif self.cfg.weighting_strategy == "uniform":
-            w = 1
-        elif self.cfg.weighting_strategy == "fantasia3d":
-            w = (alphas[t] ** 0.5 * (1 - alphas[t])).view(-1, 1, 1, 1)
-        else:
-            raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
-        grad = torch.nan_to_num((first - second) * w)
-        if self.grad_clip_val is not None:
-            grad = torch.clamp(grad, -self.grad_clip_val, self.grad_clip_val)
-        target = (latents - grad).detach()
-        loss = 0.5 * F.mse_loss(latents, target, reduction="sum") / batch_size
-        return {"loss_asd": loss, "grad_norm": grad.norm(), "min_step": self.min_step, "max_step": self.max_step}
-
-    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
-        self.min_step = int(self.num_train_timesteps * C(self.cfg.min_step_percent, epoch, global_step))
-        self.max_step = int(self.num_train_timesteps * C(self.cfg.max_step_percent, epoch, global_step))
+        if rgb_as_latents or input_is_latent:
+            raise NotImplementedError("latent-space inputs are not on the ASD hot path of any shipped config")
+        if c2w is None:
+            raise NotImplementedError("the multi-view prior is camera-conditioned: c2w is required")
+        B = rgb.shape[0]
+        emb = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+        half = emb.shape[0] // 2
+        cond, uncond = emb[:half].repeat(B // half, 1, 1), emb[half:].repeat(B // half, 1, 1)
+        context = torch.cat([cond, uncond, cond], dim=0).to(rgb.device)
+        camera = self.get_camera_cond(c2w, fovy).repeat(3, 1).to(rgb.device)
+        return self._distill(rgb, context, None, n_rep=2, shared_t=True, camera=camera, frames=self.cfg.n_view)
