@@ -204,6 +204,13 @@ int asd_compact(const float* rays_o, const float* rays_d, int32_t n_rays,
                 int64_t* ray_idx_out, float* t_start_out, float* t_end_out,
                 float* points_out /*[.,3]*/, float* dirs_out /*[.,3]*/, void* stream);
 
+/* Camera rays on the device (replaces the CPU tensor code of get_ray_directions / get_rays, threestudio/utils/ops.py:183-269, called
+ * from RandomCameraIterableDataset.collate, threestudio/data/uncond.py:326-337, and the H2D copy of the [B,H,W,3] ray tensors):
+ * d = ((i + 0.5 - W/2) / focal, -(j + 0.5 - H/2) / focal, -1), rays_d = R d (normalised when `normalize`), rays_o = c2w[:3,3].
+ * c2w: fp32 [B,4,4] row-major; focal: fp32 [B] in pixels; outputs fp32 [B,H,W,3]. */
+int asd_generate_rays(const float* c2w, const float* focal, int32_t B, int32_t H, int32_t W, int32_t normalize, float* rays_o,
+                      float* rays_d, void* stream);
+
 /* occupancy update (nerfacc update_every_n_steps -> _update):
  * occs[c] = max(occs[c]*decay, occ_new[c]) for the listed cells; then
  * threshold = min(mean(occs), occ_thre) and bits = occs > threshold (two launches inside). */

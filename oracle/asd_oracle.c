@@ -845,3 +845,28 @@ ORC_API void orc_occgrid_update(float* occs, int32_t n_cells, const int32_t* cel
         if (b) occ_bits[i >> 5] |= 1u << (i & 31);
     }
 }
+
+
+/* ---- camera rays (threestudio/utils/ops.py:183-269 get_ray_directions + get_rays, as used by RandomCameraIterableDataset.collate,
+ * threestudio/data/uncond.py:326-337): pixel-centre directions of an OpenGL camera at unit focal length divided by the focal
+ * length, rotated by c2w[:3,:3], optionally normalised (F.normalize, eps 1e-12); the origin is c2w[:3,3] for every pixel. -------- */
+ORC_API void orc_generate_rays(const float* c2w /*[B,4,4]*/, const float* focal /*[B]*/, int32_t B, int32_t H, int32_t W, int32_t normalize,
+                               float* rays_o /*[B,H,W,3]*/, float* rays_d) {
+    const float cx = (float)W / 2.0f, cy = (float)H / 2.0f;
+    for (int32_t b = 0; b < B; ++b) {
+        const float* m = c2w + (size_t)b * 16;
+        for (int32_t j = 0; j < H; ++j)
+            for (int32_t i = 0; i < W; ++i) {
+                const float d0 = (((float)i + 0.5f) - cx) / focal[b], d1 = -(((float)j + 0.5f) - cy) / focal[b], d2 = -1.0f;
+                float v[3];
+                for (int k = 0; k < 3; ++k) v[k] = d0 * m[4 * k] + d1 * m[4 * k + 1] + d2 * m[4 * k + 2];
+                if (normalize) {
+                    float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    len = len > 1e-12f ? len : 1e-12f;
+                    for (int k = 0; k < 3; ++k) v[k] = v[k] / len;
+                }
+                const size_t o = (((size_t)b * H + j) * W + i) * 3;
+                for (int k = 0; k < 3; ++k) { rays_d[o + k] = v[k]; rays_o[o + k] = m[4 * k + 3]; }
+            }
+    }
+}

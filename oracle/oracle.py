@@ -308,3 +308,15 @@ def occgrid_update(occs, cell_idx, occ_new, decay=0.95, occ_thre=0.01):
     lib().orc_occgrid_update(_p(occs), C.c_int32(n), _p(cell_idx), _p(occ_new), C.c_int32(cell_idx.shape[0]),
                              C.c_float(decay), C.c_float(occ_thre), _p(bits), _p(binaries))
     return occs, bits, binaries
+
+
+def generate_rays(c2w, focal, H: int, W: int, normalize: bool = True):
+    """c2w [B,4,4], focal [B] (pixels) -> rays_o, rays_d [B,H,W,3]  (orc_generate_rays: ops.py:183-269)"""
+    c2w = np.ascontiguousarray(c2w, np.float32)
+    focal = np.ascontiguousarray(focal, np.float32)
+    B = c2w.shape[0]
+    ro, rd = np.empty((B, H, W, 3), np.float32), np.empty((B, H, W, 3), np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().orc_generate_rays(c2w.ctypes.data_as(fp), focal.ctypes.data_as(fp), C.c_int32(B), C.c_int32(H), C.c_int32(W), C.c_int32(int(normalize)),
+                            ro.ctypes.data_as(fp), rd.ctypes.data_as(fp))
+    return ro, rd

@@ -409,6 +409,31 @@ __global__ __launch_bounds__(256) void occ_threshold_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
+// camera rays from the per-camera parameters (threestudio/utils/ops.py:183-269): one thread per pixel, same operation order as the
+// oracle (orc_generate_rays) so that both agree bit for bit
+__global__ __launch_bounds__(256) void generate_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ focal, int B, int H, int W,
+                                                            int normalize, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const size_t total = (size_t)B * H * W;
+    const float cx = (float)W / 2.0f, cy = (float)H / 2.0f;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+        const int i = (int)(p % W), j = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        const float* m = c2w + (size_t)b * 16;
+        const float f = focal[b];
+        const float d0 = (((float)i + 0.5f) - cx) / f, d1 = -(((float)j + 0.5f) - cy) / f, d2 = -1.0f;
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = d0 * m[4 * k] + d1 * m[4 * k + 1] + d2 * m[4 * k + 2];
+        if (normalize) {
+            float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            len = len > 1e-12f ? len : 1e-12f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = v[k] / len;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rays_d[p * 3 + k] = v[k]; rays_o[p * 3 + k] = m[4 * k + 3]; }
+    }
+}
+
 extern "C" {
 
 int asd_march_count(const asd_march_cfg* cfg, const float* rays_o, const float* rays_d, int32_t n_rays,
@@ -516,6 +541,15 @@ int asd_occgrid_update(float* occs, int32_t n_cells, const int32_t* cell_idx, co
     hipLaunchKernelGGL(occ_mean_kernel, dim3(1), dim3(1024), 0, s, occs, n_cells, scratch);
     hipLaunchKernelGGL(occ_threshold_kernel, dim3(asd_div_up(asd_div_up(n_cells, 32), 256)), dim3(256), 0, s, occs, n_cells,
                        scratch, occ_thre, occ_bits, binaries);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_generate_rays(const float* c2w, const float* focal, int32_t B, int32_t H, int32_t W, int32_t normalize, float* rays_o,
+                      float* rays_d, void* stream) {
+    ASD_CHECK_ARG(c2w && focal && rays_o && rays_d && B > 0 && H > 0 && W > 0, "bad argument");
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(asd_grid_for((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, c2w, focal, B, H, W,
+                       normalize, rays_o, rays_d);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

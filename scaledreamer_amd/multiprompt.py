@@ -146,8 +146,10 @@ class MultipromptRandomCameraIterableDataset(RandomCameraIterableDataset):
         assert "train" in prompt_library, "prompt library must contain train split"
         self.prompt_library = list(prompt_library["train"])[rank::n_ranks]     # multiprompt.py:177-186
 
-    def collate(self, batch=None) -> Dict[str, Any]:
-        out = super().collate(batch)
+    def cameras(self) -> Dict[str, Any]:
+        """camera draws, then the generator noise and the prompt choice (custom/amortized/data/multiprompt.py:62-83); collate() adds
+        the device rays"""
+        out = super().cameras()
         out["noise"] = torch.randn(self.batch_size, self.cfg.dim_gaussian)
         if len(self.prompt_library) < self.batch_size:
             out["prompt"] = random.choices(self.prompt_library, k=self.batch_size)
@@ -193,9 +195,9 @@ class MultiviewMultipromptRandomCameraIterableDataset(RandomMultiviewCameraItera
         assert "train" in prompt_library, "prompt library must contain train split"
         self.prompt_library = list(prompt_library["train"])[rank::n_ranks]
 
-    def collate(self, batch=None) -> Dict[str, Any]:
+    def cameras(self) -> Dict[str, Any]:
         groups = self.batch_size // self.n_view
-        out = super().collate(batch)
+        out = super().cameras()
         out["noise"] = torch.randn(groups, self.mp_cfg.dim_gaussian)
         if len(self.prompt_library) < groups:
             out["prompt"] = random.choices(self.prompt_library, k=groups)

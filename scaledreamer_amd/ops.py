@@ -192,6 +192,17 @@ def occgrid_update(occs, cell_idx, occ_new, decay: float, occ_thre: float, occ_b
                                    f32(occ_thre), ptr(occ_bits), ptr(binaries), ptr(scratch), stream()))
 
 
+def generate_rays(c2w: torch.Tensor, focal: torch.Tensor, H: int, W: int, normalize: bool = True):
+    """c2w [B,4,4], focal [B] (pixels), device tensors -> rays_o, rays_d [B,H,W,3] (include/asd_hip.h: asd_generate_rays)"""
+    _need_cuda(c2w, focal)
+    c2w, focal = _c(c2w), _c(focal)
+    B = c2w.shape[0]
+    rays_o = torch.empty((B, H, W, 3), device=c2w.device, dtype=torch.float32)
+    rays_d = torch.empty((B, H, W, 3), device=c2w.device, dtype=torch.float32)
+    check(lib().asd_generate_rays(ptr(c2w), ptr(focal), i32(B), i32(H), i32(W), i32(int(normalize)), ptr(rays_o), ptr(rays_d), stream()))
+    return rays_o, rays_d
+
+
 # ---- compositing ------------------------------------------------------------------------------
 def composite_fwd(sigma, t0, t1, rgb, offset, count, bg, mode: int = 0):
     nr, n, dev = count.shape[0], sigma.shape[0], sigma.device

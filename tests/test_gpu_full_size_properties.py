@@ -128,10 +128,8 @@ def test_second_resolution_phase_and_eval_rendering():
     g = system.geometry.encoding.encoding.encoding.params.grad
     assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
     # eval: 512 x 512, no jitter, chunked calls
-    from scaledreamer_amd.data import get_ray_directions, get_rays
-    c2w = b256["c2w"].cpu()
-    d = get_ray_directions(512, 512, focal=0.5 * 512 / 0.7).unsqueeze(0)
-    ro, rd = get_rays(d, c2w)
+    from scaledreamer_amd.data import rays_from_cameras
+    ro, rd = rays_from_cameras(b256["c2w"], torch.tensor([0.5 * 512 / 0.7]), 512, 512)
     system.eval()
     with torch.no_grad():
         ev = system({"rays_o": ro.cuda(), "rays_d": rd.cuda(), "light_positions": b256["light_positions"]})

@@ -57,9 +57,18 @@ def test_camera_batch_matches_reference_layout():
     from scaledreamer_amd import presets
     from scaledreamer_amd.data import RandomCameraIterableDataset
 
+    from oracle import oracle as O
+
+    def host_batch(ds):
+        """stages 1-2 are host logic; the rays (a HIP kernel in the product) come from the oracle's restatement here"""
+        b = ds.cameras()
+        ro, rd = O.generate_rays(b["c2w"].numpy(), b["focal_length"].numpy(), ds.height, ds.width, True)
+        b["rays_o"], b["rays_d"] = torch.from_numpy(ro), torch.from_numpy(rd)
+        return b
+
     torch.manual_seed(0)
     ds = RandomCameraIterableDataset(presets.asd_sd_nerf()["data"])
-    b = ds.collate()
+    b = host_batch(ds)
     assert b["rays_o"].shape == (1, 64, 64, 3) and b["rays_d"].shape == (1, 64, 64, 3) and b["c2w"].shape == (1, 4, 4)
     torch.testing.assert_close(b["rays_d"].norm(dim=-1), torch.ones(1, 64, 64))
     assert -10 <= float(b["elevation"]) <= 45 and 1.0 <= float(b["camera_distances"]) <= 1.5
@@ -69,7 +78,11 @@ def test_camera_batch_matches_reference_layout():
     d = torch.nn.functional.normalize(-b["camera_positions"][0], dim=0)
     assert float((torch.nn.functional.normalize(mid, dim=0) * d).sum()) > 0.999
     ds.update_step(0, 10000)
-    assert ds.collate()["rays_o"].shape == (1, 256, 256, 3)                # resolution milestone (asd_sd_nerf.yaml:11-13)
+    assert host_batch(ds)["rays_o"].shape == (1, 256, 256, 3)              # resolution milestone (asd_sd_nerf.yaml:11-13)
+    if not torch.cuda.is_available():
+        from scaledreamer_amd._lib import AsdError
+        with pytest.raises((AsdError, RuntimeError, AssertionError)):      # the rays are a device kernel: no CPU fallback
+            ds.collate()
 
 
 def test_module_and_state_dict_layout_is_the_references():
@@ -112,7 +125,8 @@ def test_hip_path_fails_loudly_without_a_gpu():
      dict(light_sample_strategy="magic3d", camera_perturb=0.1, center_perturb=0.2, up_perturb=0.02, zoom_range=[0.8, 1.0])),
 ])
 def test_camera_batches_match_reference_collate(golden, name, extra):
-    """a1: the product datamodules draw from torch / random in the reference's order (tests/golden/make_goldens_camera.py)."""
+    """a1: the product datamodules draw from torch / random in the reference's order (tests/golden/make_goldens_camera.py); the rays
+    are checked through the oracle's orc_generate_rays here and through the HIP kernel in tests/test_gpu_renderer_kernels.py."""
     import os
     import random
 
@@ -132,7 +146,10 @@ def test_camera_batches_match_reference_collate(golden, name, extra):
         ds = find(name)(cfg)
         torch.manual_seed(s)
         random.seed(s)
-        b = ds.collate(None)
+        b = ds.cameras()
+        from oracle import oracle as O
+        ro, rd = O.generate_rays(b["c2w"].numpy(), b["focal_length"].numpy(), ds.height, ds.width, True)
+        b["rays_o"], b["rays_d"] = torch.from_numpy(ro), torch.from_numpy(rd)
         for k in ["rays_o", "rays_d", "mvp_mtx", "camera_positions", "c2w", "light_positions", "elevation", "azimuth",
                   "camera_distances", "fovy"]:
             np.testing.assert_allclose(b[k].numpy(), g[f"s{s}.{k}"], rtol=2e-6, atol=2e-6, err_msg=f"{golden} seed {s} key {k}")
@@ -170,9 +187,9 @@ def test_multiprompt_datamodule_shards_library_by_rank():
     cfg = dict(batch_size=2, width=8, height=8, dim_gaussian=4, prompt_library=lib)
     d0, d1 = D(cfg, rank=0, n_ranks=4), D(cfg, rank=1, n_ranks=4)
     assert d0.prompt_library == ["p0", "p4", "p8"] and d1.prompt_library == ["p1", "p5", "p9"]
-    b = d0.collate()
+    b = d0.cameras()         # draws + cameras + noise + prompts (the rays are added on the device by collate())
     assert b["noise"].shape == (2, 4) and len(b["prompt"]) == 2 and set(b["prompt"]) <= set(d0.prompt_library)
-    assert b["rays_o"].shape == (2, 8, 8, 3)
+    assert b["c2w"].shape == (2, 4, 4) and b["focal_length"].shape == (2,)
 
 
 def test_adan_matches_reference_optimizer():
