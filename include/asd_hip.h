@@ -227,7 +227,9 @@ int asd_occgrid_update(float* occs, int32_t n_cells, const int32_t* cell_idx, co
  *   z_mean = sum (w/max(op,1e-5)) t, z_var = [op>0.5] * sum (w/max(op,1e-5)) (t-z_mean)^2,
  *   comp_rgb = rgb_fg + bg*(1-opacity).   t = (t_start+t_end)/2.
  * mode 0: sigma is a density (alpha = 1-exp(-sigma*dt)); mode 1: `sigma` already holds alpha
- *   (nerfacc.render_weight_from_alpha, generative_space_volsdf_volume_renderer.py:362-366). */
+ *   (nerfacc.render_weight_from_alpha, generative_space_volsdf_volume_renderer.py:362-366);
+ * mode 2: alpha in, and z_var is the VolSDF renderer's plain second moment sum_i w_i (t_i - depth)^2 — not normalised by the
+ *   opacity, not masked (generative_space_volsdf_volume_renderer.py:380-385) — so that renderer is ONE pass as well. */
 int asd_composite_fwd(int32_t mode, const float* sigma, const float* t_start, const float* t_end,
                       const float* rgb /*[n,3]*/, const int32_t* offset, const int32_t* count,
                       int32_t n_rays, const float* bg /*[n_rays,3]*/,

@@ -750,7 +750,9 @@ ORC_API void orc_composite_fwd(int32_t mode, const float* sigma, const float* t_
             dp = fmaf(w, t, dp);
             for (int k = 0; k < 3; ++k) c[k] = fmaf(w, rgb[3 * (size_t)i + k], c[k]);
         }
-        const float m = fmaxf(op, 1e-5f);
+        /* mode 2 = alpha compositing with the VolSDF renderer's z-variance sum_i w_i (t_i - depth)^2, un-normalised and un-masked
+         * (custom/amortized/models/renderers/generative_space_volsdf_volume_renderer.py:380-385) */
+        const float m = mode == 2 ? 1.f : fmaxf(op, 1e-5f);
         const float zm = dp / m;
         float zv = 0.f;
         for (int32_t i = b; i < e; ++i) {
@@ -759,7 +761,7 @@ ORC_API void orc_composite_fwd(int32_t mode, const float* sigma, const float* t_
         }
         opacity[r] = op;
         depth[r] = dp;
-        z_var[r] = op > 0.5f ? zv : 0.f;
+        z_var[r] = (mode == 2 || op > 0.5f) ? zv : 0.f;
         for (int k = 0; k < 3; ++k) {
             rgb_fg[3 * (size_t)r + k] = c[k];
             comp_rgb[3 * (size_t)r + k] = c[k] + bg[3 * (size_t)r + k] * (1.f - op);
@@ -775,7 +777,7 @@ ORC_API void orc_composite_bwd(int32_t mode, const float* sigma, const float* t_
                                float* d_sigma, float* d_rgb, float* d_bg) {
     for (int32_t r = 0; r < n_rays; ++r) {
         const int32_t b = offset[r], e = offset[r] + count[r];
-        const float op = opacity[r], m = fmaxf(op, 1e-5f), zm = depth[r] / m;
+        const float op = opacity[r], m = mode == 2 ? 1.f : fmaxf(op, 1e-5f), zm = depth[r] / m;
         float G[3], gop = d_opacity ? d_opacity[r] : 0.f;
         for (int k = 0; k < 3; ++k) {
             const float gc = d_comp_rgb ? d_comp_rgb[3 * (size_t)r + k] : 0.f;
@@ -784,9 +786,9 @@ ORC_API void orc_composite_bwd(int32_t mode, const float* sigma, const float* t_
             if (d_bg) d_bg[3 * (size_t)r + k] = gc * (1.f - op);
         }
         const float gdp = d_depth ? d_depth[r] : 0.f;
-        float gzv = (d_z_var && op > 0.5f) ? d_z_var[r] : 0.f;
+        float gzv = (d_z_var && (mode == 2 || op > 0.5f)) ? d_z_var[r] : 0.f;
         float zvu = 0.f;
-        if (gzv != 0.f)
+        if (gzv != 0.f && mode != 2)
             for (int32_t i = b; i < e; ++i) {
                 const float t = (t_start[i] + t_end[i]) * 0.5f;
                 zvu = fmaf(weights[i] / m, (t - zm) * (t - zm), zvu);
@@ -812,7 +814,7 @@ ORC_API void orc_composite_bwd(int32_t mode, const float* sigma, const float* t_
             const float t = (t_start[i] + t_end[i]) * 0.5f, dt = t_end[i] - t_start[i];
             float gw = gop + gdp * t + (d_weights ? d_weights[i] : 0.f);
             for (int k = 0; k < 3; ++k) gw = fmaf(G[k], rgb[3 * (size_t)i + k], gw);
-            if (gzv != 0.f) gw += gzv * ((t - zm) * (t - zm) - zvu) / m;
+            if (gzv != 0.f) gw += mode == 2 ? gzv * ((t - zm) * (t - zm) - 2.f * t * zm * (1.f - op)) : gzv * ((t - zm) * (t - zm) - zvu) / m;
             const float w = weights[i];
             if (mode == 0) {
                 d_sigma[i] = dt * (Tb[i - b] * gw - S);

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     if (r >= n_rays) return;
     const int lane = asd_lane();
     const int b = offset[r], cnt = count[r];
+    // MODE 0: density in (alpha = 1 - exp(-sigma dt)); MODE 1 / 2: alpha in.  MODE 2 differs from 1 only in z_var: the VolSDF
+    // renderer's plain second moment sum_i w_i (t_i - depth)^2 (generative_space_volsdf_volume_renderer.py:380-385) instead of the
+    // opacity-normalised, opacity-masked variance of the NeRF renderer (nerf_volume_renderer.py:335-349)
     float carry = MODE == 0 ? 0.f : 1.f;
     float op = 0.f, dp = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
     for (int j0 = 0; j0 < cnt; j0 += 64) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
     op = asd_wave_sum(op); dp = asd_wave_sum(dp);
     c0 = asd_wave_sum(c0); c1 = asd_wave_sum(c1); c2 = asd_wave_sum(c2);
-    const float m = fmaxf(op, 1e-5f), zm = dp / m;
+    const float m = MODE == 2 ? 1.f : fmaxf(op, 1e-5f), zm = dp / m;
     float zv = 0.f;
     for (int j = lane; j < cnt; j += 64) {
         const int i = b + j;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     if (lane == 0) {
         opacity[r] = op;
         depth[r] = dp;
-        z_var[r] = op > 0.5f ? zv : 0.f;
+        z_var[r] = (MODE == 2 || op > 0.5f) ? zv : 0.f;
         rgb_fg[3 * (size_t)r] = c0; rgb_fg[3 * (size_t)r + 1] = c1; rgb_fg[3 * (size_t)r + 2] = c2;
         const float k = 1.f - op;
         comp_rgb[3 * (size_t)r] = c0 + bg[3 * (size_t)r] * k;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (r >= n_rays) return;
     const int lane = asd_lane();
     const int b = offset[r], cnt = count[r];
-    const float op = opacity[r], m = fmaxf(op, 1e-5f), zm = depth[r] / m;
+    const float op = opacity[r], m = MODE == 2 ? 1.f : fmaxf(op, 1e-5f), zm = depth[r] / m;
     float G[3], gop = d_opacity ? d_opacity[r] : 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -292,9 +295,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         if (d_bg && lane == 0) d_bg[3 * (size_t)r + k] = gc * (1.f - op);
     }
     const float gdp = d_depth ? d_depth[r] : 0.f;
-    const float gzv = (d_z_var && op > 0.5f) ? d_z_var[r] : 0.f;
+    const float gzv = (d_z_var && (MODE == 2 || op > 0.5f)) ? d_z_var[r] : 0.f;
     float zvu = 0.f;
-    if (gzv != 0.f) {
+    if (gzv != 0.f && MODE != 2) {
         for (int j = lane; j < cnt; j += 64) {
             const int i = b + j;
             const float t = (t_start[i] + t_end[i]) * 0.5f;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         gw = fmaf(G[0], rgb[3 * (size_t)i], gw);
         gw = fmaf(G[1], rgb[3 * (size_t)i + 1], gw);
         gw = fmaf(G[2], rgb[3 * (size_t)i + 2], gw);
-        if (gzv != 0.f) gw += gzv * ((t - zm) * (t - zm) - zvu) / m;
+        if (gzv != 0.f) gw += MODE == 2 ? gzv * ((t - zm) * (t - zm) - 2.f * t * zm * (1.f - op)) : gzv * ((t - zm) * (t - zm) - zvu) / m;
         tot = fmaf(weights[i], gw, tot);
     }
     tot = asd_wave_sum(tot);
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             gw = fmaf(G[0], rgb[3 * (size_t)i], gw);
             gw = fmaf(G[1], rgb[3 * (size_t)i + 1], gw);
             gw = fmaf(G[2], rgb[3 * (size_t)i + 2], gw);
-            if (gzv != 0.f) gw += gzv * ((t - zm) * (t - zm) - zvu) / m;
+            if (gzv != 0.f) gw += MODE == 2 ? gzv * ((t - zm) * (t - zm) - 2.f * t * zm * (1.f - op)) : gzv * ((t - zm) * (t - zm) - zvu) / m;
         }
         const float wg = w * gw;
         const float incl_s = asd_wave_incl_scan(wg);
@@ -494,15 +497,13 @@ int asd_composite_fwd(int32_t mode, const float* sigma, const float* t_start, co
                       float* opacity, float* depth, float* rgb_fg, float* z_var, float* comp_rgb, void* stream) {
     ASD_CHECK_ARG(offset && count && bg && opacity && depth && rgb_fg && z_var && comp_rgb && n_rays >= 0,
                   "null argument");
-    ASD_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (density) or 1 (alpha)");
+    ASD_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (density), 1 (alpha) or 2 (alpha, VolSDF z-variance)");
     if (n_rays == 0) return ASD_OK;
     const dim3 g(asd_div_up(n_rays, RAYS_PER_BLOCK)), blk(256);
-    if (mode == 0)
-        hipLaunchKernelGGL((composite_fwd_kernel<0>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset,
-                           count, n_rays, bg, weights, opacity, depth, rgb_fg, z_var, comp_rgb);
-    else
-        hipLaunchKernelGGL((composite_fwd_kernel<1>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset,
-                           count, n_rays, bg, weights, opacity, depth, rgb_fg, z_var, comp_rgb);
+#define COMPOSITE_FWD(M) hipLaunchKernelGGL((composite_fwd_kernel<M>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset, \
+                           count, n_rays, bg, weights, opacity, depth, rgb_fg, z_var, comp_rgb)
+    if (mode == 0) COMPOSITE_FWD(0); else if (mode == 1) COMPOSITE_FWD(1); else COMPOSITE_FWD(2);
+#undef COMPOSITE_FWD
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -513,17 +514,14 @@ int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, co
                       const float* d_rgb_fg, const float* d_opacity, const float* d_depth, const float* d_z_var,
                       const float* d_weights, float* d_sigma, float* d_rgb, float* d_bg, void* stream) {
     ASD_CHECK_ARG(offset && count && bg && opacity && depth && n_rays >= 0, "null argument");
-    ASD_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (density) or 1 (alpha)");
+    ASD_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (density), 1 (alpha) or 2 (alpha, VolSDF z-variance)");
     if (n_rays == 0) return ASD_OK;
     const dim3 g(asd_div_up(n_rays, RAYS_PER_BLOCK)), blk(256);
-    if (mode == 0)
-        hipLaunchKernelGGL((composite_bwd_kernel<0>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset,
-                           count, n_rays, bg, weights, opacity, depth, d_comp_rgb, d_rgb_fg, d_opacity, d_depth, d_z_var,
-                           d_weights, d_sigma, d_rgb, d_bg);
-    else
-        hipLaunchKernelGGL((composite_bwd_kernel<1>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset,
-                           count, n_rays, bg, weights, opacity, depth, d_comp_rgb, d_rgb_fg, d_opacity, d_depth, d_z_var,
-                           d_weights, d_sigma, d_rgb, d_bg);
+#define COMPOSITE_BWD(M) hipLaunchKernelGGL((composite_bwd_kernel<M>), g, blk, 0, (hipStream_t)stream, sigma, t_start, t_end, rgb, offset, \
+                           count, n_rays, bg, weights, opacity, depth, d_comp_rgb, d_rgb_fg, d_opacity, d_depth, d_z_var, \
+                           d_weights, d_sigma, d_rgb, d_bg)
+    if (mode == 0) COMPOSITE_BWD(0); else if (mode == 1) COMPOSITE_BWD(1); else COMPOSITE_BWD(2);
+#undef COMPOSITE_BWD
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

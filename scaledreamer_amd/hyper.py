@@ -228,46 +228,33 @@ class Hypernet_Sdf(BaseImplicitGeometry):
         cat = lambda i: torch.cat([o[i] for o in outs], 0) if len(outs) > 1 else outs[0][i]
         return cat(0).view(-1, 1), cat(1), (cat(2), cat(3)) if output_normal else (None, None)
 
+    def _require_fused(self, points: torch.Tensor) -> None:
+        if self._fcfg is None:
+            raise NotImplementedError(
+                "Hyper-iNGP runs as the fused SDF field kernels only: 16-level x 2-feature hash grid without xyz passthrough, "
+                "hypernetwork MLPs [32, 64, 1] / [32, 64, 3], finite-difference normals, sphere or constant SDF bias "
+                "(the configuration of asd_sd_hyper_iNGP_50k.yaml); this configuration is outside that")
+        if not points.is_cuda:
+            raise _lib.AsdError("the HIP path needs device tensors (there is no CPU fallback)")
+
     def forward(self, points: torch.Tensor, space_cache: Dict, output_normal: bool = False) -> Dict[str, torch.Tensor]:
-        batch_size, n_points, _ = points.shape
+        """points [B, Np, 3] + per-prompt MLP weights from the hypernetwork -> sdf [B*Np, 1], features [B*Np, 3] and, with
+        output_normal, the finite-difference sdf_grad and its normalisation (hyper_iNGP.py:229-330), one fused kernel per prompt."""
         if output_normal and self.cfg.normal_type == "analytic":
             raise NotImplementedError("analytic normal is not implemented yet.")
-        if self._fcfg is not None and points.is_cuda:
-            sdf, feats, (normal, sdf_grad) = self._fused(points, space_cache, output_normal)
-            out = {"sdf": sdf, "features": feats}
-            if output_normal:
-                out.update({"normal": normal, "shading_normal": normal, "sdf_grad": sdf_grad})
-            return out
-        # composed path (any configuration): HIP hash grid + torch bmm
-        points_unscaled = points
-        pts = contract_to_unisphere(points, self.bbox, self.unbounded)
-        enc = self.encoding(pts.view(-1, self.cfg.n_input_dims)).view(*pts.shape[:-1], -1)
-        sdf = self.get_shifted_sdf(points_unscaled, hypernet_forward(enc, space_cache["sdf_weights"]))
-        out = {"sdf": sdf.view(batch_size * n_points, 1)}
-        if self.cfg.n_feature_dims > 0:
-            out["features"] = hypernet_forward(enc, space_cache["feature_weights"]).view(batch_size * n_points, self.cfg.n_feature_dims)
+        self._require_fused(points)
+        sdf, feats, (normal, sdf_grad) = self._fused(points, space_cache, output_normal)
+        out = {"sdf": sdf, "features": feats}
         if output_normal:
-            if self.cfg.normal_type != "finite_difference":
-                raise NotImplementedError(f"normal_type == {self.cfg.normal_type} is not implemented yet.")
-            assert self.finite_difference_normal_eps is not None
-            eps = self.finite_difference_normal_eps
-            offsets = torch.as_tensor([[eps, 0.0, 0.0], [0.0, eps, 0.0], [0.0, 0.0, eps]]).to(points_unscaled)
-            po = (points_unscaled[..., None, :] + offsets).clamp(-self.cfg.radius, self.cfg.radius)
-            sdf_offset = self.forward_sdf(po, space_cache)
-            sdf_grad = (sdf_offset[..., 0::1, 0] - sdf) / eps
-            normal = F.normalize(sdf_grad, dim=-1)
-            out.update({"normal": normal.view(-1, 3), "shading_normal": normal.view(-1, 3), "sdf_grad": sdf_grad.view(-1, 3)})
+            out.update(normal=normal, shading_normal=normal, sdf_grad=sdf_grad)
         return out
 
     def forward_sdf(self, points: torch.Tensor, space_cache: Dict) -> torch.Tensor:
-        batch_size = points.shape[0]
-        if self._fcfg is not None and points.is_cuda and not torch.is_grad_enabled():
-            sdf, _, _ = self._fused(points.reshape(batch_size, -1, 3), space_cache, False)
-            return sdf.view(*points.shape[:-1], 1)
-        pts = contract_to_unisphere(points, self.bbox, self.unbounded)
-        enc = self.encoding(pts.view(-1, self.cfg.n_input_dims)).view(*pts.shape[:-1], -1)
-        sdf = hypernet_forward(enc.view(batch_size, -1, self.encoding.n_output_dims), space_cache["sdf_weights"]).view(*pts.shape[:-1], -1)
-        return self.get_shifted_sdf(points, sdf)
+        """sdf only, [..., 1] in the shape of points[..., :1] (hyper_iNGP.py:332-349); used for evaluation / iso-surfaces"""
+        self._require_fused(points)
+        with torch.no_grad():
+            sdf, _, _ = self._fused(points.reshape(points.shape[0], -1, 3), space_cache, False)
+        return sdf.view(*points.shape[:-1], 1)
 
     def forward_field(self, points, space_cache):
         return self.forward_sdf(points, space_cache), None

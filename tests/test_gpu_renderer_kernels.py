@@ -244,7 +244,7 @@ def test_prune_and_compact(oracle):
     np.testing.assert_array_equal(kd.cpu().numpy(), d[ray_idx[sel]])
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_composite_fwd_bwd(oracle, mode):
     from scaledreamer_amd import ops
 
