@@ -118,9 +118,7 @@ class GenerativeSpaceVolSDFVolumeRenderer(VolumeRenderer):
 
     # ---- stage 1 ----------------------------------------------------------------------------------------------------------------------
     def _cache_per_view(self, space_cache, noise, text_embed, n_views: int):
-        if space_cache is None:
-            if noise is None:
-                raise AssertionError("Either space_cache or noise must be provided")
+        if space_cache is None:      # (generators that ignore the noise — the hypernetwork — are called with noise = None)
             space_cache = self.geometry.generate_space_cache(styles=noise, text_embed=text_embed)
         n_cache = _cache_batch(space_cache)
         if n_cache != n_views and self.training:       # several views of one prompt share its cache (4-view groups)

@@ -307,6 +307,8 @@ def test_generate_rays_bit_exact_vs_oracle_and_collate_matches_reference_goldens
     import random
 
     import scaledreamer_amd.data  # noqa: F401
+    from oracle import oracle as O
+    from scaledreamer_amd import ops
     from scaledreamer_amd.registry import find
 
     rng = np.random.default_rng(3)
