@@ -89,6 +89,11 @@ def to_device(batch, dev):
 PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.0e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
 
 
+# the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
+DOMINANT = "gemm"
+DOMINANT_SOURCE = "profiles/r02_a_kernel_stats.csv: gemm_f16_kernel<64,64,2,2,false> 11.95 % of kernel time (129 launches per step)"
+
+
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final7_kernel_stats_top70.csv:
     conv3x3_win2_kernel<128> + conv3x3_win_kernel<128> + conv3x3_win2_kernel<64> + conv3x3_win_kernel<64> 19.4 % of the kernel
@@ -184,15 +189,56 @@ def roofline_field_kernel(system, batch, reps: int = 20):
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_sample": bytes_per_sample}
 
 
+def roofline_field_bwd(system, batch, reps: int = 10):
+    """asd_field_bwd (field_bwd_sample_kernel + the tall-skinny weight-gradient GEMM) on the live samples of one step: the hash-table
+    gradient scatter.  Algorithmic bytes per kept sample (SURVEY.md §8d, C2 with lambda_orient = 0: one encode's scatter): 128 corner
+    updates x 8 B + 128 B saved encoding + 16 B position / sigma in; the bound that actually binds is the request rate of the
+    atomic units (tools/atomic_probe2.hip: ~21 G requests/s whatever their width), reported next to the HBM fraction."""
+    from scaledreamer_amd import ops
+
+    ren, geo = system.renderer, system.geometry
+    with torch.no_grad():
+        ri, t0, t1, pts, dirs, off, cnt = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
+        n = int(pts.shape[0])
+        if n == 0:
+            return None
+        grid = geo.encoding.encoding.encoding.params.detach()
+        w = [t.detach() for t in geo._weights()]
+        sigma, feats, normal, enc = ops.field_fwd(geo._meta, geo._fcfg, grid, *w, pts, False)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        d_sigma, d_feats = torch.randn(n, device="cuda", generator=g), torch.randn(n, 3, device="cuda", generator=g)
+        d_grid = torch.zeros_like(grid)
+        for _ in range(2):
+            ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per_sample = 128 * 8 + 128 + 16
+    achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
+    return {"kernel": "asd_field_bwd: field_bwd_sample_kernel<16,64,3> (request-coalesced gradient scatter) + field_wgrad_kernel", "bound": "hbm",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": PMC_TRAFFIC.get(("field_bwd", n // 1000)), "samples_per_launch": n, "avg_launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_sample": bytes_per_sample, "atomic_dwords_per_sample": 256,
+            "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1)}
+
+
 def cpu_baseline(system, batch, seed: int):
-    """The oracle (C/OpenMP renderer port + torch fp32 diffusion restatement) timed on this host's cores on a
-    BOUNDED sample of the same workload: the full render forward+backward of the step's camera, ONE of the five
-    UNet evaluations (x5) and the VAE forward+input-gradient at 256x256 (x4 pixels); scaled to one step."""
+    """The oracle (C/OpenMP renderer port + torch fp32 diffusion restatement) timed on this host's cores on ONE full step of the
+    same workload: render forward+backward of the step's camera (4096 rays x 512 spp), the UNet at batch 5 (77-token context) and
+    the VAE encoder forward + input gradient at 512x512.  Weight generation is excluded.  ~10-30 s of CPU work."""
+    import platform
+
     import numpy as np
     from oracle import diffusion_ref as D
     from oracle import ref_renderer as R
     from scaledreamer_amd.diffusion import weights as W
 
+    # 32 threads: measured on the 2 x 64-core EPYC 9575F box (256 hardware threads), torch's CPU kernels are 10x SLOWER with all 256
+    # threads (UNet batch 5: 164 s vs ~8 s; gpurun_out/r2/bench_full1.json) — oversubscribed oneDNN convolutions on small images
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
@@ -218,24 +264,29 @@ def cpu_baseline(system, batch, seed: int):
     vshapes, vplan = W.vae_encoder_layout(vcfg)
     up, vp = W.gen_params(layout[0], guid.cfg.weights_seed), W.gen_params(vshapes, guid.cfg.weights_seed + 1)
     g = torch.Generator().manual_seed(seed)
-    x, ctx_e = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 1024, generator=g)
+    x, ctx_e = torch.randn(5, 4, 64, 64, generator=g), torch.randn(5, 77, 1024, generator=g)
     with torch.no_grad():
         t0 = time.perf_counter()
-        D.unet_forward(up, layout, ucfg, x, torch.tensor([700]), ctx_e)
-        tm["unet_fwd_b1"] = time.perf_counter() - t0
-    img = torch.rand(1, 3, 256, 256, generator=g).requires_grad_(True)
+        D.unet_forward(up, layout, ucfg, x, torch.tensor([700, 700, 700, 700, 730]), ctx_e)
+        tm["unet_fwd_b5"] = time.perf_counter() - t0
+    img = torch.rand(1, 3, 512, 512, generator=g).requires_grad_(True)
     t0 = time.perf_counter()
     m = D.vae_encode_moments(vp, vplan, img * 2 - 1)
-    tm["vae_fwd_256"] = time.perf_counter() - t0
+    tm["vae_fwd_512"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     m.sum().backward()
-    tm["vae_bwd_256"] = time.perf_counter() - t0
-    est = tm["render_fwd"] + tm["render_bwd"] + 5 * tm["unet_fwd_b1"] + 4 * (tm["vae_fwd_256"] + tm["vae_bwd_256"])
-    return {"value": round(1.0 / est, 5), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "full render fwd+bwd (4096 rays x 512 spp) + 1 of 5 UNet evaluations (x5) + VAE fwd+input-grad at 256^2 (x4); "
-                      "oracle C/OpenMP renderer + torch fp32 diffusion; weight generation excluded",
-            "estimated_step_seconds": round(est, 2), "measured_seconds": round(sum(tm.values()), 2),
-            "host_cores_available": os.cpu_count(), "phases_s": {k: round(v, 3) for k, v in tm.items()}}
+    tm["vae_bwd_512"] = time.perf_counter() - t0
+    total = sum(tm.values())
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), cpu_model)
+    except OSError:
+        pass
+    return {"value": round(1.0 / total, 5), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "ONE full step: render fwd+bwd (4096 rays x 512 spp) + UNet batch 5 + VAE fwd+input-grad at 512^2; "
+                      "oracle C/OpenMP renderer + torch fp32 diffusion restatement; weight generation excluded",
+            "step_seconds": round(total, 2), "cpu_model": cpu_model, "host_threads_available": os.cpu_count(), "phases_s": {k: round(v, 3) for k, v in tm.items()}}
 
 
 def main():
@@ -285,8 +336,11 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one record per step: no sync, ~1 us each
+    marks[0].record()
+    for i in range(args.steps):
         loss, batch = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -297,6 +351,10 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 3)
+    ex = system.gradient_exchange() if hasattr(system, "gradient_exchange") else None
+    allreduce_ms = round(ex.exposed_ms(), 3) if ex is not None else None
     phases = None
     if args.phases and rank == 0:
         # untimed extra steps with events around the phases of train_one_step (adds host syncs: not part of `value`)
@@ -307,12 +365,19 @@ def main():
         acc = {}
         for _ in range(5):
             b = to_device(data.collate(), dev)
-            e0 = ev(); system.on_train_batch_start(); system.optimizer.zero_grad(set_to_none=True)
+            e0 = ev(); system.on_train_batch_start()
+            if ex is None:
+                system.optimizer.zero_grad(set_to_none=True)
+            else:
+                ex.prepare()
             e1 = ev(); out_r = system(b)
             e2 = ev(); g_out = system.guidance(out_r["comp_rgb"], system.prompt_utils, **b)
             loss_p = g_out["loss_asd"] + 30.0 * (out_r["opacity"] ** 2 + 0.01).sqrt().mean()
             e3 = ev(); loss_p.backward()
-            e4 = ev(); asd_dist.allreduce_mean_grads(system.optimizer); system.optimizer.step(); system.true_global_step += 1
+            e4 = ev()
+            if ex is not None:
+                ex.finish()
+            system.optimizer.step(); system.true_global_step += 1
             e5 = ev(); torch.cuda.synchronize()
             for k, (a, b_) in {"update_hooks": (e0, e1), "render_fwd": (e1, e2), "vae_fwd+unet_x5+asd": (e2, e3),
                                "backward(vae+render)": (e3, e4), "allreduce+adamw": (e4, e5)}.items():
@@ -331,11 +396,15 @@ def main():
             "config": {"workload": "asd_sd_nerf: 1 view/GPU, 64x64 rays, 512 spp occgrid march, implicit-volume iNGP "
                                    "(16x2 hash grid 2^19, MLP 64), SD-2.1 UNet batch 5 (CFG+Perp-Neg+shifted t), VAE 512^2 "
                                    "fwd+bwd, AdamW", "views_per_gpu": 1, "parallelism": f"dp{world}",
-                       "diffusion_backend": args.backend, "diffusion_weights": "seeded random init"},
+                       "diffusion_backend": args.backend, "diffusion_weights": getattr(getattr(system.guidance, "backend", None), "weights_source", "seeded random init")},
+            "step_ms_gpu": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9)},
+            "allreduce_exposed_ms": allreduce_ms,
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
         }
         if args.workload == "asd_mv_nerf":  # secondary line (not BASELINE's metric): 4 views / step / GPU
-            out.update({"metric": "ASD train steps/sec (4 views x 64x64 render, MVDream)", "rays_per_sec": round(steps_per_s * 16384, 1)})
+            out.update({"metric": "ASD train steps/sec (4 views x 64x64 render, MVDream)", "rays_per_sec": round(steps_per_s * 16384, 1),
+                        "dtype": "f32 renderer / f16 diffusion with f32 accumulate — the reference runs this prior in fp32 (mvdream_asd_guidance.py:40,67); "
+                                 "eps deviation < 1e-2 at full width, batch 12: tests/test_gpu_unet_engine.py::test_full_mvdream_unet_b12_matches_reference_golden"})
             out["config"].update({"workload": "asd_mv_nerf: 4 views/GPU, 4x64x64 rays, 256 spp occgrid march, implicit-volume iNGP, MVDream "
                                               "UNet batch 12 @32x32 latents (CFG + shifted t, cross-view attention), VAE 4x256^2 fwd+bwd, AdamW",
                                   "views_per_gpu": 4})
@@ -354,17 +423,23 @@ def main():
             out.pop("kept_samples_last_step", None)
         if phases:
             out["phases_ms"] = phases
-        out["roofline"] = roofline_conv_kernel("vae512")
-        out["roofline_unet_conv"] = roofline_conv_kernel("unet64")
-        out["roofline_gemm"] = roofline_gemm_kernel()
+        # `roofline` = the kernel rocprofv3 ranks first for this step (profiles/: see DOMINANT below); the other families follow
+        lines = {"gemm": roofline_gemm_kernel(), "vae_conv": roofline_conv_kernel("vae512"), "unet_conv": roofline_conv_kernel("unet64")}
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
-            out["roofline_renderer"] = roofline_field_kernel(system, batch)
+            lines["field_bwd"] = roofline_field_bwd(system, batch)
+            lines["renderer"] = roofline_field_kernel(system, batch)
+        out["roofline"] = lines.pop(DOMINANT)
+        out["roofline"]["rank_source"] = DOMINANT_SOURCE
+        for k, v in lines.items():
+            out["roofline_" + k] = v
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":
             out["cpu_baseline"] = cpu_baseline(system, batch, seed=10)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         asd_dist.shutdown()
+    elif ex is not None:
+        ex.close()
 
 
 if __name__ == "__main__":
