@@ -427,6 +427,28 @@ int asd_score_fwd(const float* eps_nhwc, int32_t B, int32_t C, int32_t hw, int32
 int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C,
                     int32_t hl, int32_t wl, float scaling, float* d_moments_nhwc, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer step (csrc/optim.hip): multi-tensor fused fp32 kernels for the reference's two optimizers — torch.optim.AdamW / Adam as
+ * parsed by threestudio/systems/utils.py:25-53 (per-group lr through param groups) and Adan, threestudio/systems/optimizers.py:200-315.
+ * The caller owns parameters, gradients and state; bias corrections are passed per tensor (groups keep their own step counts).
+ * ---------------------------------------------------------------------------------------------- */
+#define ASD_OPT_MAX_TENSORS 24
+typedef struct asd_opt_tensor {
+    float* p; float* g; float* m; float* v;     /* parameter, gradient, exp_avg, exp_avg_sq (AdamW) | exp_avg_diff (Adan) */
+    float* n2; float* prev;                      /* Adan only: exp_avg_sq, neg_pre_grad; NULL for AdamW */
+    int64_t n;                                   /* elements */
+    float lr, weight_decay;
+    float bias_correction1;                      /* 1 - beta1^t */
+    float bias_correction2;                      /* Adan: 1 - beta2^t */
+    float bias_correction2_sqrt;                 /* AdamW: sqrt(1 - beta2^t); Adan: sqrt(1 - beta3^t) */
+} asd_opt_tensor;
+/* AdamW: p *= 1 - lr wd; m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).
+ * adam_l2 != 0: Adam with L2 regularisation instead (g += wd p, no decoupled decay). */
+int asd_adamw_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float eps, int32_t adam_l2, void* stream);
+/* Adan step with the gradient scaled by `clip` first (global-norm clipping factor computed by the caller) */
+int asd_adan_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float beta3, float eps, float clip,
+                 int32_t no_prox, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -80,6 +80,12 @@ class GemmArgs(C.Structure):
     ]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n2", C.c_void_p), ("prev", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float), ("bias_correction1", C.c_float),
+                ("bias_correction2", C.c_float), ("bias_correction2_sqrt", C.c_float)]
+
+
 class WeightInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
@@ -115,6 +121,7 @@ SYMBOLS = [
     "asd_unet_workspace_bytes", "asd_unet_fwd",
     "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",
     "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
+    "asd_adamw_f32", "asd_adan_f32",
     "asd_version", "asd_last_error",
 ]
 

@@ -572,19 +572,23 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
 // ONE window buffer (the reload at a chunk switch is exposed; the neighbour covers it), a two-slot weight ring with a barrier
 // per tap, and the compiler's just-in-time fragment schedule (<= 128 VGPRs).  Column-keyed window swizzle as in conv3x3_win_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_args p) {
-    constexpr int WN = 2, TM = 4, TN = BN / WN / 16;
+// NW = 4 (tile configurations 13 / 14): four waves per block, each owning 4 patch rows x ALL BN channels.  A wave tile of 64 px x 64 ch
+// needs 8 KB of fragment reads per 32-deep k slice for 256 cycles of MFMA on its SIMD; the CU's LDS delivers 128 B/clk = 8 KB per
+// SIMD in those 256 cycles, i.e. the 8-wave form (64 x 64 at BN = 128, 64 x 32 at BN = 64) saturates the LDS read port before the
+// matrix pipe.  Doubling the channel extent of the wave tile cuts the reads per MFMA by a quarter / a third.
+template <int BN, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd_gemm_args p) {
+    constexpr int WN = NW / 4, TM = 4, TN = BN / WN / 16;
     constexpr int RB = 128;
     constexpr int WIN = 18, WIN_ROWS = WIN * WIN, WIN_SLABS = (WIN_ROWS + 7) / 8;      // 324 rows, 41 slabs
     constexpr int A_BYTES = WIN_SLABS * 8 * RB, W_BYTES = BN * RB;
-    constexpr int WSLABS = BN / 8, WSPW = (WSLABS + 7) / 8;
+    constexpr int WSLABS = BN / 8, WSPW = (WSLABS + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];                        // [A0 | A1 | W0 | W1]
     char* const a_buf = smem;
     char* const w_buf = smem + A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int tiles_x = p.Wout / 16, tiles_y = p.Hout / 16;
     const int tiles_m = (p.M / (p.Hout * p.Wout)) * tiles_y * tiles_x;
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_arg
         const size_t koff = ((size_t)tap * p.Cin + chunk * 64) * 2;
 #pragma unroll
         for (int j = 0; j < WSPW; ++j) {
-            const int slab = wave + j * 8;
+            const int slab = wave + j * NW;
             if (slab >= WSLABS) continue;
             const char* src = (n0 + slab * 8 + lrow < p.N) ? w0 + slab * w_slab_stride + koff : zero;
             load_slab(src, dst_buf + slab * 8 * RB);
@@ -637,14 +641,14 @@ __global__ __launch_bounds__(512, 4) void conv3x3_win2_kernel(const asd_gemm_arg
     const int fswb[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
 
     if (steps > 0) {
-        for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0, a_buf);
+        for (int slab = wave; slab < WIN_SLABS; slab += NW) load_window_slab(slab, c0, a_buf);
         load_w_tile(0, w_buf);
 #pragma unroll 1
         for (int s = 0; s < steps; ++s) {
             const int cl = s / 9, tap = s - cl * 9;
             if (tap == 0 && s > 0) {   // chunk switch: everyone is done with the old window, reload it (exposed; the co-resident block covers)
                 __builtin_amdgcn_s_barrier();
-                for (int slab = wave; slab < WIN_SLABS; slab += 8) load_window_slab(slab, c0 + cl, a_buf);
+                for (int slab = wave; slab < WIN_SLABS; slab += NW) load_window_slab(slab, c0 + cl, a_buf);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -725,14 +729,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn; };
-#define ASD_GEMM_NCFG 13
+#define ASD_GEMM_NCFG 15
 #define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
                           // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
     {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {256, 64, 4, 2}, {256, 128, 4, 2},
-    {64, 64, 2, 2}};   // 12: small tile, 32 KB LDS: five blocks per CU for the latency-bound K <= 1280 linears
-static bool asd_cfg_is_window(int cfg) { return cfg >= ASD_GEMM_WIN0 && cfg < ASD_GEMM_WIN0 + 4; }
+    {64, 64, 2, 2},    // 12: small tile, 32 KB LDS: five blocks per CU for the latency-bound K <= 1280 linears
+    {256, 64, 4, 1}, {256, 128, 4, 1}};   // 13, 14: window convolution, two blocks per CU, FOUR waves with 64 px x BN wave tiles
+static bool asd_cfg_is_window(int cfg) { return (cfg >= ASD_GEMM_WIN0 && cfg < ASD_GEMM_WIN0 + 4) || cfg == 13 || cfg == 14; }
+static bool asd_cfg_is_win2(int cfg) { return cfg == ASD_GEMM_WIN0 + 2 || cfg == ASD_GEMM_WIN0 + 3 || cfg == 13 || cfg == 14; }
 
 static bool asd_conv_window_ok(const asd_gemm_args* a) {
     return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Cin % 64 == 0 && a->Hin == a->Hout &&
@@ -902,19 +908,25 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
         const size_t lds_w = (size_t)2 * 41 * 1024 + (size_t)4 * bn * 128;
         if (a->group_m < 1 || a->group_n < 1)
-            asd_pick_group(a->M / 256, asd_div_up(a->N, bn), 256, bn, cfg >= ASD_GEMM_WIN0 + 2 ? (size_t)80 * 1024 : lds_w, &a->group_m, &a->group_n);
+            asd_pick_group(a->M / 256, asd_div_up(a->N, bn), 256, bn, asd_cfg_is_win2(cfg) ? (size_t)80 * 1024 : lds_w, &a->group_m, &a->group_n);
         const int tiles_w = 8 * asd_div_up((a->M / 256) * asd_div_up(a->N, bn) * a->split_k, 8);   // asd_xcd_item
         hipStream_t sw = (hipStream_t)stream;
-        if (cfg >= ASD_GEMM_WIN0 + 2) {     // two blocks per CU: single window buffer, two weight slots
+        if (asd_cfg_is_win2(cfg)) {     // two blocks per CU: single window buffer, two weight slots
             const size_t lds2 = (size_t)41 * 1024 + (size_t)2 * bn * 128;
-            static bool a64 = false, a128 = false;
-            if (bn == 64) {
-                if (!a64) { (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); a64 = true; }
-                hipLaunchKernelGGL((conv3x3_win2_kernel<64>), dim3(tiles_w), dim3(512), lds2, sw, *a);
-            } else {
-                if (!a128) { (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); a128 = true; }
-                hipLaunchKernelGGL((conv3x3_win2_kernel<128>), dim3(tiles_w), dim3(512), lds2, sw, *a);
-            }
+#define WIN2_LAUNCH(BN_, NW_)                                                                                                          \
+    do {                                                                                                                               \
+        static bool attr_set = false;                                                                                                  \
+        if (!attr_set) {                                                                                                               \
+            (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<BN_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+            attr_set = true;                                                                                                           \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((conv3x3_win2_kernel<BN_, NW_>), dim3(tiles_w), dim3(NW_ * 64), lds2, sw, *a);                              \
+    } while (0)
+            if (cfg == 13) WIN2_LAUNCH(64, 4);
+            else if (cfg == 14) WIN2_LAUNCH(128, 4);
+            else if (bn == 64) WIN2_LAUNCH(64, 8);
+            else WIN2_LAUNCH(128, 8);
+#undef WIN2_LAUNCH
             if (a->split_k > 1) {
                 const size_t total4 = (size_t)a->M * a->N / 4;
                 hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);

@@ -1,0 +1,109 @@
+"""the validation / test renderer path (eval mode: no stratified jitter, chunked field calls, comp_normal —
+nerf_volume_renderer.py:293-310,389-428) and the 256x256 training phase after the resolution milestone (asd_sd_nerf.yaml:11-13),
+compared with the oracle's restatement of the renderer (oracle/ref_renderer.py) on the same cameras, field and occupancy grid.
+Sample placement is bit-identical between oracle and HIP (tests/test_gpu_renderer_kernels.py), so images are compared directly:
+north_star's bound is 1e-3 abs on RGB / sigma; measured deviations are ~1e-5."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(seed=5):
+    from scaledreamer_amd import presets
+    from scaledreamer_amd.data import RandomCameraIterableDataset
+    from scaledreamer_amd.registry import find
+    import scaledreamer_amd.plugins  # noqa: F401
+
+    torch.manual_seed(seed)
+    random.seed(seed)
+    cfg = presets.asd_sd_nerf()
+    cfg["system"]["guidance_type"] = ""
+    system = find(cfg["system_type"])(cfg["system"])
+    system.train()
+    with torch.no_grad():
+        system.geometry.encoding.encoding.encoding.params.uniform_(-0.2, 0.2)
+        system.background.encoding.encoding.encoding.params.uniform_(-0.5, 0.5)
+    system.on_train_batch_start()            # occupancy grid from this field (step 0: all cells)
+    system.background.rand_fn = lambda: 0.9  # learned background, no random colour
+    return system, RandomCameraIterableDataset(cfg["data"])
+
+
+def _oracle_inputs(system, rays_o, rays_d, jitter):
+    geo, bg, ren = system.geometry, system.background, system.renderer
+    f = lambda t: t.detach().float().cpu().numpy()
+    return dict(spp=ren.cfg.num_samples_per_ray, radius=ren.cfg.radius, rays_o=f(rays_o), rays_d=f(rays_d),
+                jitter=None if jitter is None else f(jitter), occs=f(ren.estimator.occs), binaries=ren.estimator.binaries.cpu().numpy(),
+                grid=f(geo.encoding.encoding.encoding.params), w1d=f(geo.density_network.layers[0].weight),
+                w2d=f(geo.density_network.layers[2].weight), w1f=f(geo.feature_network.layers[0].weight),
+                w2f=f(geo.feature_network.layers[2].weight), bgrid=f(bg.encoding.encoding.encoding.params),
+                bw0=f(bg.network.layers[0].weight), bw1=f(bg.network.layers[2].weight), bw2=f(bg.network.layers[4].weight))
+
+
+def _close(got, want, atol, name):
+    err = float(np.abs(got - want).max())
+    assert err <= atol, f"{name}: max abs deviation {err} > {atol}"
+    return err
+
+
+def test_eval_mode_render_matches_oracle():
+    from oracle import ref_renderer as R
+    from scaledreamer_amd.data import rays_from_cameras
+
+    system, data = _system()
+    cam = data.cameras()
+    H = W = 160                                                     # an eval resolution that needs several eval_chunk_size chunks
+    ro, rd = rays_from_cameras(cam["c2w"], torch.tensor([0.5 * H / 0.7]), H, W)
+    system.eval()
+    system.renderer.cfg.eval_chunk_size = 50_000
+    with torch.no_grad():
+        out = system({"rays_o": ro, "rays_d": rd, "light_positions": cam["light_positions"].cuda()})
+    assert "weights" not in out and out["comp_rgb"].shape == (1, H, W, 3)
+    want, ctx = R.forward(_oracle_inputs(system, ro, rd, None))     # eval: no stratified jitter
+    n_rays = H * W
+    _close(out["comp_rgb"].cpu().numpy().reshape(n_rays, 3), want["comp_rgb"], 1e-4, "comp_rgb")
+    _close(out["opacity"].cpu().numpy().reshape(n_rays, 1), want["opacity"], 1e-4, "opacity")
+    _close(out["depth"].cpu().numpy().reshape(n_rays, 1), want["depth"], 2e-4, "depth")
+    _close(out["comp_rgb_bg"].cpu().numpy().reshape(n_rays, 3), want["comp_rgb_bg"], 1e-5, "comp_rgb_bg")
+    # comp_normal (eval only, :389-395): normalize(sum_i w_i n_i) mapped to [0,1], scaled by the opacity
+    acc = np.zeros((n_rays, 3), np.float64)
+    np.add.at(acc, want["ray_indices"], want["weights"].astype(np.float64) * want["normal"])
+    cn = acc / np.maximum(np.linalg.norm(acc, axis=-1, keepdims=True), 1e-12)
+    cn = (cn + 1.0) / 2.0 * want["opacity"]
+    hit = want["opacity"][:, 0] > 0.05                              # the direction of a near-zero accumulated normal is ill-conditioned
+    _close(out["comp_normal"].cpu().numpy().reshape(n_rays, 3)[hit], cn[hit], 2e-3, "comp_normal")
+    assert int(hit.sum()) > 1000
+
+
+def test_256_training_phase_matches_oracle_forward_and_gradients():
+    from oracle import ref_renderer as R
+
+    system, data = _system(seed=6)
+    data.update_step(0, 10_000)                                     # resolution milestone: 64 -> 256
+    assert (data.height, data.width) == (256, 256)
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+    n_rays = 256 * 256
+    jit = torch.rand(n_rays, device="cuda")
+    system.renderer.jitter_fn = lambda n, device: jit
+    out = system(b)
+    P = _oracle_inputs(system, b["rays_o"], b["rays_d"], jit)
+    want, ctx = R.forward(P)
+    assert out["weights"].shape[0] == want["weights"].shape[0] > 500_000
+    np.testing.assert_array_equal(out["ray_indices"].cpu().numpy(), want["ray_indices"])
+    _close(out["comp_rgb"].detach().cpu().numpy().reshape(n_rays, 3), want["comp_rgb"], 1e-4, "comp_rgb")
+    _close(out["opacity"].detach().cpu().numpy().reshape(n_rays, 1), want["opacity"], 1e-4, "opacity")
+    _close(out["density"].detach().cpu().numpy(), want["density"], 1e-3 * max(1.0, float(want["density"].max())), "sigma")
+    rng = np.random.default_rng(0)
+    g_rgb, g_op = rng.normal(size=(n_rays, 3)).astype(np.float32), rng.normal(size=(n_rays, 1)).astype(np.float32)
+    (out["comp_rgb"].reshape(n_rays, 3) * torch.from_numpy(g_rgb).cuda()).sum().add((out["opacity"].reshape(n_rays, 1) * torch.from_numpy(g_op).cuda()).sum()).backward()
+    grads = R.backward(P, ctx, d_comp_rgb=g_rgb, d_opacity=g_op)
+    geo = system.geometry
+    for name, got in (("grid", geo.encoding.encoding.encoding.params.grad), ("w1d", geo.density_network.layers[0].weight.grad),
+                      ("w2f", geo.feature_network.layers[2].weight.grad), ("bgrid", system.background.encoding.encoding.encoding.params.grad)):
+        w = grads[name].reshape(-1)
+        gnp = got.detach().cpu().numpy().reshape(-1)
+        scale = float(np.abs(w).max())
+        assert float(np.abs(gnp - w).max()) <= 2e-3 * scale, (name, float(np.abs(gnp - w).max()), scale)

@@ -1,0 +1,71 @@
+"""The optimizer step on the HIP path (csrc/optim.hip): the fused multi-tensor AdamW / Adam against torch.optim on the same device
+tensors, the fused Adan against the golden of the reference's own optimizer class (tests/golden/adan_steps.npz) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_host_logic_cpu import adan_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,kw", [("AdamW", dict(betas=(0.0, 0.99), eps=1e-15)), ("AdamW", dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)),
+                                     ("Adam", dict(betas=(0.9, 0.99), eps=1e-15)), ("Adam", dict(betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01))])
+def test_fused_adamw_matches_torch(name, kw):
+    from scaledreamer_amd.optimizers import AdamW
+
+    torch.manual_seed(0)
+    shapes = [(1_000_003,), (64, 32), (1, 64), (3, 64), (7,), (4099,)] + [(17, 5)] * 30          # > 24 tensors: two launches
+    ref_p = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    groups = lambda ps: [{"params": ps[:1], "lr": 1e-2}, {"params": ps[1:4], "lr": 1e-3}, {"params": ps[4:], "lr": 3e-3}]
+    ref = getattr(torch.optim, name)(groups(ref_p), **kw)
+    ours = AdamW(groups(our_p), adam_l2=name == "Adam", **({"weight_decay": 0.0} if name == "Adam" and "weight_decay" not in kw else {}), **kw)
+    for step in range(5):
+        for a, b in zip(ref_p, our_p):
+            g = torch.randn_like(a) * (10.0 ** (step - 2))
+            g.view(-1)[::3] = 0.0                                   # untouched entries: still decayed / their v still decays
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        ours.step()
+        for a, b in zip(ref_p, our_p):
+            torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-6, atol=1e-7)
+    sd = ours.state_dict()                                          # same state layout as torch's: loads into torch.optim and back
+    getattr(torch.optim, name)(groups([torch.nn.Parameter(p.detach().clone()) for p in our_p]), **kw).load_state_dict(sd)
+    st = ours.state[our_p[0]]
+    torch.testing.assert_close(st["exp_avg"], ref.state[ref_p[0]]["exp_avg"], rtol=2e-6, atol=1e-9)
+    assert int(st["step"]) == 5
+
+
+def test_fused_adan_matches_reference_golden_and_oracle():
+    from oracle.adan_ref import adan_step
+    from scaledreamer_amd.optimizers import Adan
+
+    g, seeded, cases = adan_cases()
+    for tag, kw in cases:
+        p1, p2 = torch.nn.Parameter(seeded("adan.p1", (7, 5)).cuda()), torch.nn.Parameter(seeded("adan.p2", (11,)).cuda())
+        opt = Adan([{"params": [p1], "lr": 0.01}, {"params": [p2], "lr": 0.003}], betas=(0.98, 0.92, 0.99), eps=1e-15, **kw)
+        for step in range(4):
+            p1.grad, p2.grad = seeded(f"adan.g1.{step}", (7, 5)).cuda(), seeded(f"adan.g2.{step}", (11,)).cuda()
+            opt.step()
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), g[f"{tag}.p1"], rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(p2.detach().cpu().numpy(), g[f"{tag}.p2"], rtol=2e-6, atol=2e-7)
+    # a larger problem against the oracle (several chunks per tensor, tail elements)
+    torch.manual_seed(1)
+    ps = [torch.randn(n) for n in (10_001, 4096, 33)]
+    ours = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    opt = Adan(ours, lr=2e-3, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0)
+    grp = [dict(params=ps, state=[{} for _ in ps], lr=2e-3)]
+    for step in range(3):
+        gs = [torch.randn_like(p) for p in ps]
+        grp[0]["grads"] = [x.clone() for x in gs]
+        adan_step(grp, step + 1, betas=(0.98, 0.92, 0.99), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0)
+        for p, x in zip(ours, gs):
+            p.grad = x.cuda()
+        opt.step()
+    for p, q in zip(ours, ps):
+        torch.testing.assert_close(p.detach().cpu(), q, rtol=1e-5, atol=1e-7)
+    with pytest.raises(TypeError):
+        cpu = torch.nn.Parameter(torch.zeros(3))
+        cpu.grad = torch.ones(3)
+        Adan([cpu]).step()

@@ -192,11 +192,10 @@ def test_multiprompt_datamodule_shards_library_by_rank():
     assert b["c2w"].shape == (2, 4, 4) and b["focal_length"].shape == (2,)
 
 
-def test_adan_matches_reference_optimizer():
+def adan_cases():
+    """the seeded parameters / gradients of tests/golden/adan_steps.npz (two groups with their own lr, four steps, three settings)"""
     import os
     import zlib
-
-    from scaledreamer_amd.optimizers import Adan
 
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "adan_steps.npz"))
     seed = int(g["seed"])
@@ -204,14 +203,24 @@ def test_adan_matches_reference_optimizer():
     def seeded(name, shape):
         gen = torch.Generator().manual_seed((seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
         return torch.randn(shape, generator=gen)
-    for tag, kw in (("plain", {}), ("clip_wd", dict(max_grad_norm=0.5, weight_decay=0.02)), ("noprox", dict(weight_decay=0.02, no_prox=True))):
-        p1, p2 = torch.nn.Parameter(seeded("adan.p1", (7, 5))), torch.nn.Parameter(seeded("adan.p2", (11,)))
-        opt = Adan([{"params": [p1], "lr": 0.01}, {"params": [p2], "lr": 0.003}], betas=(0.98, 0.92, 0.99), eps=1e-15, **kw)
+    cases = (("plain", {}), ("clip_wd", dict(max_grad_norm=0.5, weight_decay=0.02)), ("noprox", dict(weight_decay=0.02, no_prox=True)))
+    return g, seeded, cases
+
+
+def test_oracle_adan_matches_reference_optimizer():
+    """oracle/adan_ref.py vs the reference's own Adan class (golden); the product's fused kernel is compared on the GPU
+    (tests/test_gpu_optimizers.py)"""
+    from oracle.adan_ref import adan_step
+
+    g, seeded, cases = adan_cases()
+    for tag, kw in cases:
+        p1, p2 = seeded("adan.p1", (7, 5)), seeded("adan.p2", (11,))
+        groups = [dict(params=[p1], state=[{}], lr=0.01), dict(params=[p2], state=[{}], lr=0.003)]
         for step in range(4):
-            p1.grad, p2.grad = seeded(f"adan.g1.{step}", (7, 5)), seeded(f"adan.g2.{step}", (11,))
-            opt.step()
-        np.testing.assert_allclose(p1.detach().numpy(), g[f"{tag}.p1"], rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(p2.detach().numpy(), g[f"{tag}.p2"], rtol=1e-6, atol=1e-7)
+            groups[0]["grads"], groups[1]["grads"] = [seeded(f"adan.g1.{step}", (7, 5))], [seeded(f"adan.g2.{step}", (11,))]
+            adan_step(groups, step + 1, betas=(0.98, 0.92, 0.99), eps=1e-15, **kw)
+        np.testing.assert_allclose(p1.numpy(), g[f"{tag}.p1"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(p2.numpy(), g[f"{tag}.p2"], rtol=1e-6, atol=1e-7)
 
 
 def test_prompt_processor_reads_the_reference_cache_format(tmp_path):
