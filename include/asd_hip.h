@@ -276,7 +276,15 @@ typedef struct asd_gemm_args {
                                (the UNet keeps every ResBlock's time-embedding projection in one [B, sum Cout] matrix) */
     int32_t group_m, group_n; /* block order: workgroups of one XCD walk group_m x group_n super-tiles so that they share operand
                                tiles through that XCD's L2 (csrc/gemm.hip, asd_xcd_item); 0 = chosen by the library */
+    float*  gn_partials;    /* optional: GroupNorm statistics of C computed in the epilogue — one 64-float record {sum_g, sumsq_g} x 32
+                               groups per output tile, at index tile_m * tiles_n + tile_n; asd_gemm_gn_records() tells how many
+                               records per batch element this launch writes (0: not supported for this shape / plan, the pointer
+                               is ignored and the consumer runs its own statistics pass) */
+    int32_t gn_cg;          /* channels per group (N / 32) */
+    int32_t gn_rows;        /* rows of C per batch element (H*W): a tile must not straddle two of them */
 } asd_gemm_args;
+/* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
+int32_t asd_gemm_gn_records(const asd_gemm_args* args);
 int asd_gemm_f16(const asd_gemm_args* args, void* stream);
 /* Tuning hook (tools/gemm_sweep.py): force tile configuration `cfg` (index into the table of csrc/gemm.hip: 128x64, 128x128,
  * 256x64, 256x128, 128x320, 256x256, 256x320, 320x128, and for 3x3 stride-1 convolutions the LDS-window kernel with
@@ -290,6 +298,10 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
                       const void* gamma, const void* beta, float eps, int32_t silu, void* y,
                       float* stats /* ASD_GN_STATS_FLOATS(batch): [batch*32*2] sums for the backward pass + per-block partials */,
                       void* stream);
+/* the same GroupNorm when the tensor's producer already left its statistics as `records` 64-float records per batch element
+ * (asd_gemm_args.gn_partials): no statistics pass over x.  stats: [batch*64] floats, receives the per-(batch, group) sums. */
+int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta, float eps,
+                            int32_t silu, const float* partials, int32_t records, void* y, float* stats, void* stream);
 /* Input gradient of GroupNorm(+SiLU) with frozen gamma/beta (VAE encoder backward, the reference keeps the
  * VAE in the autograd graph: stable_diffusion_asd_guidance.py:171-178,225): dx from x, dy and the forward stats. */
 int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma,

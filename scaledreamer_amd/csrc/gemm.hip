@@ -67,6 +67,43 @@ __device__ __forceinline__ void asd_grouped_tile(int t, int tiles_m, int tiles_n
 // removing the global->LDS tile loads makes it 1.5-2.6x faster, and every shape lands at ~8 TB/s of aggregate L2->LDS
 // traffic.  The kernel is bound by bytes loaded per flop = (1/BM + 1/BN) / 128 B, so the tile is chosen as large as the
 // problem allows (WM x WN waves, each owning a (BM/WM) x (BN/WN) register tile), up to 256 x 320.
+// ---- GroupNorm statistics in the producer's epilogue -----------------------------------------------------------------------
+// When p.gn_partials is set, the block that stores an output tile also reduces sum / sum of squares of the (fp16-rounded) values it
+// stores per GroupNorm group (32 groups of p.gn_cg consecutive channels) and writes ONE 64-float record {sum_g, sumsq_g} at
+// index  tile_m * tiles_n + tile_n  (plain stores: nothing to zero, no global atomics).  The consumer's GroupNorm then skips its
+// statistics pass over the tensor (asd_groupnorm_apply_f16 sums the records).  A tile never straddles two batch elements: the
+// host only enables this when the rows of a batch element are a multiple of the tile's rows (asd_gemm_gn_records).
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row; valid in lane 15 of the row
+    int x;
+#define ASD_ROW_ADD(CTRL) x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true); v += __int_as_float(x)
+    ASD_ROW_ADD(0x111); ASD_ROW_ADD(0x112); ASD_ROW_ADD(0x114); ASD_ROW_ADD(0x118);
+#undef ASD_ROW_ADD
+    return v;
+}
+__device__ __forceinline__ void gn_tile_begin(float* lds64) {
+    __syncthreads();                        // every wave is done with the main loop's LDS
+    if (threadIdx.x < 64) lds64[threadIdx.x] = 0.f;
+    __syncthreads();
+}
+// s, q: this lane's column sums for channels n..n+3 (over its rows); lanes of one 16-lane row hold the same channels
+__device__ __forceinline__ void gn_tile_flush(float* lds64, floatx4 s, floatx4 q, int n, int N, int cg) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
+    if ((threadIdx.x & 15) == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= N) continue;
+            const int g = (n + r) / cg;
+            atomicAdd(&lds64[2 * g], s[r]);
+            atomicAdd(&lds64[2 * g + 1], q[r]);
+        }
+    }
+}
+__device__ __forceinline__ void gn_tile_end(const asd_gemm_args& p, const float* lds64, int record) {
+    __syncthreads();
+    if (threadIdx.x < 64) p.gn_partials[(size_t)record * 64 + threadIdx.x] = lds64[threadIdx.x];
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_args p) {
     constexpr int NW = WM * WN;
@@ -319,15 +356,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
         }
         return;
     }
+    const bool gn = p.gn_partials != nullptr;     // block-uniform
+    float* gn_lds = (float*)smem;
+    if (gn) gn_tile_begin(gn_lds);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + em;
-        if (m >= p.M) continue;
-        const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias : nullptr;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 16 + en;
+        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + en;
-            if (n >= p.N) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + em;
+            if (m >= p.M || n >= p.N) continue;
+            const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias : nullptr;
             floatx4 v = acc[i][j];
             if (p.bias) {
                 const half4 b = *(const half4*)((const half_t*)p.bias + n);
@@ -350,13 +390,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             } else {
                 half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+                if (gn) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs[r] += f; cq[r] = fmaf(f, f, cq[r]); }
+                }
             }
         }
+        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
     }
+    if (gn) gn_tile_end(p, gn_lds, (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN);
 }
 
 // bias + row_bias + SiLU + residual + store of 4 consecutive output channels of row m (shared by all GEMM / conv kernels)
-__device__ __forceinline__ void gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
+__device__ __forceinline__ floatx4 gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
     if (p.bias) {
         const half4 b = *(const half4*)((const half_t*)p.bias + n);
         v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
@@ -375,10 +421,11 @@ __device__ __forceinline__ void gemm_store4(const asd_gemm_args& p, floatx4 v, i
     }
     if (p.out_f32) {
         *(floatx4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-    } else {
-        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+        return v;
     }
+    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+    return floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};       // what a later pass over the tensor would read
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -552,17 +599,27 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
 
     // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
     const int en = (lane >> 4) * 4;
+    const bool gn = p.gn_partials != nullptr && p.split_k == 1;     // block-uniform
+    float* gn_lds = (float*)smem;
+    if (gn) gn_tile_begin(gn_lds);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 16 + en;
+        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + en;
+        for (int i = 0; i < TM; ++i) {
+            const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
             if (n >= p.N) continue;
             if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
-            else gemm_store4(p, acc[i][j], m, n);
+            else {
+                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] += o[r]; cq[r] = fmaf(o[r], o[r], cq[r]); }
+            }
         }
+        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
     }
+    if (gn) gn_tile_end(p, gn_lds, tm * tiles_n + tn_);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -678,17 +735,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
 
     // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
     const int en = (lane >> 4) * 4;
+    const bool gn = p.gn_partials != nullptr && p.split_k == 1;     // block-uniform
+    float* gn_lds = (float*)smem;
+    if (gn) gn_tile_begin(gn_lds);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 16 + en;
+        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + en;
+        for (int i = 0; i < TM; ++i) {
+            const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
             if (n >= p.N) continue;
             if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
-            else gemm_store4(p, acc[i][j], m, n);
+            else {
+                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] += o[r]; cq[r] = fmaf(o[r], o[r], cq[r]); }
+            }
         }
+        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
     }
+    if (gn) gn_tile_end(p, gn_lds, tm * tiles_n + tn_);
 }
 
 // sums the split-K slabs and applies the same epilogue (4 outputs per thread)
@@ -813,6 +880,29 @@ __global__ void asd_spin_kernel(long long cycles) {
     while (wall_clock64() - t0 < cycles) {}
 }
 
+// tile configuration of a (validated, plan-resolved: split_k >= 1) problem: the tuned one, else the cost model
+static int asd_gemm_resolve_cfg(const asd_gemm_args* a) {
+    int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
+    // without a tuned plan: the LDS-window kernel wins on every stride-1 3x3 layer with at least 16 patches (tools/gemm_sweep.py)
+    if (asd_conv_window_ok(a) && a->M >= 4096 && a->split_k <= a->Cin / 64) {
+        cfg = a->N % 128 == 0 ? 9 : 8;
+        if ((a->M / 256) * asd_div_up(a->N, asd_gemm_tiles[cfg].bn) * a->split_k >= 512) cfg += 2;   // enough blocks for two per CU
+    }
+    if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
+    if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
+    if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
+    return cfg;
+}
+
+// GroupNorm statistics in the epilogue: records per batch element, 0 when this launch cannot produce them
+static int asd_gemm_gn_records_cfg(const asd_gemm_args* a, int cfg, bool need_ptr) {
+    if ((need_ptr && !a->gn_partials) || a->split_k != 1 || a->out_f32 || a->act == 2 || a->gn_cg < 1 || a->gn_rows < 1 || a->N != 32 * a->gn_cg || a->M % a->gn_rows) return 0;
+    const int bn = asd_gemm_tiles[cfg].bn, tiles_n = asd_div_up(a->N, bn);
+    if (asd_cfg_is_window(cfg)) return (a->gn_rows / 256) * tiles_n;          // 16 x 16 patches never leave their image
+    const int bm = asd_gemm_tiles[cfg].bm;
+    return a->gn_rows % bm == 0 ? (a->gn_rows / bm) * tiles_n : 0;
+}
+
 extern "C" {
 
 int asd_gemm_force_tile(int32_t cfg) {
@@ -838,6 +928,18 @@ int asd_gemm_plan_get(const asd_gemm_args* a, int32_t* tile_cfg, int32_t* split_
     *tile_cfg = 0;
     *split_k = asd_default_split(a);
     return 1;   // not tuned: cost model + default split
+}
+
+int32_t asd_gemm_gn_records(const asd_gemm_args* a_in) {
+    if (!a_in || a_in->M <= 0 || a_in->N <= 0 || a_in->K <= 0) return 0;
+    asd_gemm_args a = *a_in;
+    if (a.split_k == 0) {
+        int32_t t = 0, sk = 1;
+        asd_gemm_plan_get(&a, &t, &sk);
+        a.split_k = sk;
+        if (a.tile_cfg == 0) a.tile_cfg = t;
+    }
+    return asd_gemm_gn_records_cfg(&a, asd_gemm_resolve_cfg(&a), false);
 }
 
 int asd_gemm_plan_count(void) {
@@ -889,20 +991,13 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     if (a->act == 2)
         ASD_CHECK_ARG(a->N % 32 == 0 && a->bias && !a->conv && !a->residual && !a->row_bias && !a->out_f32 && a->split_k == 1,
                       "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");
-    int cfg = asd_gemm_pick_tile(a->M, a->N, a->K, a->split_k);
-    // without a tuned plan: the LDS-window kernel wins on every stride-1 3x3 layer with at least 16 patches (tools/gemm_sweep.py)
-    if (asd_conv_window_ok(a) && a->M >= 4096 && a->split_k <= a->Cin / 64) {
-        cfg = a->N % 128 == 0 ? 9 : 8;
-        if ((a->M / 256) * asd_div_up(a->N, asd_gemm_tiles[cfg].bn) * a->split_k >= 512) cfg += 2;   // enough blocks for two per CU
-    }
-    if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
-    if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
-    if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
+    int cfg = asd_gemm_resolve_cfg(a);
     ASD_CHECK_ARG(a->act != 2 || (!asd_cfg_is_window(cfg) && (asd_gemm_tiles[cfg].bn / asd_gemm_tiles[cfg].wn) % 32 == 0),
                   "GEGLU epilogue needs a tile whose per-wave width is a multiple of 32 columns");
     ASD_CHECK_ARG(asd_gemm_tiles[cfg].bn == 64 || a->N % asd_gemm_tiles[cfg].bn == 0 || (asd_gemm_tiles[cfg].bn == 128 && a->N % 4 == 0),
                   "tile configuration does not divide N");
     const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;
+    if (asd_gemm_gn_records_cfg(a, cfg, true) == 0) a->gn_partials = nullptr;
     if (asd_cfg_is_window(cfg)) {
         ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
@@ -1037,6 +1132,7 @@ int asd_gemm_tune(const asd_gemm_args* a_in, void* scratch, int64_t scratch_byte
     for (int i = 0; i < n; ++i) {
         ms_of[i] = 1e30f;
         asd_gemm_args a = *a_in;
+        a.gn_partials = nullptr;          // the record count depends on the tile: the caller's buffer is sized for the final plan only
         a.tile_cfg = cand[i][0];
         a.split_k = cand[i][1];
         if (a.split_k > 1) {

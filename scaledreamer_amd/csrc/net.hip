@@ -45,6 +45,18 @@ struct Run {                // state of one pass over a schedule
     size_t scratch_bytes = 0, scratch_need = 0;
     const void* zero_page = nullptr;
     int status = ASD_OK;
+    // GroupNorm-statistics records written by producers' epilogues (asd_gemm_args.gn_partials): their count depends on the GEMM
+    // plan, so a pass that must reproduce another pass's allocation sequence (the VAE backward replaying its forward) replays the
+    // logged counts instead of asking the plan table again
+    std::vector<int>* rec_log = nullptr;
+    const std::vector<int>* rec_replay = nullptr;
+    size_t rec_pos = 0;
+};
+
+struct Act {                // an activation and, when its producer left them, its GroupNorm statistics records
+    const half_t* p = nullptr;
+    const float* rec = nullptr;
+    int nrec = 0;           // records per batch element (0: none — the consumer runs its own statistics pass)
 };
 
 struct Net {
@@ -72,9 +84,11 @@ int pad32(int c) { return (c + 31) / 32 * 32; }
 struct GemmOpt {
     const void* bias = nullptr; const void* row_bias = nullptr; int rows_per_group = 1, ld_row_bias = 0;
     const void* residual = nullptr; int ldr = 0; int act = 0; int out_f32 = 0;
+    int gn_rows = 0;        // > 0: the output feeds a GroupNorm over all N channels with this many rows per batch element
+    Act* out = nullptr;     // receives the records' location when gn_rows > 0
 };
 
-void launch_gemm(Run& r, asd_gemm_args& g) {
+void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
     g.zero_page = r.zero_page;
     g.split_k = 0;          // auto: tuned plan of this shape (asd_gemm_plan_*), else cost model
     g.tile_cfg = 0;
@@ -86,6 +100,19 @@ void launch_gemm(Run& r, asd_gemm_args& g) {
     }
     const size_t need = (size_t)asd_gemm_workspace_bytes(&g);
     if (need > r.scratch_need) r.scratch_need = need;
+    if (gn_out && g.gn_rows > 0 && g.N % 32 == 0) {     // statistics records of the output, produced in the epilogue when the plan allows
+        g.gn_cg = g.N / 32;
+        const int batch = g.M / g.gn_rows;
+        int nrec;
+        if (r.rec_replay) nrec = r.rec_pos < r.rec_replay->size() ? (*r.rec_replay)[r.rec_pos++] : 0;
+        else nrec = asd_gemm_gn_records(&g);
+        // while tuning, the plan (and with it the record count) of this shape may still change between the sizing pass and the
+        // launch: reserve the upper bound (64 x 64 tiles)
+        const int reserve = r.tune ? (g.gn_rows / 64 + 1) * (g.N / 64 + 1) : nrec;
+        if (r.rec_log) r.rec_log->push_back(nrec);
+        float* buf = (nrec > 0 || r.tune) ? r.mem.floats((size_t)batch * (reserve > nrec ? reserve : nrec) * 64) : nullptr;
+        if (nrec > 0) { g.gn_partials = buf; gn_out->rec = buf; gn_out->nrec = nrec; }
+    }
     if (r.dry || r.status != ASD_OK) return;
     if (need > r.scratch_bytes) { asd_set_error("network workspace too small for a split-K GEMM"); r.status = ASD_ERR_ARG; return; }
     g.workspace = r.scratch;
@@ -99,7 +126,9 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.bias = o.bias; g.row_bias = o.row_bias; g.rows_per_group = o.row_bias ? o.rows_per_group : 1; g.ld_row_bias = o.ld_row_bias;
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
-    launch_gemm(r, g);
+    g.gn_rows = o.gn_rows;
+    if (o.out) *o.out = Act{(const half_t*)C, nullptr, 0};
+    launch_gemm(r, g, o.out);
 }
 
 // 3x3 convolution on NHWC [B,Hin,Win,Cin] with packed weights [Cout, 9*Cin]; upsample: 0 plain, 1 nearest-2x fused, 2 transposed stride-2
@@ -110,7 +139,9 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
     g.bias = o.bias; g.row_bias = o.row_bias; g.rows_per_group = o.row_bias ? o.rows_per_group : 1; g.ld_row_bias = o.ld_row_bias;
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
     g.conv = 1; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.pad = pad; g.upsample = upsample;
-    launch_gemm(r, g);
+    g.gn_rows = o.gn_rows;
+    if (o.out) *o.out = Act{(const half_t*)y, nullptr, 0};
+    launch_gemm(r, g, o.out);
 }
 
 #define LEAF(call)                                              \
@@ -123,9 +154,12 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
 
 // GroupNorm(32)(+SiLU) of x1 (|| x2 along channels); returns y, optionally the statistics buffer (kept for a backward pass)
 half_t* groupnorm(Run& r, const void* x1, int c1, const void* x2, int c2, int B, int hw, const half_t* gamma, const half_t* beta, float eps,
-                  int silu, half_t* y = nullptr, float** stats_out = nullptr) {
+                  int silu, half_t* y = nullptr, float** stats_out = nullptr, const Act* src = nullptr) {
     if (!y) y = r.mem.halfs((size_t)B * hw * (c1 + c2));
     float* stats = r.mem.floats(ASD_GN_STATS_FLOATS(B));
+    if (src && src->nrec > 0 && !x2) {       // the producer's epilogue already reduced the statistics: no pass over x for them
+        LEAF(asd_groupnorm_apply_f16(x1, c1, B, hw, gamma, beta, eps, silu, src->rec, src->nrec, y, stats, r.stream));
+    } else
     LEAF(asd_groupnorm_f16(x1, c1, x2, c2, B, hw, gamma, beta, eps, silu, y, stats, r.stream));
     if (stats_out) *stats_out = stats;
     return y;
@@ -251,15 +285,18 @@ struct UState {             // per-forward quantities shared by the layers
     const half_t* k_all; const half_t* vT_all;
 };
 
-half_t* u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const half_t* x, int cin, int cout, int Hh, int Ww) {
+Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int cin, int cout, int Hh, int Ww) {
     const int B = s.B, hw = Hh * Ww, M = B * hw;
-    half_t* t1 = groupnorm(r, x, cin, nullptr, 0, B, hw, n.w(p + ".in_layers.0.weight"), n.w(p + ".in_layers.0.bias"), 1e-5f, 1);
+    const half_t* x = xin.p;
+    half_t* t1 = groupnorm(r, x, cin, nullptr, 0, B, hw, n.w(p + ".in_layers.0.weight"), n.w(p + ".in_layers.0.bias"), 1e-5f, 1, nullptr, nullptr, &xin);
     half_t* t2 = r.mem.halfs((size_t)M * cout);
+    Act a2;
     GemmOpt o1;
     o1.bias = n.w(p + ".in_layers.2.bias");
     o1.row_bias = s.emb_all + n.emb_off[p]; o1.rows_per_group = hw; o1.ld_row_bias = s.emb_ld;   // + emb_layers(emb)[:, :, None, None]
+    o1.gn_rows = hw; o1.out = &a2;
     conv3x3(r, t1, B, Hh, Ww, cin, n.w(p + ".in_layers.2.weight"), cout, t2, Hh, Ww, 1, 1, 0, o1);
-    half_t* t3 = groupnorm(r, t2, cout, nullptr, 0, B, hw, n.w(p + ".out_layers.0.weight"), n.w(p + ".out_layers.0.bias"), 1e-5f, 1);
+    half_t* t3 = groupnorm(r, t2, cout, nullptr, 0, B, hw, n.w(p + ".out_layers.0.weight"), n.w(p + ".out_layers.0.bias"), 1e-5f, 1, nullptr, nullptr, &a2);
     const half_t* skip = x;
     if (n.has(p + ".skip_connection.weight")) {
         half_t* sk = r.mem.halfs((size_t)M * cout);
@@ -269,10 +306,11 @@ half_t* u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const
         skip = sk;
     }
     half_t* out = r.mem.halfs((size_t)M * cout);
+    Act ao;
     GemmOpt o2;
-    o2.bias = n.w(p + ".out_layers.3.bias"); o2.residual = skip; o2.ldr = cout;
+    o2.bias = n.w(p + ".out_layers.3.bias"); o2.residual = skip; o2.ldr = cout; o2.gn_rows = hw; o2.out = &ao;
     conv3x3(r, t3, B, Hh, Ww, cout, n.w(p + ".out_layers.3.weight"), cout, out, Hh, Ww, 1, 1, 0, o2);
-    return out;
+    return ao;
 }
 
 half_t* layernorm(Run& r, const half_t* x, int rows, int c, const half_t* g, const half_t* b) {
@@ -281,9 +319,10 @@ half_t* layernorm(Run& r, const half_t* x, int rows, int c, const half_t* g, con
     return y;
 }
 
-half_t* u_transformer(UNet& n, Run& r, const UState& s, const std::string& p, const half_t* x, int C, int Hh, int Ww) {
+Act u_transformer(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int C, int Hh, int Ww) {
     const int B = s.B, L = Hh * Ww, M = B * L, heads = C / 64, F = s.F;
-    half_t* h = groupnorm(r, x, C, nullptr, 0, B, L, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 1e-6f, 0);
+    const half_t* x = xin.p;
+    half_t* h = groupnorm(r, x, C, nullptr, 0, B, L, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 1e-6f, 0, nullptr, nullptr, &xin);
     {
         half_t* h2 = r.mem.halfs((size_t)M * C);
         GemmOpt o; o.bias = n.w(p + ".proj_in.bias");
@@ -325,19 +364,21 @@ half_t* u_transformer(UNet& n, Run& r, const UState& s, const std::string& p, co
         h = h3;
     }
     half_t* out = r.mem.halfs((size_t)M * C);
-    GemmOpt o; o.bias = n.w(p + ".proj_out.bias"); o.residual = x; o.ldr = C;
+    Act ao;
+    GemmOpt o; o.bias = n.w(p + ".proj_out.bias"); o.residual = x; o.ldr = C; o.gn_rows = L; o.out = &ao;
     gemm(r, h, M, C, n.w(p + ".proj_out.weight"), C, C, C, out, C, o);
-    return out;
+    return ao;
 }
 
-const half_t* u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, const half_t* h, int* Hh, int* Ww) {
+Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh, int* Ww) {
     for (const ULayer& l : blk.layers) {
         const int B = s.B;
         if (l.kind == 0) {
             half_t* y = r.mem.halfs((size_t)B * *Hh * *Ww * l.cout);
-            GemmOpt o; o.bias = n.w(l.name + ".bias");
-            conv3x3(r, h, B, *Hh, *Ww, pad32(l.cin), n.w(l.name + ".weight"), l.cout, y, *Hh, *Ww, 1, 1, 0, o);
-            h = y;
+            Act a;
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = *Hh * *Ww; o.out = &a;
+            conv3x3(r, h.p, B, *Hh, *Ww, pad32(l.cin), n.w(l.name + ".weight"), l.cout, y, *Hh, *Ww, 1, 1, 0, o);
+            h = a;
         } else if (l.kind == 1) {
             h = u_resblock(n, r, s, l.name, h, l.cin, l.cout, *Hh, *Ww);
         } else if (l.kind == 2) {
@@ -345,14 +386,16 @@ const half_t* u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, const
         } else if (l.kind == 3) {
             const int Ho = (*Hh + 2 - 3) / 2 + 1, Wo = (*Ww + 2 - 3) / 2 + 1;
             half_t* y = r.mem.halfs((size_t)B * Ho * Wo * l.cout);
-            GemmOpt o; o.bias = n.w(l.name + ".bias");
-            conv3x3(r, h, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, Ho, Wo, 2, 1, 0, o);
-            h = y; *Hh = Ho; *Ww = Wo;
+            Act a;
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = Ho * Wo; o.out = &a;
+            conv3x3(r, h.p, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, Ho, Wo, 2, 1, 0, o);
+            h = a; *Hh = Ho; *Ww = Wo;
         } else {
             half_t* y = r.mem.halfs((size_t)B * 4 * *Hh * *Ww * l.cout);
-            GemmOpt o; o.bias = n.w(l.name + ".bias");
-            conv3x3(r, h, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, 2 * *Hh, 2 * *Ww, 1, 1, 1, o);
-            h = y; *Hh *= 2; *Ww *= 2;
+            Act a;
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = 4 * *Hh * *Ww; o.out = &a;
+            conv3x3(r, h.p, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, 2 * *Hh, 2 * *Ww, 1, 1, 1, o);
+            h = a; *Hh *= 2; *Ww *= 2;
         }
     }
     return h;
@@ -394,11 +437,12 @@ void unet_run(UNet& n, Run& r, const half_t* x, const float* t, const half_t* ct
 
     struct Skip { const half_t* p; int c; };
     std::vector<Skip> hs;
-    const half_t* h = x;
+    Act h;
+    h.p = x;
     int hh = Hh, ww = Ww;
     for (const UBlock& b : n.inputs) {
         h = u_apply(n, r, s, b, h, &hh, &ww);
-        hs.push_back(Skip{h, b.layers.back().cout});
+        hs.push_back(Skip{h.p, b.layers.back().cout});
     }
     h = u_apply(n, r, s, n.middle, h, &hh, &ww);
     int ch = n.middle.layers.back().cout;
@@ -406,11 +450,13 @@ void unet_run(UNet& n, Run& r, const half_t* x, const float* t, const half_t* ct
         const Skip sk = hs.back();
         hs.pop_back();
         half_t* cat = r.mem.halfs((size_t)B * hh * ww * (ch + sk.c));
-        LEAF(asd_concat_f16(h, ch, sk.p, sk.c, (int64_t)B * hh * ww, cat, r.stream));
-        h = u_apply(n, r, s, b, cat, &hh, &ww);
+        LEAF(asd_concat_f16(h.p, ch, sk.p, sk.c, (int64_t)B * hh * ww, cat, r.stream));
+        Act hc;          // a concatenation: the GroupNorm groups span both halves, so the halves' records do not apply
+        hc.p = cat;
+        h = u_apply(n, r, s, b, hc, &hh, &ww);
         ch = b.layers.back().cout;
     }
-    half_t* y = groupnorm(r, h, ch, nullptr, 0, B, hh * ww, n.w("out.0.weight"), n.w("out.0.bias"), 1e-5f, 1);
+    half_t* y = groupnorm(r, h.p, ch, nullptr, 0, B, hh * ww, n.w("out.0.weight"), n.w("out.0.bias"), 1e-5f, 1, nullptr, nullptr, &h);
     GemmOpt o; o.bias = n.w("out.2.bias"); o.out_f32 = 1;
     conv3x3(r, y, B, hh, ww, ch, n.w("out.2.weight"), d.out_channels, eps, hh, ww, 1, 1, 0, o);
 }
@@ -424,6 +470,7 @@ struct Vae : Net {
     asd_vae_desc d;
     std::vector<VLayer> plan;
     std::map<const void*, size_t> scratch_of;      // workspace -> split-K scratch size its last forward laid it out with
+    std::map<const void*, std::vector<int>> recs_of;   // workspace -> GroupNorm record counts of that forward, in allocation order
 };
 
 // conv: forward weights [cout, 9*pad32(cin)], input-gradient weights [pad32(cin), 9*pad32(cout)] (roles swapped, taps flipped for
@@ -501,44 +548,48 @@ void vae_forward(Vae& n, Run& r, const half_t* x32, int B, int Hh, int Ww, float
     }
     half_t* tmp = r.mem.halfs(max_act);
     saved.assign(n.plan.size(), VSaved());
-    const half_t* h = x32;
+    Act h;
+    h.p = x32;
     int hh = Hh, ww = Ww;
     for (size_t i = 0; i < n.plan.size(); ++i) {
         const VLayer& l = n.plan[i];
         VSaved& sv = saved[i];
-        sv.x = h; sv.H = hh; sv.W = ww;
+        Act produced;                               // this layer's output and, when its producer could, its GroupNorm records
+        sv.x = h.p; sv.H = hh; sv.W = ww;
         const int hw = hh * ww, M = B * hw;
         if (l.kind == 0) {
             sv.out = r.mem.halfs((size_t)M * l.cout);
-            GemmOpt o; o.bias = n.w(l.name + ".bias");
-            conv3x3(r, h, B, hh, ww, pad32(l.cin), n.w(l.name + ".fwd"), l.cout, sv.out, hh, ww, 1, 1, 0, o);
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = hw; o.out = &produced;
+            conv3x3(r, h.p, B, hh, ww, pad32(l.cin), n.w(l.name + ".fwd"), l.cout, sv.out, hh, ww, 1, 1, 0, o);
         } else if (l.kind == 1) {
             const std::string& p = l.name;
-            groupnorm(r, h, l.cin, nullptr, 0, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1e-6f, 1, tmp, &sv.st1);
+            groupnorm(r, h.p, l.cin, nullptr, 0, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1e-6f, 1, tmp, &sv.st1, &h);
             sv.t2 = r.mem.halfs((size_t)M * l.cout);
-            { GemmOpt o; o.bias = n.w(p + ".conv1.bias");
+            Act a2;
+            { GemmOpt o; o.bias = n.w(p + ".conv1.bias"); o.gn_rows = hw; o.out = &a2;
               conv3x3(r, tmp, B, hh, ww, l.cin, n.w(p + ".conv1.fwd"), l.cout, sv.t2, hh, ww, 1, 1, 0, o); }
-            groupnorm(r, sv.t2, l.cout, nullptr, 0, B, hw, n.w(p + ".norm2.weight"), n.w(p + ".norm2.bias"), 1e-6f, 1, tmp, &sv.st2);
-            const half_t* sc = h;
+            groupnorm(r, sv.t2, l.cout, nullptr, 0, B, hw, n.w(p + ".norm2.weight"), n.w(p + ".norm2.bias"), 1e-6f, 1, tmp, &sv.st2, &a2);
+            const half_t* sc = h.p;
             if (n.has(p + ".nin.w")) {
                 half_t* s2 = r.mem.halfs((size_t)M * l.cout);
                 GemmOpt o; o.bias = n.w(p + ".nin.b");
-                gemm(r, h, M, l.cin, n.w(p + ".nin.w"), l.cout, l.cin, l.cin, s2, l.cout, o);
+                gemm(r, h.p, M, l.cin, n.w(p + ".nin.w"), l.cout, l.cin, l.cin, s2, l.cout, o);
                 sc = s2;
             }
             sv.out = r.mem.halfs((size_t)M * l.cout);
             GemmOpt o; o.bias = n.w(p + ".conv2.bias"); o.residual = sc; o.ldr = l.cout;   // x + h in the conv epilogue (model.py:141-148)
+            o.gn_rows = hw; o.out = &produced;
             conv3x3(r, tmp, B, hh, ww, l.cout, n.w(p + ".conv2.fwd"), l.cout, sv.out, hh, ww, 1, 1, 0, o);
         } else if (l.kind == 2) {          // stride 2 with asymmetric (0,1,0,1) zero padding (model.py:80-85)
             const int ho = (hh + 1 - 3) / 2 + 1, wo = (ww + 1 - 3) / 2 + 1;
             sv.out = r.mem.halfs((size_t)B * ho * wo * l.cout);
-            GemmOpt o; o.bias = n.w(l.name + ".bias");
-            conv3x3(r, h, B, hh, ww, l.cin, n.w(l.name + ".fwd"), l.cout, sv.out, ho, wo, 2, 0, 0, o);
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = ho * wo; o.out = &produced;
+            conv3x3(r, h.p, B, hh, ww, l.cin, n.w(l.name + ".fwd"), l.cout, sv.out, ho, wo, 2, 0, 0, o);
             hh = ho; ww = wo;
         } else if (l.kind == 3) {          // single-head attention over the hw positions of each image
             const std::string& p = l.name;
             const int C = l.cin, L = hw;
-            groupnorm(r, h, C, nullptr, 0, B, hw, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 1e-6f, 0, tmp, &sv.st1);
+            groupnorm(r, h.p, C, nullptr, 0, B, hw, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 1e-6f, 0, tmp, &sv.st1, &h);
             sv.q = r.mem.halfs((size_t)M * C); sv.k = r.mem.halfs((size_t)M * C); sv.v = r.mem.halfs((size_t)M * C);
             half_t* dst[3] = {sv.q, sv.k, sv.v};
             const char* nm[3] = {".q", ".k", ".v"};
@@ -559,15 +610,16 @@ void vae_forward(Vae& n, Run& r, const half_t* x32, int B, int Hh, int Ww, float
                 gemm(r, P, L, L, vt, C, L, L, ao + ro, C);                                             // O = P V
             }
             sv.out = r.mem.halfs((size_t)M * C);
-            GemmOpt o; o.bias = n.w(p + ".proj_out.b"); o.residual = h; o.ldr = C;                      // x + proj_out(attn)
+            GemmOpt o; o.bias = n.w(p + ".proj_out.b"); o.residual = h.p; o.ldr = C;                    // x + proj_out(attn)
+            o.gn_rows = hw; o.out = &produced;
             gemm(r, ao, M, C, n.w(p + ".proj_out.w"), C, C, C, sv.out, C, o);
         } else {
-            groupnorm(r, h, l.cin, nullptr, 0, B, hw, n.w(l.name + ".norm_out.weight"), n.w(l.name + ".norm_out.bias"), 1e-6f, 1, tmp, &sv.st1);
+            groupnorm(r, h.p, l.cin, nullptr, 0, B, hw, n.w(l.name + ".norm_out.weight"), n.w(l.name + ".norm_out.bias"), 1e-6f, 1, tmp, &sv.st1, &h);
             GemmOpt o; o.bias = n.w(l.name + ".conv_out_quant.bias"); o.out_f32 = 1;
             conv3x3(r, tmp, B, hh, ww, l.cin, n.w(l.name + ".conv_out_quant.fwd"), l.cout, moments, hh, ww, 1, 1, 0, o);
             sv.out = nullptr;
         }
-        if (sv.out) h = sv.out;
+        if (sv.out) { h = produced; h.p = sv.out; }
     }
     r.dry = was_dry;
 }
@@ -695,6 +747,7 @@ template <class F>
 size_t plan_bytes(F&& pass, bool tune) {
     Run r;
     r.dry = true;
+    r.tune = tune;        // sizing rule of the statistics records (upper bound while plans may still change)
     pass(r);
     const size_t scratch = tune ? TUNE_SCRATCH : r.scratch_need;
     return ((scratch + 255) & ~(size_t)255) + r.mem.off + 256;
@@ -706,6 +759,7 @@ int run_pass(F&& pass, void* workspace, size_t workspace_bytes, hipStream_t stre
              size_t* scratch_io = nullptr, bool given = false) {
     Run dry;
     dry.dry = true;
+    dry.tune = tune;
     pass(dry);
     size_t scratch = ((tune ? TUNE_SCRATCH : dry.scratch_need) + 255) & ~(size_t)255;
     if (given) scratch = *scratch_io;
@@ -821,12 +875,14 @@ int asd_vae_enc_fwd(asd_vae_enc* h, const void* x_nhwc32, int32_t batch, int32_t
     if (need < 0 || need > workspace_bytes) { asd_set_error("workspace of %lld bytes is too small (need %lld)", (long long)workspace_bytes, (long long)need); return ASD_ERR_ARG; }
     // the scratch region is sized for both passes (the dry pass walks the backward as well) and remembered per workspace
     size_t scratch = 0;
+    std::vector<int> log;
     const int st = run_pass([&](Run& r) {
         std::vector<VSaved> saved;
+        if (!r.dry) r.rec_log = &log;
         vae_forward(*n, r, (const half_t*)x_nhwc32, batch, H, W, moments_nhwc, saved, true);
         if (r.dry) vae_backward(*n, r, saved, nullptr, batch, nullptr);
     }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch);
-    if (st == ASD_OK) n->scratch_of[workspace] = scratch;
+    if (st == ASD_OK) { n->scratch_of[workspace] = scratch; n->recs_of[workspace] = log; }
     return st;
 }
 int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, int32_t H, int32_t W, void* workspace, int64_t workspace_bytes,
@@ -837,8 +893,11 @@ int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, 
     auto it = n->scratch_of.find(workspace);
     ASD_CHECK_ARG(it != n->scratch_of.end(), "no forward pass has run on this workspace");
     size_t scratch = it->second;
+    const std::vector<int>& log = n->recs_of[workspace];
     return run_pass([&](Run& r) {
         std::vector<VSaved> saved;
+        r.rec_replay = &log;
+        r.rec_pos = 0;
         vae_forward(*n, r, nullptr, batch, H, W, nullptr, saved, false);     // replays the forward's allocation sequence: same addresses
         vae_backward(*n, r, saved, d_moments_nhwc, batch, (half_t*)dx_nhwc32);
     }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch, true);

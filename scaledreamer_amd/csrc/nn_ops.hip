@@ -502,6 +502,14 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
     }
 }
 
+// records[b][n][64] -> out[b][64]: the per-tile statistics records of a producer's epilogue summed per batch element
+__global__ __launch_bounds__(256) void gn_reduce_records_kernel(const float* __restrict__ records, int n, float* __restrict__ out) {
+    __shared__ float st[64];
+    __shared__ float scratch[4][64];
+    gn_reduce_partials(records, blockIdx.x, n, st, scratch);
+    if (threadIdx.x < 64) out[blockIdx.x * 64 + threadIdx.x] = st[threadIdx.x];
+}
+
 extern "C" {
 
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
@@ -524,6 +532,27 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
                        asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, partials, chunks_s, stats,
                        (half_t*)y);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta, float eps,
+                            int32_t silu, const float* partials, int32_t records, void* y, float* stats, void* stream) {
+    ASD_CHECK_ARG(x && gamma && beta && y && stats && partials && batch > 0 && hw > 0 && records > 0, "null argument");
+    ASD_CHECK_ARG(c % 32 == 0 && c % 8 == 0, "channels must be a multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = asd_div_up(hw, 16);
+    const int cap_a = asd_div_up(GN_CAP_A, batch), chunks_a = chunks > cap_a ? cap_a : chunks;
+    // every apply block sums the records of its batch element in its prologue: with many tiles, sum them once first
+    const float* part = partials;
+    int n = records;
+    if ((long long)records * chunks_a > 2048) {
+        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch), dim3(256), 0, s, partials, records, stats);
+        part = stats;
+        n = 1;
+    }
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, c, (const half_t*)nullptr, 0, hw,
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, part, n, stats, (half_t*)y);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -112,8 +112,10 @@ if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none" and os.path.exists(L.LIB_P
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
-         M: Optional[int] = None, tile_cfg: int = 0) -> torch.Tensor:
-    """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv."""
+         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0):
+    """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv.
+    gn_rows > 0: also ask the epilogue for the GroupNorm statistics records of C (rows per batch element = gn_rows); returns
+    (C, records | None, records_per_batch_element)."""
     dev = a.device
     N, K = w.shape
     if conv is None:
@@ -155,8 +157,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     if need > 0:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         g.workspace = ws.data_ptr()
+    rec, nrec = None, 0
+    if gn_rows > 0:
+        g.gn_cg, g.gn_rows = N // 32, gn_rows
+        nrec = lib().asd_gemm_gn_records(C.byref(g))
+        if nrec > 0:
+            rec = torch.empty((M // gn_rows, nrec, 64), device=dev, dtype=torch.float32)
+            g.gn_partials = rec.data_ptr()
     check(lib().asd_gemm_f16(C.byref(g), stream()))
-    return out
+    return (out, rec, nrec) if gn_rows > 0 else out
 
 
 def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1, pad: int = 1, upsample: bool = False,
@@ -175,6 +184,8 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1,
         Ho, Wo = out_hw
     conv = dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=int(upsample))  # upsample: 0/1/2
     y = gemm(x, w_packed, bias=bias, conv=conv, M=B * Ho * Wo, **kw)
+    if isinstance(y, tuple):      # gn_rows: (C, records, records per batch element)
+        return y[0].view(B, Ho, Wo, w_packed.shape[0]), y[1], y[2]
     return y.view(B, Ho, Wo, w_packed.shape[0])
 
 
@@ -196,6 +207,17 @@ def groupnorm(x1: torch.Tensor, gamma, beta, eps: float, silu: bool, x2: Optiona
     check(lib().asd_groupnorm_f16(ptr(x1), i32(c1), _p(x2), i32(c2), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps),
                                   i32(int(silu)), ptr(y), ptr(stats), stream()))
     return (y, stats[:B * 64]) if return_stats else y
+
+
+def groupnorm_apply(x: torch.Tensor, gamma, beta, eps: float, silu: bool, records: torch.Tensor):
+    """GroupNorm of x [B, HW, C] whose producer left its statistics as records [B, n, 64] (gemm(..., gn_rows=HW))"""
+    B, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c)
+    y = torch.empty_like(x)
+    stats = torch.empty(B * 64, device=x.device, dtype=torch.float32)
+    check(lib().asd_groupnorm_apply_f16(ptr(x), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)), ptr(records),
+                                        i32(records.shape[1]), ptr(y), ptr(stats), stream()))
+    return y, stats
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor,

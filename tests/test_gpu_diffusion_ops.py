@@ -244,3 +244,40 @@ def test_gemm_with_fused_geglu_epilogue(M, C_, K):
     wp, bp = H.pack_geglu_weight(w, b)
     _close(H.gemm(a, wp, bias=bp, act=2), ref)
     _close(H.geglu(H.gemm(a, w, bias=b)), ref)
+
+
+@pytest.mark.parametrize("B,hw,cin,cout,tile", [(2, 64, 128, 128, 11), (2, 64, 128, 128, 14), (1, 64, 64, 320, 10), (1, 64, 64, 320, 13), (1, 32, 128, 256, 8),
+                                                 (1, 32, 128, 256, 9), (3, 16, 64, 640, 2), (3, 16, 64, 640, 0), (2, 32, 96, 320, 12), (2, 32, 64, 320, 4),
+                                                 (1, 64, 128, 256, 5), (5, 8, 64, 320, 12)])
+def test_groupnorm_statistics_from_the_producers_epilogue(B, hw, cin, cout, tile):
+    """asd_gemm_args.gn_partials: the conv / GEMM that stores a tensor also leaves its per-group sums; GroupNorm from those records ==
+    GroupNorm with its own statistics pass (same kernel afterwards; the sums are accumulated in another order)"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(B, hw, hw, cin, seed=1)
+    w = H.pack_conv3x3_weight(_rand(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=2))
+    bias, res = _rand(cout, seed=3), _rand(B * hw * hw, cout, seed=4)
+    gamma, beta = (_rand(cout, seed=5) * 0.1 + 1).half(), (_rand(cout, seed=6) * 0.1).half()
+    y, rec, nrec = H.conv3x3(x, w, bias=bias, residual=res, tile_cfg=tile + 1, split_k=1, gn_rows=hw * hw)
+    bm = H.TILE_BM[tile]
+    if tile in H.WINDOW_TILES or (hw * hw) % bm == 0:
+        assert nrec > 0, "this plan can produce the records"
+    if nrec == 0:
+        pytest.skip("tile rows do not divide the rows of a batch element")
+    assert torch.equal(y, H.conv3x3(x, w, bias=bias, residual=res, tile_cfg=tile + 1, split_k=1).view_as(y))   # the stored tensor is unchanged
+    yv = y.view(B, hw * hw, cout)
+    want, wstats = H.groupnorm(yv, gamma, beta, 1e-5, True, return_stats=True)
+    got, gstats = H.groupnorm_apply(yv, gamma, beta, 1e-5, True, rec)
+    ref = yv.float()
+    sums = torch.stack([ref.view(B, -1, 32, cout // 32).sum(dim=(1, 3)), (ref ** 2).view(B, -1, 32, cout // 32).sum(dim=(1, 3))], -1).reshape(B * 64)
+    torch.testing.assert_close(gstats, sums, rtol=2e-4, atol=1e-2)
+    torch.testing.assert_close(gstats, wstats, rtol=2e-4, atol=1e-2)
+    assert float((got.float() - want.float()).abs().max()) <= 2e-3
+    # a plain GEMM producer (transformer proj_out) and a split-K launch (no records: the consumer falls back)
+    a, wl = _rand(B * hw * hw, 64, seed=7), _rand(cout, 64, scale=0.125, seed=8)
+    yl, rl, nl = H.gemm(a, wl, bias=bias, gn_rows=hw * hw)
+    if nl:
+        g2, _ = H.groupnorm_apply(yl.view(B, hw * hw, cout), gamma, beta, 1e-6, False, rl)
+        assert float((g2.float() - H.groupnorm(yl.view(B, hw * hw, cout), gamma, beta, 1e-6, False).float()).abs().max()) <= 2e-3
+    _, r2, n2 = H.conv3x3(x, w, bias=bias, tile_cfg=1, split_k=2, gn_rows=hw * hw)
+    assert n2 == 0 and r2 is None
