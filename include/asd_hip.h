@@ -299,7 +299,8 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
                       float* stats /* ASD_GN_STATS_FLOATS(batch): [batch*32*2] sums for the backward pass + per-block partials */,
                       void* stream);
 /* the same GroupNorm when the tensor's producer already left its statistics as `records` 64-float records per batch element
- * (asd_gemm_args.gn_partials): no statistics pass over x.  stats: [batch*64] floats, receives the per-(batch, group) sums. */
+ * (asd_gemm_args.gn_partials): no statistics pass over x.  stats: ASD_GN_STATS_FLOATS(batch) floats; its first batch*64 receive the
+ * per-(batch, group) sums (kept for a backward pass). */
 int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta, float eps,
                             int32_t silu, const float* partials, int32_t records, void* y, float* stats, void* stream);
 /* Input gradient of GroupNorm(+SiLU) with frozen gamma/beta (VAE encoder backward, the reference keeps the

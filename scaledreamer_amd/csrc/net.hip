@@ -11,6 +11,7 @@
 // device pointers to that table and owns the workspace; a forward is a single chain of kernel launches with no host
 // synchronisation, so it can be captured into a HIP graph by any host.  No kernels live here: the schedules call the leaf
 // entry points of gemm.hip / nn_ops.hip / attention.hip.
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -100,7 +101,8 @@ void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
     }
     const size_t need = (size_t)asd_gemm_workspace_bytes(&g);
     if (need > r.scratch_need) r.scratch_need = need;
-    if (gn_out && g.gn_rows > 0 && g.N % 32 == 0) {     // statistics records of the output, produced in the epilogue when the plan allows
+    static const bool gn_epilogue = !(getenv("ASD_GN_EPILOGUE") && getenv("ASD_GN_EPILOGUE")[0] == '0');    // A/B switch (tools)
+    if (gn_epilogue && gn_out && g.gn_rows > 0 && g.N % 32 == 0) {     // statistics records of the output, produced in the epilogue when the plan allows
         g.gn_cg = g.N / 32;
         const int batch = g.M / g.gn_rows;
         int nrec;

@@ -502,12 +502,18 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
     }
 }
 
-// records[b][n][64] -> out[b][64]: the per-tile statistics records of a producer's epilogue summed per batch element
+// records[b][n][64] -> out[b][gridDim.y][64]: the per-tile statistics records of a producer's epilogue, summed in gridDim.y slices per
+// batch element (the apply kernel's prologue adds the slices)
 __global__ __launch_bounds__(256) void gn_reduce_records_kernel(const float* __restrict__ records, int n, float* __restrict__ out) {
-    __shared__ float st[64];
     __shared__ float scratch[4][64];
-    gn_reduce_partials(records, blockIdx.x, n, st, scratch);
-    if (threadIdx.x < 64) out[blockIdx.x * 64 + threadIdx.x] = st[threadIdx.x];
+    const int b = blockIdx.x, S = gridDim.y, per = (n + S - 1) / S;
+    const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
+    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int c = c0 + q; c < c1; c += 4) acc += records[((size_t)b * n + c) * 64 + v];
+    scratch[q][v] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) out[((size_t)b * S + blockIdx.y) * 64 + v] = (scratch[0][v] + scratch[1][v]) + (scratch[2][v] + scratch[3][v]);
 }
 
 extern "C" {
@@ -537,7 +543,7 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
 }
 
 int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta, float eps,
-                            int32_t silu, const float* partials, int32_t records, void* y, float* stats, void* stream) {
+                            int32_t silu, const float* partials, int32_t records, void* y, float* stats /* ASD_GN_STATS_FLOATS(batch) */, void* stream) {
     ASD_CHECK_ARG(x && gamma && beta && y && stats && partials && batch > 0 && hw > 0 && records > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0 && c % 8 == 0, "channels must be a multiple of 32");
     hipStream_t s = (hipStream_t)stream;
@@ -546,10 +552,13 @@ int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw,
     // every apply block sums the records of its batch element in its prologue: with many tiles, sum them once first
     const float* part = partials;
     int n = records;
-    if ((long long)records * chunks_a > 2048) {
-        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch), dim3(256), 0, s, partials, records, stats);
-        part = stats;
-        n = 1;
+    if ((long long)records * chunks_a > 2048) {       // slices of <= 32 records, at most 16 of them left for the apply prologue
+        int slices = asd_div_up(records, 32);
+        if (slices > 16) slices = 16;
+        float* tmp = stats + 64 * batch;              // the per-block partials area of ASD_GN_STATS_FLOATS(batch)
+        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(256), 0, s, partials, records, tmp);
+        part = tmp;
+        n = slices;
     }
     hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, c, (const half_t*)nullptr, 0, hw,
                        asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, part, n, stats, (half_t*)y);

@@ -214,10 +214,10 @@ def groupnorm_apply(x: torch.Tensor, gamma, beta, eps: float, silu: bool, record
     B, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c)
     y = torch.empty_like(x)
-    stats = torch.empty(B * 64, device=x.device, dtype=torch.float32)
+    stats = torch.empty(B * 64 + (512 + B) * 64, device=x.device, dtype=torch.float32)   # ASD_GN_STATS_FLOATS(B)
     check(lib().asd_groupnorm_apply_f16(ptr(x), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)), ptr(records),
                                         i32(records.shape[1]), ptr(y), ptr(stats), stream()))
-    return y, stats
+    return y, stats[:B * 64]
 
 
 def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor,

@@ -42,3 +42,54 @@ def test_allreduce_mean_grads_runs_on_rccl_single_rank(monkeypatch):
             dist.barrier()
         finally:
             dist.destroy_process_group()
+
+
+def test_hooked_gradient_exchange_runs_inside_a_real_training_step_on_rccl(monkeypatch):
+    """the product wiring of the N > 1 path — GradientExchange.prepare -> backward whose post-accumulate hooks launch async RCCL
+    all-reduces (ReduceOp.AVG) from the autograd thread -> finish -> fused AdamW on gradients that are views of the flat bucket —
+    inside a real tiny ASD step (smoke configuration), against the same step without the exchange: identical parameters."""
+    import torch.distributed as dist
+
+    from scaledreamer_amd import dist as asd_dist
+    from scaledreamer_amd.smoke import build_smoke_system
+
+    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def run(n_steps, exchange):
+        import random
+
+        system, batches = build_smoke_system(seed=7, n_batches=n_steps)
+        losses = []
+        for b in batches:
+            torch.manual_seed(100 + len(losses))             # same noise / t / jitter / background draws in both runs
+            random.seed(100 + len(losses))
+            losses.append(float(system.train_one_step(b)))
+        ex = system.gradient_exchange()
+        assert (ex is not None) == exchange
+        if exchange:
+            assert ex.prepare_called == n_steps and ex._order_learned and sorted(ex.order) == list(range(len(ex.units)))
+            assert ex.exposed_ms() >= 0.0
+            assert any(u["flat"] is None for u in ex.units) and any(u["flat"] is not None for u in ex.units)
+        return losses, [p.grad.detach().clone() for p in system.parameters() if p.grad is not None]
+
+    run(1, exchange=False)                                         # first contact: tunes the GEMM plans of this configuration's shapes
+    ref_losses, ref_grads = run(1, exchange=False)
+    _, ref_grads2 = run(1, exchange=False)                          # run-to-run spread of the step itself (fp32 atomics order upstream of a
+                                                                    # random-weight UNet: ~1 % of the largest hash-table gradient entry)
+    with tempfile.TemporaryDirectory() as d:
+        dist.init_process_group(backend="nccl", init_method=f"file://{d}/rdv", rank=0, world_size=1)
+        try:
+            monkeypatch.setattr(asd_dist, "is_distributed", lambda: True)
+            losses, grads = run(1, exchange=True)
+            run(3, exchange=True)                                 # and it keeps running (order learned in step 1, reused afterwards)
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+    assert losses == pytest.approx(ref_losses, rel=1e-4)
+    assert len(grads) == len(ref_grads)
+    for a, b, b2 in zip(grads, ref_grads, ref_grads2):
+        # mean over one rank == the local gradient of the first step, up to the step's own run-to-run spread.  Later steps are not
+        # compared: AdamW with betas (0, 0.99) turns the sign of a noise-level gradient entry into a +-lr step
+        spread = float((b - b2).abs().max())
+        assert float((a - b).abs().max()) <= 3.0 * spread + 1e-6 * float(b.abs().max()) + 1e-12
