@@ -12,3 +12,11 @@ for (B, hw, cin, cout) in [(1, 512, 128, 128), (5, 64, 320, 320)]:
         H.conv3x3(x, w)
     torch.cuda.synchronize()
     print("plan", (B, hw, cin, cout), H.plan_table().get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1))))
+
+# the plain GEMM bench.py reports as `roofline` (rocprof's top kernel: gemm_f16_kernel<64,64>) on its most frequent shape
+M, N, K = 20480, 320, 320
+a, w = torch.randn(M, K, device="cuda").half(), torch.randn(N, K, device="cuda").half()
+for _ in range(20):
+    H.gemm(a, w)
+torch.cuda.synchronize()
+print("plan gemm", (M, N, K), H.plan_table().get((M, N, K, K)))
