@@ -121,15 +121,19 @@ __global__ __launch_bounds__(256) void voxel_sample_fwd_kernel(const float* __re
 #ifndef SCATTER_RUN
 #define SCATTER_RUN 8
 #endif
-template <int LPP>
+// Request-coalesced scatter (tools/atomic_probe2.hip: the atomic units retire ~21 G REQUESTS/s, and the lanes of one instruction that
+// fall into the same 64-byte block are one request): LPP lanes share a point and lane `sub` owns the channels sub, sub + LPP,
+// sub + 2 LPP ...  — so one atomic instruction of the group covers LPP CONSECUTIVE floats of a corner's channel-last feature row
+// (64 B = one request at LPP = 16) instead of every fourth one.
+template <int LPP, int CPL>
 __global__ __launch_bounds__(256) void voxel_sample_bwd_kernel(const float* __restrict__ d_out, int B, int D, int H, int W,
                                                                const float* __restrict__ points, int M, float* __restrict__ d_voxel) {
-    constexpr int C = LPP * 4;
+    constexpr int C = LPP * CPL;
     const long long total = (long long)B * M;
     const long long chunks = (total + SCATTER_RUN - 1) / SCATTER_RUN;
     const int sub = threadIdx.x % LPP;
     for (long long ch = ((long long)blockIdx.x * 256 + threadIdx.x) / LPP; ch < chunks; ch += (long long)gridDim.x * 256 / LPP) {
-        float4 acc[8];
+        float acc[8][CPL];
         long long cur = -1;      // linear index of the current cell's (x0, y0, z0) corner (may be "outside": handled per corner)
         int cb = 0, cx = 0, cy = 0, cz = 0;
         auto flush = [&]() {
@@ -138,9 +142,9 @@ __global__ __launch_bounds__(256) void voxel_sample_bwd_kernel(const float* __re
             for (int corner = 0; corner < 8; ++corner) {
                 const int x = cx + (corner & 1), y = cy + ((corner >> 1) & 1), z = cz + (corner >> 2);
                 if (x < 0 || x >= W || y < 0 || y >= H || z < 0 || z >= D) continue;
-                float* dst = d_voxel + ((((size_t)cb * D + z) * H + y) * W + x) * C + sub * 4;
-                atomicAdd(dst, acc[corner].x); atomicAdd(dst + 1, acc[corner].y);
-                atomicAdd(dst + 2, acc[corner].z); atomicAdd(dst + 3, acc[corner].w);
+                float* dst = d_voxel + ((((size_t)cb * D + z) * H + y) * W + x) * C + sub;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) atomicAdd(dst + k * LPP, acc[corner][k]);
             }
         };
         const long long q_end = min(total, (ch + 1) * SCATTER_RUN);
@@ -154,15 +158,19 @@ __global__ __launch_bounds__(256) void voxel_sample_bwd_kernel(const float* __re
                 flush();
                 cur = key; cb = b; cx = x0; cy = y0; cz = z0;
 #pragma unroll
-                for (int corner = 0; corner < 8; ++corner) acc[corner] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) acc[corner][k] = 0.f;
             }
-            const float4 g = *reinterpret_cast<const float4*>(d_out + (size_t)q * C + sub * 4);
+            float g[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) g[k] = d_out[(size_t)q * C + sub + k * LPP];
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
                 const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                acc[corner].x = fmaf(w, g.x, acc[corner].x); acc[corner].y = fmaf(w, g.y, acc[corner].y);
-                acc[corner].z = fmaf(w, g.z, acc[corner].z); acc[corner].w = fmaf(w, g.w, acc[corner].w);
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[corner][k] = fmaf(w, g[k], acc[corner][k]);
             }
         }
         flush();
@@ -211,18 +219,18 @@ __global__ __launch_bounds__(256) void triplane_sample_kernel(const float* __res
 }
 
 // tri-plane scatter backward with the same run accumulation: a lane group owns one plane of SCATTER_RUN consecutive points
-template <int LPP>
+template <int LPP, int CPL>
 __global__ __launch_bounds__(256) void triplane_sample_bwd_kernel(const float* __restrict__ d_out, int B, int H, int W,
                                                                   const float* __restrict__ points, int M, float coord_scale,
                                                                   float* __restrict__ d_planes) {
-    constexpr int C = LPP * 4;
+    constexpr int C = LPP * CPL;     // lane `sub` of a group owns channels sub + k * LPP (request-coalesced scatter, see voxel_sample_bwd_kernel)
     const long long total = (long long)B * M;
     const long long chunks = (total + SCATTER_RUN - 1) / SCATTER_RUN;
     const int sub = threadIdx.x % LPP;
     for (long long t = ((long long)blockIdx.x * 256 + threadIdx.x) / LPP; t < chunks * 3; t += (long long)gridDim.x * 256 / LPP) {
         const long long ch = t / 3;
         const int pl = (int)(t - ch * 3);
-        float4 acc[4];
+        float acc[4][CPL];
         long long cur = -1;
         int cb = 0, cx = 0, cy = 0;
         auto flush = [&]() {
@@ -231,9 +239,9 @@ __global__ __launch_bounds__(256) void triplane_sample_bwd_kernel(const float* _
             for (int corner = 0; corner < 4; ++corner) {
                 const int x = cx + (corner & 1), y = cy + (corner >> 1);
                 if (x < 0 || x >= W || y < 0 || y >= H) continue;
-                float* dst = d_planes + ((((size_t)cb * 3 + pl) * H + y) * W + x) * C + sub * 4;
-                atomicAdd(dst, acc[corner].x); atomicAdd(dst + 1, acc[corner].y);
-                atomicAdd(dst + 2, acc[corner].z); atomicAdd(dst + 3, acc[corner].w);
+                float* dst = d_planes + ((((size_t)cb * 3 + pl) * H + y) * W + x) * C + sub;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) atomicAdd(dst + k * LPP, acc[corner][k]);
             }
         };
         const long long q_end = min(total, (ch + 1) * SCATTER_RUN);
@@ -248,14 +256,18 @@ __global__ __launch_bounds__(256) void triplane_sample_bwd_kernel(const float* _
                 flush();
                 cur = key; cb = b; cx = x0; cy = y0;
 #pragma unroll
-                for (int corner = 0; corner < 4; ++corner) acc[corner] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int corner = 0; corner < 4; ++corner)
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) acc[corner][k] = 0.f;
             }
-            const float4 g = *reinterpret_cast<const float4*>(d_out + ((size_t)q * 3 + pl) * C + sub * 4);
+            float g[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) g[k] = d_out[((size_t)q * 3 + pl) * C + sub + k * LPP];
 #pragma unroll
             for (int corner = 0; corner < 4; ++corner) {
                 const float w = ((corner & 1) ? fx : 1.f - fx) * ((corner >> 1) ? fy : 1.f - fy);
-                acc[corner].x = fmaf(w, g.x, acc[corner].x); acc[corner].y = fmaf(w, g.y, acc[corner].y);
-                acc[corner].z = fmaf(w, g.z, acc[corner].z); acc[corner].w = fmaf(w, g.w, acc[corner].w);
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[corner][k] = fmaf(w, g[k], acc[corner][k]);
             }
         }
         flush();
@@ -323,6 +335,17 @@ int asd_merge_sorted(const float* a, int32_t na, const float* b, int32_t nb, int
         default: asd_set_error("feature channels must be 4, 8, 16, 32 or 64 (got %d)", C_); return ASD_ERR_UNSUPPORTED; \
     }
 
+// scatter kernels: up to 16 lanes per point, lane `sub` owning channels sub + k * LPP
+#define ASD_SCATTER_DISPATCH(C_, CALL)                                   \
+    switch (C_) {                                                        \
+        case 4: { constexpr int LPP = 4, CPL = 1; CALL; } break;         \
+        case 8: { constexpr int LPP = 8, CPL = 1; CALL; } break;         \
+        case 16: { constexpr int LPP = 16, CPL = 1; CALL; } break;       \
+        case 32: { constexpr int LPP = 16, CPL = 2; CALL; } break;       \
+        case 64: { constexpr int LPP = 16, CPL = 4; CALL; } break;       \
+        default: asd_set_error("feature channels must be 4, 8, 16, 32 or 64 (got %d)", C_); return ASD_ERR_UNSUPPORTED; \
+    }
+
 int asd_voxel_sample_fwd(const float* voxel_cl, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, const float* points,
                          int32_t M, float* out, void* stream) {
     if ((int64_t)B * M == 0) return ASD_OK;
@@ -339,7 +362,7 @@ int asd_voxel_sample_bwd(const float* d_out, int32_t B, int32_t D, int32_t H, in
     if ((int64_t)B * M == 0) return ASD_OK;
     ASD_CHECK_ARG(d_out && points && d_voxel_cl && B > 0 && D > 0 && H > 0 && W > 0 && M > 0, "bad argument");
     hipStream_t s = (hipStream_t)stream;
-    ASD_LPP_DISPATCH(C, hipLaunchKernelGGL((voxel_sample_bwd_kernel<LPP>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, SCATTER_RUN) * LPP, 256)),
+    ASD_SCATTER_DISPATCH(C, hipLaunchKernelGGL((voxel_sample_bwd_kernel<LPP, CPL>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, SCATTER_RUN) * LPP, 256)),
                                            dim3(256), 0, s, d_out, B, D, H, W, points, M, d_voxel_cl));
     ASD_LAUNCH_CHECK();
     return ASD_OK;
@@ -361,7 +384,7 @@ int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W,
     if ((int64_t)B * M == 0) return ASD_OK;
     ASD_CHECK_ARG(d_out && points && d_planes_cl && B > 0 && H > 0 && W > 0 && M > 0, "bad argument");
     hipStream_t s = (hipStream_t)stream;
-    ASD_LPP_DISPATCH(C, hipLaunchKernelGGL((triplane_sample_bwd_kernel<LPP>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, SCATTER_RUN) * 3 * LPP, 256)),
+    ASD_SCATTER_DISPATCH(C, hipLaunchKernelGGL((triplane_sample_bwd_kernel<LPP, CPL>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, SCATTER_RUN) * 3 * LPP, 256)),
                                            dim3(256), 0, s, d_out, B, H, W, points, M, coord_scale, d_planes_cl));
     ASD_LAUNCH_CHECK();
     return ASD_OK;
