@@ -282,6 +282,14 @@ typedef struct asd_gemm_args {
                                is ignored and the consumer runs its own statistics pass) */
     int32_t gn_cg;          /* channels per group (N / 32) */
     int32_t gn_rows;        /* rows of C per batch element (H*W): a tile must not straddle two of them */
+    /* backward form: C is the gradient dy reaching a GroupNorm(+SiLU) whose input x (fp16 [M,N]) and forward sums are given; the
+     * records then hold {sum g, sum g*xhat} per group, g = dy * silu'(z) * gamma — the two reductions of the GroupNorm input
+     * gradient (asd_groupnorm_bwd_f16's first pass), so the consumer skips its pass over (x, dy) */
+    const void* gn_bwd_x;   /* NULL: forward statistics */
+    const float* gn_bwd_fstats;            /* [batch*64] forward {sum, sumsq} per group */
+    const void* gn_bwd_gamma; const void* gn_bwd_beta;
+    float   gn_eps;
+    int32_t gn_silu;
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
 int32_t asd_gemm_gn_records(const asd_gemm_args* args);
@@ -310,6 +318,11 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
                           const void* dx_add /* optional [batch, hw, c] fp16 added to the result: the gradient reaching x through
                                                 its other consumer (the ResnetBlock shortcut, model.py:141-148) */,
                           void* dx, float* bwd_stats /* workspace: ASD_GN_STATS_FLOATS(batch) - 64*batch floats */, void* stream);
+/* the same input gradient when the producer of dy already left the two reductions as `records` 64-float records per batch element
+ * (asd_gemm_args.gn_partials with gn_bwd_x set) */
+int asd_groupnorm_bwd_apply_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta,
+                                float eps, int32_t silu, const float* fwd_stats, const float* partials, int32_t records,
+                                const void* dx_add, void* dx, float* scratch /* (16 * batch) * 64 floats */, void* stream);
 /* y[cols, rows] = x[rows, cols]^T, fp16 (operand layout changes for the attention-backward GEMMs). */
 int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream);
 /* LayerNorm over the last dim (attention.py:265-267), fp16 in/out, fp32 statistics. */

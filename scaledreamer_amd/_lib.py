@@ -78,6 +78,8 @@ class GemmArgs(C.Structure):
         ("zero_page", C.c_void_p), ("split_k", C.c_int32), ("workspace", C.c_void_p),
         ("tile_cfg", C.c_int32), ("ld_row_bias", C.c_int32), ("group_m", C.c_int32), ("group_n", C.c_int32),
         ("gn_partials", C.c_void_p), ("gn_cg", C.c_int32), ("gn_rows", C.c_int32),
+        ("gn_bwd_x", C.c_void_p), ("gn_bwd_fstats", C.c_void_p), ("gn_bwd_gamma", C.c_void_p), ("gn_bwd_beta", C.c_void_p),
+        ("gn_eps", C.c_float), ("gn_silu", C.c_int32),
     ]
 
 
@@ -115,7 +117,7 @@ SYMBOLS = [
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
     "asd_gemm_f16", "asd_gemm_force_tile", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
-    "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune", "asd_gemm_gn_records", "asd_groupnorm_apply_f16",
+    "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune", "asd_gemm_gn_records", "asd_groupnorm_apply_f16", "asd_groupnorm_bwd_apply_f16",
     "asd_pad_cast_f16",
     "asd_image_prep_fwd", "asd_image_prep_bwd", "asd_latents_fwd", "asd_score_fwd", "asd_latents_bwd",
     "asd_unet_create", "asd_unet_destroy", "asd_unet_num_weights", "asd_unet_weight_info", "asd_unet_bind_weights",

@@ -85,6 +85,44 @@ __device__ __forceinline__ void gn_tile_begin(float* lds64) {
     if (threadIdx.x < 64) lds64[threadIdx.x] = 0.f;
     __syncthreads();
 }
+// adds the statistics terms of the 4 stored values o (row m, channels n..n+3) to the lane's column sums: forward {v, v^2}, or — when
+// p.gn_bwd_x is set — the GroupNorm input-gradient reductions {g, g * xhat} with g = dy * silu'(z) * gamma (o is dy)
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float sg = 1.f / (1.f + __expf(-z));
+    return sg * (1.f + z * (1.f - sg));
+}
+struct GnCol {                 // per-column constants of the backward form, formed once per column fragment (the tile lies in ONE batch element)
+    float mean[4], rstd[4], gm[4], bt[4];
+};
+__device__ __forceinline__ void gn_col_load(const asd_gemm_args& p, int m_any, int n, GnCol& c) {
+    if (!p.gn_bwd_x || n >= p.N) return;
+    const int b = m_any / p.gn_rows;
+    const float inv_cnt = 1.f / ((float)p.gn_rows * (float)p.gn_cg);
+    const half4 gm = *(const half4*)((const half_t*)p.gn_bwd_gamma + n), bt = *(const half4*)((const half_t*)p.gn_bwd_beta + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int g = (n + r) / p.gn_cg;
+        c.mean[r] = p.gn_bwd_fstats[(b * 32 + g) * 2] * inv_cnt;
+        c.rstd[r] = rsqrtf(fmaxf(p.gn_bwd_fstats[(b * 32 + g) * 2 + 1] * inv_cnt - c.mean[r] * c.mean[r], 0.f) + p.gn_eps);
+        c.gm[r] = (float)gm[r]; c.bt[r] = (float)bt[r];
+    }
+}
+__device__ __forceinline__ void gn_tile_accum(const asd_gemm_args& p, const GnCol& c, const floatx4& o, int m, int n, floatx4& cs, floatx4& cq) {
+    if (!p.gn_bwd_x) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[r] += o[r]; cq[r] = fmaf(o[r], o[r], cq[r]); }
+        return;
+    }
+    const half4 xv = *(const half4*)((const half_t*)p.gn_bwd_x + (size_t)m * p.N + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float xh = ((float)xv[r] - c.mean[r]) * c.rstd[r];
+        float gg = o[r] * c.gm[r];
+        if (p.gn_silu) gg *= silu_grad_f(fmaf(xh, c.gm[r], c.bt[r]));
+        cs[r] += gg;
+        cq[r] = fmaf(gg, xh, cq[r]);
+    }
+}
 // s, q: this lane's column sums for channels n..n+3 (over its rows); lanes of one 16-lane row hold the same channels
 __device__ __forceinline__ void gn_tile_flush(float* lds64, floatx4 s, floatx4 q, int n, int N, int cg) {
 #pragma unroll
@@ -363,6 +401,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 16 + en;
         floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+        GnCol gc;
+        if (gn) gn_col_load(p, m0, n, gc);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + em;
@@ -390,10 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             } else {
                 half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
-                if (gn) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs[r] += f; cq[r] = fmaf(f, f, cq[r]); }
-                }
+                if (gn) gn_tile_accum(p, gc, floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]}, m, n, cs, cq);
             }
         }
         if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
@@ -606,6 +643,8 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 16 + en;
         floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+        GnCol gc;
+        if (gn) gn_col_load(p, b * p.Hout * p.Wout, n, gc);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
@@ -613,8 +652,7 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
             if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
             else {
                 const floatx4 o = gemm_store4(p, acc[i][j], m, n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[r] += o[r]; cq[r] = fmaf(o[r], o[r], cq[r]); }
+                if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
             }
         }
         if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
@@ -742,6 +780,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 16 + en;
         floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+        GnCol gc;
+        if (gn) gn_col_load(p, b * p.Hout * p.Wout, n, gc);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
@@ -749,8 +789,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
             if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
             else {
                 const floatx4 o = gemm_store4(p, acc[i][j], m, n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[r] += o[r]; cq[r] = fmaf(o[r], o[r], cq[r]); }
+                if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
             }
         }
         if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
@@ -896,6 +935,7 @@ static int asd_gemm_resolve_cfg(const asd_gemm_args* a) {
 
 // GroupNorm statistics in the epilogue: records per batch element, 0 when this launch cannot produce them
 static int asd_gemm_gn_records_cfg(const asd_gemm_args* a, int cfg, bool need_ptr) {
+    if (a->gn_bwd_x && !(a->gn_bwd_fstats && a->gn_bwd_gamma && a->gn_bwd_beta && a->ldc == a->N)) return 0;
     if ((need_ptr && !a->gn_partials) || a->split_k != 1 || a->out_f32 || a->act == 2 || a->gn_cg < 1 || a->gn_rows < 1 || a->N != 32 * a->gn_cg || a->M % a->gn_rows) return 0;
     const int bn = asd_gemm_tiles[cfg].bn, tiles_n = asd_div_up(a->N, bn);
     if (asd_cfg_is_window(cfg)) return (a->gn_rows / 256) * tiles_n;          // 16 x 16 patches never leave their image

@@ -87,7 +87,15 @@ struct GemmOpt {
     const void* residual = nullptr; int ldr = 0; int act = 0; int out_f32 = 0;
     int gn_rows = 0;        // > 0: the output feeds a GroupNorm over all N channels with this many rows per batch element
     Act* out = nullptr;     // receives the records' location when gn_rows > 0
+    // backward form (the output is the gradient dy reaching a GroupNorm with input gn_x): records of {sum g, sum g * xhat}
+    const half_t* gn_x = nullptr; const float* gn_fstats = nullptr; const half_t* gn_gamma = nullptr; const half_t* gn_beta = nullptr;
+    int gn_silu = 0;
 };
+
+void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
+    g.gn_bwd_x = o.gn_x; g.gn_bwd_fstats = o.gn_fstats; g.gn_bwd_gamma = o.gn_gamma; g.gn_bwd_beta = o.gn_beta;
+    g.gn_eps = 1e-6f; g.gn_silu = o.gn_silu;
+}
 
 void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
     g.zero_page = r.zero_page;
@@ -107,7 +115,11 @@ void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
         const int batch = g.M / g.gn_rows;
         int nrec;
         if (r.rec_replay) nrec = r.rec_pos < r.rec_replay->size() ? (*r.rec_replay)[r.rec_pos++] : 0;
-        else nrec = asd_gemm_gn_records(&g);
+        else {
+            asd_gemm_args q = g;             // the answer depends on shape and plan only (dry passes carry null pointers)
+            q.gn_bwd_x = nullptr;
+            nrec = asd_gemm_gn_records(&q);
+        }
         // while tuning, the plan (and with it the record count) of this shape may still change between the sizing pass and the
         // launch: reserve the upper bound (64 x 64 tiles)
         const int reserve = r.tune ? (g.gn_rows / 64 + 1) * (g.N / 64 + 1) : nrec;
@@ -129,6 +141,7 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     g.bias = o.bias; g.row_bias = o.row_bias; g.rows_per_group = o.row_bias ? o.rows_per_group : 1; g.ld_row_bias = o.ld_row_bias;
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
     g.gn_rows = o.gn_rows;
+    if (o.gn_x) set_gn_bwd(g, o);
     if (o.out) *o.out = Act{(const half_t*)C, nullptr, 0};
     launch_gemm(r, g, o.out);
 }
@@ -142,6 +155,7 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
     g.conv = 1; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.pad = pad; g.upsample = upsample;
     g.gn_rows = o.gn_rows;
+    if (o.gn_x) set_gn_bwd(g, o);
     if (o.out) *o.out = Act{(const half_t*)y, nullptr, 0};
     launch_gemm(r, g, o.out);
 }
@@ -627,10 +641,20 @@ void vae_forward(Vae& n, Run& r, const half_t* x32, int B, int Hh, int Ww, float
 }
 
 half_t* gn_bwd(Run& r, const half_t* x, const half_t* dy, int c, int B, int hw, const half_t* g, const half_t* b, int silu, const float* st,
-               const half_t* dx_add, half_t* dx) {
+               const half_t* dx_add, half_t* dx, const Act* src = nullptr) {
     float* bst = r.mem.floats(ASD_GN_STATS_FLOATS(B) - 64 * B);
+    if (src && src->nrec > 0) {          // the conv / GEMM that produced dy left the two reductions behind: no pass over (x, dy) for them
+        LEAF(asd_groupnorm_bwd_apply_f16(x, dy, c, B, hw, g, b, 1e-6f, silu, st, src->rec, src->nrec, dx_add, dx, bst, r.stream));
+    } else
     LEAF(asd_groupnorm_bwd_f16(x, dy, c, B, hw, g, b, 1e-6f, silu, st, dx_add, dx, bst, r.stream));
     return dx;
+}
+
+// options of a launch whose output is the gradient reaching GroupNorm(x) [+ SiLU]
+GemmOpt feeds_gn_bwd(Act* out, int hw, const half_t* x, const float* fstats, const half_t* gamma, const half_t* beta, int silu) {
+    GemmOpt o;
+    o.gn_rows = hw; o.out = out; o.gn_x = x; o.gn_fstats = fstats; o.gn_gamma = gamma; o.gn_beta = beta; o.gn_silu = silu;
+    return o;
 }
 
 void vae_backward(Vae& n, Run& r, const std::vector<VSaved>& saved, const float* d_moments, int B, half_t* dx32) {
@@ -655,8 +679,10 @@ void vae_backward(Vae& n, Run& r, const std::vector<VSaved>& saved, const float*
             half_t* dm = other(1);
             LEAF(asd_pad_cast_f16(d_moments, M, l.cout, dm, cp, r.stream));
             half_t* dt = other(2);
-            conv3x3(r, dm, B, hh, ww, cp, n.w(l.name + ".conv_out_quant.bwd"), l.cin, dt, hh, ww, 1, 1, 0);
-            gn_bwd(r, sv.x, dt, l.cin, B, hw, n.w(l.name + ".norm_out.weight"), n.w(l.name + ".norm_out.bias"), 1, sv.st1, nullptr, buf[cur]);
+            Act at;
+            conv3x3(r, dm, B, hh, ww, cp, n.w(l.name + ".conv_out_quant.bwd"), l.cin, dt, hh, ww, 1, 1, 0,
+                    feeds_gn_bwd(&at, hw, sv.x, sv.st1, n.w(l.name + ".norm_out.weight"), n.w(l.name + ".norm_out.bias"), 1));
+            gn_bwd(r, sv.x, dt, l.cin, B, hw, n.w(l.name + ".norm_out.weight"), n.w(l.name + ".norm_out.bias"), 1, sv.st1, nullptr, buf[cur], &at);
             dy = buf[cur];
         } else if (l.kind == 3) {
             const std::string& p = l.name;
@@ -684,9 +710,11 @@ void vae_backward(Vae& n, Run& r, const std::vector<VSaved>& saved, const float*
             gemm(r, dq, M, C, n.w(p + ".q.wt"), C, C, C, d1, C);
             half_t* d2 = other(3);
             { GemmOpt o; o.residual = d1; o.ldr = C; gemm(r, dk, M, C, n.w(p + ".k.wt"), C, C, C, d2, C, o); }
-            { GemmOpt o; o.residual = d2; o.ldr = C; gemm(r, dv, M, C, n.w(p + ".v.wt"), C, C, C, d1, C, o); }
+            Act a1;
+            { GemmOpt o = feeds_gn_bwd(&a1, hw, sv.x, sv.st1, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 0);
+              o.residual = d2; o.ldr = C; gemm(r, dv, M, C, n.w(p + ".v.wt"), C, C, C, d1, C, o); }
             half_t* dx = other(3);
-            gn_bwd(r, sv.x, d1, C, B, hw, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 0, sv.st1, dy, dx);   // + the residual path
+            gn_bwd(r, sv.x, d1, C, B, hw, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 0, sv.st1, dy, dx, &a1);   // + the residual path
             cur = (cur + 3) & 3;
             dy = buf[cur];
         } else if (l.kind == 2) {
@@ -697,21 +725,24 @@ void vae_backward(Vae& n, Run& r, const std::vector<VSaved>& saved, const float*
         } else if (l.kind == 1) {
             const std::string& p = l.name;
             half_t* d3 = other(1);
-            conv3x3(r, dy, B, hh, ww, l.cout, n.w(p + ".conv2.bwd"), l.cout, d3, hh, ww, 1, 1, 0);
+            Act a3, a1;
+            conv3x3(r, dy, B, hh, ww, l.cout, n.w(p + ".conv2.bwd"), l.cout, d3, hh, ww, 1, 1, 0,
+                    feeds_gn_bwd(&a3, hw, sv.t2, sv.st2, n.w(p + ".norm2.weight"), n.w(p + ".norm2.bias"), 1));
             half_t* d2 = other(2);
-            gn_bwd(r, sv.t2, d3, l.cout, B, hw, n.w(p + ".norm2.weight"), n.w(p + ".norm2.bias"), 1, sv.st2, nullptr, d2);
+            gn_bwd(r, sv.t2, d3, l.cout, B, hw, n.w(p + ".norm2.weight"), n.w(p + ".norm2.bias"), 1, sv.st2, nullptr, d2, &a3);
             half_t* d1 = other(1);
-            conv3x3(r, d2, B, hh, ww, l.cout, n.w(p + ".conv1.bwd"), l.cin, d1, hh, ww, 1, 1, 0);
+            conv3x3(r, d2, B, hh, ww, l.cout, n.w(p + ".conv1.bwd"), l.cin, d1, hh, ww, 1, 1, 0,
+                    feeds_gn_bwd(&a1, hw, sv.x, sv.st1, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1));
             if (n.has(p + ".nin.w")) {
                 half_t* dmain = other(2);
-                gn_bwd(r, sv.x, d1, l.cin, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1, sv.st1, nullptr, dmain);
+                gn_bwd(r, sv.x, d1, l.cin, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1, sv.st1, nullptr, dmain, &a1);
                 half_t* dx = other(3);
                 GemmOpt o; o.residual = dmain; o.ldr = l.cin;
                 gemm(r, dy, M, l.cout, n.w(p + ".nin.wt"), l.cin, l.cout, l.cout, dx, l.cin, o);
                 cur = (cur + 3) & 3;
             } else {
                 half_t* dx = other(2);
-                gn_bwd(r, sv.x, d1, l.cin, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1, sv.st1, dy, dx);   // + shortcut
+                gn_bwd(r, sv.x, d1, l.cin, B, hw, n.w(p + ".norm1.weight"), n.w(p + ".norm1.bias"), 1, sv.st1, dy, dx, &a1);   // + shortcut
                 cur = (cur + 2) & 3;
             }
             dy = buf[cur];

@@ -586,6 +586,30 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     return ASD_OK;
 }
 
+int asd_groupnorm_bwd_apply_f16(const void* x, const void* dy, int32_t c, int32_t batch, int32_t hw, const void* gamma, const void* beta,
+                                float eps, int32_t silu, const float* fwd_stats, const float* partials, int32_t records,
+                                const void* dx_add, void* dx, float* scratch, void* stream) {
+    ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && partials && dx && scratch && batch > 0 && hw > 0 && records > 0, "null argument");
+    ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = asd_div_up(hw, 16);
+    const int cap_a = asd_div_up(GN_CAP_A, batch), chunks_a = chunks > cap_a ? cap_a : chunks;
+    const float* part = partials;
+    int n = records;
+    if ((long long)records * chunks_a > 2048) {
+        int slices = asd_div_up(records, 32);
+        if (slices > 16) slices = 16;
+        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(256), 0, s, partials, records, scratch);
+        part = scratch;
+        n = slices;
+    }
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                       asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, part, n,
+                       (const half_t*)dx_add, (half_t*)dx);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
 int asd_transpose_f16(const void* x, int32_t rows, int32_t cols, int32_t ldx, void* y, int32_t ldy, void* stream) {
     ASD_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= rows, "bad argument");
     hipLaunchKernelGGL(transpose_f16_kernel, dim3(asd_div_up(cols, 64), asd_div_up(rows, 64)), dim3(256), 0, (hipStream_t)stream,
