@@ -932,6 +932,7 @@ int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, 
         r.rec_replay = &log;
         r.rec_pos = 0;
         vae_forward(*n, r, nullptr, batch, H, W, nullptr, saved, false);     // replays the forward's allocation sequence: same addresses
+        r.rec_replay = nullptr;                                              // the backward's own launches size their records from the plans
         vae_backward(*n, r, saved, d_moments_nhwc, batch, (half_t*)dx_nhwc32);
     }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch, true);
 }

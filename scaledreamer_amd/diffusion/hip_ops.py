@@ -112,10 +112,11 @@ if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none" and os.path.exists(L.LIB_P
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
-         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0):
+         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0, gn_bwd: Optional[dict] = None):
     """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv.
     gn_rows > 0: also ask the epilogue for the GroupNorm statistics records of C (rows per batch element = gn_rows); returns
-    (C, records | None, records_per_batch_element)."""
+    (C, records | None, records_per_batch_element).  gn_bwd = dict(x, fstats, gamma, beta, eps, silu): C is the gradient reaching
+    GroupNorm(x)[+SiLU] and the records carry that layer's two backward reductions instead (asd_gemm_args.gn_bwd_x)."""
     dev = a.device
     N, K = w.shape
     if conv is None:
@@ -160,6 +161,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     rec, nrec = None, 0
     if gn_rows > 0:
         g.gn_cg, g.gn_rows = N // 32, gn_rows
+        if gn_bwd is not None:
+            g.gn_bwd_x, g.gn_bwd_fstats = gn_bwd["x"].data_ptr(), gn_bwd["fstats"].data_ptr()
+            g.gn_bwd_gamma, g.gn_bwd_beta = gn_bwd["gamma"].data_ptr(), gn_bwd["beta"].data_ptr()
+            g.gn_eps, g.gn_silu = float(gn_bwd["eps"]), int(gn_bwd["silu"])
         nrec = lib().asd_gemm_gn_records(C.byref(g))
         if nrec > 0:
             rec = torch.empty((M // gn_rows, nrec, 64), device=dev, dtype=torch.float32)
@@ -231,6 +236,18 @@ def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, si
         assert dx_add.is_contiguous() and dx_add.numel() == x.numel() and dx_add.dtype == x.dtype
     check(lib().asd_groupnorm_bwd_f16(ptr(x), ptr(dy), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)),
                                       ptr(stats), ptr(dx_add), ptr(dx), ptr(bstats), stream()))
+    return dx
+
+
+def groupnorm_bwd_apply(x: torch.Tensor, dy: torch.Tensor, gamma, beta, eps: float, silu: bool, stats: torch.Tensor, records: torch.Tensor,
+                        dx_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """groupnorm_bwd whose two reductions were left behind by dy's producer (gemm(..., gn_rows=HW, gn_bwd=...))"""
+    B, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c)
+    dx = torch.empty_like(x)
+    bstats = torch.empty((512 + B) * 64, device=x.device, dtype=torch.float32)
+    check(lib().asd_groupnorm_bwd_apply_f16(ptr(x), ptr(dy), i32(c), i32(B), i32(hw), ptr(gamma), ptr(beta), f32(eps), i32(int(silu)),
+                                            ptr(stats), ptr(records), i32(records.shape[1]), ptr(dx_add), ptr(dx), ptr(bstats), stream()))
     return dx
 
 

@@ -281,3 +281,47 @@ def test_groupnorm_statistics_from_the_producers_epilogue(B, hw, cin, cout, tile
         assert float((g2.float() - H.groupnorm(yl.view(B, hw * hw, cout), gamma, beta, 1e-6, False).float()).abs().max()) <= 2e-3
     _, r2, n2 = H.conv3x3(x, w, bias=bias, tile_cfg=1, split_k=2, gn_rows=hw * hw)
     assert n2 == 0 and r2 is None
+
+
+@pytest.mark.parametrize("B,hw,c,tile,silu", [(2, 64, 128, 11, True), (1, 64, 128, 14, True), (2, 32, 256, 8, True), (1, 32, 128, 1, False),
+                                              (3, 16, 320, 2, True), (2, 32, 64, 0, False)])
+def test_groupnorm_backward_reductions_from_the_dgrad_epilogue(B, hw, c, tile, silu):
+    """asd_gemm_args.gn_bwd_x: the launch that produces dy (the gradient reaching GroupNorm(x)[+SiLU]) also leaves that layer's two
+    reductions {sum g, sum g*xhat}; the apply-only backward on those records == the backward with its own reduction pass"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(B, hw * hw, c, seed=1)
+    gamma, beta = (_rand(c, seed=5) * 0.1 + 1).half(), (_rand(c, seed=6) * 0.1).half()
+    _, stats = H.groupnorm(x, gamma, beta, 1e-6, silu, return_stats=True)
+    up = _rand(B, hw, hw, c, seed=2)                                    # gradient w.r.t. the conv output
+    w = H.pack_conv3x3_weight(_rand(c, c, 3, 3, scale=(9 * c) ** -0.5, seed=3))
+    dx_add = _rand(B, hw * hw, c, seed=4)
+    spec = dict(x=x, fstats=stats, gamma=gamma, beta=beta, eps=1e-6, silu=silu)
+    dy, rec, nrec = H.conv3x3(up, w, tile_cfg=tile + 1, split_k=1, gn_rows=hw * hw, gn_bwd=spec)
+    if tile in H.WINDOW_TILES or (hw * hw) % H.TILE_BM[tile] == 0:
+        assert nrec > 0, "this plan can produce the records"
+    if nrec == 0:
+        pytest.skip("tile rows do not divide the rows of a batch element")
+    assert torch.equal(dy, H.conv3x3(up, w, tile_cfg=tile + 1, split_k=1).view_as(dy))
+    dyv = dy.view(B, hw * hw, c)
+    want = H.groupnorm_bwd(x, dyv, gamma, beta, 1e-6, silu, stats, dx_add=dx_add)
+    got = H.groupnorm_bwd_apply(x, dyv, gamma, beta, 1e-6, silu, stats, rec, dx_add=dx_add)
+    # fp32 restatement of the two sums
+    xf, cg, n = x.float().view(B, -1, 32, c // 32), c // 32, hw * hw * (c // 32)
+    mean = xf.mean(dim=(1, 3), keepdim=True)
+    rstd = (xf.var(dim=(1, 3), unbiased=False, keepdim=True) + 1e-6).rsqrt()
+    xh = (xf - mean) * rstd
+    gm, bt = gamma.float().view(1, 1, 32, cg), beta.float().view(1, 1, 32, cg)
+    z = xh * gm + bt
+    g = dyv.float().view(B, -1, 32, cg) * gm
+    if silu:
+        sg = torch.sigmoid(z)
+        g = g * sg * (1 + z * (1 - sg))
+    sums = torch.stack([g.sum(dim=(1, 3)), (g * xh).sum(dim=(1, 3))], -1)                        # [B, 32, 2]
+    recsum = rec.view(B, nrec, 32, 2).sum(1) if rec.shape[-1] == 64 else None
+    scale = float(g.abs().sum(dim=(1, 3)).max())
+    assert float((recsum - sums).abs().max()) <= 2e-3 * scale + 1e-3
+    ref = (g - (sums[..., 0].view(B, 1, 32, 1) + xh * sums[..., 1].view(B, 1, 32, 1)) / n) * rstd
+    ref = ref.reshape(B, hw * hw, c) + dx_add.float()
+    assert float((got.float() - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+    assert float((got.float() - want.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
