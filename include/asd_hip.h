@@ -290,6 +290,8 @@ typedef struct asd_gemm_args {
     const void* gn_bwd_gamma; const void* gn_bwd_beta;
     float   gn_eps;
     int32_t gn_silu;
+    int32_t wide_rows;      /* set by the library: the W tile is staged in a permuted row order so that every lane stores 8 consecutive
+                               channels (16 B) per row (csrc/gemm.hip, tile_epilogue); callers leave it 0 */
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
 int32_t asd_gemm_gn_records(const asd_gemm_args* args);

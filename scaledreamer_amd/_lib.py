@@ -79,7 +79,7 @@ class GemmArgs(C.Structure):
         ("tile_cfg", C.c_int32), ("ld_row_bias", C.c_int32), ("group_m", C.c_int32), ("group_n", C.c_int32),
         ("gn_partials", C.c_void_p), ("gn_cg", C.c_int32), ("gn_rows", C.c_int32),
         ("gn_bwd_x", C.c_void_p), ("gn_bwd_fstats", C.c_void_p), ("gn_bwd_gamma", C.c_void_p), ("gn_bwd_beta", C.c_void_p),
-        ("gn_eps", C.c_float), ("gn_silu", C.c_int32),
+        ("gn_eps", C.c_float), ("gn_silu", C.c_int32), ("wide_rows", C.c_int32),
     ]
 
 

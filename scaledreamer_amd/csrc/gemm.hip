@@ -142,6 +142,134 @@ __device__ __forceinline__ void gn_tile_end(const asd_gemm_args& p, const float*
     if (threadIdx.x < 64) p.gn_partials[(size_t)record * 64 + threadIdx.x] = lds64[threadIdx.x];
 }
 
+// bias + row_bias + SiLU + residual + store of 4 consecutive output channels of row m (shared by all GEMM / conv kernels)
+__device__ __forceinline__ floatx4 gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
+    if (p.bias) {
+        const half4 b = *(const half4*)((const half_t*)p.bias + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.row_bias) {
+        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+    }
+    if (p.residual) {
+        const half4 b = *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    if (p.out_f32) {
+        *(floatx4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+        return v;
+    }
+    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+    return floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};       // what a later pass over the tensor would read
+}
+
+// ---- wide-row epilogue -------------------------------------------------------------------------------------------------
+// The 16x16x32 MFMA leaves a lane with 4 consecutive output channels of one row (pixel): with the W tile in natural row order a wave
+// store covers 16 rows x 32 B.  When asd_gemm_args.wide_rows is set the W tile is brought into LDS in a permuted ROW order instead —
+// inside every aligned group of 32 channels, LDS row jj*16 + g*4 + r holds channel g*8 + jj*4 + r — so fragments 2s and 2s+1 of a
+// lane are 8 CONSECUTIVE channels: one 16-byte store (and one 16-byte bias / residual load) per row, 64 B runs per row and
+// instruction, half the epilogue's memory instructions.  Only the global source row of each LDS row changes; fragment reads, the
+// swizzle and the MFMA order are untouched, so results are bit-identical.
+__device__ __forceinline__ int wide_slab_rows(int ws) { return (ws >> 2) * 32 + (ws & 1) * 16 + ((ws >> 1) & 1) * 4; }   // first channel of 8-row slab ws
+__device__ __forceinline__ int wide_lane_row(int lrow) { return (lrow >> 2) * 8 + (lrow & 3); }                        // + this for row lrow of the slab
+
+__device__ __forceinline__ void gemm_store8(const asd_gemm_args& p, floatx4& lo, floatx4& hi, int m, int n) {
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (p.bias) {
+        const half8 b = *(const half8*)((const half_t*)p.bias + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)b[k];
+    }
+    if (p.row_bias) {
+        const half8 b = *(const half8*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)b[k];
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] / (1.f + __expf(-v[k]));
+    }
+    if (p.residual) {
+        const half8 b = *(const half8*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)b[k];
+    }
+    if (p.out_f32) {
+        float* dst = (float*)p.C + (size_t)m * p.ldc + n;
+        *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
+        *(floatx4*)(dst + 4) = floatx4{v[4], v[5], v[6], v[7]};
+        lo = floatx4{v[0], v[1], v[2], v[3]}; hi = floatx4{v[4], v[5], v[6], v[7]};
+        return;
+    }
+    const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+    *(half8*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+    lo = floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]}; hi = floatx4{(float)o[4], (float)o[5], (float)o[6], (float)o[7]};
+}
+
+// Epilogue of a wave's TM x TN fragment tile (all GEMM / conv kernels): split-K partial slabs, or bias / row_bias / SiLU / residual /
+// store, plus the GroupNorm reductions when asked.  nb = first channel of the wave, row(i) = output row of fragment row i (< 0: none),
+// row0 = any row of the tile (the batch element of the GroupNorm constants).
+template <int TM, int TN, typename RowFn>
+__device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&acc)[TM][TN], int nb, int kz, int row0, RowFn row, bool gn, float* gn_lds) {
+    const int g = (threadIdx.x & 63) >> 4;
+    if constexpr (TN % 2 == 0) {
+        if (p.wide_rows) {
+#pragma unroll
+            for (int s2 = 0; s2 < TN / 2; ++s2) {
+                const int n = nb + s2 * 32 + g * 8;
+                floatx4 cs0 = {0.f, 0.f, 0.f, 0.f}, cq0 = cs0, cs1 = cs0, cq1 = cs0;     // forward statistics only (the backward form keeps
+                                                                                         // 16 constants per 4 channels live: narrow path)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = row(i);
+                    if (m < 0 || n >= p.N) continue;
+                    if (p.split_k > 1) {
+                        float* dst = p.workspace + ((size_t)kz * p.M + m) * p.N + n;
+                        *(floatx4*)dst = acc[i][2 * s2];
+                        *(floatx4*)(dst + 4) = acc[i][2 * s2 + 1];
+                    } else {
+                        floatx4 lo = acc[i][2 * s2], hi = acc[i][2 * s2 + 1];
+                        gemm_store8(p, lo, hi, m, n);
+                        if (gn) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                cs0[r] += lo[r]; cq0[r] = fmaf(lo[r], lo[r], cq0[r]);
+                                cs1[r] += hi[r]; cq1[r] = fmaf(hi[r], hi[r], cq1[r]);
+                            }
+                        }
+                    }
+                }
+                if (gn) { gn_tile_flush(gn_lds, cs0, cq0, n, p.N, p.gn_cg); gn_tile_flush(gn_lds, cs1, cq1, n + 4, p.N, p.gn_cg); }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nb + j * 16 + g * 4;
+        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+        GnCol gc;
+        if (gn) gn_col_load(p, row0, n, gc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = row(i);
+            if (m < 0 || n >= p.N) continue;
+            if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
+            else {
+                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
+                if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
+            }
+        }
+        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_args p) {
     constexpr int NW = WM * WN;
@@ -200,8 +328,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             c_yx[j] = (y << 16) | x;
         }
     }
-    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
-    const size_t a_slab_stride = (size_t)8 * p.lda * 2, w_slab_stride = (size_t)8 * p.ldw * 2;
+    constexpr bool WIDE_OK = (BN / WN) % 32 == 0;                       // wave extents that hold whole 32-channel groups
+    const bool wide = WIDE_OK && p.wide_rows;                          // W tile in permuted row order (tile_epilogue)
+    const int wl = wide ? wide_lane_row(lrow) : lrow;
+    auto w_slab_rows = [&](int ws) { return wide ? wide_slab_rows(ws) : ws * 8; };
+    const char* w0 = (const char*)p.W + (size_t)(n0 + wl) * p.ldw * 2 + lch * 16;
+    const size_t a_slab_stride = (size_t)8 * p.lda * 2, w_row_stride = (size_t)p.ldw * 2;
     // Row-major operands (W always, A of a plain GEMM): one 32-bit byte offset per slab against the scalar operand base
     // (global_load_lds saddr + voffset), advanced by 128 B per k-step — 3 instructions per 1-KiB wave-level load.  Rows past
     // M / N are clamped to the last row (their outputs are never stored), so every offset is always valid; only a ragged last
@@ -210,7 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
         const int slab = wave + j * NW;
-        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + (slab - ASLABS) * 8 + lrow, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + ks0 * 128;
+        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + w_slab_rows(slab - ASLABS) + wl, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + ks0 * 128;
         else roff[j] = CONV ? 0u : (unsigned)min(m0 + slab * 8 + lrow, p.M - 1) * (unsigned)(p.lda * 2) + lch * 16 + ks0 * 128;
     }
 
@@ -250,7 +382,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             const char* src;
             if (slab >= ASLABS) {
                 const int ws = slab - ASLABS;
-                src = (k_ok && n0 + ws * 8 + lrow < p.N) ? w0 + (ws + opaque) * w_slab_stride + (size_t)k0 * 2 : zero;
+                const int wr = w_slab_rows(ws);
+                src = (k_ok && n0 + wr + wl < p.N) ? w0 + (wr + opaque) * w_row_stride + (size_t)k0 * 2 : zero;
             } else if (!CONV) {
                 src = (k_ok && m0 + slab * 8 + lrow < p.M) ? a0 + (slab + opaque) * a_slab_stride + (size_t)k0 * 2 : zero;
             } else {
@@ -357,18 +490,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
     const int em = lane & 15, en = (lane >> 4) * 4;
+    auto out_row = [&](int i) { const int m = m0 + wm * (BM / WM) + i * 16 + em; return m < p.M ? m : -1; };
     if (p.split_k > 1) {  // split-K: fp32 partial slabs, finished by splitk_epilogue_kernel
-        float* ws = p.workspace + (size_t)kz * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + em;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / WN) + j * 16 + en;
-                if (n < p.N) *(floatx4*)(ws + (size_t)m * p.N + n) = acc[i][j];
-            }
-        }
+        tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, false, nullptr);
         return;
     }
     if (p.act == 2) {
@@ -397,72 +521,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     const bool gn = p.gn_partials != nullptr;     // block-uniform
     float* gn_lds = (float*)smem;
     if (gn) gn_tile_begin(gn_lds);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 16 + en;
-        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
-        GnCol gc;
-        if (gn) gn_col_load(p, m0, n, gc);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + em;
-            if (m >= p.M || n >= p.N) continue;
-            const half_t* rb = p.row_bias ? (const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias : nullptr;
-            floatx4 v = acc[i][j];
-            if (p.bias) {
-                const half4 b = *(const half4*)((const half_t*)p.bias + n);
-                v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-            }
-            if (rb) {
-                const half4 b = *(const half4*)(rb + n);
-                v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
-            }
-            if (p.residual) {
-                const half4 b = *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
-                v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-            }
-            if (p.out_f32) {
-                *(floatx4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-            } else {
-                half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
-                if (gn) gn_tile_accum(p, gc, floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]}, m, n, cs, cq);
-            }
-        }
-        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
-    }
+    tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, gn, gn_lds);
     if (gn) gn_tile_end(p, gn_lds, (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN);
-}
-
-// bias + row_bias + SiLU + residual + store of 4 consecutive output channels of row m (shared by all GEMM / conv kernels)
-__device__ __forceinline__ floatx4 gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
-    if (p.bias) {
-        const half4 b = *(const half4*)((const half_t*)p.bias + n);
-        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-    }
-    if (p.row_bias) {
-        const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
-        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-    }
-    if (p.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
-    }
-    if (p.residual) {
-        const half4 b = *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
-        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-    }
-    if (p.out_f32) {
-        *(floatx4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-        return v;
-    }
-    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-    *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
-    return floatx4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};       // what a later pass over the tensor would read
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -521,8 +581,10 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     const int lrow = lane >> 3, pchunk = lane & 7;
     const char* zero = (const char*)p.zero_page;
     const char* img = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + (pchunk ^ lrow) * 16;
-    const size_t w_slab_stride = (size_t)8 * p.ldw * 2;
+    const bool wide = p.wide_rows != 0;                                // W tile in permuted row order (tile_epilogue)
+    const int wl = wide ? wide_lane_row(lrow) : lrow;
+    const char* w0 = (const char*)p.W + (size_t)(n0 + wl) * p.ldw * 2 + (pchunk ^ lrow) * 16;
+    const size_t w_row_stride = (size_t)p.ldw * 2;
 
     auto load_window_slab = [&](int slab, int chunk, char* dst_buf) {   // slab: wave-uniform, < WIN_SLABS
         const int wrow = slab * 8 + lrow;
@@ -539,7 +601,8 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
         for (int j = 0; j < WSPW; ++j) {
             const int slab = wave + j * 8;
             if (slab >= WSLABS) continue;
-            const char* src = (n0 + slab * 8 + lrow < p.N) ? w0 + slab * w_slab_stride + koff : zero;
+            const int wr = wide ? wide_slab_rows(slab) : slab * 8;
+            const char* src = (n0 + wr + wl < p.N) ? w0 + wr * w_row_stride + koff : zero;
             load_slab(src, dst_buf + slab * 8 * RB);
         }
     };
@@ -635,28 +698,11 @@ __global__ __launch_bounds__(512) void conv3x3_win_kernel(const asd_gemm_args p)
     }
 
     // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
-    const int en = (lane >> 4) * 4;
     const bool gn = p.gn_partials != nullptr && p.split_k == 1;     // block-uniform
     float* gn_lds = (float*)smem;
     if (gn) gn_tile_begin(gn_lds);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 16 + en;
-        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
-        GnCol gc;
-        if (gn) gn_col_load(p, b * p.Hout * p.Wout, n, gc);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
-            if (n >= p.N) continue;
-            if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
-            else {
-                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
-                if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
-            }
-        }
-        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
-    }
+    tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, b * p.Hout * p.Wout,
+                          [&](int i) { return (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow; }, gn, gn_lds);
     if (gn) gn_tile_end(p, gn_lds, tm * tiles_n + tn_);
 }
 
@@ -702,8 +748,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
     const int lrow = lane >> 3, pchunk = lane & 7, lch = pchunk ^ lrow;
     const char* zero = (const char*)p.zero_page;
     const char* img = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-    const char* w0 = (const char*)p.W + (size_t)(n0 + lrow) * p.ldw * 2 + lch * 16;
-    const size_t w_slab_stride = (size_t)8 * p.ldw * 2;
+    const bool wide = p.wide_rows != 0;                                // W tile in permuted row order (tile_epilogue)
+    const int wl = wide ? wide_lane_row(lrow) : lrow;
+    const char* w0 = (const char*)p.W + (size_t)(n0 + wl) * p.ldw * 2 + lch * 16;
+    const size_t w_row_stride = (size_t)p.ldw * 2;
 
     auto load_window_slab = [&](int slab, int chunk, char* dst_buf) {   // slab: wave-uniform, < WIN_SLABS
         const int wrow = slab * 8 + lrow;
@@ -720,7 +768,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
         for (int j = 0; j < WSPW; ++j) {
             const int slab = wave + j * NW;
             if (slab >= WSLABS) continue;
-            const char* src = (n0 + slab * 8 + lrow < p.N) ? w0 + slab * w_slab_stride + koff : zero;
+            const int wr = wide ? wide_slab_rows(slab) : slab * 8;
+            const char* src = (n0 + wr + wl < p.N) ? w0 + wr * w_row_stride + koff : zero;
             load_slab(src, dst_buf + slab * 8 * RB);
         }
     };
@@ -735,18 +784,31 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
     const int fb0 = (wn * (BN / WN) + frow) * RB;
     const int fswb[2] = {((fq) ^ (frow & 7)) * 16, ((4 + fq) ^ (frow & 7)) * 16};
 
+#ifdef ASD_WIN_PROFILE     // tools/win_profile.py: where a wave's cycles go (s_memtime), written to p.workspace (split_k == 1 only)
+    unsigned long long pt_start = __builtin_amdgcn_s_memtime(), pt_wait = 0, pt_first = 0, pt_reload = 0, pt_loop_end = 0;
+#define PT_NOW() __builtin_amdgcn_s_memtime()
+#endif
     if (steps > 0) {
         for (int slab = wave; slab < WIN_SLABS; slab += NW) load_window_slab(slab, c0, a_buf);
         load_w_tile(0, w_buf);
 #pragma unroll 1
         for (int s = 0; s < steps; ++s) {
             const int cl = s / 9, tap = s - cl * 9;
+#ifdef ASD_WIN_PROFILE
+            const unsigned long long pt_a = PT_NOW();
+#endif
             if (tap == 0 && s > 0) {   // chunk switch: everyone is done with the old window, reload it (exposed; the co-resident block covers)
                 __builtin_amdgcn_s_barrier();
                 for (int slab = wave; slab < WIN_SLABS; slab += NW) load_window_slab(slab, c0 + cl, a_buf);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef ASD_WIN_PROFILE
+            {
+                const unsigned long long pt_b = PT_NOW();
+                if (s == 0) pt_first = pt_b - pt_a; else if (tap == 0) pt_reload += pt_b - pt_a; else pt_wait += pt_b - pt_a;
+            }
+#endif
             if (s + 1 < steps) load_w_tile(s + 1, w_buf + ((s + 1) & 1) * W_BYTES);
             const char* Wt = w_buf + (s & 1) * W_BYTES;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -754,6 +816,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
             // c ^ ((frow + kx) & 7) — independent of i and ky, so patch row i is an immediate offset from row 0
             const char* Ar = a_buf + ((wm * 4 + ky) * WIN + frow + kx) * RB;
             const int csw = (frow + kx) & 7;
+            if constexpr (NW == 4) {
+                // 256 registers per wave: both k halves' fragments are requested up front, so the LDS latency is paid once per tap
+                // (under the other resident waves' MFMAs) instead of before every group of MFMAs
+                half8 xa[2][TM], wb[2][TN];
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const char* Ak = Ar + (((kh * 4 + fq) ^ csw) * 16);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) xa[kh][i] = *(const half8*)(Ak + i * WIN * RB);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) wb[kh][j] = *(const half8*)(Wt + fb0 + fswb[kh] + j * 16 * RB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[kh][j], xa[kh][i], acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
                 half8 xa[TM], wb[TN];
@@ -768,33 +851,30 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_win2_kernel(const asd
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
             }
+            }
         }
     }
 
     // acc[i][j][r] = C[pixel (y0 + wm*4 + i, x0 + (lane&15))][n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r]
-    const int en = (lane >> 4) * 4;
+#ifdef ASD_WIN_PROFILE
+    pt_loop_end = PT_NOW();
+#endif
     const bool gn = p.gn_partials != nullptr && p.split_k == 1;     // block-uniform
     float* gn_lds = (float*)smem;
     if (gn) gn_tile_begin(gn_lds);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 16 + en;
-        floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
-        GnCol gc;
-        if (gn) gn_col_load(p, b * p.Hout * p.Wout, n, gc);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow;
-            if (n >= p.N) continue;
-            if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
-            else {
-                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
-                if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
-            }
-        }
-        if (gn) gn_tile_flush(gn_lds, cs, cq, n, p.N, p.gn_cg);
-    }
+    tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, b * p.Hout * p.Wout,
+                          [&](int i) { return (b * p.Hout + y0 + wm * 4 + i) * p.Wout + x0 + frow; }, gn, gn_lds);
     if (gn) gn_tile_end(p, gn_lds, tm * tiles_n + tn_);
+#ifdef ASD_WIN_PROFILE
+    if (p.split_k == 1 && p.workspace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = (unsigned long long*)p.workspace + ((size_t)item * NW + wave) * 8;
+        o[0] = pt_start; o[1] = PT_NOW(); o[2] = pt_first; o[3] = pt_wait; o[4] = pt_reload; o[5] = pt_loop_end;
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[6] = hwid; o[7] = xcc;
+    }
+#endif
 }
 
 // sums the split-K slabs and applies the same epilogue (4 outputs per thread)
@@ -1038,6 +1118,19 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
                   "tile configuration does not divide N");
     const int bm = asd_gemm_tiles[cfg].bm, bn = asd_gemm_tiles[cfg].bn;
     if (asd_gemm_gn_records_cfg(a, cfg, true) == 0) a->gn_partials = nullptr;
+    {   // wide-row epilogue (tile_epilogue): whole 32-channel groups per wave, 16-byte aligned rows everywhere
+        static const bool wide_on = !(getenv("ASD_WIDE_ROWS") && getenv("ASD_WIDE_ROWS")[0] == '0');     // A/B switch (tools)
+        auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        const int wave_n = bn / asd_gemm_tiles[cfg].wn;
+        a->wide_rows = wide_on && wave_n % 32 == 0 && a->act != 2 && a->N % 8 == 0 && a->ldc % 8 == 0 && al16(a->C) && (!a->bias || al16(a->bias)) &&
+                       (!a->row_bias || (al16(a->row_bias) && a->ld_row_bias % 8 == 0)) && (!a->residual || (al16(a->residual) && a->ldr % 8 == 0)) &&
+                       !(a->gn_partials && a->gn_bwd_x);
+    }
+    static const bool trace = getenv("ASD_GEMM_TRACE") != nullptr;      // tools/gemm_shapes.py: one line per launch
+    if (trace)
+        fprintf(stderr, "ASD_GEMM %d %d %d conv=%d %d %d %d %d %d s=%d p=%d u=%d cfg=%d split=%d act=%d res=%d f32=%d gn=%d\n", a->M, a->N, a->K, a->conv, a->Hin,
+                a->Win, a->Cin, a->Hout, a->Wout, a->stride, a->pad, a->upsample, cfg, a->split_k, a->act, a->residual != nullptr, a->out_f32,
+                a->gn_partials ? (a->gn_bwd_x ? 2 : 1) : 0);
     if (asd_cfg_is_window(cfg)) {
         ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
         ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");

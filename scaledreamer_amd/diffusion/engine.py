@@ -10,6 +10,8 @@ in HBM) and capturing the ~450 launches of a forward into one HIP graph per inpu
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -81,7 +83,7 @@ class HipUNet:
         if self.cfg.num_head_channels != 64:
             raise NotImplementedError("the attention kernel is built for head_dim 64")
         self.device = torch.device(device)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and os.environ.get("ASD_UNET_GRAPH", "1") != "0"     # 0: eager launches (tools/gemm_shapes.py traces them)
         self._graphs: Dict[Tuple, Tuple] = {}
         self.net = CNet("unet", unet_desc(self.cfg), W.pack_unet(params, self.cfg), self.device)
 
