@@ -451,6 +451,16 @@ int asd_latents_fwd(const float* moments_nhwc, const float* post_noise, const fl
 int asd_score_fwd(const float* eps_nhwc, int32_t B, int32_t C, int32_t hw, int32_t n_neg, const float* neg_w, float guidance_scale,
                   const int64_t* t, const float* alphas_cumprod, int32_t weighting, float grad_clip, float* grad, float* sumsq,
                   float* loss_and_norm, void* stream);
+/* View-dependent prompt selection written into the UNet's context buffer (replaces prompt_processors/base.py:82-167
+ * get_text_embeddings_perp_neg / :169-199 get_text_embeddings and the torch.cat of stable_diffusion_asd_guidance.py:377-394).
+ * text_vd, uncond_vd: fp32 [n_dir, n_tok, dim] in the order side / front / back / overhead (n_dir = 4) or one embedding (n_dir = 1, no
+ * view dependence); elevation, azimuth: fp32 [batch] degrees.  layout 0: context rows of [text | uncond | text] (3 * batch samples);
+ * layout 1 (Perp-Neg): [pos | uncond | neg1_0, neg2_0, neg1_1, ... | pos] (5 * batch) and neg_w[batch, 2] = neg_scale * the reference's
+ * weights.  params15 (host): overhead / front / back thresholds, then perp_neg_f_sb, f_fsb, f_fs, f_sf (3 floats each).
+ * context_f16: fp16 [samples * ctx_stride, dim]; rows n_tok..ctx_stride-1 of a sample are not touched. */
+int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_dir, int32_t n_tok, int32_t dim, const float* elevation,
+                       const float* azimuth, int32_t batch, int32_t layout, const float* params15, float neg_scale, void* context_f16,
+                       int32_t ctx_stride, float* neg_w, void* stream);
 /* d loss / d moments (fp32 [B,hl,wl,2C]) given grad: d z = upstream * grad / B (upstream: device scalar or NULL = 1) */
 int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C,
                     int32_t hl, int32_t wl, float scaling, float* d_moments_nhwc, void* stream);

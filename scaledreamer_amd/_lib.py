@@ -119,7 +119,7 @@ SYMBOLS = [
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
     "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune", "asd_gemm_gn_records", "asd_groupnorm_apply_f16", "asd_groupnorm_bwd_apply_f16",
     "asd_pad_cast_f16",
-    "asd_image_prep_fwd", "asd_image_prep_bwd", "asd_latents_fwd", "asd_score_fwd", "asd_latents_bwd",
+    "asd_image_prep_fwd", "asd_image_prep_bwd", "asd_latents_fwd", "asd_score_fwd", "asd_latents_bwd", "asd_prompt_context",
     "asd_unet_create", "asd_unet_destroy", "asd_unet_num_weights", "asd_unet_weight_info", "asd_unet_bind_weights",
     "asd_unet_workspace_bytes", "asd_unet_fwd",
     "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",

@@ -1,4 +1,4 @@
-// asd_glue.hip — the latent-space arithmetic of the ASD guidance between the renderer's image and the scalar loss, as five small
+// asd_glue.hip — the latent-space arithmetic of the ASD guidance between the renderer's image and the scalar loss, as six small
 // fused kernels (everything here is elementwise or a per-sample reduction over 4*64*64 values: one pass each, no torch glue):
 //   asd_image_prep_fwd/bwd   rgb[B,h,w,3] -> bilinear (align_corners=False) resize to HxW, *2-1, NHWC fp16 padded to 32 channels
 //                            (stable_diffusion_asd_guidance.py:196-209 get_latents, :171-175 encode_images' imgs*2-1) and its adjoint
@@ -8,6 +8,8 @@
 //                            (:263-271), nan_to_num (:274), optional clamp (:276-277); grad, loss = 0.5*sum(grad^2)/B (:281-283:
 //                            MSE against the detached target), grad_norm
 //   asd_latents_bwd          d loss / d moments through the posterior sample (gradient reaches the VAE encoder, :225)
+//   asd_prompt_context       view-dependent / Perp-Neg prompt selection (prompt_processors/base.py:82-167, 262-294) written into the
+//                            UNet's context buffer in get_eps' batch order, with the Perp-Neg weights
 // MVDream (mvdream_asd_guidance.py:181-304) is the same with n_rep = 2, n_neg = 0 and one t per 4-view group.
 #include "asd_common.h"
 
@@ -217,6 +219,80 @@ __global__ __launch_bounds__(256) void latents_bwd_kernel(const float* __restric
     }
 }
 
+
+// ---- view-dependent prompt selection, written straight into the UNet's context buffer ---------------------------------------------
+// prompt_processors/base.py:82-167 (get_text_embeddings_perp_neg) and :262-294 (direction by thresholds: side < front < back <
+// overhead), as one launch: a block owns one output token row.  Row blends keep the reference's fp32 arithmetic
+// (r * a + (1 - r) * b: two products and a sum, no fma) before the fp16 rounding of the UNet input.
+struct PromptParams {
+    float overhead_thr, front_thr, back_thr;
+    float f_sb[3], f_fsb[3], f_fs[3], f_sf[3];
+};
+
+__device__ __forceinline__ float shifted_azimuth(float az) {      // (az + 180) % 360 - 180 with Python's sign convention
+    float r = fmodf(az + 180.f, 360.f);
+    if (r != 0.f && r < 0.f) r += 360.f;
+    return r - 180.f;
+}
+__device__ __forceinline__ float exp_decay(const float* f, float r) { return f[0] * expf(-f[1] * r) + f[2]; }
+
+// segments of the output batch: layout 0 = [text | uncond | text], layout 1 = [pos | uncond | neg1_0, neg2_0, neg1_1, ... | pos]
+__global__ __launch_bounds__(128) void prompt_context_kernel(const float* __restrict__ text_vd, const float* __restrict__ uncond_vd, int n_dir,
+                                                             int n_tok, int dim, const float* __restrict__ elevation,
+                                                             const float* __restrict__ azimuth, int B, int layout, PromptParams pp,
+                                                             float neg_scale, half_t* __restrict__ ctx, int ctx_stride,
+                                                             float* __restrict__ neg_w) {
+    const int tok = blockIdx.x % n_tok, slot = blockIdx.x / n_tok;          // slot: sample of the UNet batch
+    int b, kind;                                                             // kind 0 text / pos, 1 uncond, 2 neg1, 3 neg2
+    if (layout == 0) { kind = slot / B == 1 ? 1 : 0; b = slot % B; }
+    else if (slot < 2 * B) { kind = slot / B; b = slot % B; }
+    else if (slot < 4 * B) { b = (slot - 2 * B) >> 1; kind = 2 + ((slot - 2 * B) & 1); }
+    else { kind = 0; b = slot - 4 * B; }
+    const float azi = shifted_azimuth(azimuth[b]);
+    int idx = 0;
+    if (n_dir > 1) {
+        if (azi > -pp.front_thr && azi < pp.front_thr) idx = 1;
+        if (azi > 180.f - pp.back_thr || azi < -180.f + pp.back_thr) idx = 2;
+        if (elevation[b] > pp.overhead_thr) idx = 3;
+    }
+    const float a = fabsf(azi);
+    const bool over = idx == 3, is_front = a < 90.f;
+    const float r_f = 1.f - a / 90.f, r_b = 2.0f - a / 90.f;
+    // row = wa * A + wb * Bm (wb == 0: plain copy of A)
+    const float* A;
+    const float* Bm = nullptr;
+    float wa = 1.f, wb = 0.f;
+    const size_t row = (size_t)tok * dim, tab = (size_t)n_tok * dim;
+    if (kind == 1 || (over && kind >= 2)) A = uncond_vd + idx * tab;
+    else if (layout == 0 || n_dir == 1) A = text_vd + idx * tab;
+    else if (kind == 0) {
+        if (over) A = text_vd + 3 * tab;
+        else if (is_front) { A = text_vd + 1 * tab; Bm = text_vd; wa = r_f; wb = 1.f - r_f; }            // front <-> side
+        else { A = text_vd; Bm = text_vd + 2 * tab; wa = r_b; wb = 1.f - r_b; }                           // side <-> back
+    } else if (kind == 2) A = is_front ? text_vd + 1 * tab : text_vd;
+    else A = is_front ? text_vd : text_vd + 1 * tab;
+    half_t* dst = ctx + ((size_t)slot * ctx_stride + tok) * dim;
+    for (int c = threadIdx.x * 4; c < dim; c += 128 * 4) {
+        const float4 va = *(const float4*)(A + row + c);
+        float4 v = va;
+        if (Bm) {
+            const float4 vb = *(const float4*)(Bm + row + c);
+            v.x = wa * va.x + wb * vb.x; v.y = wa * va.y + wb * vb.y; v.z = wa * va.z + wb * vb.z; v.w = wa * va.w + wb * vb.w;
+        }
+        half_t o[4] = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        *(uint2*)(dst + c) = *(const uint2*)o;
+    }
+    if (neg_w && layout == 1 && tok == 0 && kind == 0 && slot < B && threadIdx.x == 0) {
+        float w1 = 0.f, w2 = 0.f;
+        if (!over) {
+            w1 = is_front ? -exp_decay(pp.f_fs, r_f) : -exp_decay(pp.f_sb, r_b);
+            w2 = is_front ? -exp_decay(pp.f_sf, 1.f - r_f) : -exp_decay(pp.f_fsb, r_b);
+        }
+        neg_w[2 * b] = w1 * neg_scale;
+        neg_w[2 * b + 1] = w2 * neg_scale;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -268,6 +344,22 @@ int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* p
     ASD_CHECK_ARG(grad && moments_nhwc && post_noise && d_moments_nhwc && C == 4 && B > 0 && hl > 0 && wl > 0, "bad argument");
     hipLaunchKernelGGL((latents_bwd_kernel<4>), dim3(asd_div_up(B * hl * wl, 256)), dim3(256), 0, (hipStream_t)stream, grad, moments_nhwc, post_noise,
                        upstream, B, hl * wl, scaling, d_moments_nhwc);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_dir, int32_t n_tok, int32_t dim, const float* elevation,
+                       const float* azimuth, int32_t batch, int32_t layout, const float* params15, float neg_scale, void* context_f16,
+                       int32_t ctx_stride, float* neg_w, void* stream) {
+    ASD_CHECK_ARG(text_vd && uncond_vd && elevation && azimuth && params15 && context_f16, "null argument");
+    ASD_CHECK_ARG((n_dir == 1 || n_dir == 4) && n_tok > 0 && dim > 0 && dim % 4 == 0 && batch > 0 && ctx_stride >= n_tok, "bad sizes");
+    ASD_CHECK_ARG(layout == 0 || (layout == 1 && n_dir == 4 && neg_w), "layout 1 (Perp-Neg) needs the four view-dependent embeddings and neg_w");
+    PromptParams pp;
+    pp.overhead_thr = params15[0]; pp.front_thr = params15[1]; pp.back_thr = params15[2];
+    for (int i = 0; i < 3; ++i) { pp.f_sb[i] = params15[3 + i]; pp.f_fsb[i] = params15[6 + i]; pp.f_fs[i] = params15[9 + i]; pp.f_sf[i] = params15[12 + i]; }
+    const int slots = (layout == 0 ? 3 : 5) * batch;
+    hipLaunchKernelGGL(prompt_context_kernel, dim3(slots * n_tok), dim3(128), 0, (hipStream_t)stream, text_vd, uncond_vd, n_dir, n_tok, dim, elevation,
+                       azimuth, batch, layout, pp, neg_scale, (half_t*)context_f16, ctx_stride, neg_w);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -214,8 +214,12 @@ class _ScoreDistillation(torch.autograd.Function):
         check(l.asd_image_prep_fwd(ptr(rgb32), i32(B), i32(h), i32(w), i32(H), i32(H), ptr(x), stream()))
         moments, saved = backend.vae_forward(x)
         n_rep, n_neg = job["n_rep"], job["n_neg"]
-        io = backend.unet_buffers((n_rep + 1) * B, hl, hl, job["context"].shape[1], job["frames"])
-        io.set_context(job["context"])
+        io = backend.unet_buffers((n_rep + 1) * B, hl, hl, job["n_ctx"], job["frames"])
+        neg_w = job["neg_w"]
+        if job.get("context_fill") is not None:
+            neg_w = job["context_fill"](io)          # asd_prompt_context: prompt selection written into io.context on the device
+        else:
+            io.set_context(job["context"])
         if io.camera is not None:
             io.camera.copy_(job["camera"])
         latents = torch.empty((B, C_, hl, hl), device=dev, dtype=torch.float32)
@@ -225,7 +229,7 @@ class _ScoreDistillation(torch.autograd.Function):
         eps = backend.unet_run(io)
         grad = torch.empty_like(latents)
         scratch = torch.empty(B + 2, device=dev, dtype=torch.float32)
-        check(l.asd_score_fwd(ptr(eps), i32(B), i32(C_), i32(hl * hl), i32(n_neg), ptr(job["neg_w"]), f32(job["guidance_scale"]), ptr(job["t"]), ptr(alphas),
+        check(l.asd_score_fwd(ptr(eps), i32(B), i32(C_), i32(hl * hl), i32(n_neg), ptr(neg_w), f32(job["guidance_scale"]), ptr(job["t"]), ptr(alphas),
                               i32(job["weighting"]), f32(job["grad_clip"] or 0.0), ptr(grad), ptr(scratch), ptr(scratch[B:]), stream()))
         ctx.backend, ctx.saved_vae, ctx.dims, ctx.in_dtype = backend, saved, (B, h, w, H, hl, C_), rgb.dtype
         ctx.save_for_backward(grad, moments, job["post_noise"])
@@ -292,8 +296,10 @@ class _AsdGuidanceBase(BaseObject):
             room = room * self.rand_fn(t.shape, t.device)
         return (t + room.to(torch.long)).clamp(1, T - 1)
 
-    def _distill(self, rgb: torch.Tensor, context: torch.Tensor, neg_w: Optional[torch.Tensor], n_rep: int, shared_t: bool,
-                 camera: Optional[torch.Tensor] = None, frames: int = 1) -> Dict[str, Any]:
+    def _distill(self, rgb: torch.Tensor, context: Optional[torch.Tensor], neg_w: Optional[torch.Tensor], n_rep: int, shared_t: bool,
+                 camera: Optional[torch.Tensor] = None, frames: int = 1, context_fill=None, n_ctx: Optional[int] = None,
+                 n_neg: Optional[int] = None) -> Dict[str, Any]:
+        """context [ (n_rep + 1) * B, n_ctx, D ] + neg_w [B, n_neg], or context_fill(io) -> neg_w which writes io.context itself"""
         if not rgb.is_cuda:
             from ._lib import AsdError
 
@@ -306,8 +312,10 @@ class _AsdGuidanceBase(BaseObject):
         t_plus = self.get_t_plus(t)
         if shared_t:                                                             # one t for the views of a group
             t, t_plus = t.repeat(B), t_plus.repeat(B)
-        job = dict(image_size=self.image_size, n_rep=n_rep, n_neg=0 if neg_w is None else neg_w.shape[1], frames=frames,
-                   context=context, camera=camera, post_noise=post_noise, noise=noise, t=t.contiguous(), t_plus=t_plus.contiguous(),
+        if n_neg is None:
+            n_neg = 0 if neg_w is None else neg_w.shape[1]
+        job = dict(image_size=self.image_size, n_rep=n_rep, n_neg=n_neg, frames=frames, context_fill=context_fill,
+                   n_ctx=context.shape[1] if n_ctx is None else n_ctx, context=context, camera=camera, post_noise=post_noise, noise=noise, t=t.contiguous(), t_plus=t_plus.contiguous(),
                    alphas=self.alphas.to(dev), neg_w=None if neg_w is None else neg_w.float().contiguous(),
                    guidance_scale=float(self.cfg.guidance_scale), weighting=WEIGHTING[self.cfg.weighting_strategy], grad_clip=self.grad_clip_val)
         loss, norm = _ScoreDistillation.apply(rgb, self.backend, job)
@@ -369,9 +377,52 @@ class SDTimestepShiftedScoreDistillationGuidance(_AsdGuidanceBase):
                  guidance_eval=False, **kwargs) -> Dict[str, Any]:
         if rgb_as_latents:
             raise NotImplementedError("rgb_as_latents=True (latent-space rendering) is not on the ASD hot path of any shipped config")
+        fill = self._device_conditioning(prompt_utils, elevation, azimuth, rgb) if rgb.is_cuda else None
+        if fill is not None:
+            return self._distill(rgb, None, None, 4 if self.use_perp_neg else 2, shared_t=False, context_fill=fill,
+                                 n_ctx=prompt_utils.text_embeddings_vd.shape[1], n_neg=2 if self.use_perp_neg else 0)
         context, neg_w = self.conditioning(prompt_utils, elevation, azimuth, camera_distances)
         n_rep = context.shape[0] // rgb.shape[0] - 1
         return self._distill(rgb, context.to(rgb.device), None if neg_w is None else neg_w.to(rgb.device), n_rep, shared_t=False)
+
+    def _device_conditioning(self, prompt_utils, elevation, azimuth, rgb):
+        """`conditioning` as one kernel launch that writes the UNet's context buffer (csrc/asd_glue.hip: asd_prompt_context) — for the
+        stock PromptUtils; any other prompt processor goes through its own get_text_embeddings* methods."""
+        if type(prompt_utils) is not PromptUtils:
+            return None
+        vd = self.cfg.view_dependent_prompting
+        if self.use_perp_neg and not (vd and prompt_utils.use_perp_neg):
+            return None                                  # conditioning() raises the reference's errors for these
+        import ctypes as C_
+
+        from ._lib import check, f32, i32, lib, ptr, stream
+
+        dev = rgb.device
+        key = (id(prompt_utils), vd, str(dev))
+        cache = self.__dict__.setdefault("_prompt_tables", {})
+        if key not in cache:                             # fp32 tables on the device, once per prompt processor
+            if vd:
+                text, unc = prompt_utils.text_embeddings_vd, prompt_utils.uncond_text_embeddings_vd
+            else:
+                text, unc = prompt_utils.text_embeddings[None], prompt_utils.uncond_text_embeddings[None]
+            pu = prompt_utils
+            params = [pu.overhead_threshold, pu.front_threshold, pu.back_threshold, *pu.perp_neg_f_sb, *pu.perp_neg_f_fsb, *pu.perp_neg_f_fs,
+                      *pu.perp_neg_f_sf]
+            cache[key] = (text.to(dev, torch.float32).contiguous(), unc.to(dev, torch.float32).contiguous(), (C_.c_float * 15)(*params), prompt_utils)
+        text, unc, params, _keep = cache[key]
+        B = rgb.shape[0]
+        el, az = elevation.to(dev, torch.float32).contiguous(), azimuth.to(dev, torch.float32).contiguous()
+        perp, scale = self.use_perp_neg, -1.0 * self.cfg.guidance_perp_neg
+
+        def fill(io):
+            n_tok, dim = text.shape[1], text.shape[2]
+            stride = io.context.shape[0] // io.key[0]
+            w = torch.empty((B, 2), device=dev, dtype=torch.float32) if perp else None
+            check(lib().asd_prompt_context(ptr(text), ptr(unc), i32(text.shape[0]), i32(n_tok), i32(dim), ptr(el), ptr(az), i32(B), i32(int(perp)),
+                                           params, f32(scale), ptr(io.context), i32(stride), ptr(w), stream()))
+            return w
+
+        return fill
 
 
 def normalize_camera(camera_matrix: torch.Tensor) -> torch.Tensor:

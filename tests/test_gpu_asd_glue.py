@@ -186,3 +186,45 @@ def test_mvdream_guidance_matches_reference_call_golden():
     assert float(np.sqrt(np.mean((got - g["grad_rgb"] / scale) ** 2))) < 2e-3
     with pytest.raises(NotImplementedError):
         guid(rgb, pu, el, az, di, None)
+
+
+@pytest.mark.parametrize("perp_neg", [True, False])
+def test_prompt_context_kernel_matches_the_prompt_processor(perp_neg):
+    """asd_prompt_context vs PromptUtils.get_text_embeddings[_perp_neg] (pinned against the reference's own outputs in
+    tests/test_goldens_diffusion_cpu.py) over every branch: overhead, front / side / back, both azimuth signs, wrap-around at +-180"""
+    import ctypes as C
+
+    from scaledreamer_amd._lib import check, f32, i32, lib, ptr, stream
+    from scaledreamer_amd.guidance import PromptUtils
+
+    dev = torch.device("cuda", 0)
+    pu = PromptUtils.synthetic(seed=5)
+    el = torch.tensor([10.0, 75.0, 0.0, -20.0, 30.0, 61.0, 15.0, 5.0, 59.9, 12.0, 3.0])
+    az = torch.tensor([0.0, 10.0, 44.0, -60.0, 100.0, 170.0, -179.0, 200.0, -100.0, 89.5, -400.0])
+    B, n_tok, dim = el.shape[0], 77, 1024
+    stride = 80
+    n_rep = 4 if perp_neg else 2
+    ctx = torch.zeros(((n_rep + 1) * B * stride, dim), device=dev, dtype=torch.float16)
+    w = torch.full((B, 2), 7.0, device=dev)
+    params = [pu.overhead_threshold, pu.front_threshold, pu.back_threshold, *pu.perp_neg_f_sb, *pu.perp_neg_f_fsb, *pu.perp_neg_f_fs, *pu.perp_neg_f_sf]
+    text, unc = pu.text_embeddings_vd.to(dev).contiguous(), pu.uncond_text_embeddings_vd.to(dev).contiguous()
+    el_d, az_d = el.to(dev), az.to(dev)               # named: a temporary would be freed (and its block reused) before the launch
+    check(lib().asd_prompt_context(ptr(text), ptr(unc), i32(4), i32(n_tok), i32(dim), ptr(el_d), ptr(az_d), i32(B), i32(int(perp_neg)),
+                                   (C.c_float * 15)(*params), f32(-0.5), ptr(ctx), i32(stride), ptr(w) if perp_neg else None, stream()))
+    got = ctx.view((n_rep + 1) * B, stride, dim)
+    assert float(got[:, n_tok:].abs().max()) == 0.0                      # padding rows untouched
+    if perp_neg:
+        emb, wr = pu.get_text_embeddings_perp_neg(el, az, torch.ones(B), True)
+        want = torch.cat([emb, emb[:B]], 0)
+        torch.testing.assert_close(w.cpu(), wr * -0.5, rtol=2e-6, atol=1e-7)
+    else:
+        emb = pu.get_text_embeddings(el, az, torch.ones(B), True)
+        want = torch.cat([emb, emb[:B]], 0)
+    assert torch.equal(got[:, :n_tok].cpu(), want.half())                # same fp32 blend, same rounding
+    # no view dependence: one embedding for every camera
+    ctx.zero_()
+    t1, u1 = pu.text_embeddings[None].to(dev).contiguous(), pu.uncond_text_embeddings[None].to(dev).contiguous()
+    check(lib().asd_prompt_context(ptr(t1), ptr(u1), i32(1), i32(n_tok), i32(dim), ptr(el_d), ptr(az_d), i32(B), i32(0),
+                                   (C.c_float * 15)(*params), f32(0.0), ptr(ctx), i32(stride), None, stream()))
+    emb = pu.get_text_embeddings(el, az, torch.ones(B), False)
+    assert torch.equal(ctx[:3 * B * stride].view(3 * B, stride, dim)[:, :n_tok].cpu(), torch.cat([emb, emb[:B]], 0).half())
