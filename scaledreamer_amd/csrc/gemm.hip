@@ -283,9 +283,25 @@ __device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_args p) {
-    constexpr int NW = WM * WN;
+// wait until at most min(ahead, MAX) tiles of PER loads each are still in flight (s_waitcnt takes an immediate)
+template <int PER, int MAX>
+__device__ __forceinline__ void ring_wait(int ahead) {
+    if constexpr (MAX <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (ahead >= MAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAX * PER) : "memory");
+        else ring_wait<PER, MAX - 1>(ahead);
+    }
+}
+
+// KG > 1: intra-block split-K.  KG groups of WM x WN waves share the block's barriers; group g owns its own pair of LDS stages and
+// the k-steps ks0 + g, ks0 + g + KG, ...; at the end the groups' accumulators are summed through LDS and group 0 runs the epilogue.
+// For launches with few blocks (M <= 1280): a 64x64 block alone on its CU runs ONE wave per SIMD, so every k-step exposes its LDS
+// read latency and its barrier (1280^3: ~1100 cycles per k-step for 512 cycles of MFMA); two or four waves per SIMD overlap them
+// and the barrier count per K halves / quarters — without the fp32 slabs and the second launch of split-K across blocks.
+template <int BM, int BN, int WM, int WN, bool CONV, int NST = 2, int KG = 1>
+__global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_gemm_args p) {
+    constexpr int NW = WM * WN;               // waves per k-group
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int RB = 128;                   // LDS row bytes (64 halfs)
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
@@ -293,10 +309,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     constexpr int ASLABS = BM / 8, TSLABS = (BM + BN) / 8;   // 8-row slabs (1 KiB per wave instruction); A first, then W
     constexpr int SPW = (TSLABS + NW - 1) / NW;            // slabs per wave (slab id = wave + j * NW)
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tile must be a multiple of 16 x 16");
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A | W]
+    static_assert(NST == 2 || TSLABS % NW == 0, "ring variants count their loads per wave: every wave must own the same number of slabs");
+    static_assert(KG == 1 || NST == 2, "k-groups use the two-stage loop");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [KG][NST][A | W]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: slab ids, LDS destinations (M0) and operand bases stay in SGPRs
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: slab ids, LDS destinations (M0) and operand bases stay in SGPRs
+    const int kg = KG > 1 ? wave_all / NW : 0;                        // k-group of this wave
+    const int wave = wave_all - kg * NW;                              // wave within its group
+    char* const gsm = smem + kg * (NST * STAGE_BYTES);
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int item, tm_, tn_;
@@ -355,12 +376,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
         const int slab = wave + j * NW;
-        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + w_slab_rows(slab - ASLABS) + wl, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + ks0 * 128;
-        else roff[j] = CONV ? 0u : (unsigned)min(m0 + slab * 8 + lrow, p.M - 1) * (unsigned)(p.lda * 2) + lch * 16 + ks0 * 128;
+        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + w_slab_rows(slab - ASLABS) + wl, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + (ks0 + kg) * 128;
+        else roff[j] = CONV ? 0u : (unsigned)min(m0 + slab * 8 + lrow, p.M - 1) * (unsigned)(p.lda * 2) + lch * 16 + (ks0 + kg) * 128;
     }
 
     auto issue_rows = [&](int stage) __attribute__((always_inline)) {
-        char* st = smem + stage * STAGE_BYTES;
+        char* st = gsm + stage * STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < SPW; ++j) {
             const int slab = wave + j * NW;
@@ -368,12 +389,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             if (CONV && slab < ASLABS) continue;
             const char* base = slab >= ASLABS ? (const char*)p.W : (const char*)p.A;
             load_slab(base + roff[j], st + slab * 8 * RB);
-            roff[j] += 128;
+            roff[j] += 128 * KG;
         }
     };
     // general path: conv A slabs (only_conv_a) or every slab with per-lane zero-page substitution
     auto issue_general = [&](int ks, int stage, bool only_conv_a) __attribute__((always_inline)) {
-        char* st = smem + stage * STAGE_BYTES;    // slab s of the stage lives at st + s * 1 KiB (A slabs, then W slabs)
+        char* st = gsm + stage * STAGE_BYTES;     // slab s of the stage lives at st + s * 1 KiB (A slabs, then W slabs)
         const int k0 = ks * 64;
         const int kc = k0 + lch * 8;              // first k of this lane's chunk
         const bool k_ok = kc < p.K;
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
     // When the whole tile lies in ONE image row (always at W >= BM), the k-steps of the other ky parity multiply zero pages for
     // every row of the tile: skip them (wave-uniform) — 6 or 3 of the 9 taps remain, 2x fewer k-steps on average.
     int live_ky_parity = -1;    // -1: every k-step is live
-    if (CONV && p.upsample == 2 && (p.Cin & 63) == 0) {
+    if (NST == 2 && KG == 1 && CONV && p.upsample == 2 && (p.Cin & 63) == 0) {
         const int m_last = min(m0 + BM, p.M) - 1;
         if (m0 / p.Wout == m_last / p.Wout) live_ky_parity = ((m0 / p.Wout) % p.Hout + p.pad) & 1;
     }
@@ -466,11 +487,85 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
         const int ky = ((ks * 64) / p.Cin) / 3;
         return (ky & 1) == live_ky_parity;
     };
+    auto compute = [&](const char* As) __attribute__((always_inline)) {
+        // big register tiles: keep ONE set of fragments live (no cross-kh prefetch), the loop is load-bound anyway
+#pragma unroll TM * TN >= 32 ? 1 : 2
+        for (int kh = 0; kh < 2; ++kh) {
+            half8 xa[TM], wb[TN];
+            const int fs = TM * TN >= 32 ? (((kh * 4 + fq) ^ (frow & 7)) * 16) : fsw[kh];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *(const half8*)(As + fa0 + fs + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(As + fb0 + fs + j * 16 * RB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (KG > 1) {
+        int k = ks0 + kg;
+        const int iters = (ks1 - ks0 + KG - 1) / KG;     // block-uniform: every group passes every barrier
+        if (k < ks1) issue(k, 0);
+        for (int it = 0, stage = 0; it < iters; ++it, stage ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int kn = k + KG;
+            if (kn < ks1) issue(kn, stage ^ 1);
+            if (k < ks1) compute(gsm + stage * STAGE_BYTES);
+            k = kn;
+        }
+        // sum the groups' accumulators into group 0: [wave][fragment][lane] floatx4, 16 B per lane (conflict-free)
+        floatx4* red = (floatx4*)smem;
+#pragma unroll 1
+        for (int g = KG - 1; g >= 1; --g) {
+            __syncthreads();     // main loop / previous round done with this LDS
+            if (kg == g) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) red[((wave * TM + i) * TN + j) * 64 + lane] = acc[i][j];
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const floatx4 t = red[((wave * TM + i) * TN + j) * 64 + lane];
+                        acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
+                    }
+            }
+        }
+    } else if constexpr (NST > 2) {
+        // Ring of NST stages for launches with FEW blocks (M <= 1280 layers, weight-streaming low-resolution convolutions): a block
+        // that is alone on its CU cannot rely on co-resident blocks to cover its load latency, and with two stages each k-step
+        // costs one full L2 / HBM round trip (~0.6 us: 1280^3 takes 14 us for 1.7 us of MFMA work).  NST - 1 tiles are in flight;
+        // every wave owns SPW loads per tile and loads retire in order, so "tile i has landed" is vmcnt(<= tiles still allowed
+        // in flight * SPW); the barrier then makes tile i visible and guarantees that everyone is done with tile i - 1, whose
+        // stage the next issue overwrites.
+        const int nk = ks1 - ks0;
+        if (nk > 0) {
+#pragma unroll
+            for (int s = 0; s < NST - 1; ++s)
+                if (s < nk) issue(ks0 + s, s);
+            int stage = 0, fill = NST - 1;
+            for (int i = 0; i < nk; ++i) {
+                ring_wait<SPW, NST - 2>(nk - 1 - i);
+                __builtin_amdgcn_s_barrier();
+                if (i + NST - 1 < nk) issue(ks0 + i + NST - 1, fill);
+                compute(gsm + stage * STAGE_BYTES);
+                stage = stage + 1 == NST ? 0 : stage + 1;
+                fill = fill + 1 == NST ? 0 : fill + 1;
+            }
+        }
+    } else {
     int k = ks0;
     while (k < ks1 && !live(k)) ++k;
     if (k < ks1) {
         // Two stages.  Measured (tools/map_ab.py): 3- and 4-stage rings with vmcnt(n) waits are 5-40 % SLOWER on every shape of the
-        // step, small K included — the extra LDS costs the second / third co-resident block per CU, and it is the co-resident
+        // step with MANY blocks — the extra LDS costs the second / third co-resident block per CU, and it is the co-resident
         // blocks (independent barriers, out of phase) that fill each other's load and barrier bubbles.
         issue(k, 0);
         for (int stage = 0;; stage ^= 1) {
@@ -479,31 +574,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16_kernel(const asd_gemm_a
             int kn = k + 1;
             while (kn < ks1 && !live(kn)) ++kn;
             if (kn < ks1) issue(kn, stage ^ 1);
-            const char* As = smem + stage * STAGE_BYTES;
-            // big register tiles: keep ONE set of fragments live (no cross-kh prefetch), the loop is load-bound anyway
-#pragma unroll TM * TN >= 32 ? 1 : 2
-            for (int kh = 0; kh < 2; ++kh) {
-                half8 xa[TM], wb[TN];
-                const int fs = TM * TN >= 32 ? (((kh * 4 + fq) ^ (frow & 7)) * 16) : fsw[kh];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) xa[i] = *(const half8*)(As + fa0 + fs + i * 16 * RB);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wb[j] = *(const half8*)(As + fb0 + fs + j * 16 * RB);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-            }
+            compute(gsm + stage * STAGE_BYTES);
             if (kn >= ks1) break;
             k = kn;
         }
+    }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
     const int em = lane & 15, en = (lane >> 4) * 4;
     auto out_row = [&](int i) { const int m = m0 + wm * (BM / WM) + i * 16 + em; return m < p.M ? m : -1; };
+    if (KG > 1 && kg != 0) {    // group 0 stores; the others only keep the GroupNorm reduction's block barriers company
+        if (p.split_k == 1 && p.act != 2 && p.gn_partials != nullptr) {
+            __syncthreads(); __syncthreads();    // gn_tile_begin
+            __syncthreads();                     // gn_tile_end
+        }
+        return;
+    }
     if (p.split_k > 1) {  // split-K: fp32 partial slabs, finished by splitk_epilogue_kernel
         tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, false, nullptr);
         return;
@@ -927,15 +1015,21 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
 
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
-struct asd_gemm_tile { int bm, bn, wm, wn; };
-#define ASD_GEMM_NCFG 15
+struct asd_gemm_tile { int bm, bn, wm, wn, nst, kg; };   // nst: stages of the operand ring (0 = the default two); kg: k-groups (0 = one)
+#define ASD_GEMM_NCFG 20
 #define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
                           // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {128, 320, 2, 4}, {256, 256, 2, 4}, {256, 320, 2, 4},
     {320, 128, 5, 2}, {256, 64, 4, 2}, {256, 128, 4, 2}, {256, 64, 4, 2}, {256, 128, 4, 2},
     {64, 64, 2, 2},    // 12: small tile, 32 KB LDS: five blocks per CU for the latency-bound K <= 1280 linears
-    {256, 64, 4, 1}, {256, 128, 4, 1}};   // 13, 14: window convolution, two blocks per CU, FOUR waves with 64 px x BN wave tiles
+    {256, 64, 4, 1}, {256, 128, 4, 1},    // 13, 14: window convolution, two blocks per CU, FOUR waves with 64 px x BN wave tiles
+    // 15-19: for launches with few blocks (a block alone on its CU runs one wave per SIMD and has nobody to hide its LDS / barrier /
+    // load latencies): 15 = 64x64 with a 4-stage operand ring; 16-19 = intra-block split-K (k-groups sharing the block's barriers):
+    // 64x64 x 2 groups, 64x64 x 4 groups, 128x64 x 2, 128x128 x 2
+    {64, 64, 2, 2, 4, 1}, {64, 64, 2, 2, 2, 2}, {64, 64, 2, 2, 2, 4}, {128, 64, 2, 2, 2, 2}, {128, 128, 2, 2, 2, 2}};
+static int asd_cfg_stages(int cfg) { return asd_gemm_tiles[cfg].nst > 2 ? asd_gemm_tiles[cfg].nst : 2; }
+static int asd_cfg_kgroups(int cfg) { return asd_gemm_tiles[cfg].kg > 1 ? asd_gemm_tiles[cfg].kg : 1; }
 static bool asd_cfg_is_window(int cfg) { return (cfg >= ASD_GEMM_WIN0 && cfg < ASD_GEMM_WIN0 + 4) || cfg == 13 || cfg == 14; }
 static bool asd_cfg_is_win2(int cfg) { return cfg == ASD_GEMM_WIN0 + 2 || cfg == ASD_GEMM_WIN0 + 3 || cfg == 13 || cfg == 14; }
 
@@ -1191,24 +1285,25 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         return ASD_OK;
     }
     const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
-    const size_t lds = (size_t)2 * (bm + bn) * 128;
+    const size_t lds = (size_t)asd_cfg_stages(cfg) * asd_cfg_kgroups(cfg) * (bm + bn) * 128;
     if (a->group_m < 1 || a->group_n < 1) asd_pick_group(asd_div_up(a->M, bm), asd_div_up(a->N, bn), bm, bn, lds, &a->group_m, &a->group_n);
-    const dim3 grid(8 * asd_div_up(tiles * a->split_k, 8)), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * 64);   // asd_xcd_item
+    const dim3 grid(8 * asd_div_up(tiles * a->split_k, 8)), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * asd_cfg_kgroups(cfg) * 64);   // asd_xcd_item
     hipStream_t s = (hipStream_t)stream;
-#define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_)                                                                           \
+#define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_, NST_, KG_)                                                                \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM_ + BN_) * 128);                \
+            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NST_ * KG_ * (BM_ + BN_) * 128);       \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_>), grid, block, lds, s, *a);                       \
+        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_>), grid, block, lds, s, *a);            \
     } while (0)
-#define GEMM_CASE(IDX_, BM_, BN_, WM_, WN_)                                                                              \
+#define GEMM_CASE_N(IDX_, BM_, BN_, WM_, WN_, NST_, KG_)                                                                 \
     case IDX_:                                                                                                           \
-        if (a->conv) GEMM_LAUNCH(BM_, BN_, WM_, WN_, true); else GEMM_LAUNCH(BM_, BN_, WM_, WN_, false);                 \
+        if (a->conv) GEMM_LAUNCH(BM_, BN_, WM_, WN_, true, NST_, KG_); else GEMM_LAUNCH(BM_, BN_, WM_, WN_, false, NST_, KG_); \
         break
+#define GEMM_CASE(IDX_, BM_, BN_, WM_, WN_) GEMM_CASE_N(IDX_, BM_, BN_, WM_, WN_, 2, 1)
     switch (cfg) {
         GEMM_CASE(0, 128, 64, 2, 2);
         GEMM_CASE(1, 128, 128, 2, 2);
@@ -1219,9 +1314,15 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         GEMM_CASE(6, 256, 320, 2, 4);
         GEMM_CASE(7, 320, 128, 5, 2);
         GEMM_CASE(12, 64, 64, 2, 2);
+        GEMM_CASE_N(15, 64, 64, 2, 2, 4, 1);
+        GEMM_CASE_N(16, 64, 64, 2, 2, 2, 2);
+        GEMM_CASE_N(17, 64, 64, 2, 2, 2, 4);
+        GEMM_CASE_N(18, 128, 64, 2, 2, 2, 2);
+        GEMM_CASE_N(19, 128, 128, 2, 2, 2, 2);
         default: asd_set_error("bad tile configuration %d", cfg); return ASD_ERR_ARG;
     }
 #undef GEMM_CASE
+#undef GEMM_CASE_N
 #undef GEMM_LAUNCH
     if (a->split_k > 1) {
         const size_t total4 = (size_t)a->M * a->N / 4;
@@ -1249,6 +1350,7 @@ static int asd_tune_candidates(const asd_gemm_args* a, int (*out)[2], int max_ou
             continue;
         }
         if (bn != 64 && a->N % bn != 0) continue;
+        if ((asd_gemm_tiles[t].nst > 2 || asd_gemm_tiles[t].kg > 1) && ((a->conv && a->upsample == 2) || (long long)asd_div_up(a->M, bm) * asd_div_up(a->N, bn) > 1024)) continue;
         if (geglu && (t == 4 || t == 6)) continue;
         if (bn == 64 && a->N % 128 == 0 && a->N >= 256 && bm == 128) continue;
         const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);

@@ -20,6 +20,10 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff
 #ifndef GN_CAP_A
 #define GN_CAP_A 512  // apply blocks per launch
 #endif
+#ifndef GN_FOLD_RECORDS
+#define GN_FOLD_RECORDS 96   // up to this many epilogue records per batch element are summed by every apply block itself (24 KB of L2
+                             // reads, four loads in flight per thread); above it a reduce launch (~5 us) runs first
+#endif
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x1, int c1, const half_t* __restrict__ x2,
                                                        int c2, int hw, int rows_per_block, float* __restrict__ stats) {
@@ -78,13 +82,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
-// sum of the statistics partials of batch element b -> st[64] (LDS); 256 threads
+// sum of the statistics partials of batch element b -> st[64] (LDS); 256 threads.  Four independent loads in flight per thread:
+// the partials are the head of the kernel's dependency chain (partials -> scale/shift -> first store), and these launches are short
+// enough (5-10 us) that every serialized L2/HBM round trip shows.
 __device__ __forceinline__ void gn_reduce_partials(const float* __restrict__ partials, int b, int n_chunks, float* st /*[64]*/,
                                                    float (*scratch)[64] /*[4][64]*/) {
     const int tid = threadIdx.x, v = tid & 63, q = tid >> 6;
-    float acc = 0.f;
-    for (int c = q; c < n_chunks; c += 4) acc += partials[((size_t)b * n_chunks + c) * 64 + v];
-    scratch[q][v] = acc;
+    const float* src = partials + (size_t)b * n_chunks * 64 + v;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = q;
+    for (; c + 12 < n_chunks; c += 16) {
+        const float t0 = src[(size_t)c * 64], t1 = src[(size_t)(c + 4) * 64], t2 = src[(size_t)(c + 8) * 64], t3 = src[(size_t)(c + 12) * 64];
+        a0 += t0; a1 += t1; a2 += t2; a3 += t3;
+    }
+    for (; c < n_chunks; c += 4) a0 += src[(size_t)c * 64];
+    scratch[q][v] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (tid < 64) st[tid] = (scratch[0][tid] + scratch[1][tid]) + (scratch[2][tid] + scratch[3][tid]);
     __syncthreads();
@@ -103,50 +115,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     __shared__ float scratch[4][64];
     const int C = c1 + c2, slots = C / 8, cg = C / 32;
     const int b = blockIdx.x, tid = threadIdx.x;
-    gn_reduce_partials(partials, b, n_chunks, st, scratch);
-    if (blockIdx.y == 0 && tid < 64) stats_out[b * 64 + tid] = st[tid];   // kept for the backward pass
-    const float* stats = st - b * 64;                                        // (indexing below is (b*32 + g)*2)
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
     const int rsub = slots >= 256 ? 0 : tid / slots;
     const int slot0 = slots >= 256 ? tid : tid % slots;
+    // The first trip's rows and the affine parameters do not depend on the statistics: request them BEFORE the partials are
+    // reduced (the compiler cannot move loads across the barrier inside gn_reduce_partials), so the launch pays one memory
+    // round trip before its first store instead of three in a row — most of these launches are 5-10 us long.
+    const bool act0 = slot0 < slots && rsub < rows_in_flight;
+    const int cA = slot0 * 8;
+    const half_t* baseA = cA < c1 ? x1 + (size_t)b * hw * c1 + cA : x2 + (size_t)b * hw * c2 + (cA - c1);
+    const size_t rstrideA = cA < c1 ? c1 : c2;
+    half8 pre[GN_UNR], gpre = {}, bpre = {};
+    const int rA = r0 + rsub;
+    const bool pre_ok = act0 && rA + (GN_UNR - 1) * rows_in_flight < r1;
+    if (act0) { gpre = *(const half8*)(gamma + cA); bpre = *(const half8*)(beta + cA); }
+    if (pre_ok) {
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) pre[u] = *(const half8*)(baseA + (size_t)(rA + u * rows_in_flight) * rstrideA);
+    }
+    gn_reduce_partials(partials, b, n_chunks, st, scratch);
+    if (blockIdx.y == 0 && tid < 64) stats_out[b * 64 + tid] = st[tid];   // kept for the backward pass
 #pragma unroll
     for (int j = 0; j < 2; ++j) {  // second pass only when more than 256 slots (C = 2560)
         const int slot = slot0 + j * 256;
         if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
         const int c = slot * 8;
+        half8 gv = gpre, bv = bpre;
+        if (j == 1) { gv = *(const half8*)(gamma + c); bv = *(const half8*)(beta + c); }
         float sa[8], sb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int g = (c + k) / cg;
-            const float mean = stats[(b * 32 + g) * 2] * inv_cnt;
-            const float var = fmaxf(stats[(b * 32 + g) * 2 + 1] * inv_cnt - mean * mean, 0.f);
-            sa[k] = rsqrtf(var + eps) * (float)gamma[c + k];
-            sb[k] = (float)beta[c + k] - mean * sa[k];
+            const float mean = st[g * 2] * inv_cnt;
+            const float var = fmaxf(st[g * 2 + 1] * inv_cnt - mean * mean, 0.f);
+            sa[k] = rsqrtf(var + eps) * (float)gv[k];
+            sb[k] = (float)bv[k] - mean * sa[k];
         }
         const half_t* base = c < c1 ? x1 + (size_t)b * hw * c1 + c : x2 + (size_t)b * hw * c2 + (c - c1);
         const size_t rstride = c < c1 ? c1 : c2;
         half_t* ybase = y + (size_t)b * hw * C + c;
-        int r = r0 + rsub;
-        for (; r + (GN_UNR - 1) * rows_in_flight < r1; r += GN_UNR * rows_in_flight) {
-            half8 v[GN_UNR];
-#pragma unroll
-            for (int u = 0; u < GN_UNR; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
-#pragma unroll
-            for (int u = 0; u < GN_UNR; ++u) {
-                half8 o;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float f = fmaf((float)v[u][k], sa[k], sb[k]);
-                    if (silu) f = silu_f(f);
-                    o[k] = (half_t)f;
-                }
-                *(half8*)(ybase + (size_t)(r + u * rows_in_flight) * C) = o;
-            }
-        }
-        for (; r < r1; r += rows_in_flight) {
-            const half8 v = *(const half8*)(base + (size_t)r * rstride);
+        auto emit = [&](const half8& v, int r) __attribute__((always_inline)) {
             half8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -155,7 +165,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                 o[k] = (half_t)f;
             }
             *(half8*)(ybase + (size_t)r * C) = o;
+        };
+        int r = r0 + rsub;
+        if (j == 0 && pre_ok) {
+#pragma unroll
+            for (int u = 0; u < GN_UNR; ++u) emit(pre[u], r + u * rows_in_flight);
+            r += GN_UNR * rows_in_flight;
         }
+        for (; r + (GN_UNR - 1) * rows_in_flight < r1; r += GN_UNR * rows_in_flight) {
+            half8 v[GN_UNR];
+#pragma unroll
+            for (int u = 0; u < GN_UNR; ++u) v[u] = *(const half8*)(base + (size_t)(r + u * rows_in_flight) * rstride);
+#pragma unroll
+            for (int u = 0; u < GN_UNR; ++u) emit(v[u], r + u * rows_in_flight);
+        }
+        for (; r < r1; r += rows_in_flight) emit(*(const half8*)(base + (size_t)r * rstride), r);
     }
 }
 
@@ -253,30 +277,43 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restr
     __shared__ float scratch[4][64];
     const int slots = C / 8, cg = C / 32;
     const int b = blockIdx.x, tid = threadIdx.x;
-    gn_reduce_partials(bpartials, b, n_chunks, st, scratch);
-    const float* bstats = st - b * 64;
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
     const int rsub = slots >= 256 ? 0 : tid / slots;
     const int slot0 = slots >= 256 ? tid : tid % slots;
+    // first two rows (x, dy, dx_add) and the affine parameters are requested before the partials are reduced (see gn_apply_kernel)
+    const bool act0 = slot0 < slots && rsub < rows_in_flight;
+    const int cA = slot0 * 8, rA = r0 + rsub;
+    const bool pre_ok = act0 && rA + rows_in_flight < r1;
+    half8 gpre = {}, bpre = {}, px[2], pd[2], pa[2] = {};
+    if (act0) { gpre = *(const half8*)(gamma + cA); bpre = *(const half8*)(beta + cA); }
+    if (pre_ok) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t off = ((size_t)b * hw + rA + u * rows_in_flight) * C + cA;
+            px[u] = *(const half8*)(x + off); pd[u] = *(const half8*)(dy + off);
+            if (dx_add) pa[u] = *(const half8*)(dx_add + off);
+        }
+    }
+    gn_reduce_partials(bpartials, b, n_chunks, st, scratch);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = slot0 + j * 256;
         if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
         const int c = slot * 8;
+        half8 gv = gpre, bv = bpre;
+        if (j == 1) { gv = *(const half8*)(gamma + c); bv = *(const half8*)(beta + c); }
         float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int g = (c + k) / cg;
             mean[k] = fstats[(b * 32 + g) * 2] * inv_cnt;
             rstd[k] = rsqrtf(fmaxf(fstats[(b * 32 + g) * 2 + 1] * inv_cnt - mean[k] * mean[k], 0.f) + eps);
-            gm[k] = (float)gamma[c + k]; bt[k] = (float)beta[c + k];
-            m1[k] = bstats[(b * 32 + g) * 2] * inv_cnt; m2[k] = bstats[(b * 32 + g) * 2 + 1] * inv_cnt;
+            gm[k] = (float)gv[k]; bt[k] = (float)bv[k];
+            m1[k] = st[g * 2] * inv_cnt; m2[k] = st[g * 2 + 1] * inv_cnt;
         }
-        for (int r = r0 + rsub; r < r1; r += rows_in_flight) {
-            const size_t off = ((size_t)b * hw + r) * C + c;
-            const half8 xv = *(const half8*)(x + off), dv = *(const half8*)(dy + off);
+        auto emit = [&](const half8& xv, const half8& dv, const half8& av, int r) __attribute__((always_inline)) {
             half8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -286,11 +323,31 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const half_t* __restr
                 o[k] = (half_t)(rstd[k] * (gg - m1[k] - xh * m2[k]));
             }
             if (dx_add) {   // the gradient of the block's other consumer (ResnetBlock shortcut) is accumulated here
-                const half8 av = *(const half8*)(dx_add + off);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (half_t)((float)o[k] + (float)av[k]);
             }
-            *(half8*)(dx + off) = o;
+            *(half8*)(dx + ((size_t)b * hw + r) * C + c) = o;
+        };
+        int r = r0 + rsub;
+        if (j == 0 && pre_ok) {
+            emit(px[0], pd[0], pa[0], r);
+            emit(px[1], pd[1], pa[1], r + rows_in_flight);
+            r += 2 * rows_in_flight;
+        }
+        for (; r + rows_in_flight < r1; r += 2 * rows_in_flight) {   // two rows (4-6 loads) in flight per thread
+            const size_t off0 = ((size_t)b * hw + r) * C + c, off1 = off0 + (size_t)rows_in_flight * C;
+            const half8 xv0 = *(const half8*)(x + off0), dv0 = *(const half8*)(dy + off0);
+            const half8 xv1 = *(const half8*)(x + off1), dv1 = *(const half8*)(dy + off1);
+            half8 av0 = {}, av1 = {};
+            if (dx_add) { av0 = *(const half8*)(dx_add + off0); av1 = *(const half8*)(dx_add + off1); }
+            emit(xv0, dv0, av0, r);
+            emit(xv1, dv1, av1, r + rows_in_flight);
+        }
+        for (; r < r1; r += rows_in_flight) {
+            const size_t off = ((size_t)b * hw + r) * C + c;
+            half8 av = {};
+            if (dx_add) av = *(const half8*)(dx_add + off);
+            emit(*(const half8*)(x + off), *(const half8*)(dy + off), av, r);
         }
     }
 }
@@ -504,16 +561,36 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
 
 // records[b][n][64] -> out[b][gridDim.y][64]: the per-tile statistics records of a producer's epilogue, summed in gridDim.y slices per
 // batch element (the apply kernel's prologue adds the slices)
-__global__ __launch_bounds__(256) void gn_reduce_records_kernel(const float* __restrict__ records, int n, float* __restrict__ out) {
-    __shared__ float scratch[4][64];
+// 1024 threads = 16 record lanes x 64 values; 8 independent loads in flight per thread: with 4 lanes and one load per trip the 8192
+// records of a 64x64-tiled 512x512 layer were 128 dependent L2/HBM round trips per block (125 us for 2 MB).
+__global__ __launch_bounds__(1024) void gn_reduce_records_kernel(const float* __restrict__ records, int n, float* __restrict__ out) {
+    __shared__ float scratch[16][64];
     const int b = blockIdx.x, S = gridDim.y, per = (n + S - 1) / S;
     const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
     const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float acc = 0.f;
-    for (int c = c0 + q; c < c1; c += 4) acc += records[((size_t)b * n + c) * 64 + v];
-    scratch[q][v] = acc;
+    const float* src = records + (size_t)b * n * 64 + v;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int c = c0 + q;
+    for (; c + 7 * 16 < c1; c += 8 * 16) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(c + u * 16) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += t[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (c + u * 16 < c1) acc[u] += src[(size_t)(c + u * 16) * 64];
+    scratch[q][v] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    if (threadIdx.x < 64) out[((size_t)b * S + blockIdx.y) * 64 + v] = (scratch[0][v] + scratch[1][v]) + (scratch[2][v] + scratch[3][v]);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += scratch[u][v];
+        out[((size_t)b * S + blockIdx.y) * 64 + v] = s;
+    }
 }
 
 extern "C" {
@@ -524,6 +601,7 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     const int C = c1 + (x2 ? c2 : 0);
     if (!x2) c2 = 0;
     ASD_CHECK_ARG(C % 32 == 0 && C % 8 == 0 && c1 % 8 == 0, "channels must be a multiple of 32");
+    ASD_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "gamma / beta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* partials = stats + 64 * batch;   // [batch, chunks_s, 64] per-block partial sums (plain stores: nothing to zero)
     // statistics: >= 16 rows per block and at most ~512 blocks (each ends with 64 atomics on one hot set of addresses);
@@ -546,17 +624,18 @@ int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw,
                             int32_t silu, const float* partials, int32_t records, void* y, float* stats /* ASD_GN_STATS_FLOATS(batch) */, void* stream) {
     ASD_CHECK_ARG(x && gamma && beta && y && stats && partials && batch > 0 && hw > 0 && records > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0 && c % 8 == 0, "channels must be a multiple of 32");
+    ASD_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "gamma / beta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = asd_div_up(hw, 16);
     const int cap_a = asd_div_up(GN_CAP_A, batch), chunks_a = chunks > cap_a ? cap_a : chunks;
     // every apply block sums the records of its batch element in its prologue: with many tiles, sum them once first
     const float* part = partials;
     int n = records;
-    if ((long long)records * chunks_a > 2048) {       // slices of <= 32 records, at most 16 of them left for the apply prologue
+    if (records > GN_FOLD_RECORDS) {                  // slices of <= 32 records, at most 16 of them left for the apply prologue
         int slices = asd_div_up(records, 32);
         if (slices > 16) slices = 16;
         float* tmp = stats + 64 * batch;              // the per-block partials area of ASD_GN_STATS_FLOATS(batch)
-        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(256), 0, s, partials, records, tmp);
+        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(1024), 0, s, partials, records, tmp);
         part = tmp;
         n = slices;
     }
@@ -571,6 +650,7 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
                           float* bwd_stats, void* stream) {
     ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && dx && bwd_stats && batch > 0 && hw > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
+    ASD_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "gamma / beta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int chunks = asd_div_up(hw, 16);
     // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
@@ -591,15 +671,16 @@ int asd_groupnorm_bwd_apply_f16(const void* x, const void* dy, int32_t c, int32_
                                 const void* dx_add, void* dx, float* scratch, void* stream) {
     ASD_CHECK_ARG(x && dy && gamma && beta && fwd_stats && partials && dx && scratch && batch > 0 && hw > 0 && records > 0, "null argument");
     ASD_CHECK_ARG(c % 32 == 0, "channels must be a multiple of 32");
+    ASD_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "gamma / beta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = asd_div_up(hw, 16);
     const int cap_a = asd_div_up(GN_CAP_A, batch), chunks_a = chunks > cap_a ? cap_a : chunks;
     const float* part = partials;
     int n = records;
-    if ((long long)records * chunks_a > 2048) {
+    if (records > GN_FOLD_RECORDS) {
         int slices = asd_div_up(records, 32);
         if (slices > 16) slices = 16;
-        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(256), 0, s, partials, records, scratch);
+        hipLaunchKernelGGL(gn_reduce_records_kernel, dim3(batch, slices), dim3(1024), 0, s, partials, records, scratch);
         part = scratch;
         n = slices;
     }

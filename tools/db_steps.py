@@ -1,0 +1,42 @@
+"""Per-step kernel-family breakdown and idle time from a rocprofv3 rocpd database (the default output of rocprofv3 7.x when no
+--output-format is given).   python tools/db_steps.py <p_results.db> [n_last_steps] [--csv out.csv]
+A step starts at the marcher's first kernel; the LAST n steps (default 10) are averaged."""
+import re, sqlite3, sys
+
+db = sys.argv[1]
+nlast = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 10
+c = sqlite3.connect(db)
+rows = c.execute("select start, end, name from kernels order by start").fetchall()
+short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "")).replace("at::native::", "")[:64]
+starts = [i for i, r in enumerate(rows) if "march_kernel" in r[2]]
+starts = [s for k, s in enumerate(starts) if k == 0 or s - starts[k - 1] > 50]
+# bench.py: the steps are followed by roofline micro-benchmarks that also march; use --skip-last S to stay inside the timed region
+skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0
+a, b = starts[-nlast - 1 - skip], starts[-1 - skip]
+n = nlast
+seg = rows[a:b]
+wall = (rows[b][0] - rows[a][0]) / n / 1e6
+fam, cnt = {}, {}
+busy_end, idle = seg[0][0], 0
+for s, e, nm in seg:
+    k = short(nm)
+    fam[k] = fam.get(k, 0) + (e - s)
+    cnt[k] = cnt.get(k, 0) + 1
+    if s > busy_end:
+        idle += s - busy_end
+    busy_end = max(busy_end, e)
+tot = sum(fam.values())
+print(f"{n} steps: wall {wall:.3f} ms/step, kernel sum {tot / n / 1e6:.3f} ms/step, idle {idle / n / 1e6:.3f} ms/step, {len(seg) / n:.0f} launches/step")
+for k, v in sorted(fam.items(), key=lambda x: -x[1])[:50]:
+    print(f"{v / n / 1e6:7.3f} ms {cnt[k] / n:7.1f} x {v / cnt[k] / 1e3:8.1f} us  {k}")
+if "--csv" in sys.argv:
+    out = sys.argv[sys.argv.index("--csv") + 1]
+    allfam = {}
+    for s, e, nm in rows:
+        d = allfam.setdefault(nm, [0, 0, 10**18, 0])
+        d[0] += 1; d[1] += e - s; d[2] = min(d[2], e - s); d[3] = max(d[3], e - s)
+    gt = sum(d[1] for d in allfam.values())
+    with open(out, "w") as fh:
+        fh.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+        for nm, d in sorted(allfam.items(), key=lambda x: -x[1][1])[:80]:
+            fh.write(f'"{nm[:160]}",{d[0]},{d[1]},{d[1] / d[0]:.1f},{100 * d[1] / gt:.2f},{d[2]},{d[3]}\n')
