@@ -22,6 +22,30 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+// max of three (one VALU instruction; exact).  Written as asm because fmaxf() makes the compiler canonicalise every operand that
+// comes out of an MFMA with an extra v_max x, x: 52 instructions for the 16-score maximum instead of 8.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// Reductions over the four 16-lane rows of the wave (the lanes l, l^16, l^32, l^48 hold the same query column): gfx950's row swaps
+// (v_permlane16_swap / v_permlane32_swap: VALU, no LDS round trip) instead of two ds_bpermute + s_waitcnt lgkmcnt(0) each.
+__device__ __forceinline__ float rows_max(float v) {
+    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = max3f(__uint_as_float(t[0]), __uint_as_float(t[1]), -3.0e38f);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max3f(__uint_as_float(t[0]), __uint_as_float(t[1]), -3.0e38f);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
 #define HD 64      // head dim
 #define KT 64      // keys per tile
 #define QW 32      // queries per wave
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         // the last tile, and the accumulator rescale is skipped while no
         // lane's running max moved.
         const int key_base = t * KT + lg * 4;
-        half4 pf[4][2];  // probabilities, fp16: [kt][qs] -> 4 consecutive keys
+        half8 pb[2][2];  // probabilities, fp16: [j][qs] = B operand of PV k-step j: keys of sub-tiles kt = 2j (elements 0-3) and 2j + 1 (4-7)
         if (t == n_tiles - 1 && (p.lk & (KT - 1)) != 0) {
             asm volatile("" ::: "memory");   // keep this a (wave-uniform) branch: if-converted it costs 32 selects on every tile
 #pragma unroll
@@ -142,26 +166,29 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         }
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            float mx = fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qs][0], s[kt][qs][1]), fmaxf(s[kt][qs][2], s[kt][qs][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qs], mx * sl2);          // running max of scale*log2e*s (scale > 0)
+            // 16 scores per lane -> 8 x v_max3_f32 (depth 3); fmaxf() costs a canonicalising v_max per MFMA-produced operand on top
+            const float a0 = max3f(s[0][qs][0], s[0][qs][1], s[0][qs][2]), a1 = max3f(s[0][qs][3], s[1][qs][0], s[1][qs][1]);
+            const float a2 = max3f(s[1][qs][2], s[1][qs][3], s[2][qs][0]), a3 = max3f(s[2][qs][1], s[2][qs][2], s[2][qs][3]);
+            const float a4 = max3f(s[3][qs][0], s[3][qs][1], s[3][qs][2]);
+            float mx = max3f(max3f(a0, a1, a2), max3f(a3, a4, s[3][qs][3]), -3.0e38f);
+            mx = rows_max(mx);                                       // over the 4 lane groups that share this query column
+            const float m_new = max3f(m_run[qs], mx * sl2, -3.0e38f);   // running max of scale*log2e*s (scale > 0)
             const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
-            float sum = 0.f;
+            const float2_ sl2v = {sl2, sl2}, nm = {-m_new, -m_new};
+            float2_ sum2 = {0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][0], sl2, -m_new));
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][1], sl2, -m_new));
-                const float e2 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][2], sl2, -m_new));
-                const float e3 = __builtin_amdgcn_exp2f(fmaf(s[kt][qs][3], sl2, -m_new));
-                sum += (e0 + e1) + (e2 + e3);
-                pf[kt][qs] = half4{(half_t)e0, (half_t)e1, (half_t)e2, (half_t)e3};   // v_cvt_pk_f16_f32 (RNE) x2
+                // v_pk_fma_f32: two exponents per instruction
+                const float2_ x01 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 0, 1), sl2v, nm);
+                const float2_ x23 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 2, 3), sl2v, nm);
+                const float2_ e01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
+                const float2_ e23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+                sum2 += e01 + e23;
+                half8& dst = pb[kt >> 1][qs];                              // v_cvt_pk_f16_f32 (RNE) x2, written in place
+                dst[(kt & 1) * 4 + 0] = (half_t)e01[0]; dst[(kt & 1) * 4 + 1] = (half_t)e01[1];
+                dst[(kt & 1) * 4 + 2] = (half_t)e23[0]; dst[(kt & 1) * 4 + 3] = (half_t)e23[1];
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            const float sum = rows_sum(sum2[0] + sum2[1]);
             l_run[qs] = l_run[qs] * alpha + sum;
             if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {   // wave-uniform: some query's max moved
 #pragma unroll
@@ -174,23 +201,19 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         // ---- O^T += V^T P^T : k-step j covers keys 32j..32j+31 in the permuted order --------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            half8 pb[2];
-#pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
-                const half4 lo = pf[2 * j][qs], hi = pf[2 * j + 1][qs];
-                pb[qs] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int row = dt * 16 + lq16;
                 const int sw = (row >> 1) & 7;
                 // keys 32j + 4*lg .. +4 live in chunk (4j + lg/2), byte (lg&1)*8; keys +16 in chunk (4j + 2 + lg/2)
                 const int c_lo = (4 * j + (lg >> 1)) ^ sw, c_hi = (4 * j + 2 + (lg >> 1)) ^ sw;
-                const half4 v_lo = *(const half4*)(Vs + row * 128 + c_lo * 16 + (lg & 1) * 8);
-                const half4 v_hi = *(const half4*)(Vs + row * 128 + c_hi * 16 + (lg & 1) * 8);
+                // volatile: two ds_read_b64 (2 LDS cycles each).  Left to itself the compiler pairs the reads of DIFFERENT fragments
+                // into ds_read2st64_b64 (8 cycles per pair) and then needs 6 v_mov per pair to sort the halves out.
+                const half4 v_lo = *(const volatile LDS_AS half4*)(Vs + row * 128 + c_lo * 16 + (lg & 1) * 8);
+                const half4 v_hi = *(const volatile LDS_AS half4*)(Vs + row * 128 + c_hi * 16 + (lg & 1) * 8);
                 const half8 vf = half8{v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[qs], oacc[qs][dt], 0, 0, 0);
+                for (int qs = 0; qs < 2; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[j][qs], oacc[qs][dt], 0, 0, 0);
             }
         }
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done with this buffer

@@ -76,7 +76,7 @@ def test_conv3x3_variants(B, H_, W_, Cin, Cout, stride, pad, up):
     _close(got.permute(0, 3, 1, 2), ref)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1)])
 def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
     """all GEMM tile shapes (implicit GEMM 128x64 ... 256x320, 320x128) and the LDS-window kernels (16x16-pixel patches x 64 /
@@ -248,7 +248,7 @@ def test_gemm_with_fused_geglu_epilogue(M, C_, K):
 
 @pytest.mark.parametrize("B,hw,cin,cout,tile", [(2, 64, 128, 128, 11), (2, 64, 128, 128, 14), (1, 64, 64, 320, 10), (1, 64, 64, 320, 13), (1, 32, 128, 256, 8),
                                                  (1, 32, 128, 256, 9), (3, 16, 64, 640, 2), (3, 16, 64, 640, 0), (2, 32, 96, 320, 12), (2, 32, 64, 320, 4),
-                                                 (1, 64, 128, 256, 5), (5, 8, 64, 320, 12)])
+                                                 (1, 64, 128, 256, 5), (5, 8, 64, 320, 12), (5, 8, 64, 320, 16), (2, 16, 128, 256, 19), (3, 16, 64, 640, 15)])
 def test_groupnorm_statistics_from_the_producers_epilogue(B, hw, cin, cout, tile):
     """asd_gemm_args.gn_partials: the conv / GEMM that stores a tensor also leaves its per-group sums; GroupNorm from those records ==
     GroupNorm with its own statistics pass (same kernel afterwards; the sums are accumulated in another order)"""
