@@ -90,8 +90,10 @@ PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("une
 
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
-DOMINANT = "gemm"
-DOMINANT_SOURCE = "profiles/r02_a_kernel_stats.csv: gemm_f16_kernel<64,64,2,2,false> 11.95 % of kernel time (129 launches per step)"
+DOMINANT = "field_bwd"
+DOMINANT_SOURCE = ("profiles/r02_d_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
+                   "inside the timed steps alone (profiles/r02_d_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.45 ms, gemm_f16_kernel<256,64> 1.37 ms, "
+                   "attention_fwd_kernel 1.34 ms and field_bwd_sample_kernel 1.27 ms per step are within 15 % of each other: see roofline_vae_conv / roofline_gemm")
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
@@ -210,20 +212,42 @@ def roofline_field_bwd(system, batch, reps: int = 10):
         d_grid = torch.zeros_like(grid)
         for _ in range(2):
             ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
+        # the scatter kernel alone: the library records the caller's two events immediately around field_bwd_sample_kernel on the
+        # launch stream (asd_probe_events), the other launches of the call (weight-gradient GEMM, slab reductions) stay outside
+        import ctypes as C
+        from scaledreamer_amd._lib import lib
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(); e1.record()          # creates the hipEvent_t handles
+        torch.cuda.synchronize()
+        lib().asd_probe_events(C.c_void_p(e0.cuda_event), C.c_void_p(e1.cuda_event))
+        ms_k = []
+        try:
+            for _ in range(reps):
+                ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
+                torch.cuda.synchronize()
+                ms_k.append(e0.elapsed_time(e1))
+        finally:
+            lib().asd_probe_events(None, None)
+        t0_, t1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0_.record()
         for _ in range(reps):
             ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
-        e1.record()
+        t1_.record()
         torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = sum(ms_k) / len(ms_k)
+    ms_call = t0_.elapsed_time(t1_) / reps
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
-    return {"kernel": "asd_field_bwd: field_bwd_sample_kernel<16,64,3> (request-coalesced gradient scatter) + field_wgrad_kernel", "bound": "hbm",
+    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r02_pmc_*_per_kernel.csv, 433 k samples): WRITE_SIZE 616.2 MB +
+    # FETCH_SIZE 36.1 MB (gfx950 correction applied) per launch = 1506 B per sample; scaled to this launch's sample count
+    traffic = n * (616.16e6 + 36.05e6) / 433138.0
+    return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC.get(("field_bwd", n // 1000)), "samples_per_launch": n, "avg_launch_ms": round(ms, 4),
-            "algorithmic_bytes_per_sample": bytes_per_sample, "atomic_dwords_per_sample": 256,
-            "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1)}
+            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE, profiles/r02_pmc_*_per_kernel.csv, scaled by samples)",
+            "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
+            "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
+            "atomic_dwords_per_sample": 256, "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1),
+            "binding_limit": "atomic request rate of the L2 (tools/atomic_probe2.hip: ~21 G requests/s; 4 dwords per request after coalescing), not bytes"}
 
 
 def cpu_baseline(system, batch, seed: int):

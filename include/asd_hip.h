@@ -490,6 +490,11 @@ int asd_adan_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1, 
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);
+/* Measurement hook (bench.py's `roofline` leg): two hipEvent_t created by the caller (timing enabled).  While they are set, entry
+ * points that launch more than one kernel record `start` / `stop` on their stream immediately around their DOMINANT kernel
+ * (asd_field_bwd: field_bwd_sample_kernel, the gradient scatter), so its duration can be read with hipEventElapsedTime without a
+ * profiler.  Pass NULL, NULL to clear.  Process-wide; not meant for concurrent callers. */
+int asd_probe_events(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

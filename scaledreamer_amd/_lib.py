@@ -125,7 +125,7 @@ SYMBOLS = [
     "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",
     "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
     "asd_adamw_f32", "asd_adan_f32",
-    "asd_version", "asd_last_error",
+    "asd_version", "asd_last_error", "asd_probe_events",
 ]
 
 

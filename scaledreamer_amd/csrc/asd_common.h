@@ -261,4 +261,10 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
         }
     }
 }
+
+// measurement hook (asd_probe_events): events recorded around an entry point's dominant kernel
+extern hipEvent_t g_asd_probe_start, g_asd_probe_stop;
+#define ASD_PROBE_START(s) do { if (g_asd_probe_start) (void)hipEventRecord(g_asd_probe_start, (s)); } while (0)
+#define ASD_PROBE_STOP(s) do { if (g_asd_probe_stop) (void)hipEventRecord(g_asd_probe_stop, (s)); } while (0)
+
 #endif  // __HIPCC__

@@ -619,7 +619,15 @@ void asd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+hipEvent_t g_asd_probe_start = nullptr, g_asd_probe_stop = nullptr;
+
 extern "C" {
+
+int asd_probe_events(void* start_event, void* stop_event) {
+    g_asd_probe_start = (hipEvent_t)start_event;
+    g_asd_probe_stop = (hipEvent_t)stop_event;
+    return ASD_OK;
+}
 
 const char* asd_last_error(void) { return g_err; }
 const char* asd_version(void) { return "asd_hip 0.1 (gfx950)"; }
@@ -741,6 +749,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     float* enc_fd = with_normal ? da + rows * 128 : nullptr;
     float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);
     const dim3 grid(asd_div_up(n, 256)), block(256);
+    ASD_PROBE_START(s);
     if (cfg->n_feature_dims == 3)
         hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
                            w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
@@ -749,6 +758,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
         hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 0>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
                            w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
                            d_normal, d_fd_grad, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+    ASD_PROBE_STOP(s);
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);
     // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks

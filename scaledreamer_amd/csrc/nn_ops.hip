@@ -89,14 +89,19 @@ __device__ __forceinline__ void gn_reduce_partials(const float* __restrict__ par
                                                    float (*scratch)[64] /*[4][64]*/) {
     const int tid = threadIdx.x, v = tid & 63, q = tid >> 6;
     const float* src = partials + (size_t)b * n_chunks * 64 + v;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int c = q;
-    for (; c + 12 < n_chunks; c += 16) {
-        const float t0 = src[(size_t)c * 64], t1 = src[(size_t)(c + 4) * 64], t2 = src[(size_t)(c + 8) * 64], t3 = src[(size_t)(c + 12) * 64];
-        a0 += t0; a1 += t1; a2 += t2; a3 += t3;
+    // eight loads per trip, all requested before the first is consumed (index clamped, contribution masked): up to 96 folded
+    // records per batch element are three round trips, not twenty-four
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int c = q; c < n_chunks; c += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)min(c + 4 * u, n_chunks - 1) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += c + 4 * u < n_chunks ? t[u] : 0.f;
     }
-    for (; c < n_chunks; c += 4) a0 += src[(size_t)c * 64];
-    scratch[q][v] = (a0 + a1) + (a2 + a3);
+    scratch[q][v] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (tid < 64) st[tid] = (scratch[0][tid] + scratch[1][tid]) + (scratch[2][tid] + scratch[3][tid]);
     __syncthreads();

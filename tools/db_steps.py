@@ -40,3 +40,16 @@ if "--csv" in sys.argv:
         fh.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
         for nm, d in sorted(allfam.items(), key=lambda x: -x[1][1])[:80]:
             fh.write(f'"{nm[:160]}",{d[0]},{d[1]},{d[1] / d[0]:.1f},{100 * d[1] / gt:.2f},{d[2]},{d[3]}\n')
+
+if "--gaps" in sys.argv:     # idle gaps above a threshold (us) inside the last analysed step, in program order
+    thr = float(sys.argv[sys.argv.index("--gaps") + 1]) * 1e3
+    step = rows[starts[-2 - skip]:starts[-1 - skip]]
+    end, tot_idle = step[0][0], 0
+    print(f"last step: {len(step)} kernels, {(step[-1][1] - step[0][0]) / 1e6:.3f} ms")
+    for i, (s_, e_, nm) in enumerate(step):
+        if s_ - end > thr:
+            print(f"  idle {(s_ - end) / 1e3:7.1f} us | prev: {short(step[i - 1][2])[:48]} | next: {short(nm)[:48]}   [#{i}]")
+        if s_ > end:
+            tot_idle += s_ - end
+        end = max(end, e_)
+    print(f"idle total {tot_idle / 1e6:.3f} ms")

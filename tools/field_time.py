@@ -26,3 +26,13 @@ for normal in (True, False):
         ops.field_fwd(geo._meta, geo._fcfg, grid, *w, pts, normal)
     e1.record(); torch.cuda.synchronize()
     print("want_normal", normal, e0.elapsed_time(e1) / 10 * 1e3, "us")
+# density only (the pruning pass's kernel: same 128 gathers per sample, density MLP only, nothing saved) on the same points
+for _ in range(3):
+    ops.field_density(geo._meta, geo._fcfg, grid, w[0], w[1], pts)
+torch.cuda._sleep(600000)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.field_density(geo._meta, geo._fcfg, grid, w[0], w[1], pts)
+e1.record(); torch.cuda.synchronize()
+print("density only", e0.elapsed_time(e1) / 10 * 1e3, "us")
