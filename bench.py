@@ -91,9 +91,9 @@ PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("une
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
 DOMINANT = "field_bwd"
-DOMINANT_SOURCE = ("profiles/r02_d_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
-                   "inside the timed steps alone (profiles/r02_d_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.45 ms, gemm_f16_kernel<256,64> 1.37 ms, "
-                   "attention_fwd_kernel 1.34 ms and field_bwd_sample_kernel 1.27 ms per step are within 15 % of each other: see roofline_vae_conv / roofline_gemm")
+DOMINANT_SOURCE = ("profiles/r02_e_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
+                   "inside the timed steps alone (profiles/r02_e_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.47 ms, gemm_f16_kernel<256,64> 1.40 ms, "
+                   "attention_fwd_kernel 1.38 ms and field_bwd_sample_kernel 1.26 ms per step are within 15 % of each other: see roofline_vae_conv / roofline_gemm")
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
@@ -223,6 +223,7 @@ def roofline_field_bwd(system, batch, reps: int = 10):
         ms_k = []
         try:
             for _ in range(reps):
+                d_grid.zero_()           # as in the step: the gradient table is cleared once per step, the scatter starts on clean lines
                 ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
                 torch.cuda.synchronize()
                 ms_k.append(e0.elapsed_time(e1))
@@ -452,8 +453,9 @@ def main():
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
             lines["field_bwd"] = roofline_field_bwd(system, batch)
             lines["renderer"] = roofline_field_kernel(system, batch)
-        out["roofline"] = lines.pop(DOMINANT)
-        out["roofline"]["rank_source"] = DOMINANT_SOURCE
+        dom = DOMINANT if DOMINANT in lines and lines[DOMINANT] is not None else "gemm"     # secondary workloads: no implicit-volume scatter
+        out["roofline"] = lines.pop(dom)
+        out["roofline"]["rank_source"] = DOMINANT_SOURCE if dom == DOMINANT else "secondary workload: most frequent GEMM of the diffusion prior"
         for k, v in lines.items():
             out["roofline_" + k] = v
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":

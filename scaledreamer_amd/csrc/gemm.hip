@@ -1013,6 +1013,71 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const asd_gemm_arg
     }
 }
 
+// Split-K epilogue that also leaves the GroupNorm statistics records of its output (asd_gemm_args.gn_partials): the low-resolution
+// convolutions of the UNet (8x8, 16x16: M = 64 / 256 rows per batch element) are the split-K layers, and their consumer is a
+// GroupNorm whose separate statistics launch costs as much as the reduction itself.  A block owns 64 rows x 64 channels
+// (16 float4 columns x 16 row lanes x 4 passes), sums the slabs, applies the epilogue, stores fp16 and reduces sum / sum of squares of
+// the stored values per group into ONE record at index (m / 64) * (N / 64) + n / 64 — (gn_rows / 64) * (N / 64) records per batch element.
+__global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const asd_gemm_args p, int splits) {
+    __shared__ float lds64[64];
+    const int tiles_n = p.N / 64;
+    const int mb = blockIdx.x / tiles_n, nb = blockIdx.x - mb * tiles_n;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = nb * 64 + tx * 4;
+    if (threadIdx.x < 64) lds64[threadIdx.x] = 0.f;
+    __syncthreads();
+    floatx4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+    half4 bias = {0, 0, 0, 0};
+    if (p.bias) bias = *(const half4*)((const half_t*)p.bias + n);
+    // slabs outermost, the block's four row passes inside: four independent 16-byte loads per trip (the trip count is `splits`,
+    // as in splitk_epilogue_kernel; with the rows outermost it was 4 x splits dependent round trips)
+    floatx4 v[4];
+    int mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        mrow[i] = min(mb * 64 + i * 16 + ty, p.M - 1);
+    }
+    for (int s = 0; s < splits; ++s) {
+        floatx4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = *(const floatx4*)(p.workspace + ((size_t)s * p.M + mrow[i]) * p.N + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i][0] += t[i][0]; v[i][1] += t[i][1]; v[i][2] += t[i][2]; v[i][3] += t[i][3]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mb * 64 + i * 16 + ty;
+        if (m >= p.M) continue;
+        floatx4 w = v[i];
+        w[0] += (float)bias[0]; w[1] += (float)bias[1]; w[2] += (float)bias[2]; w[3] += (float)bias[3];
+        if (p.row_bias) {
+            const half4 b = *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n);
+            w[0] += (float)b[0]; w[1] += (float)b[1]; w[2] += (float)b[2]; w[3] += (float)b[3];
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = w[r] / (1.f + __expf(-w[r]));
+        }
+        if (p.residual) {
+            const half4 b = *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n);
+            w[0] += (float)b[0]; w[1] += (float)b[1]; w[2] += (float)b[2]; w[3] += (float)b[3];
+        }
+        const half4 o = {(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
+        *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs[r] += f; cq[r] = fmaf(f, f, cq[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int g = (n + r) / p.gn_cg;
+        atomicAdd(&lds64[2 * g], cs[r]);
+        atomicAdd(&lds64[2 * g + 1], cq[r]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) p.gn_partials[(size_t)blockIdx.x * 64 + threadIdx.x] = lds64[threadIdx.x];
+}
+
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn, nst, kg; };   // nst: stages of the operand ring (0 = the default two); kg: k-groups (0 = one)
@@ -1120,10 +1185,16 @@ static int asd_gemm_resolve_cfg(const asd_gemm_args* a) {
     return cfg;
 }
 
+#define ASD_SPLITK_GN_MAX_RECORDS 96     // = GN_FOLD_RECORDS of nn_ops.hip: the apply kernel sums them in its prologue, no reduce launch
 // GroupNorm statistics in the epilogue: records per batch element, 0 when this launch cannot produce them
 static int asd_gemm_gn_records_cfg(const asd_gemm_args* a, int cfg, bool need_ptr) {
     if (a->gn_bwd_x && !(a->gn_bwd_fstats && a->gn_bwd_gamma && a->gn_bwd_beta && a->ldc == a->N)) return 0;
-    if ((need_ptr && !a->gn_partials) || a->split_k != 1 || a->out_f32 || a->act == 2 || a->gn_cg < 1 || a->gn_rows < 1 || a->N != 32 * a->gn_cg || a->M % a->gn_rows) return 0;
+    if ((need_ptr && !a->gn_partials) || a->split_k < 1 || a->out_f32 || a->act == 2 || a->gn_cg < 1 || a->gn_rows < 1 || a->N != 32 * a->gn_cg || a->M % a->gn_rows) return 0;
+    if (a->split_k > 1) {     // statistics in the split-K epilogue (splitk_epilogue_gn_kernel): 64 x 64 blocks, few enough records to fold
+        if (a->gn_bwd_x || a->N % 64 || a->gn_rows % 64 || a->ldc % 4) return 0;
+        const int nrec = (a->gn_rows / 64) * (a->N / 64);
+        return nrec <= ASD_SPLITK_GN_MAX_RECORDS ? nrec : 0;
+    }
     const int bn = asd_gemm_tiles[cfg].bn, tiles_n = asd_div_up(a->N, bn);
     if (asd_cfg_is_window(cfg)) return (a->gn_rows / 256) * tiles_n;          // 16 x 16 patches never leave their image
     const int bm = asd_gemm_tiles[cfg].bm;
@@ -1264,7 +1335,8 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
 #undef WIN2_LAUNCH
             if (a->split_k > 1) {
                 const size_t total4 = (size_t)a->M * a->N / 4;
-                hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+                if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, sw, *a, a->split_k);
+                else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
             }
             ASD_LAUNCH_CHECK();
             return ASD_OK;
@@ -1279,7 +1351,8 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         }
         if (a->split_k > 1) {
             const size_t total4 = (size_t)a->M * a->N / 4;
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+            if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, sw, *a, a->split_k);
+                else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
         }
         ASD_LAUNCH_CHECK();
         return ASD_OK;
@@ -1326,7 +1399,8 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
 #undef GEMM_LAUNCH
     if (a->split_k > 1) {
         const size_t total4 = (size_t)a->M * a->N / 4;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);
+        if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, s, *a, a->split_k);
+        else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);
     }
     ASD_LAUNCH_CHECK();
     return ASD_OK;

@@ -90,6 +90,7 @@ struct GemmOpt {
     // backward form (the output is the gradient dy reaching a GroupNorm with input gn_x): records of {sum g, sum g * xhat}
     const half_t* gn_x = nullptr; const float* gn_fstats = nullptr; const half_t* gn_gamma = nullptr; const half_t* gn_beta = nullptr;
     int gn_silu = 0;
+    bool gn_bwd_form = false;   // set with gn_x (dry passes carry null pointers: the record count must still be the backward form's)
 };
 
 void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
@@ -97,7 +98,7 @@ void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
     g.gn_eps = 1e-6f; g.gn_silu = o.gn_silu;
 }
 
-void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
+void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr, bool gn_bwd_form = false) {
     g.zero_page = r.zero_page;
     g.split_k = 0;          // auto: tuned plan of this shape (asd_gemm_plan_*), else cost model
     g.tile_cfg = 0;
@@ -116,9 +117,14 @@ void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr) {
         int nrec;
         if (r.rec_replay) nrec = r.rec_pos < r.rec_replay->size() ? (*r.rec_replay)[r.rec_pos++] : 0;
         else {
-            asd_gemm_args q = g;             // the answer depends on shape and plan only (dry passes carry null pointers)
+            asd_gemm_args q = g;             // the answer depends on shape, plan and form only (dry passes carry null pointers)
             q.gn_bwd_x = nullptr;
             nrec = asd_gemm_gn_records(&q);
+            if (gn_bwd_form && q.split_k == 0) {        // the backward form has no split-K variant (splitk_epilogue_gn_kernel is forward only)
+                int32_t t = 0, sk = 1;
+                asd_gemm_plan_get(&q, &t, &sk);
+                if (sk > 1) nrec = 0;
+            }
         }
         // while tuning, the plan (and with it the record count) of this shape may still change between the sizing pass and the
         // launch: reserve the upper bound (64 x 64 tiles)
@@ -143,7 +149,7 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     g.gn_rows = o.gn_rows;
     if (o.gn_x) set_gn_bwd(g, o);
     if (o.out) *o.out = Act{(const half_t*)C, nullptr, 0};
-    launch_gemm(r, g, o.out);
+    launch_gemm(r, g, o.out, o.gn_bwd_form);
 }
 
 // 3x3 convolution on NHWC [B,Hin,Win,Cin] with packed weights [Cout, 9*Cin]; upsample: 0 plain, 1 nearest-2x fused, 2 transposed stride-2
@@ -157,7 +163,7 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
     g.gn_rows = o.gn_rows;
     if (o.gn_x) set_gn_bwd(g, o);
     if (o.out) *o.out = Act{(const half_t*)y, nullptr, 0};
-    launch_gemm(r, g, o.out);
+    launch_gemm(r, g, o.out, o.gn_bwd_form);
 }
 
 #define LEAF(call)                                              \
@@ -654,6 +660,7 @@ half_t* gn_bwd(Run& r, const half_t* x, const half_t* dy, int c, int B, int hw, 
 GemmOpt feeds_gn_bwd(Act* out, int hw, const half_t* x, const float* fstats, const half_t* gamma, const half_t* beta, int silu) {
     GemmOpt o;
     o.gn_rows = hw; o.out = out; o.gn_x = x; o.gn_fstats = fstats; o.gn_gamma = gamma; o.gn_beta = beta; o.gn_silu = silu;
+    o.gn_bwd_form = true;
     return o;
 }
 

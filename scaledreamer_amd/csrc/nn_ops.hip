@@ -598,6 +598,15 @@ __global__ __launch_bounds__(1024) void gn_reduce_records_kernel(const float* __
     }
 }
 
+// apply blocks per batch element: one trip of the row loop (GN_UNR rows x the rows a block holds in flight) per block while that
+// keeps the launch under GN_CAP_A blocks — the small low-resolution tensors (8x8 ... 32x32) are latency-, not bandwidth-bound, and a
+// block that walks 16 rows of a 1280-channel tensor four at a time spends its life in four dependent memory round trips
+static int gn_apply_chunks(int hw, int C, int batch) {
+    const int slots = C / 8, rif = slots >= 256 ? 1 : 256 / slots;
+    const int chunks = asd_div_up(hw, GN_UNR * rif), cap_a = asd_div_up(GN_CAP_A, batch);
+    return chunks > cap_a ? cap_a : chunks;
+}
+
 extern "C" {
 
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
@@ -614,8 +623,8 @@ int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, in
     int chunks = asd_div_up(hw, 16);
     // every apply block sums its batch element's statistics partials in its prologue (chunks_s x 256 B from L2): keep
     // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
-    const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(GN_CAP_A, batch);
-    const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
+    const int cap_s = asd_div_up(256, batch);
+    const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = gn_apply_chunks(hw, C, batch);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
                        asd_div_up(hw, chunks_s), partials);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x1, c1, (const half_t*)x2, c2, hw,
@@ -631,8 +640,7 @@ int asd_groupnorm_apply_f16(const void* x, int32_t c, int32_t batch, int32_t hw,
     ASD_CHECK_ARG(c % 32 == 0 && c % 8 == 0, "channels must be a multiple of 32");
     ASD_CHECK_ARG(((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "gamma / beta must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = asd_div_up(hw, 16);
-    const int cap_a = asd_div_up(GN_CAP_A, batch), chunks_a = chunks > cap_a ? cap_a : chunks;
+    const int chunks_a = gn_apply_chunks(hw, c, batch);
     // every apply block sums the records of its batch element in its prologue: with many tiles, sum them once first
     const float* part = partials;
     int n = records;
