@@ -48,8 +48,12 @@ __device__ __forceinline__ float rows_sum(float v) {
 
 #define HD 64      // head dim
 #define KT 64      // keys per tile
-#define QW 32      // queries per wave
-#define QB 128     // queries per block
+// queries per wave = 16 * QS, per block = 64 * QS (4 waves).  QS = 2: 128 registers, four waves per SIMD.  QS = 4 (self-attention
+// over >= 2048 keys): every K / V^T fragment read from LDS and every tile brought from L2 serves twice the MFMAs, half the barriers
+// per flop; 218 registers, two waves per SIMD: 210 -> 196 us at L = 4096 (same-box A/B), nothing at L = 1024, slower below.
+// Measured and NOT kept on the wide form: the loop body as one basic block (unconditional accumulator rescale) with
+// sched_group_barrier pipelines asking for the second query group's MFMAs under the first group's softmax — the scheduler keeps
+// the MFMAs clustered and the kernel is 2-5 % slower (200-206 us).
 
 struct AttnArgs {
     const half_t* q; int ldq;
@@ -64,7 +68,9 @@ struct AttnArgs {
 // launch bounds: with plain __launch_bounds__(256) hipcc parked the MFMA results in AGPRs and moved 192 registers per key tile
 // between the two files (v_accvgpr_read / _write around the softmax: 330 VALU instructions per tile instead of ~140); naming
 // 4 waves per SIMD keeps everything in 128 VGPRs.  L = 4096: 265 -> 199 us.
-__global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p) {
+template <int QS>
+__global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(const AttnArgs p) {
+    constexpr int QW = 16 * QS, QB = 4 * QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile 8 KB | V^T tile 8 KB]
     constexpr int TILE_BYTES = KT * HD * 2;                         // 8192
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,9 +84,9 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
     const int lq16 = lane & 15, lg = lane >> 4;
 
     // ---- Q fragments (B operand): lane holds Q[q = q0 + 16*qs + (l&15)][d = 32*ks + (l>>4)*8 .. +8] --------
-    half8 qf[2][2];
+    half8 qf[QS][2];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) {
         int qi = q0 + qs * 16 + lq16;
         if (qi >= p.lq) qi = p.lq - 1;
         const half_t* src = p.q + ((size_t)b * p.lq + qi) * p.ldq + h * HD;
@@ -113,12 +119,14 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         }
     };
 
-    floatx4 oacc[2][4];  // [qs][dt]: O[q = 16qs + (l&15)][d = 16dt + (l>>4)*4 + r]
+    floatx4 oacc[QS][4];  // [qs][dt]: O[q = 16qs + (l&15)][d = 16dt + (l>>4)*4 + r]
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs)
+    for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[qs][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    float m_run[QS], l_run[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -1e30f; l_run[qs] = 0.f; }
 
     const int n_tiles = (p.lk + KT - 1) / KT;
     const float sl2 = p.scale * 1.44269504088896340736f;   // softmax in the log2 domain
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         const char* Vs = Ks + TILE_BYTES;
 
         // ---- S^T = K Q^T --------------------------------------------------------------------------------
-        floatx4 s[4][2];
+        floatx4 s[4][QS];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const int row = kt * 16 + lq16;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[ks] = *(const half8*)(Ks + row * 128 + (((ks * 4 + lg) ^ (row & 7)) * 16));
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < QS; ++qs) {
                 floatx4 a = {0.f, 0.f, 0.f, 0.f};
                 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[qs][0], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[qs][1], a, 0, 0, 0);
@@ -155,11 +163,11 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
         // the last tile, and the accumulator rescale is skipped while no
         // lane's running max moved.
         const int key_base = t * KT + lg * 4;
-        half8 pb[2][2];  // probabilities, fp16: [j][qs] = B operand of PV k-step j: keys of sub-tiles kt = 2j (elements 0-3) and 2j + 1 (4-7)
+        half8 pb[2][QS];  // probabilities, fp16: [j][qs] = B operand of PV k-step j: keys of sub-tiles kt = 2j (elements 0-3) and 2j + 1 (4-7)
         if (t == n_tiles - 1 && (p.lk & (KT - 1)) != 0) {
             asm volatile("" ::: "memory");   // keep this a (wave-uniform) branch: if-converted it costs 32 selects on every tile
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs)
+            for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
                         if (key_base + kt * 16 + r >= p.lk) s[kt][qs][r] = -1e30f;
         }
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
+        for (int qs = 0; qs < QS; ++qs) {
             // 16 scores per lane -> 8 x v_max3_f32 (depth 3); fmaxf() costs a canonicalising v_max per MFMA-produced operand on top
             const float a0 = max3f(s[0][qs][0], s[0][qs][1], s[0][qs][2]), a1 = max3f(s[0][qs][3], s[1][qs][0], s[1][qs][1]);
             const float a2 = max3f(s[1][qs][2], s[1][qs][3], s[2][qs][0]), a3 = max3f(s[2][qs][1], s[2][qs][2], s[2][qs][3]);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
                 const half4 v_hi = *(const volatile LDS_AS half4*)(Vs + row * 128 + c_hi * 16 + (lg & 1) * 8);
                 const half8 vf = half8{v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[j][qs], oacc[qs][dt], 0, 0, 0);
+                for (int qs = 0; qs < QS; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[j][qs], oacc[qs][dt], 0, 0, 0);
             }
         }
 #ifndef ASD_ATTN_ABL_NOBARRIER  // ablation: wrong results, no per-tile block barrier
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd_kernel(const AttnArgs p)
 
     // ---- normalise and store: lane owns query (l&15), 4 consecutive d -----------------------------------------
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) {
         const int qi = q0 + qs * 16 + lq16;
         if (qi >= p.lq) continue;
         const float inv = 1.f / l_run[qs];
@@ -254,8 +262,15 @@ int asd_attention_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, co
                   "leading dimensions / key stride must keep 16-byte alignment");
     AttnArgs a{(const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)vT, ldv, (half_t*)o, ldo,
                batch, heads, lq, lk, lk_stride, scale, (const char*)zero_page};
-    const dim3 grid(8 * asd_div_up(asd_div_up(lq, QB) * heads * batch, 8));
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 4 * KT * HD * 2, (hipStream_t)stream, a);
+    static const int qs_env = getenv("ASD_ATTN_QS") ? atoi(getenv("ASD_ATTN_QS")) : 0;     // A/B switch (tools): force 2 or 4
+    const bool wide = qs_env ? qs_env == 4 : (lk >= 2048 && lq >= 2048);
+    if (wide) {
+        const dim3 grid(8 * asd_div_up(asd_div_up(lq, 256) * heads * batch, 8));
+        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(256), 4 * KT * HD * 2, (hipStream_t)stream, a);
+    } else {
+        const dim3 grid(8 * asd_div_up(asd_div_up(lq, 128) * heads * batch, 8));
+        hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(256), 4 * KT * HD * 2, (hipStream_t)stream, a);
+    }
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
