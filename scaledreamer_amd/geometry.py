@@ -242,12 +242,14 @@ class ImplicitVolume(BaseImplicitGeometry):
             out.update({"normal": normal, "shading_normal": normal})
         return out
 
-    def forward_density(self, points: torch.Tensor) -> torch.Tensor:
+    def forward_density(self, points: torch.Tensor, n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """n_dev (extension of the reference signature): int32 device scalar, the number of leading points that are valid — the
+        renderer passes capacity-sized candidate buffers and the marcher's device-side count instead of reading the count back."""
         if self.fused and points.is_cuda and not (torch.is_grad_enabled() and self.encoding.encoding.encoding.params.requires_grad):
             w1d, w2d, _, _ = self._weights()
             grid = self.encoding.encoding.encoding.params
             flat = points.reshape(-1, 3).contiguous().float()
-            s = ops.field_density(self._meta, self._fcfg, grid.detach(), w1d.detach(), w2d.detach(), flat)
+            s = ops.field_density(self._meta, self._fcfg, grid.detach(), w1d.detach(), w2d.detach(), flat, n_dev=n_dev)
             return s.view(*points.shape[:-1], 1)
         if self.fused and points.is_cuda:
             return self._forward_fused(points, False)["density"]

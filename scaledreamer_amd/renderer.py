@@ -138,8 +138,14 @@ class NeRFVolumeRenderer(VolumeRenderer):
         jitter = self.jitter_fn(n_rays, rays_o_flatten.device) if self.randomized else None
         cfg = est.march_cfg(self.cfg.near_plane, self.cfg.far_plane, self.render_step_size)
         bits = est._bits()
-        count, offset, total, ray_idx, t0, t1, pts = ops.march(cfg, rays_o_flatten, rays_d_flatten, bits, jitter)
+        # Candidate buffers at their upper bound (every ray at most max_steps lattice points) with the count left on the device:
+        # the pruning pass below only ever looks at [offset, offset + count) of each ray, and the density kernel takes the total
+        # as a device scalar — no device->host read of the candidate count (one of the two syncs of this method; the kept count
+        # below stays, it sizes every tensor of the output dictionary).
         prune = self.cfg.grid_prune and self.cfg.prune_alpha_threshold
+        fused_density = self.training and prune and getattr(self.geometry, "fused", False) and rays_o_flatten.is_cuda
+        n_cap = n_rays * int(cfg.max_steps) if fused_density else None
+        count, offset, total, ray_idx, t0, t1, pts = ops.march(cfg, rays_o_flatten, rays_d_flatten, bits, jitter, n_max=n_cap)
         if self.cfg.grid_prune:
             early_stop_eps, alpha_thre = 1e-4, (0.01 if self.cfg.prune_alpha_threshold else 0.0)
         else:
@@ -149,7 +155,9 @@ class NeRFVolumeRenderer(VolumeRenderer):
             if ray_idx.shape[0] > 0:
                 # sigma at the candidate mid-points (the reference's sigma_fn, nerf_volume_renderer.py:153-167);
                 # the marcher already produced the positions o + d*(t0+t1)/2
-                if self.training:
+                if fused_density:
+                    sigma = self.geometry.forward_density(pts, n_dev=total)[..., 0]
+                elif self.training:
                     sigma = self.geometry.forward_density(pts)[..., 0]
                 else:
                     sigma = chunk_batch(self.geometry.forward_density, self.cfg.eval_chunk_size, pts)[..., 0]
