@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--workload", default="asd_sd_nerf", choices=["asd_sd_nerf", "asd_mv_nerf", "asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"],
                     help="asd_sd_nerf = BASELINE configs[1] (the headline metric); asd_mv_nerf = SURVEY C3 (MVDream, 4 views), secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--render", type=int, default=0, help="secondary workloads only: render size override (e.g. 256 for BASELINE's wording of configs[4])")
     ap.add_argument("--phases", action="store_true", help="also report per-phase milliseconds (adds syncs; untimed extra steps)")
     args = ap.parse_args()
 
@@ -342,6 +343,8 @@ def main():
 
     # per-rank seed = cfg.seed + rank (launch.py:171): different cameras / noise / t per rank
     cfg, system, data = build_system(args.backend, seed=10 + rank, workload=args.workload)
+    if args.render and args.workload != "asd_sd_nerf":
+        data.width = data.height = args.render
     asd_dist.broadcast_parameters(system)  # identical initial parameters (DDP wrap-time broadcast)
 
     # The camera batch of step i+1 is sampled (host) and uploaded while the GPU still executes step i — the prefetch a
@@ -440,6 +443,9 @@ def main():
                                                "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer (fp32 library ops) -> 3x[32,64,64] "
                                                                   "planes, HIP tri-plane samplers, VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
             out.pop("kept_samples_last_step", None)
+            if args.render:
+                out["config"]["render"] = f"{args.render}x{args.render} (override; the shipped YAML renders 64x64)"
+                out["rays_per_sec"] = round(steps_per_s * args.render * args.render * (4 if args.workload == "asd_mv_triplane" else 1), 1)
         if args.workload == "asd_sd_hyper_ingp":  # secondary line: amortized multi-prompt training
             out.update({"metric": "ASD train steps/sec (64x64 render, SD2.1, Hyper-iNGP amortized)"})
             out["config"].update({"workload": "asd_sd_hyper_iNGP: 1 prompt+view/GPU, 64x64 rays, importance-sampled VolSDF renderer (128 proposal + "

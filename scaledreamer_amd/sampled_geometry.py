@@ -59,7 +59,26 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             raise ValueError(f"Unknown sdf bias {c.sdf_bias}")
         return sdf + bias
 
+    # Above this many points per call the heads run chunk by chunk under activation checkpointing: the un-fused library MLP heads keep
+    # ~1.2 KB of autograd state per point and SDF evaluation (4 evaluations per point with the finite-difference normal), i.e.
+    # 245 GB for the 50.6 M samples of a 256 x 256 x 4-view step — more than the 288 GB GPU leaves.  Chunks are recomputed in the
+    # backward pass (one extra forward); values and gradients are those of the un-chunked graph.
+    CHECKPOINT_ABOVE = 8 * 1024 * 1024
+    CHECKPOINT_CHUNK = 2 * 1024 * 1024
+
     def forward(self, points: torch.Tensor, space_cache: Any, output_normal: bool = False) -> Dict[str, torch.Tensor]:
+        batch_size, n_points, _ = points.shape
+        if torch.is_grad_enabled() and batch_size * n_points > self.CHECKPOINT_ABOVE:
+            from torch.utils.checkpoint import checkpoint
+
+            per = max(1, self.CHECKPOINT_CHUNK // batch_size)
+            parts = [checkpoint(self._forward_points, points[:, i:i + per], space_cache, output_normal, use_reentrant=False)
+                     for i in range(0, n_points, per)]
+            return {k: torch.cat([p[k] for p in parts], dim=1).reshape(batch_size * n_points, -1) for k in parts[0]}
+        return {k: v.reshape(batch_size * n_points, -1) for k, v in self._forward_points(points, space_cache, output_normal).items()}
+
+    def _forward_points(self, points: torch.Tensor, space_cache: Any, output_normal: bool) -> Dict[str, torch.Tensor]:
+        """outputs as [batch, points, k] (the public forward flattens them batch-major, as the reference does)"""
         batch_size, n_points, _ = points.shape
         points_unscaled = points
         pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
@@ -67,9 +86,9 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             raise NotImplementedError("analytic normal is not implemented yet.")
         enc = self.interpolate_encodings(pts, space_cache)
         sdf = self.get_shifted_sdf(points_unscaled, self.sdf_network(enc).view(*pts.shape[:-1], 1))
-        out = {"sdf": sdf.view(batch_size * n_points, 1)}
+        out = {"sdf": sdf.view(batch_size, n_points, 1)}
         if self.cfg.n_feature_dims > 0:
-            out["features"] = self.feature_network(enc).view(batch_size * n_points, self.cfg.n_feature_dims)
+            out["features"] = self.feature_network(enc).view(batch_size, n_points, self.cfg.n_feature_dims)
         if output_normal:
             if self.cfg.normal_type != "finite_difference":
                 raise NotImplementedError(f"normal_type == {self.cfg.normal_type} is not implemented yet.")
@@ -80,7 +99,8 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             sdf_offset = self.forward_sdf(po, space_cache)
             sdf_grad = (sdf_offset[..., 0::1, 0] - sdf) / eps
             normal = F.normalize(sdf_grad, dim=-1)
-            out.update({"normal": normal.view(-1, 3), "shading_normal": normal.view(-1, 3), "sdf_grad": sdf_grad.view(-1, 3)})
+            out.update({"normal": normal.view(batch_size, n_points, 3), "shading_normal": normal.view(batch_size, n_points, 3),
+                        "sdf_grad": sdf_grad.view(batch_size, n_points, 3)})
         return out
 
     def forward_sdf(self, points: torch.Tensor, space_cache: Any) -> torch.Tensor:

@@ -235,6 +235,22 @@ def test_sampled_geometry_classes_match_reference_golden(name):
     hg = {f"{tag}.{k}": p.grad for tag, net in (("sdf_network", geo.sdf_network), ("feature_network", geo.feature_network))
           for k, p in net.named_parameters()}
     check_sampled_geometry(out, hg, cache_d.grad, name, g, tol=2.0)
+    # the chunked / checkpointed evaluation used for very large sample counts (CHECKPOINT_ABOVE) is the same function
+    for p_ in geo.parameters():
+        p_.grad = None
+    geo.CHECKPOINT_ABOVE, geo.CHECKPOINT_CHUNK = 0, 7 * pts.shape[0]        # ragged chunks of 7 points per batch element
+    cache_c = cache.detach().cuda().requires_grad_(True)
+    out_c = geo(pts.cuda(), cache_c, output_normal=True)
+    # (fp32 library GEMMs of another row count sum in another order: 1e-7 on the SDF, x 1 / eps = 100 on the finite differences)
+    for k in out:
+        assert float((out_c[k] - out[k]).abs().max()) <= 2e-3 * float(out[k].abs().max()) + 1e-5, k
+    sampled_geometry_loss(out_c, name, int(g["seed"]), device="cuda").backward()
+    scale = float(cache_d.grad.abs().max())
+    assert float((cache_c.grad - cache_d.grad).abs().max()) <= 2e-3 * scale
+    for tag, net in (("sdf_network", geo.sdf_network), ("feature_network", geo.feature_network)):
+        for k, p_ in net.named_parameters():
+            ref = hg[f"{tag}.{k}"]
+            assert float((p_.grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("kind", ["3dconv", "triplane"])

@@ -140,15 +140,14 @@ def test_second_resolution_phase_and_eval_rendering():
     assert torch.equal(ev["comp_rgb"], ev2["comp_rgb"]), "eval rendering must be deterministic"
 
 
-@pytest.mark.parametrize("workload,render", [("asd_sd_3dconv_net", 64), ("asd_mv_triplane", 64), ("asd_mv_triplane", 128)])
+@pytest.mark.parametrize("workload,render", [("asd_sd_3dconv_net", 64), ("asd_mv_triplane", 64), ("asd_mv_triplane", 256)])
 def test_full_size_generator_configs_step(workload, render):
     """BASELINE.json configs[3] / configs[4] at the reference's FULL generator sizes (StyleGAN-3D at 128^3 x 32 channels;
-    12-layer / 768-wide triplane transformer, 4 views, MVDream guidance in fp16, Adan) — and configs[4] towards BASELINE's wording
-    ("256 x 256 render"; the shipped YAML renders 64 x 64, configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:12-13):
-    128 x 128 x 4 views = 65 536 rays x 193 samples.  The full 256 x 256 x 4 views (262 144 rays, 50.6 M samples, 200 M SDF-head
-    evaluations with the finite-difference normals) was run and does NOT fit: the un-fused library MLP heads of the sampled geometry
-    keep 245 GB of autograd state and the backward's next 36 GB allocation fails on the 288 GB GPU — that
-    configuration stays untested until the heads are fused into the sampler kernels.  The oracle cannot run these sizes in test
+    12-layer / 768-wide triplane transformer, 4 views, MVDream guidance in fp16, Adan) — and configs[4] as BASELINE words it:
+    256 x 256 render = 262 144 rays x 193 samples = 50.6 M samples per step (the shipped YAML renders 64 x 64,
+    configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:12-13).  At that size the library MLP heads of the sampled
+    geometry run chunk by chunk under activation checkpointing (sampled_geometry.CHECKPOINT_ABOVE; un-chunked they kept 245 GB of
+    autograd state and the step ran out of the GPU's 288 GB).  The oracle cannot run these sizes in test
     time, so the checks are the size-independent ones: finite loss and image, opacity in [0, 1], every generator parameter
     receives a finite gradient and moves, and two systems built from the same seed render the same first image."""
     import bench
