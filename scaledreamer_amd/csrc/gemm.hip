@@ -1424,12 +1424,14 @@ static int asd_tune_candidates(const asd_gemm_args* a, int (*out)[2], int max_ou
             continue;
         }
         if (bn != 64 && a->N % bn != 0) continue;
-        if ((asd_gemm_tiles[t].nst > 2 || asd_gemm_tiles[t].kg > 1) && ((a->conv && a->upsample == 2) || (long long)asd_div_up(a->M, bm) * asd_div_up(a->N, bn) > 1024)) continue;
+        const bool few = asd_gemm_tiles[t].nst > 2 || asd_gemm_tiles[t].kg > 1;      // the few-block variants: only where they can win
+        if (few && ((a->conv && a->upsample == 2) || (long long)asd_div_up(a->M, bm) * asd_div_up(a->N, bn) > 512 || a->K < 512)) continue;
         if (geglu && (t == 4 || t == 6)) continue;
         if (bn == 64 && a->N % 128 == 0 && a->N >= 256 && bm == 128) continue;
         const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
         for (int sk : sk_plain) {
             if (sk > 1 && (geglu || a->K / sk < 256 || tiles * sk > 1536)) continue;
+            if (few && sk != 1 && sk != 2 && sk != 4) continue;     // (tuning time: every candidate is launched six times)
             if (n < max_out) { out[n][0] = t + 1; out[n][1] = sk; ++n; }
         }
     }
