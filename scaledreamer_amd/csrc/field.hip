@@ -293,6 +293,11 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
             float e2[NIN];
             rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
             nr[k] = fd_sign * (field_act(c, rawk[k]) - s) / c.fd_eps;
+            // the encoding of the offset point is needed again below (its row of the weight-gradient GEMM and the back-propagation
+            // through the density MLP): park it in enc_fd now instead of gathering its 128 corners a second time
+            float4* dst = reinterpret_cast<float4*>(enc_fd + ((size_t)k * n + i) * NIN);
+#pragma unroll
+            for (int q = 0; q < NIN / 4; ++q) dst[q] = make_float4(e2[4 * q], e2[4 * q + 1], e2[4 * q + 2], e2[4 * q + 3]);
         }
         float dnr[3] = {0.f, 0.f, 0.f};
         if (d_normal) {
@@ -338,18 +343,19 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
             qx = asd_clampf(px + (k == 0 ? c.fd_eps : 0.f), -c.radius, c.radius);
             qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
             qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
-            if (active) asd_encode<L>(m, grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, e);
-            else {
+            if (active) {       // written by this thread above
+                const float4* src = reinterpret_cast<const float4*>(enc_fd + ((size_t)k * n + i) * NIN);
+#pragma unroll
+                for (int q = 0; q < NIN / 4; ++q) {
+                    const float4 v = src[q];
+                    e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+                }
+            } else {
 #pragma unroll
                 for (int q = 0; q < NIN; ++q) e[q] = 0.f;
             }
             draw = dsk[k] * field_act_grad(c, rawk[k]);
             row = (size_t)n + (size_t)k * n + i;  // FD rows live behind the n centre rows
-            if (active) {
-                float4* dst = reinterpret_cast<float4*>(enc_fd + ((size_t)k * n + i) * NIN);
-#pragma unroll
-                for (int q = 0; q < NIN / 4; ++q) dst[q] = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
-            }
         }
         float denc[NIN];
 #pragma unroll
@@ -471,14 +477,33 @@ __global__ __launch_bounds__(256) void field_wgrad_kernel(const float* __restric
         *reinterpret_cast<float4*>(slab + (h0 + i) * NIN + k0) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 }
 
-// sum the per-block slabs: out[j] += sum_b slabs[b][j]   (deterministic order)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int n_blocks, int stride,
-                                                          int len, float* __restrict__ out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= len) return;
-    float acc = 0.f;
-    for (int b = 0; b < n_blocks; ++b) acc += slabs[(size_t)b * stride + j];
-    out[j] += acc;
+// sum the per-block slabs: out[j] += sum_b slabs[b][j]   (fixed order: reproducible).  A block owns 32 consecutive outputs x 32 slab
+// lanes, four loads in flight per thread: the one-thread-per-output loop was a chain of n_blocks dependent round trips (503 us for
+// the 1543 slabs of a Hyper-iNGP step, 42 us for the 211 of the headline step).
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_blocks, int stride,
+                                                           int len, float* __restrict__ out) {
+    __shared__ float part[32][33];
+    const int jl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < len) {
+        const float* src = slabs + j;
+        int b = lane;
+        for (; b + 96 < n_blocks; b += 128) {
+            const float t0 = src[(size_t)b * stride], t1 = src[(size_t)(b + 32) * stride], t2 = src[(size_t)(b + 64) * stride],
+                        t3 = src[(size_t)(b + 96) * stride];
+            a0 += t0; a1 += t1; a2 += t2; a3 += t3;
+        }
+        for (; b < n_blocks; b += 32) a0 += src[(size_t)b * stride];
+    }
+    part[lane][jl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (lane == 0 && j < len) {
+        float acc = 0.f;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) acc += part[l][jl];
+        out[j] += acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -762,10 +787,10 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);
     // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 256)), block, 0, s, slabs, chunks, 128 * 32, 64 * 32,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, chunks, 128 * 32, 64 * 32,
                        dw1_density);
     if (cfg->n_feature_dims == 3)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 256)), block, 0, s, slabs + 64 * 32, chunks, 128 * 32,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, chunks, 128 * 32,
                            64 * 32, dw1_feature);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
