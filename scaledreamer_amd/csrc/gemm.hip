@@ -319,12 +319,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     const int wave = wave_all - kg * NW;                              // wave within its group
     char* const gsm = smem + kg * (NST * STAGE_BYTES);
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    // (parity form of the upsampling convolution, upsample == 3: every parity's rows are tiled on their own, so a block lies in one
+    // parity whatever the row count; its rows are valid below m_lim = the end of that parity's rows)
+    const bool up3 = CONV && p.upsample == 3;
+    const int up_mq = up3 ? p.M >> 2 : 1;
+    const int tiles_pp = (up_mq + BM - 1) / BM;                  // M tiles per parity
+    const int tiles_m = up3 ? 4 * tiles_pp : (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int item, tm_, tn_;
     if (!asd_xcd_item(blockIdx.x, tiles_m * tiles_n * p.split_k, item)) return;
     const int kz = item / (tiles_m * tiles_n);  // split-K slice
     asd_grouped_tile(item - kz * tiles_m * tiles_n, tiles_m, tiles_n, p.group_m, p.group_n, tm_, tn_);
-    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int parity = up3 ? tm_ / tiles_pp : 0;
+    const int m0 = up3 ? parity * up_mq + (tm_ - parity * tiles_pp) * BM : tm_ * BM, n0 = tn_ * BN;
+    const int m_lim = up3 ? (parity + 1) * up_mq : p.M;
     const int k_steps_total = (p.K + 63) / 64;
     const int k_per = (k_steps_total + p.split_k - 1) / p.split_k;
     const int ks0 = kz * k_per, ks1 = min(k_steps_total, ks0 + k_per);
@@ -335,7 +342,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     // fast conv addressing: when every 64-wide k-step lies inside one filter tap (Cin % 64 == 0) and the input is sampled
     // on a regular lattice (no fused upsample / transposed mode), the tap decode is wave-uniform (scalar) and a lane only
     // adds a uniform byte offset to the address of its output pixel's centre tap
-    const bool fast_conv = CONV && p.upsample == 0 && (p.Cin & 63) == 0;
+    const bool fast_conv = CONV && (p.upsample == 0 || p.upsample == 3) && (p.Cin & 63) == 0;
+    // upsample == 3: the 3x3 convolution over the nearest-2x upsampled image as FOUR 2x2 convolutions over the low-resolution image,
+    // one per output-pixel parity (a, b) = (Y & 1, X & 1): output row Y = 2y + a reads image rows y - 1 + a .. y + a, so the nine taps
+    // collapse onto 2 x 2 input pixels with pre-summed weights (packed per parity: W[4][N][4 * Cin]) — 4/9 of the multiply-adds.
+    // The M axis is ordered [parity][batch][y][x] over LOW-resolution positions.
+    const int par_a = parity >> 1, par_b = parity & 1;
+    const char* const Wp = (const char*)p.W + ((CONV && p.upsample == 3) ? (size_t)parity * p.N * p.ldw * 2 : 0);
     // Descriptors are kept small (the accumulators need the registers): the swizzled chunk of a lane is the same in every
     // slab (row & 7 == lane >> 3), plain row-major operands are addressed as base + slab * stride, and only the conv
     // A slabs carry per-slab state (centre-tap address + packed (y, x)).
@@ -350,10 +363,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
 #pragma unroll
         for (int j = 0; j < ASPW; ++j) {
             const int slab = wave + j * NW;
-            const int m = min(m0 + slab * 8 + lrow, p.M - 1);   // clamped: validity is re-derived from the row index
-            const int hw = p.Hout * p.Wout;
+            int m = min(m0 + slab * 8 + lrow, m_lim - 1);   // clamped: validity is re-derived from the row index
+            int hw = p.Hout * p.Wout, wrow = p.Wout;
+            if (p.upsample == 3) { m -= parity * up_mq; hw = p.Hin * p.Win; wrow = p.Win; }   // low-resolution position
             const int b = m / hw, r = m - b * hw;
-            int y = r / p.Wout, x = r - y * p.Wout;
+            int y = r / wrow, x = r - y * wrow;
             c_base[j] = (const char*)p.A + (size_t)b * p.Hin * p.Win * p.Cin * 2;
             if (fast_conv) {
                 y *= p.stride; x *= p.stride;                    // input-lattice coordinates of the centre tap (before -pad)
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     const bool wide = WIDE_OK && p.wide_rows;                          // W tile in permuted row order (tile_epilogue)
     const int wl = wide ? wide_lane_row(lrow) : lrow;
     auto w_slab_rows = [&](int ws) { return wide ? wide_slab_rows(ws) : ws * 8; };
-    const char* w0 = (const char*)p.W + (size_t)(n0 + wl) * p.ldw * 2 + lch * 16;
+    const char* w0 = Wp + (size_t)(n0 + wl) * p.ldw * 2 + lch * 16;
     const size_t a_slab_stride = (size_t)8 * p.lda * 2, w_row_stride = (size_t)p.ldw * 2;
     // Row-major operands (W always, A of a plain GEMM): one 32-bit byte offset per slab against the scalar operand base
     // (global_load_lds saddr + voffset), advanced by 128 B per k-step — 3 instructions per 1-KiB wave-level load.  Rows past
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
             const int slab = wave + j * NW;
             if (j * NW + NW - 1 >= TSLABS && slab >= TSLABS) continue;    // only the last j can run past the tile (wave-uniform)
             if (CONV && slab < ASLABS) continue;
-            const char* base = slab >= ASLABS ? (const char*)p.W : (const char*)p.A;
+            const char* base = slab >= ASLABS ? Wp : (const char*)p.A;
             load_slab(base + roff[j], st + slab * 8 * RB);
             roff[j] += 128 * KG;
         }
@@ -404,8 +418,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
         long long toff = 0;
         if (fast_conv) {
             const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;           // wave-uniform
-            const int ky = tap / 3, kx = tap - ky * 3;
-            tdy = ky - p.pad; tdx = kx - p.pad;
+            if (p.upsample == 3) { tdy = (tap >> 1) - 1 + par_a; tdx = (tap & 1) - 1 + par_b; }
+            else { const int ky = tap / 3, kx = tap - ky * 3; tdy = ky - p.pad; tdx = kx - p.pad; }
             toff = ((long long)(tdy * p.Win + tdx) * p.Cin + c0) * 2;
         }
 #pragma unroll
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
             } else {
                 constexpr int JA = CONV ? ASPW : 1;
                 const int ja = j < JA ? j : JA - 1;      // A slabs of a wave are its first ones
-                const bool row_ok = m0 + slab * 8 + lrow < p.M;
+                const bool row_ok = m0 + slab * 8 + lrow < m_lim;
                 const int sy = c_yx[ja] >> 16, sx = c_yx[ja] & 0xffff;
                 if (fast_conv) {
                     const int yi = sy + tdy, xi = sx + tdx;
@@ -434,7 +448,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
                     const int ky = tap / 3, kx = tap - ky * 3;
                     int yi = sy * p.stride + ky - p.pad, xi = sx * p.stride + kx - p.pad;
                     bool ok = row_ok && k_ok;
-                    if (p.upsample == 1) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
+                    if (p.upsample == 3) {  // parity form: 2 x 2 taps over the low-resolution image
+                        yi = sy + (tap >> 1) - 1 + par_a; xi = sx + (tap & 1) - 1 + par_b;
+                        ok = ok && yi >= 0 && xi >= 0 && yi < p.Hin && xi < p.Win;
+                    } else if (p.upsample == 1) {  // conv over the nearest-2x upsampled image: bounds in the upsampled frame
                         ok = ok && yi >= 0 && xi >= 0 && yi < 2 * p.Hin && xi < 2 * p.Win;
                         yi >>= 1; xi >>= 1;
                     } else if (p.upsample == 2) {
@@ -584,7 +601,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
     const int em = lane & 15, en = (lane >> 4) * 4;
-    auto out_row = [&](int i) { const int m = m0 + wm * (BM / WM) + i * 16 + em; return m < p.M ? m : -1; };
+    auto out_row = [&](int i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + em;
+        if (m >= m_lim) return -1;
+        if (CONV && p.upsample == 3) {      // [parity][b][y][x] -> output pixel (b, 2y + a, 2x + b)
+            const int q = m - parity * up_mq, hwq = p.Hin * p.Win;
+            const int bb = q / hwq, r = q - bb * hwq, y = r / p.Win, x = r - y * p.Win;
+            return (bb * p.Hout + 2 * y + par_a) * p.Wout + 2 * x + par_b;
+        }
+        return m;
+    };
     if (KG > 1 && kg != 0) {    // group 0 stores; the others only keep the GroupNorm reduction's block barriers company
         if (p.split_k == 1 && p.act != 2 && p.gn_partials != nullptr) {
             __syncthreads(); __syncthreads();    // gn_tile_begin
@@ -1192,6 +1218,7 @@ static int asd_gemm_resolve_cfg(const asd_gemm_args* a) {
     if (a->act == 2 && (cfg == 4 || cfg == 6)) cfg = a->N % 256 == 0 ? 5 : (a->N % 128 == 0 ? 3 : 2);   // per-wave width % 32
     if (a->tile_cfg >= 1 && a->tile_cfg <= ASD_GEMM_NCFG) cfg = a->tile_cfg - 1;
     if (g_force_tile >= 0 && g_force_tile < ASD_GEMM_NCFG) cfg = g_force_tile;
+    if (a->conv && a->upsample == 3 && asd_cfg_is_window(cfg)) cfg = a->N % 128 == 0 ? 1 : 0;
     return cfg;
 }
 
@@ -1200,6 +1227,7 @@ static int asd_gemm_resolve_cfg(const asd_gemm_args* a) {
 static int asd_gemm_gn_records_cfg(const asd_gemm_args* a, int cfg, bool need_ptr) {
     if (a->gn_bwd_x && !(a->gn_bwd_fstats && a->gn_bwd_gamma && a->gn_bwd_beta && a->ldc == a->N)) return 0;
     if ((need_ptr && !a->gn_partials) || a->split_k < 1 || a->out_f32 || a->act == 2 || a->gn_cg < 1 || a->gn_rows < 1 || a->N != 32 * a->gn_cg || a->M % a->gn_rows) return 0;
+    if (a->conv && a->upsample == 3) return 0;      // parity-major row order: the tiles of a batch element are not contiguous
     if (a->split_k > 1) {     // statistics in the split-K epilogue (splitk_epilogue_gn_kernel): 64 x 64 blocks, few enough records to fold
         if (a->gn_bwd_x || a->N % 64 || a->gn_rows % 64 || a->ldc % 4) return 0;
         const int nrec = (a->gn_rows / 64) * (a->N / 64);
@@ -1290,7 +1318,9 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     ASD_CHECK_ARG(a->N % 4 == 0 && a->ldc % 4 == 0, "N and ldc must be multiples of 4");
     ASD_CHECK_ARG(a->ldw % 8 == 0 && (a->conv || a->lda % 8 == 0), "leading dimensions must be multiples of 8 halfs (16 B)");
     if (a->conv) {
-        ASD_CHECK_ARG(a->Cin % 8 == 0 && a->K == 9 * a->Cin, "conv: Cin must be a multiple of 8 and K = 9*Cin");
+        ASD_CHECK_ARG(a->Cin % 8 == 0 && a->K == (a->upsample == 3 ? 4 : 9) * a->Cin, "conv: Cin must be a multiple of 8 and K = 9*Cin (4*Cin in the parity form)");
+        ASD_CHECK_ARG(a->upsample != 3 || (a->stride == 1 && a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win && !a->gn_bwd_x),
+                      "parity-form upsample conv: stride 1, Hout = 2*Hin, Wout = 2*Win");
         ASD_CHECK_ARG(a->Hout > 0 && a->Wout > 0 && a->M % (a->Hout * a->Wout) == 0, "conv: M must be B*Hout*Wout");
     }
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
@@ -1367,7 +1397,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         ASD_LAUNCH_CHECK();
         return ASD_OK;
     }
-    const int tiles = asd_div_up(a->M, bm) * asd_div_up(a->N, bn);
+    const int tiles = (a->conv && a->upsample == 3 ? 4 * asd_div_up(a->M / 4, bm) : asd_div_up(a->M, bm)) * asd_div_up(a->N, bn);
     const size_t lds = (size_t)asd_cfg_stages(cfg) * asd_cfg_kgroups(cfg) * (bm + bn) * 128;
     if (a->group_m < 1 || a->group_n < 1) asd_pick_group(asd_div_up(a->M, bm), asd_div_up(a->N, bn), bm, bn, lds, &a->group_m, &a->group_n);
     const dim3 grid(8 * asd_div_up(tiles * a->split_k, 8)), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * asd_cfg_kgroups(cfg) * 64);   // asd_xcd_item

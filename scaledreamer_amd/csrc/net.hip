@@ -152,11 +152,13 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     launch_gemm(r, g, o.out, o.gn_bwd_form);
 }
 
-// 3x3 convolution on NHWC [B,Hin,Win,Cin] with packed weights [Cout, 9*Cin]; upsample: 0 plain, 1 nearest-2x fused, 2 transposed stride-2
+// 3x3 convolution on NHWC [B,Hin,Win,Cin] with packed weights [Cout, 9*Cin]; upsample: 0 plain, 1 nearest-2x fused, 2 transposed stride-2,
+// 3 nearest-2x fused in its parity form (four 2x2 convolutions over the low-resolution image, weights [4][Cout][4*Cin])
 void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void* W, int Cout, void* y, int Hout, int Wout, int stride,
              int pad, int upsample, const GemmOpt& o = GemmOpt()) {
     asd_gemm_args g = asd_gemm_args{};
-    g.A = x; g.W = W; g.C = y; g.M = B * Hout * Wout; g.N = Cout; g.K = 9 * Cin; g.lda = 0; g.ldw = 9 * Cin; g.ldc = Cout;
+    const int taps = upsample == 3 ? 4 : 9;
+    g.A = x; g.W = W; g.C = y; g.M = B * Hout * Wout; g.N = Cout; g.K = taps * Cin; g.lda = 0; g.ldw = taps * Cin; g.ldc = Cout;
     g.bias = o.bias; g.row_bias = o.row_bias; g.rows_per_group = o.row_bias ? o.rows_per_group : 1; g.ld_row_bias = o.ld_row_bias;
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
     g.conv = 1; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.pad = pad; g.upsample = upsample;
@@ -286,7 +288,8 @@ void unet_build(UNet& n) {
             }
             if (lvl && i == d.num_res_blocks) {
                 const std::string q = p + "." + std::to_string(k) + ".conv";
-                u_conv(n, q, ch, ch);
+                // the upsampling convolution in its parity form: [4 parities][cout][2 x 2 taps x cin] pre-summed taps (weights.pack_unet)
+                n.add(q + ".weight", 4 * ch, 4 * pad32(ch)); n.add(q + ".bias", 1, ch);
                 b.layers.push_back(ULayer{4, q, ch, ch});
                 --ds;
             }
@@ -416,7 +419,7 @@ Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh,
             half_t* y = r.mem.halfs((size_t)B * 4 * *Hh * *Ww * l.cout);
             Act a;
             GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = 4 * *Hh * *Ww; o.out = &a;
-            conv3x3(r, h.p, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, 2 * *Hh, 2 * *Ww, 1, 1, 1, o);
+            conv3x3(r, h.p, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, 2 * *Hh, 2 * *Ww, 1, 1, 3, o);
             h = a; *Hh *= 2; *Ww *= 2;
         }
     }

@@ -120,6 +120,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
     GroupNorm(x)[+SiLU] and the records carry that layer's two backward reductions instead (asd_gemm_args.gn_bwd_x)."""
     dev = a.device
     N, K = w.shape
+    if conv is not None and int(conv.get("upsample", 0)) == 3:     # parity form: w = [4 parities][Cout][4 * Cin]
+        N //= 4
     if conv is None:
         assert a.stride(-1) == 1 and a.dim() == 2
         M = a.shape[0]
@@ -176,7 +178,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
 
 def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1, pad: int = 1, upsample: bool = False,
             out_hw=None, **kw) -> torch.Tensor:
-    """x: NHWC fp16 [B,H,W,Cin]; w_packed: [Cout, 9*Cin] with k = (ky, kx, cin). Returns [B,Ho,Wo,Cout]."""
+    """x: NHWC fp16 [B,H,W,Cin]; w_packed: [Cout, 9*Cin] with k = (ky, kx, cin). Returns [B,Ho,Wo,Cout].
+    upsample: 0 plain, 1 fused nearest-2x, 2 input gradient of a stride-2 conv, 3 fused nearest-2x in its parity form
+    (w_packed = pack_upsample_conv3x3_weight(w): [4 * Cout, 4 * Cin], four 2x2 convolutions over the low-resolution image)."""
     B, H, W_, Cin = x.shape
     assert x.is_contiguous()
     if out_hw is None:
@@ -190,9 +194,16 @@ def conv3x3(x: torch.Tensor, w_packed: torch.Tensor, bias=None, stride: int = 1,
         Ho, Wo = out_hw
     conv = dict(Hin=H, Win=W_, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=int(upsample))  # upsample: 0/1/2
     y = gemm(x, w_packed, bias=bias, conv=conv, M=B * Ho * Wo, **kw)
+    cout = w_packed.shape[0] // 4 if int(upsample) == 3 else w_packed.shape[0]
     if isinstance(y, tuple):      # gn_rows: (C, records, records per batch element)
-        return y[0].view(B, Ho, Wo, w_packed.shape[0]), y[1], y[2]
-    return y.view(B, Ho, Wo, w_packed.shape[0])
+        return y[0].view(B, Ho, Wo, cout), y[1], y[2]
+    return y.view(B, Ho, Wo, cout)
+
+
+def pack_upsample_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
+    from .weights import _pack_upsample_conv3x3
+
+    return _pack_upsample_conv3x3(w).contiguous()
 
 
 def pack_conv3x3_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:

@@ -253,6 +253,28 @@ def _pack_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tenso
     return wp.reshape(cout, 9 * cp)
 
 
+def _pack_upsample_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """Upsample.conv (openaimodel.py:99-131: nearest 2x, then 3x3 / pad 1) in its parity form: output pixel (2y + a, 2x + b) only
+    sees the 2 x 2 input pixels (y - 1 + a + dy, x - 1 + b + dx), dy, dx in {0, 1}, with the taps that land on the same pixel summed:
+    rows a = 0: {ky = 0} -> dy = 0, {1, 2} -> dy = 1;  a = 1: {0, 1} -> dy = 0, {2} -> dy = 1 (columns alike).
+    PyTorch [Cout, Cin, 3, 3] -> [4 * Cout, 4 * Cin'] = [parity (a, b)][cout][(dy, dx, cin)], summed in fp32."""
+    cout, cin = w.shape[:2]
+    cp = (cin + 31) // 32 * 32
+    taps = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    wf = w.float()
+    out = torch.zeros((2, 2, cout, 2, 2, cp), dtype=torch.float32, device=w.device)
+    for a in (0, 1):
+        for b in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    acc = 0
+                    for ky in taps[a][dy]:
+                        for kx in taps[b][dx]:
+                            acc = acc + wf[:, :, ky, kx]
+                    out[a, b, :, dy, dx, :cin] = acc
+    return out.reshape(4 * cout, 4 * cp).to(w.dtype)
+
+
 def _geglu_rows(c: int) -> torch.Tensor:
     """GEGLU.proj rows [value (c) | gate (c)] (attention.py:49-56) -> interleaved in 32-row groups [16 value | 16 gate]: the layout
     the fused epilogue of asd_gemm_f16 (act = 2) reads."""
@@ -265,11 +287,15 @@ def pack_unet(p: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Te
     _, inputs, middle, outputs = unet_layout(cfg)
     out: Dict[str, torch.Tensor] = {}
     emb_w, emb_b, ck, cv = [], [], [], []
+    up_convs = {n + ".weight" for blk in outputs for kind, n, _, _ in blk.layers if kind == "up"}
     for name, t in p.items():
         if ".emb_layers.1." in name or any(k in name for k in (".attn1.to_q.", ".attn1.to_k.", ".attn2.to_k.", ".attn2.to_v.")):
             continue
         if name.endswith(".weight") and t.ndim == 4:
-            out[name] = _pack_conv3x3(t) if t.shape[-1] == 3 else t.reshape(t.shape[0], t.shape[1])   # 1x1 conv == Linear on NHWC
+            if name in up_convs:
+                out[name] = _pack_upsample_conv3x3(t)
+            else:
+                out[name] = _pack_conv3x3(t) if t.shape[-1] == 3 else t.reshape(t.shape[0], t.shape[1])   # 1x1 conv == Linear on NHWC
         else:
             out[name] = t
     for blk in list(inputs) + [middle] + list(outputs):            # the order csrc/net.hip assigns the column offsets in

@@ -76,6 +76,29 @@ def test_conv3x3_variants(B, H_, W_, Cin, Cout, stride, pad, up):
     _close(got.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("B,hw,cin,cout", [(5, 32, 640, 640), (5, 16, 1280, 1280), (5, 8, 1280, 1280), (2, 16, 96, 64), (1, 8, 40, 320), (3, 24, 64, 128)])
+@pytest.mark.parametrize("tile,sk", [(0, 1), (12, 1), (2, 3), (16, 1), (1, 2)])
+def test_upsample_conv_parity_form(B, hw, cin, cout, tile, sk):
+    """Upsample.conv (nearest 2x, then 3x3) as four 2x2 convolutions over the low-resolution image with pre-summed taps (asd_gemm_args
+    upsample = 3) against F.interpolate + F.conv2d, and against the nine-tap fused form (upsample = 1) of the same kernel; tiles whose
+    rows do not divide a parity's rows are replaced by the library (the result must not depend on the request)"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(B, cin, hw, hw, seed=21)
+    w = _rand(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=22)
+    bias, res = _rand(cout, seed=23), _rand(B, 2 * hw, 2 * hw, cout, seed=24)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1) + res.float()
+    cp = (cin + 31) // 32 * 32
+    xn = torch.zeros(B, hw, hw, cp, dtype=torch.float16, device="cuda")
+    xn[..., :cin] = x.permute(0, 2, 3, 1)
+    if sk > 1 and (4 * cp) // sk < 256:
+        pytest.skip("split deeper than the reduction")
+    got = H.conv3x3(xn, H.pack_upsample_conv3x3_weight(w), bias=bias, residual=res.view(-1, cout), upsample=3, tile_cfg=tile + 1, split_k=sk)
+    _close(got, ref)
+    nine = H.conv3x3(xn, H.pack_conv3x3_weight(w), bias=bias, residual=res.view(-1, cout), upsample=1, split_k=1)
+    assert float((got.float() - nine.float()).abs().max()) <= 4e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1)])
 def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
