@@ -409,6 +409,20 @@ int asd_unet_fwd(asd_unet* h, const void* x_nhwc, const float* t, const void* co
                  int32_t W, int32_t n_ctx, int32_t num_frames, void* workspace, int64_t workspace_bytes, float* eps_nhwc, int32_t tune,
                  void* stream);
 
+/* The same forward when several batch entries are known to carry the SAME (x, t, camera) and differ only in their text context —
+ * the ASD step evaluates one noised latent under 4 prompts (CFG + Perp-Neg, stable_diffusion_asd_guidance.py:333-428): everything
+ * in front of the first cross-attention (conv_in, the first ResBlock, proj_in and the first self-attention, the 4096-token one) is
+ * computed once per distinct input and broadcast.  uniq_src_dev[n_uniq]: batch index of each distinct input (ascending; for the
+ * camera-conditioned UNet whole groups of num_frames); expand_dev[batch]: index into that list for every batch entry.  Device
+ * int32 arrays owned by the caller.  n_uniq == batch (or NULL arrays) is asd_unet_fwd. */
+int64_t asd_unet_workspace_bytes_shared(asd_unet* h, int32_t batch, int32_t H, int32_t W, int32_t n_ctx, int32_t num_frames, int32_t tune,
+                                        int32_t n_uniq);
+int asd_unet_fwd_shared(asd_unet* h, const void* x_nhwc, const float* t, const void* context, const void* camera, int32_t batch, int32_t H,
+                        int32_t W, int32_t n_ctx, int32_t num_frames, const int32_t* uniq_src_dev, const int32_t* expand_dev, int32_t n_uniq,
+                        void* workspace, int64_t workspace_bytes, float* eps_nhwc, int32_t tune, void* stream);
+/* dst[i][:] = src[idx_dev[i]][:], rows of row_halfs fp16 values (multiple of 8) */
+int asd_gather_rows_f16(const void* src, const int32_t* idx_dev, int32_t n_out, int64_t row_halfs, void* dst, void* stream);
+
 typedef struct asd_vae_desc {           /* first_stage_config.ddconfig of sd-v2-base.yaml:33-50 */
     int32_t in_channels, ch, n_levels, ch_mult[8], num_res_blocks, z_channels, embed_dim;
 } asd_vae_desc;

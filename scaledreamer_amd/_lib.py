@@ -121,7 +121,7 @@ SYMBOLS = [
     "asd_pad_cast_f16",
     "asd_image_prep_fwd", "asd_image_prep_bwd", "asd_latents_fwd", "asd_score_fwd", "asd_latents_bwd", "asd_prompt_context",
     "asd_unet_create", "asd_unet_destroy", "asd_unet_num_weights", "asd_unet_weight_info", "asd_unet_bind_weights",
-    "asd_unet_workspace_bytes", "asd_unet_fwd",
+    "asd_unet_workspace_bytes", "asd_unet_fwd", "asd_unet_workspace_bytes_shared", "asd_unet_fwd_shared", "asd_gather_rows_f16",
     "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",
     "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
     "asd_adamw_f32", "asd_adan_f32",
@@ -143,7 +143,7 @@ def lib() -> C.CDLL:
         l.asd_version.restype = C.c_char_p
         l.asd_grid_meta_init.restype = C.c_uint32
         l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
-        for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_vae_enc_workspace_bytes"):
+        for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_unet_workspace_bytes_shared", "asd_vae_enc_workspace_bytes"):
             getattr(l, fn).restype = C.c_int64
         l.asd_unet_destroy.restype = None
         l.asd_vae_enc_destroy.restype = None

@@ -308,7 +308,19 @@ struct UState {             // per-forward quantities shared by the layers
     int B, F, n_ctx, ctx_stride;
     const half_t* emb_all; int emb_ld;
     const half_t* k_all; const half_t* vT_all;
+    // shared-input prefix (asd_unet_fwd_shared): while `full` is set this state describes the batch of DISTINCT inputs; the first
+    // transformer switches to *full after its first self-attention (the first layer that reads the text context is the cross-
+    // attention behind it) by broadcasting its activations with `expand` (int32 [full->B] on the device)
+    const UState* full = nullptr;
+    const int* expand = nullptr;
 };
+
+// rows of `row_halfs` fp16 values: dst[i] = src[idx[i]]
+half_t* gather_rows(Run& r, const half_t* src, const int* idx, int n_out, size_t row_halfs) {
+    half_t* dst = r.mem.halfs((size_t)n_out * row_halfs);
+    LEAF(asd_gather_rows_f16(src, idx, n_out, (int64_t)row_halfs, dst, r.stream));
+    return dst;
+}
 
 Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int cin, int cout, int Hh, int Ww) {
     const int B = s.B, hw = Hh * Ww, M = B * hw;
@@ -344,8 +356,10 @@ half_t* layernorm(Run& r, const half_t* x, int rows, int c, const half_t* g, con
     return y;
 }
 
-Act u_transformer(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int C, int Hh, int Ww) {
-    const int B = s.B, L = Hh * Ww, M = B * L, heads = C / 64, F = s.F;
+Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, const Act& xin, int C, int Hh, int Ww) {
+    const UState* sp = &s_in;
+    int B = sp->B, L = Hh * Ww, M = B * L;
+    const int heads = C / 64, F = sp->F;
     const half_t* x = xin.p;
     half_t* h = groupnorm(r, x, C, nullptr, 0, B, L, n.w(p + ".norm.weight"), n.w(p + ".norm.bias"), 1e-6f, 0, nullptr, nullptr, &xin);
     {
@@ -367,6 +381,13 @@ Act u_transformer(UNet& n, Run& r, const UState& s, const std::string& p, const 
         half_t* h1 = r.mem.halfs((size_t)M * C);
         { GemmOpt o; o.bias = n.w(b + ".attn1.to_out.0.bias"); o.residual = h; o.ldr = C;
           gemm(r, o1, M, C, n.w(b + ".attn1.to_out.0.weight"), C, C, C, h1, C, o); }
+        if (sp->full) {          // end of the shared prefix: every batch entry gets its distinct input's activations
+            const UState* f = sp->full;
+            h1 = gather_rows(r, h1, sp->expand, f->B, (size_t)L * C);
+            x = gather_rows(r, x, sp->expand, f->B, (size_t)L * C);      // the block's residual input (proj_out below)
+            sp = f; B = f->B; M = B * L;
+        }
+        const UState& s = *sp;
         // cross-attention on the text context (K / V^T of every layer were projected once per forward)
         y = layernorm(r, h1, M, C, n.w(b + ".norm2.weight"), n.w(b + ".norm2.bias"));
         half_t* q = r.mem.halfs((size_t)M * C);
@@ -428,7 +449,7 @@ Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh,
 
 // UNetModel.forward (openaimodel.py:771-808) / MultiViewUNetModel.forward (:1175-1213)
 void unet_run(UNet& n, Run& r, const half_t* x, const float* t, const half_t* ctx, const half_t* camera, int B, int Hh, int Ww, int n_ctx,
-              int num_frames, float* eps) {
+              int num_frames, float* eps, const int* uniq_src = nullptr, const int* expand = nullptr, int Bu = 0) {
     const asd_unet_desc& d = n.d;
     const int mc = d.model_channels, emb = 4 * mc;
     UState s;
@@ -465,7 +486,31 @@ void unet_run(UNet& n, Run& r, const half_t* x, const float* t, const half_t* ct
     Act h;
     h.p = x;
     int hh = Hh, ww = Ww;
-    for (const UBlock& b : n.inputs) {
+    size_t first = 0;
+    if (Bu > 0 && Bu < B && !n.inputs.empty()) {
+        // shared-input prefix: conv_in (and, when the second block opens with ResBlock + transformer, everything up to its first
+        // cross-attention) on the Bu distinct inputs only
+        UState su = s;
+        su.B = Bu; su.full = &s; su.expand = expand;
+        su.emb_all = gather_rows(r, emb_all, uniq_src, Bu, (size_t)n.emb_total);
+        Act hu;
+        hu.p = gather_rows(r, x, uniq_src, Bu, (size_t)Hh * Ww * 32);
+        hu = u_apply(n, r, su, n.inputs[0], hu, &hh, &ww);
+        const int c0 = n.inputs[0].layers.back().cout;
+        bool has_attn = false;
+        if (n.inputs.size() > 1)
+            for (const ULayer& l : n.inputs[1].layers) has_attn = has_attn || l.kind == 2;
+        h = Act{gather_rows(r, hu.p, expand, B, (size_t)hh * ww * c0), nullptr, 0};
+        hs.push_back(Skip{h.p, c0});
+        first = 1;
+        if (has_attn && n.inputs[1].layers.front().kind != 3 && n.inputs[1].layers.front().kind != 4) {
+            h = u_apply(n, r, su, n.inputs[1], hu, &hh, &ww);        // leaves the prefix inside its first transformer: full batch
+            hs.push_back(Skip{h.p, n.inputs[1].layers.back().cout});
+            first = 2;
+        }
+    }
+    for (size_t bi = first; bi < n.inputs.size(); ++bi) {
+        const UBlock& b = n.inputs[bi];
         h = u_apply(n, r, s, b, h, &hh, &ww);
         hs.push_back(Skip{h.p, b.layers.back().cout});
     }
@@ -851,15 +896,29 @@ int asd_unet_bind_weights(asd_unet* h, const void* const* ptrs, int32_t count) {
     ASD_CHECK_ARG(h && ptrs, "null argument");
     return bind(*(UNet*)h, ptrs, count);
 }
-int64_t asd_unet_workspace_bytes(asd_unet* h, int32_t batch, int32_t H, int32_t W, int32_t n_ctx, int32_t num_frames, int32_t tune) {
+int64_t asd_unet_workspace_bytes_shared(asd_unet* h, int32_t batch, int32_t H, int32_t W, int32_t n_ctx, int32_t num_frames, int32_t tune,
+                                        int32_t n_uniq) {
     UNet* n = (UNet*)h;
     if (!n || batch < 1 || H < 1 || W < 1 || n_ctx < 1) return -1;
-    return (int64_t)plan_bytes([&](Run& r) { unet_run(*n, r, nullptr, nullptr, nullptr, nullptr, batch, H, W, n_ctx, num_frames, nullptr); }, tune != 0);
+    return (int64_t)plan_bytes([&](Run& r) { unet_run(*n, r, nullptr, nullptr, nullptr, nullptr, batch, H, W, n_ctx, num_frames, nullptr,
+                                                      nullptr, nullptr, n_uniq); }, tune != 0);
+}
+int64_t asd_unet_workspace_bytes(asd_unet* h, int32_t batch, int32_t H, int32_t W, int32_t n_ctx, int32_t num_frames, int32_t tune) {
+    return asd_unet_workspace_bytes_shared(h, batch, H, W, n_ctx, num_frames, tune, 0);
 }
 int asd_unet_fwd(asd_unet* h, const void* x_nhwc, const float* t, const void* context, const void* camera, int32_t batch, int32_t H,
                  int32_t W, int32_t n_ctx, int32_t num_frames, void* workspace, int64_t workspace_bytes, float* eps_nhwc, int32_t tune,
                  void* stream) {
+    return asd_unet_fwd_shared(h, x_nhwc, t, context, camera, batch, H, W, n_ctx, num_frames, nullptr, nullptr, 0, workspace, workspace_bytes,
+                               eps_nhwc, tune, stream);
+}
+
+int asd_unet_fwd_shared(asd_unet* h, const void* x_nhwc, const float* t, const void* context, const void* camera, int32_t batch, int32_t H,
+                        int32_t W, int32_t n_ctx, int32_t num_frames, const int32_t* uniq_src_dev, const int32_t* expand_dev, int32_t n_uniq,
+                        void* workspace, int64_t workspace_bytes, float* eps_nhwc, int32_t tune, void* stream) {
     UNet* n = (UNet*)h;
+    if (!uniq_src_dev || !expand_dev || n_uniq >= batch) n_uniq = 0;
+    ASD_CHECK_ARG(n_uniq == 0 || (n_uniq > 0 && n_uniq % (num_frames > 0 ? num_frames : 1) == 0), "distinct inputs must come in whole groups of num_frames");
     ASD_CHECK_ARG(n && x_nhwc && t && context && workspace && eps_nhwc, "null argument");
     ASD_CHECK_ARG(n->bound, "weights are not bound (asd_unet_bind_weights)");
     ASD_CHECK_ARG((n->d.camera_dim > 0) == (camera != nullptr), "camera is given iff the UNet is camera-conditioned");
@@ -867,7 +926,7 @@ int asd_unet_fwd(asd_unet* h, const void* x_nhwc, const float* t, const void* co
     const int levels = n->d.n_levels - 1;
     ASD_CHECK_ARG(H % (1 << levels) == 0 && W % (1 << levels) == 0, "H and W must be divisible by 2^(levels-1)");
     return run_pass([&](Run& r) { unet_run(*n, r, (const half_t*)x_nhwc, t, (const half_t*)context, (const half_t*)camera, batch, H, W, n_ctx,
-                                           num_frames, eps_nhwc); },
+                                           num_frames, eps_nhwc, (const int*)uniq_src_dev, (const int*)expand_dev, n_uniq); },
                     workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page);
 }
 

@@ -607,7 +607,27 @@ static int gn_apply_chunks(int hw, int C, int batch) {
     return chunks > cap_a ? cap_a : chunks;
 }
 
+// dst[i][:] = src[idx[i]][:] for rows of row16 16-byte words (batch-entry gather / broadcast of NHWC activations)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ idx, size_t row16,
+                                                          uint4* __restrict__ dst) {
+    const size_t i = blockIdx.y;
+    const uint4* s = src + (size_t)idx[i] * row16;
+    uint4* d = dst + i * row16;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < row16; q += (size_t)gridDim.x * 256) d[q] = s[q];
+}
+
 extern "C" {
+
+int asd_gather_rows_f16(const void* src, const int32_t* idx_dev, int32_t n_out, int64_t row_halfs, void* dst, void* stream) {
+    ASD_CHECK_ARG(src && idx_dev && dst && n_out > 0 && row_halfs > 0 && row_halfs % 8 == 0, "bad argument");
+    const size_t row16 = (size_t)row_halfs / 8;
+    int bx = (int)((row16 + 1023) / 1024);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, n_out), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (const int*)idx_dev, row16,
+                       (uint4*)dst);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
 
 int asd_groupnorm_f16(const void* x1, int32_t c1, const void* x2, int32_t c2, int32_t batch, int32_t hw, const void* gamma,
                       const void* beta, float eps, int32_t silu, void* y, float* stats, void* stream) {

@@ -74,6 +74,40 @@ def test_full_sd21_unet_matches_reference_golden():
         assert l2 < 1e-2 and mx < 1e-2, (i, l2, mx)
 
 
+@pytest.mark.parametrize("camera", [False, True])
+def test_shared_input_prefix_equals_the_plain_forward(camera):
+    """asd_unet_fwd_shared: a batch laid out as the ASD step lays it out — r repetitions of G inputs under different contexts, then G
+    more inputs — run with the prefix in front of the first cross-attention computed once per distinct input, against the plain
+    forward of the same batch (SD layout r = 4, G = 1; MVDream r = 2, G = 4 views with cross-view self-attention)."""
+    from scaledreamer_amd.diffusion import weights as W
+    from scaledreamer_amd.diffusion.engine import HipUNet
+
+    cfg = W.UNetConfig(model_channels=128, context_dim=128, camera_dim=16 if camera else None)
+    p = W.gen_params(W.unet_layout(cfg)[0], 5, dtype=torch.float16)
+    eng = HipUNet(p, cfg, "cuda", use_graph=True)
+    r, G, frames = (2, 4, 4) if camera else (4, 1, 1)
+    N = (r + 1) * G
+    xa, xb = rnd("in.xa", (G, 4, 32, 32), 31), rnd("in.xb", (G, 4, 32, 32), 32)
+    x = torch.cat([xa] * r + [xb]).cuda()
+    t = torch.cat([torch.full((r * G,), 611.0), torch.full((G,), 640.0)]).cuda()
+    ctx = rnd("in.ctx", (N, 77, 128), 33).cuda()
+    cam = torch.cat([rnd("in.cam", (G, 16), 34)] * (r + 1)).cuda() if camera else None
+    plain_key = eng.staging(N, 32, 32, 77, frames)[1][6]
+    shared_key = eng.staging(N, 32, 32, 77, frames, shared_reps=r)[1][6]
+    assert plain_key != shared_key and shared_key[5] == r
+    outs = []
+    for key in (plain_key, shared_key):
+        xin, tin, cin, cm, out = eng._graphs[key][1][:5]
+        xin.zero_(); xin[..., :4].copy_(x.permute(0, 2, 3, 1)); tin.copy_(t)
+        cin.view(N, -1, cin.shape[-1])[:, :77].copy_(ctx)
+        if cm is not None:
+            cm.copy_(cam)
+        outs.append(eng.replay(key).clone())
+    l2, mx = _rel(outs[1], outs[0])
+    assert l2 < 3e-3 and mx < 1e-2, (l2, mx)      # other batch sizes in the prefix pick other tile / split-K plans: fp16 rounding only
+    assert float((outs[1][0] - outs[1][G]).abs().max()) > 0     # different contexts still give different predictions
+
+
 def test_mvdream_unet_matches_oracle():
     """MultiViewUNetModel (openaimodel.py:811-1213): camera embedding + self-attention across the 4 views of a group
     (BasicTransformerBlock3D, attention.py:343-354); the oracle is pinned by tests/golden/diffusion_mvunet_small.npz."""
