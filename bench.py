@@ -424,7 +424,10 @@ def main():
             "config": {"workload": "asd_sd_nerf: 1 view/GPU, 64x64 rays, 512 spp occgrid march, implicit-volume iNGP "
                                    "(16x2 hash grid 2^19, MLP 64), SD-2.1 UNet batch 5 (CFG+Perp-Neg+shifted t), VAE 512^2 "
                                    "fwd+bwd, AdamW", "views_per_gpu": 1, "parallelism": f"dp{world}",
-                       "diffusion_backend": args.backend, "diffusion_weights": getattr(getattr(system.guidance, "backend", None), "weights_source", "seeded random init")},
+                       "diffusion_backend": args.backend, "diffusion_weights": getattr(getattr(system.guidance, "backend", None), "weights_source", "seeded random init"),
+                       "exact_restructurings": "UNet upsampling convs as four 2x2 parity convs (4/9 of their multiply-adds); layers in front of the first "
+                                               "cross-attention computed once per distinct (x, t) of the batch of 5 (2 distinct) — same eps within fp16 rounding, "
+                                               "tests/test_gpu_unet_engine.py, tests/test_gpu_diffusion_ops.py"},
             "step_ms_gpu": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9)},
             "allreduce_exposed_ms": allreduce_ms,
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
