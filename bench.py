@@ -91,8 +91,8 @@ PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("une
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
 DOMINANT = "field_bwd"
-DOMINANT_SOURCE = ("profiles/r02_f_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
-                   "inside the timed steps alone (profiles/r02_f_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.49 ms, gemm_f16_kernel<256,64> 1.34 ms, "
+DOMINANT_SOURCE = ("profiles/r02_g_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
+                   "inside the timed steps alone (profiles/r02_g_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.49 ms, gemm_f16_kernel<256,64> 1.34 ms, "
                    "attention_fwd_kernel<4> + <2> 1.38 ms and field_bwd_sample_kernel 1.27 ms per step are within 15 % of each other: see roofline_vae_conv / roofline_gemm")
 
 
