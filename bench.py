@@ -85,8 +85,8 @@ def to_device(batch, dev):
 
 # HBM-side bytes per launch from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under `--pmc FETCH_SIZE` and
 # `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; summaries in
-# profiles/r01_final3_pmc_roofline_kernel.txt, r01_final2_* for the earlier plans), keyed by (op, autotuned plan).
-PMC_TRAFFIC = {("vae512", (12, 1)): 136.9e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.0e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
+# profiles/r02_g_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.csv for the current plans, r01_final* for the earlier ones), keyed by (op, autotuned plan).
+PMC_TRAFFIC = {("vae512", (12, 1)): 140.3e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.1e6, ("gemm320", (3, 1)): 37.1e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
 
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
@@ -157,7 +157,8 @@ def roofline_gemm_kernel(reps: int = 50):
     return {"kernel": f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}> split_k={plan[1]} on linear 320->320, M=20480 (UNet 64x64 tokens x batch 5)"
                       if plan[0] else "gemm_f16_kernel<model tile> on linear 320->320, M=20480",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4)}
+            "traffic": PMC_TRAFFIC.get(("gemm320", plan)), "traffic_unit": "bytes/launch (PMC, profiles/)", "bytes_per_launch": nbytes,
+            "avg_launch_ms": round(ms, 4)}
 
 
 def roofline_field_kernel(system, batch, reps: int = 20):
