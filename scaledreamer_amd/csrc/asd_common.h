@@ -179,11 +179,30 @@ __device__ __forceinline__ void asd_scatter(const asd_grid_meta& m, float* __res
 //     lanes (segmented shuffle reduction on the run id); the run head then issues f0 while the run's second lane issues the f1 of
 //     the same entry in the same instruction (one request); single-lane runs fall back to a second instruction.
 // Must be called by all 64 lanes (inactive lanes pass active=false).
-template <int L, int NAGG>
+//   * levels < NPRIV (the coarsest, a few thousand entries that EVERY sample of the step updates: ~1 % of the atomics but ~10 % of
+//     the kernel's time — same-line serialisation, tools/field_bwd_ab.py): each XCD adds into its own copy `priv + xcd * priv_stride`
+//     (ASD_PRIV_COPIES copies, that many times fewer collisions per line); asd_priv_reduce_kernel folds the copies into dparams afterwards.
+#ifndef ASD_PRIV_COPIES
+#define ASD_PRIV_COPIES 8
+#endif
+template <int L, int NAGG, int NPRIV = 0>
 __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* __restrict__ dparams, float x, float y,
-                                                 float z, const float (&denc)[2 * L], bool active) {
+                                                 float z, const float (&denc)[2 * L], bool active, float* __restrict__ priv = nullptr,
+                                                 uint32_t priv_stride = 0) {
+    static_assert(NPRIV <= NAGG, "only run-aggregated levels have per-XCD copies");
     x = asd_unit(x); y = asd_unit(y); z = asd_unit(z);
     const int lane = asd_lane();
+    if (NPRIV > 0) {
+        unsigned xcc, copy;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        copy = xcc & 7u;
+        if (ASD_PRIV_COPIES > 8) {   // more copies: the XCD's CUs are split by the low bits of their id (HW_ID[11:8])
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            copy = copy * (ASD_PRIV_COPIES / 8) + ((hwid >> 8) & (ASD_PRIV_COPIES / 8 - 1));
+        }
+        priv += (size_t)copy * priv_stride;
+    }
 #pragma unroll
     for (int l = 0; l < (NAGG < L ? NAGG : L); ++l) {
         const float g0 = active ? denc[2 * l] : 0.f, g1 = active ? denc[2 * l + 1] : 0.f;
@@ -192,7 +211,7 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
         const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
         const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
         const float wx = px - fx, wy = py - fy, wz = pz - fz;
-        float* __restrict__ tab = dparams + 2u * (size_t)m.offset[l];
+        float* __restrict__ tab = (l < NPRIV ? priv : dparams) + 2u * (size_t)m.offset[l];
         const uint32_t res = m.resolution[l];
         const uint32_t key = active ? cx + (cy + cz * res) * res : 0xFFFFFFFFu - (uint32_t)lane;
         const uint32_t prev = __shfl_up(key, 1, 64);
@@ -227,8 +246,19 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
             // the carrier sits in the head's cell, so it forms the same idx
             const float val = issue ? v[2 * c] : f1_prev;
             float* dst = tab + 2u * (size_t)idx + (issue ? 0 : 1);
+#ifdef ASD_ABLATE_COARSE_BELOW      // tools/field_bwd_ab.py: timing-only builds (wrong results) — no atomics on levels < / >= a bound
+            if (l < ASD_ABLATE_COARSE_BELOW) continue;
+#endif
+#ifdef ASD_ABLATE_COARSE_FROM
+            if (l >= ASD_ABLATE_COARSE_FROM) continue;
+#endif
+#ifndef ASD_ABLATE_COARSE_ATOMICS
             if ((issue || carrier) && val != 0.f) atomicAdd(dst, val);
             if (self_f1 && v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
+#else
+            if ((issue || carrier) && val == 12345.678f) atomicAdd(dst, val);
+            if (self_f1 && v[2 * c + 1] == 12345.678f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
+#endif
         }
     }
     if (NAGG >= L) return;
@@ -256,7 +286,11 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
                 // same product order as the one-lane-per-sample form: (ax * ay) * az
                 const float wt = ax * ((c & 1) ? wy : 1.f - wy) * ((c & 2) ? wz : 1.f - wz);
                 const uint32_t idx = asd_grid_index(m, l, cx, cy + (c & 1), cz + ((c >> 1) & 1));
+#ifndef ASD_ABLATE_FINE_ATOMICS
                 atomicAdd(tab + 2u * (size_t)idx, wt * g);
+#else
+                if (wt * g == 12345.678f) atomicAdd(tab + 2u * (size_t)idx, wt * g);
+#endif
             }
         }
     }

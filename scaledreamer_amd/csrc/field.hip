@@ -241,6 +241,15 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 //      slab_reduce_kernel in a fixed order.
 // DA costs 512 B/row of HBM write+read (288 GB of HBM3E: materialise instead of re-synchronising).
 // ---------------------------------------------------------------------------------------------------
+#ifndef ASD_FIELD_NAGG
+#define ASD_FIELD_NAGG 6   // levels scattered with wave-level run aggregation (asd_scatter_runs)
+#endif
+#ifndef ASD_FIELD_NPRIV
+#define ASD_FIELD_NPRIV 3   // levels whose gradient is accumulated in per-XCD copies first (asd_scatter_runs)
+#endif
+#ifndef ASD_FIELD_PRIV_CAP
+#define ASD_FIELD_PRIV_CAP (1 << 17)   // floats per copy reserved in the workspace (levels 0-2 of the 16-level grid: 106 034)
+#endif
 #define WG_ROWS 2048   // rows per wgrad block
 #define WG_TILE 64     // rows per LDS tile
 
@@ -252,7 +261,8 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
     const int* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_features,
     const float* __restrict__ d_normal, const float* __restrict__ d_fd_grad, float* __restrict__ d_grid,
     float* __restrict__ da_out /*[rows,2H]*/,
-    float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f) {
+    float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f,
+    float* __restrict__ priv /*[ASD_PRIV_COPIES][priv_stride] per-XCD copies of the gradient of levels < ASD_FIELD_NPRIV*/, uint32_t priv_stride) {
     constexpr int NIN = 2 * L;
     __shared__ float w2_acc[(C > 0 ? C : 1) * H + H];
     const int nn = n_dev ? min(*n_dev, n) : n;
@@ -413,13 +423,27 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                 if (active) *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
-        asd_scatter_runs<L, 8>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by, (qz - c.bbox_min[2]) / bz, denc,
-                               active);
+        asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by,
+                                                             (qz - c.bbox_min[2]) / bz, denc, active, priv, priv_stride);
     }
     __syncthreads();
     for (int q = tid; q < H; q += 256) atomicAdd(&dw2d[q], w2_acc[q]);
     if (C > 0 && dw2f)
         for (int q = tid; q < C * H; q += 256) atomicAdd(&dw2f[q], w2_acc[H + q]);
+}
+
+// folds the per-XCD copies of the coarsest levels' gradient into the table: d_grid[j] += sum_x priv[x][j]  (fixed order)
+__global__ __launch_bounds__(256) void asd_priv_reduce_kernel(const float* __restrict__ priv, uint32_t stride, uint32_t len,
+                                                              float* __restrict__ d_grid) {
+    const uint32_t j = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (j >= len) return;      // len and stride are multiples of 4 (two floats per entry, offsets of levels are multiples of 8 entries)
+    float4 a = *reinterpret_cast<const float4*>(d_grid + j);
+#pragma unroll
+    for (int x = 0; x < ASD_PRIV_COPIES; ++x) {
+        const float4 v = *reinterpret_cast<const float4*>(priv + (size_t)x * stride + j);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(d_grid + j) = a;
 }
 
 // slab[b][h][k] = sum over the block's rows of DA[row][h] * ENC[row][k]   (h < HH = 128, k < 32)
@@ -749,7 +773,9 @@ int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_no
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
     const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
     // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs [chunks, 128*32]
-    *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64;
+    //   + the per-XCD copies of the gradient of the ASD_FIELD_NPRIV coarsest levels (ASD_FIELD_PRIV_CAP floats each)
+    *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 +
+                (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0);
     return ASD_OK;
 }
 
@@ -773,16 +799,28 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     float* da = workspace;
     float* enc_fd = with_normal ? da + rows * 128 : nullptr;
     float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);
+    float* priv = slabs + (int64_t)chunks * 128 * 32 + 64;
+    uint32_t priv_stride = ASD_FIELD_NPRIV > 0 ? 2u * meta->offset[ASD_FIELD_NPRIV] : 0u;   // floats per copy
+    if (priv_stride > (uint32_t)ASD_FIELD_PRIV_CAP) priv_stride = 0;    // a grid with larger coarse levels: straight into the table
+    if (priv_stride > 0) {
+        if (hipMemsetAsync(priv, 0, (size_t)ASD_PRIV_COPIES * priv_stride * sizeof(float), s) != hipSuccess) {
+            asd_set_error("hipMemsetAsync of the per-XCD gradient copies failed");
+            return ASD_ERR_LAUNCH;
+        }
+    } else {
+        priv = d_grid_params;
+    }
     const dim3 grid(asd_div_up(n, 256)), block(256);
     ASD_PROBE_START(s);
-    if (cfg->n_feature_dims == 3)
-        hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
-                           w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
-                           d_normal, d_fd_grad, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
-    else
-        hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 0>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density,
-                           w2_density, w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features,
-                           d_normal, d_fd_grad, d_grid_params, da, enc_fd, dw2_density, dw2_feature);
+#define ASD_FIELD_BWD_LAUNCH(C_)                                                                                                     \
+    hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, C_>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density, w2_density,  \
+                       w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features, d_normal, d_fd_grad,        \
+                       d_grid_params, da, enc_fd, dw2_density, dw2_feature, priv, priv_stride)
+    if (cfg->n_feature_dims == 3) ASD_FIELD_BWD_LAUNCH(3); else ASD_FIELD_BWD_LAUNCH(0);
+#undef ASD_FIELD_BWD_LAUNCH
+    if (priv_stride > 0)
+        hipLaunchKernelGGL(asd_priv_reduce_kernel, dim3(asd_div_up(priv_stride / 4, 256)), block, 0, s, priv, priv_stride, priv_stride,
+                           d_grid_params);
     ASD_PROBE_STOP(s);
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);
