@@ -381,14 +381,21 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
+#ifndef ASD_ABLATE_WSUM     // timing-only builds (tools/field_bwd_ab.py; wrong dw2)
                 const float v = asd_wave_sum(active ? draw * fmaxf(a, 0.f) : 0.f);
                 if (lead) atomicAdd(&w2_acc[h], v);
+#endif
                 const float da = (active && a > 0.f) ? draw * w2d[h] : 0.f;
                 dav[j] = da;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1d[h * NIN + k], denc[k]);
             }
-            if (active) *reinterpret_cast<float4*>(da_row + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
+#ifdef ASD_ABLATE_DA_STORE
+            if (active && dav[0] == 12345.678f)
+#else
+            if (active)
+#endif
+                *reinterpret_cast<float4*>(da_row + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
         }
         // ---- feature MLP (centre point only) -------------------------------------------------------------------
         if (C > 0) {
@@ -411,8 +418,12 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
 #pragma unroll
                         for (int o = 0; o < C; ++o) {
                             dh = fmaf(df[o], w2f[o * H + h], dh);
+#ifndef ASD_ABLATE_WSUM
                             const float v = asd_wave_sum(df[o] * hv);
                             if (lead) atomicAdd(&w2_acc[H + o * H + h], v);
+#else
+                            if (df[o] * hv == 12345.678f) w2_acc[H] = 1.f;
+#endif
                         }
                         da = a > 0.f ? dh : 0.f;
 #pragma unroll
@@ -420,7 +431,12 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                     }
                     dav[j] = da;
                 }
-                if (active) *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
+#ifdef ASD_ABLATE_DA_STORE
+                if (active && dav[0] == 12345.678f)
+#else
+                if (active)
+#endif
+                    *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
         asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by,

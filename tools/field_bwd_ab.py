@@ -39,6 +39,8 @@ else:
         sigma, feats, normal, enc = ops.field_fwd(geo._meta, geo._fcfg, grid, *w, pts, False)
         g = torch.Generator(device="cuda").manual_seed(0)
         d_sigma, d_feats = torch.randn(n, device="cuda", generator=g), torch.randn(n, 3, device="cuda", generator=g)
+        if os.environ.get("FB_NO_FEAT"):      # ablation: no feature-network gradient (the kernel skips that MLP)
+            d_feats = None
         d_grid = torch.zeros_like(grid)
         ops.field_bwd(geo._meta, geo._fcfg, grid, *w, pts, enc, sigma, d_sigma, d_feats, None, d_grid)
         chk = (float(d_grid.double().sum()), float(d_grid.double().abs().sum()))
