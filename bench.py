@@ -91,9 +91,9 @@ PMC_TRAFFIC = {("vae512", (12, 1)): 140.3e6, ("vae512", (10, 1)): 145.5e6, ("une
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
 DOMINANT = "field_bwd"
-DOMINANT_SOURCE = ("profiles/r02_g_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
-                   "inside the timed steps alone (profiles/r02_g_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.49 ms, gemm_f16_kernel<256,64> 1.34 ms, "
-                   "attention_fwd_kernel<4> + <2> 1.38 ms and field_bwd_sample_kernel 1.27 ms per step are within 15 % of each other: see roofline_vae_conv / roofline_gemm")
+DOMINANT_SOURCE = ("profiles/r02_h_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
+                   "inside the timed steps alone (profiles/r02_h_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.47 ms, gemm_f16_kernel<256,64> 1.36 ms, "
+                   "attention_fwd_kernel<4> + <2> 1.27 ms and field_bwd_sample_kernel 1.12 ms per step are within 25 % of each other: see roofline_vae_conv / roofline_gemm")
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
@@ -240,12 +240,15 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     ms_call = t0_.elapsed_time(t1_) / reps
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
-    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r02_pmc_*_per_kernel.csv, 433 k samples): WRITE_SIZE 616.2 MB +
-    # FETCH_SIZE 36.1 MB (gfx950 correction applied) per launch = 1506 B per sample; scaled to this launch's sample count
-    traffic = n * (616.16e6 + 36.05e6) / 433138.0
-    return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics; one launch per step)", "bound": "hbm",
+    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 20 launches
+    # of the kernel = this leg, 433 172 samples each: profiles/r02_h_pmc_roofline_kernel.txt): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
+    # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
+    # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
+    # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
+    traffic = n * (1059.38e6 + 69.00e6) / 433172.0
+    return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE, profiles/r02_pmc_*_per_kernel.csv, scaled by samples)",
+            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 20 launches, profiles/r02_h_pmc_roofline_kernel.txt, scaled by samples)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
             "atomic_dwords_per_sample": 256, "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1),
