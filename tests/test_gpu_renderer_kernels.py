@@ -91,11 +91,17 @@ def test_field_density_and_forward(oracle):
     assert (out[1234:] == -7.0).all()
 
 
-@pytest.mark.parametrize("with_normal,n", [(False, 3000), (True, 1500), (False, 1), (False, 257)])
-def test_field_backward(oracle, with_normal, n):
+GEOM_BIG_COARSE = (16, 2, 19, 48, 1.3)   # levels 0-2 hold 1.8 M floats: more than the per-XCD gradient copies reserve -> the
+                                         # scatter of asd_field_bwd adds straight into the table (its fallback path)
+
+
+@pytest.mark.parametrize("with_normal,n,geom", [(False, 3000, GEOM), (True, 1500, GEOM), (False, 1, GEOM), (False, 257, GEOM),
+                                                (False, 200000, GEOM),            # ~800 blocks: every XCD's private copy is written
+                                                (False, 3000, GEOM_BIG_COARSE), (True, 700, GEOM_BIG_COARSE)])
+def test_field_backward(oracle, with_normal, n, geom):
     from scaledreamer_amd import ops
 
-    om, hm = _metas(oracle, GEOM)
+    om, hm = _metas(oracle, geom)
     oc = oracle.field_cfg()
     hc = _hip_cfg(oc)
     rng = np.random.default_rng(12)
