@@ -15,6 +15,7 @@
 
 #include "asd_common.h"
 
+
 // ---------------------------------------------------------------------------------------------------
 // generic tcnn.Encoding forward / backward: one thread per (point, level)
 // ---------------------------------------------------------------------------------------------------

@@ -54,6 +54,20 @@ else:
             torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1))
         lib().asd_probe_events(None, None)
+    def timed(fn, reps=12):
+        fn(); fn()
+        t = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            t.append(a.elapsed_time(b))
+        t.sort()
+        return round(t[len(t) // 2] * 1e3, 1)
+    with torch.no_grad():
+        fwd_n = timed(lambda: ops.field_fwd(geo._meta, geo._fcfg, grid, *w, pts, True))
+        fwd_1 = timed(lambda: ops.field_fwd(geo._meta, geo._fcfg, grid, *w, pts, False))
+        dens = timed(lambda: ops.field_density(geo._meta, geo._fcfg, grid, w[0], w[1], pts))
+    print("   field_fwd(normal) us", fwd_n, " field_fwd(no normal) us", fwd_1, " field_density us", dens, "(call times incl. launch)")
     ms.sort()
     print(os.path.basename(os.environ.get("ASD_HIP_LIB", "") or "default"), "samples", n, "median_us", round(ms[len(ms) // 2] * 1e3, 1),
           "min_us", round(ms[0] * 1e3, 1), "checksum", chk)
