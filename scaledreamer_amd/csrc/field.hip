@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 //      slab_reduce_kernel in a fixed order.
 // DA costs 512 B/row of HBM write+read (288 GB of HBM3E: materialise instead of re-synchronising).
 // ---------------------------------------------------------------------------------------------------
+#ifndef ASD_FIELD_W2_COPIES
+#define ASD_FIELD_W2_COPIES 16
+#endif
 #ifndef ASD_FIELD_NAGG
 #define ASD_FIELD_NAGG 6   // levels scattered with wave-level run aggregation (asd_scatter_runs)
 #endif
@@ -265,10 +268,15 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
     float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f,
     float* __restrict__ priv /*[ASD_PRIV_COPIES][priv_stride] per-XCD copies of the gradient of levels < ASD_FIELD_NPRIV*/, uint32_t priv_stride) {
     constexpr int NIN = 2 * L;
-    __shared__ float w2_acc[(C > 0 ? C : 1) * H + H];
+    // second-layer weight-gradient sums of the block.  ASD_FIELD_W2_COPIES > 1: no wave-level reduction — every lane adds its own
+    // term with an LDS atomic into copy (lane & 15) of the accumulator (row stride W2N + 1: the 16 copies of one h sit in 16 banks, the
+    // four lanes of a copy serialise), the copies are summed at the end.  1: six DPP adds + readlane + one LDS atomic per sum.
+    constexpr int W2N = (C > 0 ? C : 1) * H + H, W2S = ASD_FIELD_W2_COPIES > 1 ? W2N + 1 : W2N;
+    __shared__ float w2_acc[ASD_FIELD_W2_COPIES * W2S];
+    const int w2c = ASD_FIELD_W2_COPIES > 1 ? (threadIdx.x & (ASD_FIELD_W2_COPIES - 1)) * W2S : 0;
     const int nn = n_dev ? min(*n_dev, n) : n;
     const int tid = threadIdx.x;
-    for (int q = tid; q < (C > 0 ? C : 1) * H + H; q += 256) w2_acc[q] = 0.f;
+    for (int q = tid; q < ASD_FIELD_W2_COPIES * W2S; q += 256) w2_acc[q] = 0.f;
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     const bool active = i < nn;
@@ -383,8 +391,13 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
 #ifndef ASD_ABLATE_WSUM     // timing-only builds (tools/field_bwd_ab.py; wrong dw2)
-                const float v = asd_wave_sum(active ? draw * fmaxf(a, 0.f) : 0.f);
-                if (lead) atomicAdd(&w2_acc[h], v);
+                if (ASD_FIELD_W2_COPIES > 1) {
+                    const float v = active ? draw * fmaxf(a, 0.f) : 0.f;
+                    if (v != 0.f) atomicAdd(&w2_acc[w2c + h], v);
+                } else {
+                    const float v = asd_wave_sum(active ? draw * fmaxf(a, 0.f) : 0.f);
+                    if (lead) atomicAdd(&w2_acc[h], v);
+                }
 #endif
                 const float da = (active && a > 0.f) ? draw * w2d[h] : 0.f;
                 dav[j] = da;
@@ -420,8 +433,13 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                         for (int o = 0; o < C; ++o) {
                             dh = fmaf(df[o], w2f[o * H + h], dh);
 #ifndef ASD_ABLATE_WSUM
-                            const float v = asd_wave_sum(df[o] * hv);
-                            if (lead) atomicAdd(&w2_acc[H + o * H + h], v);
+                            if (ASD_FIELD_W2_COPIES > 1) {
+                                const float v = df[o] * hv;
+                                if (v != 0.f) atomicAdd(&w2_acc[w2c + H + o * H + h], v);
+                            } else {
+                                const float v = asd_wave_sum(df[o] * hv);
+                                if (lead) atomicAdd(&w2_acc[H + o * H + h], v);
+                            }
 #else
                             if (df[o] * hv == 12345.678f) w2_acc[H] = 1.f;
 #endif
@@ -444,6 +462,15 @@ __global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
                                                              (qz - c.bbox_min[2]) / bz, denc, active, priv, priv_stride);
     }
     __syncthreads();
+    if (ASD_FIELD_W2_COPIES > 1) {
+        for (int q = tid; q < W2N; q += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int cpy = 0; cpy < ASD_FIELD_W2_COPIES; ++cpy) a += w2_acc[cpy * W2S + q];
+            w2_acc[q] = a;       // copy 0's slot q is only read by this thread
+        }
+        __syncthreads();
+    }
     for (int q = tid; q < H; q += 256) atomicAdd(&dw2d[q], w2_acc[q]);
     if (C > 0 && dw2f)
         for (int q = tid; q < C * H; q += 256) atomicAdd(&dw2f[q], w2_acc[H + q]);
