@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 //      slab_reduce_kernel in a fixed order.
 // DA costs 512 B/row of HBM write+read (288 GB of HBM3E: materialise instead of re-synchronising).
 // ---------------------------------------------------------------------------------------------------
+#ifndef ASD_FIELD_BWD_BLOCKS
+#define ASD_FIELD_BWD_BLOCKS 2   // blocks per CU the sample pass is compiled for (213 VGPRs; 3 was measured: see DESIGN.md)
+#endif
 #ifndef ASD_FIELD_W2_COPIES
 #define ASD_FIELD_W2_COPIES 16
 #endif
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #define WG_TILE 64     // rows per LDS tile
 
 template <int L, int H, int C>
-__global__ __launch_bounds__(256, 2) void field_bwd_sample_kernel(
+__global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_kernel(
     const asd_grid_meta m, const asd_field_cfg c, const float* __restrict__ grid, const float* __restrict__ w1d,
     const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
     const float* __restrict__ points, const float* __restrict__ enc_save, const float* __restrict__ sigma, int n,
