@@ -79,6 +79,44 @@ def build_hyper_system(backend: str, seed: int, workload: str = "asd_sd_hyper_in
     return cfg, system, data
 
 
+def build_stub_system(seed: int):
+    """ASD_BENCH_STUB=1 — NOT a benchmark: a CPU stand-in (tiny torch renderer + quadratic guidance) behind the real
+    StableDreamer.train_one_step / GradientExchange wiring, so that the multi-process contract of this script (per-rank seeds,
+    parameter broadcast, barrier order, max-over-ranks timing, rank-0-only JSON line, exchange timing) is exercised on CPU with gloo
+    by tests/test_dist_cpu.py before the first N > 1 run on real GPUs.  Its JSON line says `"data": "stub"`."""
+    from scaledreamer_amd.base import Updateable
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    torch.manual_seed(seed)
+
+    class Renderer(torch.nn.Module, Updateable):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(1_500_000) * 1e-3)       # > IN_PLACE_BYTES: its own in-place unit
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+        def forward(self, rays_d, **kw):
+            rgb = torch.sigmoid(self.mlp(rays_d) + self.table[:3])
+            return {"comp_rgb": rgb, "opacity": rgb.mean(-1, keepdim=True).clamp(0, 1)}
+
+    class Guidance(Updateable):
+        def __call__(self, rgb, prompt_utils, rgb_as_latents=False, **batch):
+            return {"loss_asd": (rgb ** 2).sum(), "grad_norm": rgb.detach().norm()}
+
+    class Data:
+        def collate(self):
+            return {"rays_d": torch.randn(1, 8, 8, 3)}
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.cfg = ConfigDict(stage="coarse", loss=ConfigDict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=2.0, lambda_opaque=0.0, lambda_z_variance=0.0))
+    s.current_epoch, s.true_global_step, s.logged = 0, 0, {}
+    s.renderer, s.guidance, s.prompt_utils = Renderer(), Guidance(), None
+    s.optimizer = torch.optim.SGD(s.renderer.parameters(), lr=0.1)
+    return {}, s, Data()
+
+
 def to_device(batch, dev):
     return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
@@ -337,6 +375,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("ASD_BENCH_STUB") == "1":
+        return main_stub(args, rank, world)
     torch.cuda.set_device(local_rank)
     # the host side of a step is ~60 tiny CPU tensor ops (camera sampling): with torch's default of one OpenMP
     # thread per core (256 on the GPU box) every one of them pays a fork/join; keep the host path single-threaded
@@ -479,6 +519,50 @@ def main():
         asd_dist.shutdown()
     elif ex is not None:
         ex.close()
+
+
+def main_stub(args, rank, world):
+    """the timing / reporting skeleton of main() on CPU tensors (see build_stub_system): same barrier order, same max-over-ranks
+    reduction, same single JSON line from rank 0"""
+    from scaledreamer_amd import dist as asd_dist
+
+    torch.set_num_threads(1)
+    if world > 1:
+        asd_dist.init_from_env("gloo")
+    cfg, system, data = build_stub_system(seed=10 + rank)
+    asd_dist.broadcast_parameters(system)
+    for _ in range(args.warmup):
+        system.train_one_step(data.collate())
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = system.train_one_step(data.collate())
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ex = system.gradient_exchange()
+    digest = torch.cat([p.detach().reshape(-1)[:64] for p in system.renderer.parameters()]).double().sum()
+    if world > 1:       # replicas must have stayed identical
+        lo, hi = digest.clone(), digest.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert float(hi - lo) <= 1e-9 * max(1.0, abs(float(hi))), "replicas diverged"
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (CPU plumbing test of the multi-process contract, not a measurement)", "value": round(world * args.steps / dt, 4),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "stub", "parallelism": f"dp{world}"},
+                          "allreduce_exposed_ms": None if ex is None else round(ex.exposed_ms(), 3),
+                          "exchange_units": None if ex is None else len(ex.units), "exchange_steps": None if ex is None else ex.prepare_called,
+                          "loss": float(loss.item())}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        asd_dist.shutdown()
 
 
 if __name__ == "__main__":

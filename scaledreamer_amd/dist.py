@@ -101,10 +101,19 @@ class GradientExchange:
             size += nb
         if cur:
             self.units.append(self._flat_unit(cur))
-        self._unit_of = {}
+        self._unit_of, self._index_of = {}, {}
         for ui, u in enumerate(self.units):
             for p in u["params"]:
                 self._unit_of[id(p)] = ui
+        for i, p in enumerate(self.params):
+            self._index_of[id(p)] = i
+        self._check_same_units_everywhere()
+        # which parameters received a gradient on ANY rank this step (one tiny MAX all-reduce next to the buckets): a parameter no
+        # rank touched keeps `.grad = None`, so the optimizer skips it exactly as the single-process path does (no weight decay, no
+        # moment decay, no step count for an unused branch)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self._touched_host = torch.zeros(len(self.params), dtype=torch.int32, pin_memory=dev.type == "cuda")
+        self._touched_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self.order = list(range(len(self.units)))      # launch order (positions into self.units)
         self._order_learned = False
         self._seen_order: List[int] = []
@@ -113,14 +122,38 @@ class GradientExchange:
         self.exposed_ms_events = None                   # (start, end) CUDA events of the last finish(): un-overlapped exchange time
         self.prepare_called = 0
 
-    @staticmethod
-    def _flat_unit(ps):
-        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
-        views, off = [], 0
+    ALIGN_BYTES = 16          # every gradient view starts on a 16-byte boundary: the optimizer kernels use 16-byte accesses
+
+    @classmethod
+    def _flat_unit(cls, ps):
+        step = max(1, cls.ALIGN_BYTES // ps[0].element_size())
+        offs, off = [], 0
         for p in ps:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            offs.append(off)
+            off += (p.numel() + step - 1) // step * step
+        flat = torch.zeros(off, dtype=ps[0].dtype, device=ps[0].device)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)]
         return dict(params=list(ps), flat=flat, views=views)
+
+    def _check_same_units_everywhere(self) -> None:
+        """the ranks must cut the exchange into the same units (same parameter list, same sizes): a mismatch would otherwise show up
+        as a hang or as silently mis-added gradients inside the first collective"""
+        if not is_distributed():
+            return
+        sig = [len(self.units)]
+        for u in self.units:
+            sig += [len(u["params"]), sum(p.numel() for p in u["params"]), 0 if u["flat"] is None else u["flat"].numel()]
+        dev = self.params[0].device if self.params and dist.get_backend() == "nccl" else "cpu"
+        n = torch.tensor([len(sig)], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=0)
+        ref = torch.tensor(sig if len(sig) == int(n) else [0] * int(n), dtype=torch.int64, device=dev)
+        mine = ref.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([int(len(sig) == int(n) and torch.equal(ref, mine))], dtype=torch.int64, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if int(same) != 1:
+            raise RuntimeError(f"GradientExchange: rank {dist.get_rank()} built a different unit table than rank 0 "
+                               f"({len(self.units)} units, signature {sig[:16]}...): the ranks do not hold the same trainable parameters")
 
     # ---- per step -----------------------------------------------------------------------------------------------------------
     def prepare(self) -> None:
@@ -138,6 +171,7 @@ class GradientExchange:
         self._launched = 0                              # number of positions of self.order already launched
         self._works = []
         self._seen_order = []
+        self._touched_host.zero_()
         self._armed = True
         self.prepare_called += 1
 
@@ -145,6 +179,7 @@ class GradientExchange:
         if not self._armed:
             return
         ui = self._unit_of[id(p)]
+        self._touched_host[self._index_of[id(p)]] = 1
         self._pending[ui] -= 1
         if self._pending[ui] == 0:
             self._ready[ui] = True
@@ -182,6 +217,8 @@ class GradientExchange:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         self._launch_ready(force=True)
+        self._touched_dev.copy_(self._touched_host, non_blocking=True)
+        self._works.append(dist.all_reduce(self._touched_dev, op=dist.ReduceOp.MAX, async_op=True))
         for w in self._works:
             w.wait()
         if dist.get_backend() != "nccl":
@@ -191,6 +228,12 @@ class GradientExchange:
         if on_gpu:
             e1.record()
             self.exposed_ms_events = (e0, e1)
+        if int(self._touched_host.sum()) < len(self.params):
+            # this rank produced nothing for some parameter: read the global flags (the only device->host read of the exchange, and
+            # only on ranks / steps with such a parameter) and leave what NO rank touched without a gradient
+            for i, hit in enumerate(self._touched_dev.tolist()):
+                if not hit:
+                    self.params[i].grad = None
         if not self._order_learned:                     # adopt rank 0's readiness order of this first step
             seen = self._seen_order + [i for i in range(len(self.units)) if i not in self._seen_order]
             t = torch.tensor(seen, dtype=torch.int64, device=self.params[0].device if on_gpu else "cpu")

@@ -19,6 +19,7 @@ class BaseMaterial(BaseModule):
     cfg: Config
     requires_normal: bool = False
     requires_tangent: bool = False
+    reads_normal: bool = True      # does forward() use `normal` / `shading_normal`?  (False lets the renderer defer them)
 
     def configure(self):
         pass
@@ -38,6 +39,7 @@ class NoMaterial(BaseMaterial):
         requires_normal: bool = False
 
     cfg: Config
+    reads_normal = False           # colour = activation(features): the normals are never looked at (no_material.py:41-54)
 
     def configure(self) -> None:
         self.use_network = False

@@ -39,13 +39,28 @@ class AdamW(Optimizer):
     """torch.optim.AdamW (decoupled weight decay) or, with adam_l2=True, torch.optim.Adam — amsgrad / maximize / capturable unsupported
     (the reference never sets them).  The whole step is ONE kernel launch per 24 tensors."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, adam_l2: bool = False, **unsupported):
-        bad = {k: v for k, v in unsupported.items() if k in ("amsgrad", "maximize", "capturable", "differentiable") and v}
+    _TORCH_ONLY = ("amsgrad", "maximize", "capturable", "differentiable", "foreach", "fused")     # torch.optim.AdamW keywords
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, adam_l2: bool = False, **torch_kw):
+        unknown = sorted(k for k in torch_kw if k not in self._TORCH_ONLY)
+        if unknown:
+            raise TypeError(f"AdamW.__init__() got unexpected keyword arguments {unknown}")
+        bad = sorted(k for k in ("amsgrad", "maximize", "capturable", "differentiable") if torch_kw.get(k))
         if bad:
-            raise NotImplementedError(f"fused AdamW: unsupported options {sorted(bad)}")
+            raise NotImplementedError(f"fused AdamW: unsupported options {bad}")
         if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
             raise ValueError("Invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, adam_l2=adam_l2))
+
+    def __setstate__(self, state):
+        """load_state_dict replaces param_groups with the saved ones: a state dict written by torch.optim.AdamW / Adam (or a reference
+        checkpoint) has no `adam_l2` key — keep this optimizer's own rule — and may carry options this kernel does not implement."""
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault("adam_l2", self.defaults["adam_l2"])
+            bad = sorted(k for k in ("amsgrad", "maximize", "capturable", "differentiable") if group.get(k))
+            if bad:
+                raise NotImplementedError(f"fused AdamW: the loaded state uses unsupported options {bad}")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -65,10 +80,14 @@ class AdamW(Optimizer):
                 if not st:
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format), torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not torch.is_tensor(st["step"]):          # old torch state dicts hold a python int
+                    st["step"] = torch.tensor(float(st["step"]))
+                elif st["step"].is_cuda:                      # Optimizer.load_state_dict moves per-parameter state next to the parameter:
+                    st["step"] = st["step"].cpu()             # one read at load time, not one per step
                 st["step"] += 1
                 t = int(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_hyper.setdefault((b1, b2, group["eps"], bool(group["adam_l2"])), []).append(
+                by_hyper.setdefault((b1, b2, group["eps"], bool(group.get("adam_l2", self.defaults["adam_l2"]))), []).append(
                     dict(p=p.data, g=g, m=st["exp_avg"], v=st["exp_avg_sq"], lr=group["lr"], wd=group["weight_decay"],
                          bc1=1.0 - b1 ** t, bc2s=math.sqrt(1.0 - b2 ** t)))
         for (b1, b2, eps, l2), entries in by_hyper.items():

@@ -79,6 +79,64 @@ def chunk_batch(func, chunk_size: int, *args, **kwargs):
     return torch.cat(outs, 0)
 
 
+class LazyOutputs(dict):
+    """Output dictionary whose expensive entries nobody may ever read are produced on first access.
+
+    The reference returns `normal` / `shading_normal` (three extra hash encodes per kept sample: the finite-difference normal,
+    implicit_volume.py:137-177) whenever `material.requires_normal` is set (nerf_volume_renderer.py:281-283), although the shipped
+    asd_sd_nerf config neither shades with them (NoMaterial) nor weights a loss on them (lambda_orient = 0, asd_sd_nerf.yaml:106).
+    Same surface here — the keys exist, `in`, indexing, `.get`, `.items()`, `**out` all work and hand out real, differentiable
+    tensors — but an entry registered with `defer` costs nothing until somebody asks for it."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._deferred = {}
+
+    def defer(self, keys, produce):
+        """`produce()` -> dict holding every key of `keys`; called at most once, on the first access to any of them"""
+        cell = {"fn": produce, "keys": tuple(keys)}
+        for k in keys:
+            self._deferred[k] = cell
+
+    def _force(self, key):
+        cell = self._deferred.get(key)
+        if cell is not None:
+            vals = cell["fn"]()
+            for k in cell["keys"]:
+                self._deferred.pop(k, None)
+                dict.__setitem__(self, k, vals[k])
+
+    def __getitem__(self, key):
+        self._force(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._deferred
+
+    def __iter__(self):                    # (also sends `{**out}` / dict(out) down the keys() + __getitem__ path)
+        yield from dict.__iter__(self)
+        yield from list(self._deferred)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._deferred)
+
+    def keys(self):
+        return list(iter(self))
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def pending(self):
+        """keys not produced yet (tests / tools)"""
+        return set(self._deferred)
+
+
 def validate_empty_rays(ray_indices, t_start, t_end):
     """threestudio/utils/ops.py:514-520: substitute one dummy sample when nothing was sampled."""
     if ray_indices.nelement() == 0:
@@ -110,6 +168,9 @@ class NeRFVolumeRenderer(VolumeRenderer):
         num_samples_per_ray_importance: int = 64
 
     cfg: Config
+    # upper bound of the sync-free candidate buffers (~28 B per candidate across ray_idx / t0 / t1 / points / sigma / keep: 1.3 GB);
+    # also keeps every 3-component index of those buffers far below 2^31
+    MAX_CANDIDATE_CAPACITY = 48 << 20
 
     def configure(self, geometry, material, background) -> None:
         super().configure(geometry, material, background)
@@ -145,6 +206,8 @@ class NeRFVolumeRenderer(VolumeRenderer):
         prune = self.cfg.grid_prune and self.cfg.prune_alpha_threshold
         fused_density = self.training and prune and getattr(self.geometry, "fused", False) and rays_o_flatten.is_cuda
         n_cap = n_rays * int(cfg.max_steps) if fused_density else None
+        if n_cap is not None and n_cap > self.MAX_CANDIDATE_CAPACITY:
+            n_cap = None     # large batches (256^2 x 4 views: 1.3e8 lattice points): exact-size buffers after one count read-back
         count, offset, total, ray_idx, t0, t1, pts = ops.march(cfg, rays_o_flatten, rays_d_flatten, bits, jitter, n_max=n_cap)
         if self.cfg.grid_prune:
             early_stop_eps, alpha_thre = 1e-4, (0.01 if self.cfg.prune_alpha_threshold else 0.0)
@@ -197,8 +260,17 @@ class NeRFVolumeRenderer(VolumeRenderer):
         t_positions = (t_starts + t_ends) / 2.0
         t_intervals = t_ends - t_starts
 
+        lazy_normal = None
         if self.training:
-            geo_out = self.geometry(positions, output_normal=self.material.requires_normal)
+            # the normal is evaluated with the field only if something inside this call reads it (a shading material, comp_normal,
+            # normal_perturb); otherwise it becomes a deferred entry of the output dictionary (LazyOutputs)
+            want_normal = bool(self.material.requires_normal)
+            now = want_normal and (getattr(self.material, "reads_normal", True) or self.cfg.return_comp_normal or self.cfg.return_normal_perturb)
+            geo_out = self.geometry(positions, output_normal=now)
+            if want_normal and not now:
+                def lazy_normal(geometry=self.geometry, pts=positions):
+                    g = geometry(pts, output_normal=True)
+                    return {"normal": g["normal"], "shading_normal": g["shading_normal"]}
             rgb_fg_all = self.material(viewdirs=t_dirs, positions=positions, light_positions=t_light_positions,
                                        **geo_out, **kwargs)
             comp_rgb_bg = self.background(dirs=rays_d)
@@ -224,14 +296,14 @@ class NeRFVolumeRenderer(VolumeRenderer):
         weights = weights_[..., None]
         opacity, depth, z_variance = opacity_[..., None], depth_[..., None], z_variance_[..., None]
 
-        out = {
+        out = LazyOutputs({
             "comp_rgb": comp_rgb.view(batch_size, height, width, -1),
             "comp_rgb_fg": comp_rgb_fg.view(batch_size, height, width, -1),
             "comp_rgb_bg": comp_rgb_bg.view(batch_size, height, width, -1),
             "opacity": opacity.view(batch_size, height, width, 1),
             "depth": depth.view(batch_size, height, width, 1),
             "z_variance": z_variance.view(batch_size, height, width, 1),
-        }
+        })
 
         def comp_normal_of(normal):
             cn = nerfacc_api.accumulate_along_rays(weights[..., 0], values=normal, ray_indices=ray_indices, n_rays=n_rays)
@@ -241,6 +313,8 @@ class NeRFVolumeRenderer(VolumeRenderer):
         if self.training:
             out.update({"weights": weights, "t_points": t_positions, "t_intervals": t_intervals, "t_dirs": t_dirs,
                         "ray_indices": ray_indices, "points": positions, **geo_out})
+            if lazy_normal is not None:
+                out.defer(("normal", "shading_normal"), lazy_normal)
             if "normal" in geo_out:
                 if self.cfg.return_comp_normal:
                     out["comp_normal"] = comp_normal_of(geo_out["normal"])

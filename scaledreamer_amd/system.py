@@ -126,7 +126,7 @@ class StableDreamer(nn.Module, Updateable):
         self.logged[name] = value
 
     def forward(self, batch: Dict[str, Any]) -> Dict[str, Any]:
-        return {**self.renderer(**batch)}
+        return self.renderer(**batch)      # (a LazyOutputs: copying it with {**out} would force its deferred entries)
 
     def on_train_batch_start(self, batch_idx: int = 0):
         """systems/base.py:180-184: per-step update hooks (occupancy grid, timestep annealing, resolution).  The guidance is a

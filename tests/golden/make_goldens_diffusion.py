@@ -74,6 +74,30 @@ def make_unet_golden(name, cfg: W.UNetConfig, batch, hw, n_ctx, seed, num_frames
     print(f"{name}: params={W.count_params(shapes)} eps mean|.|={eps.abs().mean():.4f} std={eps.std():.4f}")
 
 
+def make_unet_shared_golden(name, cfg: W.UNetConfig, reps, group, hw, n_ctx, seed, num_frames=1):
+    """The batch layout the ASD step hands to the UNet (stable_diffusion_asd_guidance.py:377-394, mvdream_asd_guidance.py:231-246):
+    `reps` repetitions of `group` inputs (x, t[, camera]) under DIFFERENT text contexts, then `group` more inputs at the shifted
+    timestep t+ — the form asd_unet_fwd_shared computes with the prefix in front of the first cross-attention shared."""
+    shapes, *_ = W.unet_layout(cfg)
+    cls = MultiViewUNetModel if cfg.camera_dim is not None else UNetModel
+    model = cls(**unet_kwargs(cfg)).eval()
+    model.load_state_dict(W.gen_params(shapes, seed), strict=True)
+    N = (reps + 1) * group
+    xa, xb = rnd("in.xa", (group, cfg.in_channels, hw, hw), seed), rnd("in.xb", (group, cfg.in_channels, hw, hw), seed)
+    x = torch.cat([xa] * reps + [xb])
+    t0, t1 = 611, 640
+    t = torch.tensor([t0] * (reps * group) + [t1] * group, dtype=torch.long)
+    ctx = rnd("in.context", (N, n_ctx, cfg.context_dim), seed)
+    kw = {}
+    if cfg.camera_dim is not None:
+        kw = dict(camera=torch.cat([rnd("in.camera", (group, cfg.camera_dim), seed)] * (reps + 1)), num_frames=num_frames)
+    with torch.no_grad():
+        eps = model(x, t, context=ctx, **kw)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, reps=reps, group=group, hw=hw, n_ctx=n_ctx, num_frames=num_frames,
+                        t=t.numpy(), eps=eps.numpy())
+    print(f"{name}: batch={N} eps mean|.|={eps.abs().mean():.4f} std={eps.std():.4f}")
+
+
 def make_vae_golden(name, cfg: W.VAEConfig, batch, res, seed, grad_stride):
     shapes, plan = W.vae_encoder_layout(cfg)
     enc = Encoder(ch=cfg.ch, out_ch=3, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, attn_resolutions=[],
@@ -287,6 +311,11 @@ if __name__ == "__main__":
     if "--round2" in sys.argv:   # the headline config's own shapes: only these two files are (re)written
         make_vae_golden("diffusion_vae_full_512", W.VAEConfig(), batch=1, res=512, seed=2, grad_stride=8)
         make_unet_golden("diffusion_mvunet_full_b12", W.UNetConfig(camera_dim=16), batch=12, hw=32, n_ctx=77, seed=4, num_frames=4)
+        sys.exit(0)
+    if "--round3" in sys.argv:   # the call forms the bench times: shared-prefix batches, 4 x 256^2 VAE
+        make_unet_shared_golden("diffusion_unet_sd21_shared_b5", W.UNetConfig(), reps=4, group=1, hw=64, n_ctx=77, seed=1)
+        make_unet_shared_golden("diffusion_mvunet_shared_b12", W.UNetConfig(camera_dim=16), reps=2, group=4, hw=32, n_ctx=77, seed=4, num_frames=4)
+        make_vae_golden("diffusion_vae_full_256_b4", W.VAEConfig(), batch=4, res=256, seed=2, grad_stride=4)
         sys.exit(0)
     small = W.UNetConfig(model_channels=64, num_head_channels=32, context_dim=96)
     make_unet_golden("diffusion_unet_small", small, batch=3, hw=16, n_ctx=7, seed=3)

@@ -72,6 +72,7 @@ def _system_worker(rank, world, port, out_dir):
             self.table = torch.nn.Parameter(torch.randn(300_000))       # > IN_PLACE_BYTES: its own in-place unit
             self.mlp = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
             self.sometimes_unused = torch.nn.Parameter(torch.randn(7))
+            self.never_used = torch.nn.Parameter(torch.randn(5))         # no rank ever produces a gradient for it
             self.register_buffer("grid_bits", torch.rand(64) > 0.5)       # bool buffer (the occupancy grid's `binaries`)
             self.updates = []
 
@@ -101,8 +102,8 @@ def _system_worker(rank, world, port, out_dir):
     s.renderer, s.guidance, s.prompt_utils = Renderer(), Guidance(), None
     asd_dist.broadcast_parameters(s)
     init = {k: v.clone() for k, v in s.state_dict().items()}
-    s.optimizer = torch.optim.SGD([{"params": [s.renderer.table]}, {"params": list(s.renderer.mlp.parameters()) + [s.renderer.sometimes_unused]}], lr=0.5)
-    local = []
+    s.optimizer = torch.optim.SGD([{"params": [s.renderer.table]}, {"params": list(s.renderer.mlp.parameters()) + [s.renderer.sometimes_unused, s.renderer.never_used]}], lr=0.5)
+    local, untouched_grad_is_none = [], []
     for step in range(2):
         batch = {"rays_d": torch.randn(1, 4, 4, 3)}    # different data per rank (torch.manual_seed(seed) above)
         # this rank's own gradient, computed on the side
@@ -111,11 +112,12 @@ def _system_worker(rank, world, port, out_dir):
         local.append([torch.zeros_like(p) if g is None else g.clone() for p, g in zip(s.renderer.parameters(), gs)])
         before = [p.detach().clone() for p in s.renderer.parameters()]
         s.train_one_step(batch)
+        untouched_grad_is_none.append(s.renderer.never_used.grad is None and s.renderer.sometimes_unused.grad is not None)
         applied = [(b - p.detach()) / 0.5 for b, p in zip(before, s.renderer.parameters())]   # SGD: the averaged gradient
         local[-1] = (local[-1], applied)
     ex = s.gradient_exchange()
     torch.save({"init": init, "steps": local, "order": ex.order, "n_units": len(ex.units), "updates": s.renderer.updates,
-                "guidance_updates": Guidance.calls, "final": [p.detach().clone() for p in s.renderer.parameters()]},
+                "guidance_updates": Guidance.calls, "untouched_none": untouched_grad_is_none, "final": [p.detach().clone() for p in s.renderer.parameters()]},
                os.path.join(out_dir, f"s{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -129,11 +131,14 @@ def test_two_rank_real_system_wiring(tmp_path):
         assert torch.equal(r0["init"][k], r1["init"][k]), f"{k} was not broadcast from rank 0"
     assert r0["order"] == r1["order"] and sorted(r0["order"]) == list(range(r0["n_units"])) and r0["n_units"] == 2
     assert r0["updates"] == [0, 1] and r0["guidance_updates"] == 2          # hooks once per step, guidance not updated twice
+    # a parameter NO rank touched keeps grad = None on every rank (the optimizer skips it as in a single process); one that only
+    # rank 0 touched gets the mean everywhere
+    assert r0["untouched_none"] == [True, True] and r1["untouched_none"] == [True, True]
     for (g0, a0), (g1, a1) in zip(r0["steps"], r1["steps"]):
         for x0, x1, y0, y1 in zip(g0, g1, a0, a1):
             torch.testing.assert_close(y0, (x0 + x1) / 2, rtol=1e-4, atol=1e-6)   # what the optimizer applied = mean over ranks
             torch.testing.assert_close(y1, y0)
-        assert g1[1].abs().sum() == 0 and g0[1].abs().sum() > 0              # `sometimes_unused` (parameters(): table, sometimes_unused, mlp...): rank 1 never touched it, it still gets rank 0's half
+        assert g1[1].abs().sum() == 0 and g0[1].abs().sum() > 0              # `sometimes_unused` (parameters(): table, sometimes_unused, never_used, mlp...): rank 1 never touched it, it still gets rank 0's half
     for a, b in zip(r0["final"], r1["final"]):
         torch.testing.assert_close(a, b)                                      # replicas stay identical
 
@@ -166,3 +171,24 @@ def test_stdout_to_stderr_keeps_c_level_prints_off_stdout():
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip() == '{"json": 1}'
     assert "BANNER from C" in r.stderr and "python print inside" in r.stderr
+
+
+def test_bench_two_ranks_under_torchrun_prints_one_json_line():
+    """bench.py's N > 1 contract as the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2), on CPU with gloo
+    and the stub system (ASD_BENCH_STUB=1): rank 0 alone prints ONE JSON line on stdout, both ranks pass the barriers and exit 0, the
+    gradient exchange ran in every step, the replicas stayed identical (asserted inside the script)."""
+    import json
+    import subprocess
+
+    port = 33500 + (os.getpid() % 2000)
+    env = dict(os.environ, ASD_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak" and out["data"] == "stub"
+    assert out["exchange_units"] == 2 and out["exchange_steps"] == 6          # the table in place + one bucket; every step exchanged
+    assert out["allreduce_exposed_ms"] is not None and out["value"] > 0

@@ -45,6 +45,37 @@ def test_fused_adamw_matches_torch(name, kw):
     assert int(st["step"]) == 5
 
 
+@pytest.mark.parametrize("name", ["AdamW", "Adam"])
+def test_torch_optimizer_state_loads_into_the_fused_one_and_steps(name):
+    """the direction a reference checkpoint takes: a state dict written by torch.optim (no `adam_l2` key in its param_groups, `step`
+    moved to the device by load_state_dict) is loaded into the fused optimizer, which then continues exactly like torch does"""
+    from scaledreamer_amd.optimizers import AdamW
+
+    torch.manual_seed(1)
+    ref_p = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in [(4099,), (64, 32)]]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    ref = getattr(torch.optim, name)(ref_p, **kw)
+    grads = [[torch.randn_like(p) for p in ref_p] for _ in range(5)]
+    for step in range(3):
+        for p, g in zip(ref_p, grads[step]):
+            p.grad = g.clone()
+        ref.step()
+    ours = AdamW(our_p, adam_l2=name == "Adam", **kw)
+    ours.load_state_dict(ref.state_dict())
+    assert all(g["adam_l2"] == (name == "Adam") for g in ours.param_groups)
+    for a, b in zip(ref_p, our_p):
+        b.data.copy_(a.data)
+    for step in range(3, 5):
+        for a, b, g in zip(ref_p, our_p, grads[step]):
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        ours.step()
+    for a, b in zip(ref_p, our_p):
+        _same_update(b.detach(), a.detach())
+    assert int(ours.state[our_p[0]]["step"]) == 5 and not ours.state[our_p[0]]["step"].is_cuda
+
+
 def test_fused_adan_matches_reference_golden_and_oracle():
     from oracle.adan_ref import adan_step
     from scaledreamer_amd.optimizers import Adan

@@ -85,6 +85,32 @@ def test_hip_renderer_matches_reference_outputs_and_grads(name):
     np.testing.assert_allclose(gb[idx] / np.abs(val).max(), val / np.abs(val).max(), rtol=0, atol=3e-3)
 
 
+def test_unread_normals_are_deferred_and_equal_the_eager_ones():
+    """C2 sets `requires_normal` on a material that never reads normals and lambda_orient = 0: the finite-difference normal (three
+    more encodes per kept sample) must not be evaluated unless somebody indexes it — and when somebody does, it is the same tensor the
+    eager call gives, gradients included."""
+    g = load_renderer_golden(RENDERER_GOLDENS[0])
+    geo, mat, bg, ren = build_system(g)
+    assert mat.requires_normal and not mat.reads_normal
+    dev = lambda k: torch.from_numpy(g[k]).cuda()
+    out = ren(rays_o=dev("rays_o"), rays_d=dev("rays_d"), light_positions=dev("light_positions"))
+    assert out.pending() == {"normal", "shading_normal"} and "normal" in out
+    (out["comp_rgb"].sum() + out["opacity"].sum()).backward()
+    assert out.pending() == {"normal", "shading_normal"}          # a step that never reads them never pays for them
+    lazy = out["normal"]
+    assert not out.pending()
+    eager = geo(out["points"], output_normal=True)["normal"]
+    assert torch.equal(lazy, eager) and lazy.requires_grad
+    p = geo.encoding.encoding.encoding.params
+    p.grad = None
+    (lazy * out["t_dirs"]).sum().backward()
+    g_lazy = p.grad.clone()
+    p.grad = None
+    (eager * out["t_dirs"]).sum().backward()
+    scale = float(p.grad.abs().max())
+    assert scale > 0 and float((g_lazy - p.grad).abs().max()) <= 1e-4 * scale      # atomics: summation order only
+
+
 def test_eval_mode_and_empty_rays():
     g = load_renderer_golden(RENDERER_GOLDENS[0])
     geo, mat, bg, ren = build_system(g)

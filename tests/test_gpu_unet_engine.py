@@ -108,6 +108,44 @@ def test_shared_input_prefix_equals_the_plain_forward(camera):
     assert float((outs[1][0] - outs[1][G]).abs().max()) > 0     # different contexts still give different predictions
 
 
+@pytest.mark.parametrize("name", ["diffusion_unet_sd21_shared_b5", "diffusion_mvunet_shared_b12"])
+def test_full_width_shared_prefix_form_matches_reference_golden(name):
+    """The call form bench.py times (guidance -> unet_buffers(shared_reps) -> asd_unet_fwd_shared) at FULL width against the
+    reference's own UNetModel / MultiViewUNetModel in fp32 (make_goldens_diffusion.py --round3): SD layout = 4 x (x, t) under four
+    different contexts + 1 x (x+, t+) under a fifth (stable_diffusion_asd_guidance.py:377-394); MVDream layout = 2 x 4 views + 4 views
+    at t+ (mvdream_asd_guidance.py:231-246).  Every batch entry is compared on its own, north_star's 1e-2."""
+    from scaledreamer_amd.diffusion import weights as W
+    from scaledreamer_amd.diffusion.engine import HipUNet
+
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    mv = "mvunet" in name
+    cfg = W.UNetConfig(camera_dim=16 if mv else None)
+    seed, r, G, hw, n_ctx, frames = (int(g[k]) for k in ("seed", "reps", "group", "hw", "n_ctx", "num_frames"))
+    N = (r + 1) * G
+    p = W.gen_params(W.unet_layout(cfg)[0], seed, dtype=torch.float16)
+    eng = HipUNet(p, cfg, "cuda", use_graph=True)
+    del p
+    xa, xb = rnd("in.xa", (G, 4, hw, hw), seed), rnd("in.xb", (G, 4, hw, hw), seed)
+    x = torch.cat([xa] * r + [xb]).cuda()
+    t = torch.from_numpy(g["t"]).float().cuda()
+    ctx = rnd("in.context", (N, n_ctx, 1024), seed).cuda()
+    cam = torch.cat([rnd("in.camera", (G, 16), seed)] * (r + 1)).cuda() if mv else None
+    key = eng.staging(N, hw, hw, n_ctx, frames, shared_reps=r)[1][6]
+    assert key[5] == r and eng._graphs[key][1][7] is not None      # the shared form really is what runs
+    ref = torch.from_numpy(g["eps"])
+    for rep in range(2):
+        xin, tin, cin, cm, out = eng._graphs[key][1][:5]
+        xin.zero_(); xin[..., :4].copy_(x.permute(0, 2, 3, 1)); tin.copy_(t)
+        cin.view(N, -1, cin.shape[-1])[:, :n_ctx].copy_(ctx)
+        if cm is not None:
+            cm.copy_(cam)
+        got = eng.replay(key).permute(0, 3, 1, 2).float()
+        for i in range(N):
+            l2, mx = _rel(got[i:i + 1], ref[i:i + 1])
+            assert l2 < 1e-2 and mx < 1e-2, (rep, i, l2, mx)
+    assert float((got[0] - got[G]).abs().max()) > 1e-3         # different contexts, different predictions
+
+
 def test_mvdream_unet_matches_oracle():
     """MultiViewUNetModel (openaimodel.py:811-1213): camera embedding + self-attention across the 4 views of a group
     (BasicTransformerBlock3D, attention.py:343-354); the oracle is pinned by tests/golden/diffusion_mvunet_small.npz."""

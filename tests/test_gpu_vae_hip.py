@@ -72,7 +72,7 @@ def test_conv_dgrad_and_groupnorm_bwd_ops():
         assert _rel(fused, plain.float() + extra.float())[1] < 2e-3, (Cc, silu)
 
 
-@pytest.mark.parametrize("name", ["diffusion_vae_small", "diffusion_vae_full_256", "diffusion_vae_full_512"])
+@pytest.mark.parametrize("name", ["diffusion_vae_small", "diffusion_vae_full_256", "diffusion_vae_full_512", "diffusion_vae_full_256_b4"])
 def test_hip_vae_matches_reference_golden(name):
     from scaledreamer_amd.diffusion import weights as W
     from scaledreamer_amd.diffusion.vae_hip import HipVAEEncoder

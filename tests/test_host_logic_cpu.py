@@ -494,3 +494,47 @@ def test_converted_arguments_outlive_the_launch():
     pa, pb = k(a), k(b)
     assert len(k.held) == 2 and pa.value != pb.value and k.held[0].data_ptr() == pa.value
     assert k(None).value in (None, 0) and len(k.held) == 2
+
+
+def test_lazy_outputs_defer_until_first_access_and_survive_unpacking():
+    """renderer.LazyOutputs: the `normal` / `shading_normal` entries of the training output dictionary exist (`in`, keys, len) but are
+    produced on first access only — by indexing, .get, .items() or `**out` — and exactly once."""
+    from scaledreamer_amd.renderer import LazyOutputs
+
+    calls = []
+    out = LazyOutputs({"comp_rgb": 1})
+    out.update({"weights": 2})
+    out.defer(("normal", "shading_normal"), lambda: (calls.append(1), {"normal": 10, "shading_normal": 11})[1])
+    assert "normal" in out and len(out) == 4 and out.pending() == {"normal", "shading_normal"} and not calls
+    assert set(out.keys()) == {"comp_rgb", "weights", "normal", "shading_normal"}
+    assert out["comp_rgb"] == 1 and out.get("missing") is None and not calls
+    assert {**out} == {"comp_rgb": 1, "weights": 2, "normal": 10, "shading_normal": 11} and len(calls) == 1
+    assert out["shading_normal"] == 11 and len(calls) == 1 and not out.pending()
+    out2 = LazyOutputs({"a": 1})
+    out2.defer(("n",), lambda: {"n": 5})
+    assert (lambda a, **kw: kw)(**out2) == {"n": 5}
+
+
+def test_fused_adamw_host_side_accepts_torch_state_and_rejects_typos():
+    """optimizers.AdamW without a device: construction, unknown / unsupported keywords, and load_state_dict of a torch.optim state
+    (whose param_groups have no `adam_l2`) — the step itself is HIP-only (tests/test_gpu_optimizers.py)."""
+    import pytest
+
+    from scaledreamer_amd.optimizers import AdamW
+
+    p = [torch.nn.Parameter(torch.randn(5))]
+    with pytest.raises(TypeError):
+        AdamW(p, lr=1e-3, weight_decya=0.1)
+    with pytest.raises(NotImplementedError):
+        AdamW(p, amsgrad=True)
+    AdamW(p, foreach=None, fused=None, amsgrad=False)           # torch keywords that change nothing are accepted
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.randn(5))], lr=2e-3)
+    ref.param_groups[0]["params"][0].grad = torch.ones(5)
+    ref.step()
+    ours = AdamW(p, lr=1e-3, adam_l2=True)
+    ours.load_state_dict(ref.state_dict())
+    assert ours.param_groups[0]["adam_l2"] is True and ours.param_groups[0]["lr"] == 2e-3
+    assert int(ours.state[p[0]]["step"]) == 1
+    bad = torch.optim.AdamW([torch.nn.Parameter(torch.randn(5))], amsgrad=True)
+    with pytest.raises(NotImplementedError):
+        AdamW([torch.nn.Parameter(torch.randn(5))]).load_state_dict(bad.state_dict())
