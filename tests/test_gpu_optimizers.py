@@ -62,7 +62,9 @@ def test_torch_optimizer_state_loads_into_the_fused_one_and_steps(name):
             p.grad = g.clone()
         ref.step()
     ours = AdamW(our_p, adam_l2=name == "Adam", **kw)
-    ours.load_state_dict(ref.state_dict())
+    import copy
+
+    ours.load_state_dict(copy.deepcopy(ref.state_dict()))     # what a checkpoint file hands over (load_state_dict aliases same-device tensors)
     assert all(g["adam_l2"] == (name == "Adam") for g in ours.param_groups)
     for a, b in zip(ref_p, our_p):
         b.data.copy_(a.data)
