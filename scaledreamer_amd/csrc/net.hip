@@ -544,10 +544,12 @@ struct Vae : Net {
 };
 
 // conv: forward weights [cout, 9*pad32(cin)], input-gradient weights [pad32(cin), 9*pad32(cout)] (roles swapped, taps flipped for
-// stride 1; the stride-2 gradient uses the kernel's transposed gather), bias
-void v_conv(Vae& n, const std::string& p, int cin, int cout) {
+// stride 1; the stride-2 gradient is FOUR 2x2 convolutions over the low-resolution gradient image, one per input-pixel parity — the
+// kernel's upsample == 3 form, weights.py: _pack_stride2_dgrad_conv3x3), bias
+void v_conv(Vae& n, const std::string& p, int cin, int cout, bool stride2 = false) {
     n.add(p + ".fwd", cout, 9 * pad32(cin));
-    n.add(p + ".bwd", pad32(cin), 9 * pad32(cout));
+    if (stride2) n.add(p + ".bwd", 4 * pad32(cin), 4 * pad32(cout));    // parity form: [4 parities][cin][2 x 2 tap slots x cout]
+    else n.add(p + ".bwd", pad32(cin), 9 * pad32(cout));
     n.add(p + ".bias", 1, cout);
 }
 void v_norm(Vae& n, const std::string& p, int c) { n.add(p + ".weight", 1, c); n.add(p + ".bias", 1, c); }
@@ -573,7 +575,7 @@ void vae_build(Vae& n) {
         }
         if (lvl != d.n_levels - 1) {
             const std::string p = "encoder.down." + std::to_string(lvl) + ".downsample.conv";
-            v_conv(n, p, block_in, block_in);
+            v_conv(n, p, block_in, block_in, true);
             n.plan.push_back(VLayer{2, p, block_in, block_in});
         }
     }
@@ -774,7 +776,8 @@ void vae_backward(Vae& n, Run& r, const std::vector<VSaved>& saved, const float*
             dy = buf[cur];
         } else if (l.kind == 2) {
             half_t* dx = other(1);
-            conv3x3(r, dy, B, (hh + 1 - 3) / 2 + 1, (ww + 1 - 3) / 2 + 1, l.cout, n.w(l.name + ".bwd"), l.cin, dx, hh, ww, 1, 0, 2);
+            // (hh, ww even: the low-resolution image is exactly half; 9 of the 16 tap slots carry weights)
+            conv3x3(r, dy, B, hh / 2, ww / 2, l.cout, n.w(l.name + ".bwd"), l.cin, dx, hh, ww, 1, 1, 3);
             cur = (cur + 1) & 3;
             dy = buf[cur];
         } else if (l.kind == 1) {
@@ -972,6 +975,8 @@ int asd_vae_enc_fwd(asd_vae_enc* h, const void* x_nhwc32, int32_t batch, int32_t
     Vae* n = (Vae*)h;
     ASD_CHECK_ARG(n && x_nhwc32 && workspace && moments_nhwc, "null argument");
     ASD_CHECK_ARG(n->bound, "weights are not bound (asd_vae_enc_bind_weights)");
+    ASD_CHECK_ARG(H > 0 && W > 0 && H % (1 << (n->d.n_levels - 1)) == 0 && W % (1 << (n->d.n_levels - 1)) == 0,
+                  "H and W must be multiples of 2^(levels - 1): every Downsample halves the image exactly (parity-form input gradient)");
     // size check against the forward + backward plan, so that the backward can never overrun what the forward accepted
     const int64_t need = asd_vae_enc_workspace_bytes(h, batch, H, W, tune);
     if (need < 0 || need > workspace_bytes) { asd_set_error("workspace of %lld bytes is too small (need %lld)", (long long)workspace_bytes, (long long)need); return ASD_ERR_ARG; }

@@ -317,10 +317,31 @@ def pack_unet(p: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Te
     return out
 
 
+def _pack_stride2_dgrad_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """Input gradient of the encoder's Downsample convolution (model.py:80-85: pad (0,1,0,1), then 3x3 / stride 2 / pad 0) in the parity
+    form of the upsampling-convolution kernel (asd_gemm_args.upsample = 3): dX[Y, X] = sum_{ky, kx} dY[(Y - ky) / 2, (X - kx) / 2] W[ky, kx]
+    over the taps with even numerators, so input row Y = 2y + a only sees the low-resolution rows y - 1 + a + ty, ty in {0, 1}:
+    a = 0: ty = 0 <- ky = 2, ty = 1 <- ky = 0;  a = 1: ty = 0 <- ky = 1, ty = 1 <- nothing (columns alike).  9 of the 16 tap slots are
+    live: 4/9 of the multiply-adds of the nine-tap gather form (asd_gemm_args.upsample = 2), whose other taps multiply zero pages.
+    Forward weight [Cout, Cin, 3, 3] -> [4 * Cin', 4 * Cout'] = [parity (a, b)][cin][(ty, tx, cout)]."""
+    cout, cin = w.shape[:2]
+    cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    taps = {0: (2, 0), 1: (1, None)}
+    out = torch.zeros((2, 2, cin_p, 2, 2, cout_p), dtype=torch.float32, device=w.device)
+    for a in (0, 1):
+        for b in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    ky, kx = taps[a][ty], taps[b][tx]
+                    if ky is not None and kx is not None:
+                        out[a, b, :cin, ty, tx, :cout] = w[:, :, ky, kx].float().t()
+    return out.reshape(4 * cin_p, 4 * cout_p)
+
+
 def pack_vae_encoder(p: Dict[str, torch.Tensor], cfg: VAEConfig) -> Dict[str, torch.Tensor]:
     """LDM first-stage encoder state dict -> the C table of csrc/net.hip: vae_build.  Every convolution gets its forward matrix and
-    the matrix of its input gradient (roles of the channel axes swapped, taps flipped for stride 1; the stride-2 gradient uses the
-    kernel's transposed gather); conv_out and quant_conv are both linear and are composed into one convolution (exact)."""
+    the matrix of its input gradient (roles of the channel axes swapped, taps flipped for stride 1; the stride-2 gradient in the parity
+    form of _pack_stride2_dgrad_conv3x3); conv_out and quant_conv are both linear and are composed into one convolution (exact)."""
     _, plan = vae_encoder_layout(cfg)
     out: Dict[str, torch.Tensor] = {}
 
@@ -334,7 +355,7 @@ def pack_vae_encoder(p: Dict[str, torch.Tensor], cfg: VAEConfig) -> Dict[str, to
             wb = wb.flip(2, 3)
         if cin_p != cin:                                  # gradient w.r.t. the zero-padded input channels
             wb = torch.cat([wb, wb.new_zeros(cin_p - cin, *wb.shape[1:])], 0)
-        out[name + ".bwd"] = _pack_conv3x3(wb)
+        out[name + ".bwd"] = _pack_conv3x3(wb) if stride == 1 else _pack_stride2_dgrad_conv3x3(wt)
         out[name + ".bias"] = bias.float()
 
     for kind, name, cin, cout in plan:

@@ -538,3 +538,32 @@ def test_fused_adamw_host_side_accepts_torch_state_and_rejects_typos():
     bad = torch.optim.AdamW([torch.nn.Parameter(torch.randn(5))], amsgrad=True)
     with pytest.raises(NotImplementedError):
         AdamW([torch.nn.Parameter(torch.randn(5))]).load_state_dict(bad.state_dict())
+
+
+def test_stride2_input_gradient_parity_packing_matches_autograd():
+    """weights._pack_stride2_dgrad_conv3x3: the Downsample convolution's input gradient as four 2x2 convolutions over the low-resolution
+    gradient image (the layout csrc/net.hip feeds to the upsample == 3 kernel), evaluated here in torch against autograd of the
+    reference form (model.py:80-85: pad (0,1,0,1), 3x3 / stride 2 / pad 0)"""
+    import torch
+    import torch.nn.functional as F
+
+    from scaledreamer_amd.diffusion.weights import _pack_stride2_dgrad_conv3x3
+
+    torch.manual_seed(3)
+    cin, cout, Hh = 32, 64, 12
+    w = torch.randn(cout, cin, 3, 3, dtype=torch.float64)
+    x = torch.randn(2, cin, Hh, Hh, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2)
+    dy = torch.randn_like(y)
+    (want,) = torch.autograd.grad(y, x, dy)
+    w4 = _pack_stride2_dgrad_conv3x3(w.float()).double().view(2, 2, cin, 2, 2, cout)      # [a][b][cin][ty][tx][cout]
+    hl = Hh // 2
+    dyp = F.pad(dy, (1, 1, 1, 1))                                                          # low-resolution rows -1 .. hl
+    got = torch.zeros_like(want)
+    for a in (0, 1):
+        for b in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    src = dyp[:, :, a + ty:a + ty + hl, b + tx:b + tx + hl]                # rows y - 1 + a + ty of the unpadded image
+                    got[:, :, a::2, b::2] += torch.einsum("bohw,io->bihw", src, w4[a, b, :, ty, tx, :])
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
