@@ -292,6 +292,17 @@ typedef struct asd_gemm_args {
     int32_t gn_silu;
     int32_t wide_rows;      /* set by the library: the W tile is staged in a permuted row order so that every lane stores 8 consecutive
                                channels (16 B) per row (csrc/gemm.hip, tile_epilogue); callers leave it 0 */
+    /* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock: attn(norm(x)), ff(norm(x)), attention.py:246-275): with
+     * W' = gamma (.) W, s = rowsum(W') and c = W beta prepared at pack time,  LN(x) W^T = rstd * (x W'^T - mean * s) + c,  so the
+     * normalised tensor is never written or read — the main loop runs on the RAW rows, only the epilogue changes.
+     *   ln_mode 1: A holds the raw rows; their mean / rstd (over all K columns; plain GEMM, split_k is forced to 1) are reduced from
+     *              the A fragments in the main loop; ln_sc = {s[N], c[N]} fp32; ln_stats (optional) receives {mean, rstd} per row.
+     *   ln_mode 2: the W operand holds the raw rows (C^T form, e.g. V^T = W_v LN(x)^T): their statistics are READ from ln_stats
+     *              [N][2] (left there by a mode-1 launch over the same rows); ln_sc = {s[M], c[M]}. */
+    int32_t ln_mode;
+    float   ln_eps;
+    const float* ln_sc;
+    float*  ln_stats;
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
 int32_t asd_gemm_gn_records(const asd_gemm_args* args);

@@ -80,6 +80,7 @@ class GemmArgs(C.Structure):
         ("gn_partials", C.c_void_p), ("gn_cg", C.c_int32), ("gn_rows", C.c_int32),
         ("gn_bwd_x", C.c_void_p), ("gn_bwd_fstats", C.c_void_p), ("gn_bwd_gamma", C.c_void_p), ("gn_bwd_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("gn_silu", C.c_int32), ("wide_rows", C.c_int32),
+        ("ln_mode", C.c_int32), ("ln_eps", C.c_float), ("ln_sc", C.c_void_p), ("ln_stats", C.c_void_p),
     ]
 
 

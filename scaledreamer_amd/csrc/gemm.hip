@@ -31,7 +31,14 @@
 // For launches with few blocks (M <= 1280): a 64x64 block alone on its CU runs ONE wave per SIMD, so every k-step exposes its LDS
 // read latency and its barrier (1280^3: ~1100 cycles per k-step for 512 cycles of MFMA); two or four waves per SIMD overlap them
 // and the barrier count per K halves / quarters — without the fp32 slabs and the second launch of split-K across blocks.
-template <int BM, int BN, int WM, int WN, bool CONV, int NST = 2, int KG = 1>
+// LN (asd_gemm_args.ln_mode == 1): the rows of A are the INPUT of a LayerNorm folded into this GEMM (gemm_tile.h: ln_fold): their sum and
+// sum of squares are reduced from the A fragments as they pass through the main loop, so the normalised tensor never exists and the
+// LayerNorm launch and its pass over the activations are gone.  The reduction runs on the MATRIX pipe, which these load-bound launches
+// leave 80 % idle: mfma(ones, x) puts sum_k x[row] into every register of the lane that owns the row's outputs, mfma(x, x) the Gram
+// block whose diagonal is sum_k x^2 — two MFMAs per fragment and 32-wide k slice with operands already in registers, exact fp16
+// products accumulated in fp32.  (The first version used 8 v_dot2_f32_f16 per fragment and slice: the VALU issue slots it took made the
+// 20480-row launches 40 % slower, more than the LayerNorm kernel had cost.)
+template <int BM, int BN, int WM, int WN, bool CONV, int NST = 2, int KG = 1, bool LN = false>
 __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_gemm_args p) {
     constexpr int NW = WM * WN;               // waves per k-group
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -215,6 +222,24 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 sacc[LN ? TM : 1], qacc[LN ? TM : 1];      // LN: sum x (every register) and the Gram block of fragment row i
+#pragma unroll
+    for (int i = 0; i < (LN ? TM : 1); ++i) sacc[i] = qacc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const half8 ln_ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+    float ls1[LN ? TM : 1], ls2[LN ? TM : 1];          // sum x, sum x^2 of row (lane & 15) of fragment row i, once the loop is done
+    // sum x sits in every register of the lane; the Gram block's diagonal element of row b = lane & 15 sits in lane b + 16 (b >> 2),
+    // register b & 3 (the MFMA result layout: lane (col, 4-row group g) holds rows 4 g .. 4 g + 3 of column col)
+    auto ln_extract = [&]() __attribute__((always_inline)) {
+        if constexpr (LN) {
+            const int b = lane & 15;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ls1[i] = sacc[i][0];
+                const float d = (b & 2) ? ((b & 1) ? qacc[i][3] : qacc[i][2]) : ((b & 1) ? qacc[i][1] : qacc[i][0]);
+                ls2[i] = __shfl(d, b + 16 * (b >> 2), 64);
+            }
+        }
+    };
 
     // fragment reads: lane -> row (lane&15) of a 16-row sub-tile, k-quarter (lane>>4); chunk = kh*4 + quarter.  Sub-tiles
     // start at multiples of 16 rows, so the swizzle term (row & 7) is the same for all of them: two lane offsets (kh = 0, 1)
@@ -251,6 +276,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            if constexpr (LN) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    sacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ln_ones, xa[i], sacc[i], 0, 0, 0);
+                    qacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[i], xa[i], qacc[i], 0, 0, 0);
+                }
+            }
         }
     };
     if constexpr (KG > 1) {
@@ -265,6 +297,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
             if (k < ks1) compute(gsm + stage * STAGE_BYTES);
             k = kn;
         }
+        ln_extract();
         // sum the groups' accumulators into group 0: [wave][fragment][lane] floatx4, 16 B per lane (conflict-free)
         floatx4* red = (floatx4*)smem;
 #pragma unroll 1
@@ -285,6 +318,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
                         const floatx4 t = red[((wave * TM + i) * TN + j) * 64 + lane];
                         acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
                     }
+            }
+            if constexpr (LN) {      // the groups saw disjoint k-steps of the rows: their partial sums add up the same way
+                float* redf = (float*)(red + NW * TM * TN * 64);
+                __syncthreads();
+                if (kg == g) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { redf[((wave * TM + i) * 2) * 64 + lane] = ls1[i]; redf[((wave * TM + i) * 2 + 1) * 64 + lane] = ls2[i]; }
+                }
+                __syncthreads();
+                if (kg == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { ls1[i] += redf[((wave * TM + i) * 2) * 64 + lane]; ls2[i] += redf[((wave * TM + i) * 2 + 1) * 64 + lane]; }
+                }
             }
         }
     } else if constexpr (NST > 2) {
@@ -329,6 +375,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
         }
     }
     }
+    if constexpr (KG == 1) ln_extract();
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*(BM/WM) + i*16 + (lane&15)][n = n0 + wn*(BN/WN) + j*16 + (lane>>4)*4 + r]
@@ -354,6 +401,17 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
         tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, false, nullptr);
         return;
     }
+    float ln_mean[LN ? TM : 1], ln_rstd[LN ? TM : 1];
+    if constexpr (LN) {
+        const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ln_mean[i] = ls1[i] * inv_k;
+            ln_rstd[i] = rsqrtf(fmaxf(ls2[i] * inv_k - ln_mean[i] * ln_mean[i], 0.f) + p.ln_eps);
+            const int m = m0 + wm * (BM / WM) + i * 16 + em;
+            if (p.ln_stats && n0 == 0 && wn == 0 && lane < 16 && m < p.M) { p.ln_stats[2 * m] = ln_mean[i]; p.ln_stats[2 * m + 1] = ln_rstd[i]; }
+        }
+    }
     if (p.act == 2) {
         // fused GEGLU (attention.py:49-56): the weight rows were interleaved in 32-row groups [16 value | 16 gate] at pack
         // time, so fragments 2j' / 2j'+1 of a lane hold value and gate of the same 4 channels; output has N/2 columns
@@ -367,10 +425,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
                     const int n = n0 + wn * (BN / WN) + j * 16 + en;      // value columns n..n+3, gate columns n+16..n+19
                     if (n + 16 >= p.N) continue;
                     const half4 bx = *(const half4*)((const half_t*)p.bias + n), bg = *(const half4*)((const half_t*)p.bias + n + 16);
+                    float va[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    float vg[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                    if (p.ln_mode) {
+                        ln_fold<4>(p, va, m, n, LN ? ln_mean[i] : 0.f, LN ? ln_rstd[i] : 0.f);
+                        ln_fold<4>(p, vg, m, n + 16, LN ? ln_mean[i] : 0.f, LN ? ln_rstd[i] : 0.f);
+                    }
                     half4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        o[r] = (half_t)((acc[i][j][r] + (float)bx[r]) * gelu_erf(acc[i][j + 1][r] + (float)bg[r]));
+                        o[r] = (half_t)((va[r] + (float)bx[r]) * gelu_erf(vg[r] + (float)bg[r]));
                     *(half4*)((half_t*)p.C + (size_t)m * p.ldc + (n >> 5) * 16 + (n & 15)) = o;
                 }
             }
@@ -380,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
     const bool gn = p.gn_partials != nullptr;     // block-uniform
     float* gn_lds = (float*)smem;
     if (gn) gn_tile_begin(gn_lds);
-    tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, gn, gn_lds);
+    tile_epilogue<TM, TN>(p, acc, n0 + wn * (BN / WN), kz, m0, out_row, gn, gn_lds, LN ? ln_mean : nullptr, LN ? ln_rstd : nullptr);
     if (gn) gn_tile_end(p, gn_lds, (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN);
 }
 
@@ -1072,6 +1136,12 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     if (a->act == 2)
         ASD_CHECK_ARG(a->N % 32 == 0 && a->bias && !a->conv && !a->residual && !a->row_bias && !a->out_f32 && a->split_k == 1,
                       "GEGLU epilogue: N % 32 == 0, bias required, no conv / residual / row_bias / fp32 output / split-K");
+    if (a->ln_mode) {
+        ASD_CHECK_ARG((a->ln_mode == 1 || a->ln_mode == 2) && a->ln_sc && !a->out_f32, "LayerNorm fold: ln_mode 1 | 2, ln_sc required, fp16 output");
+        ASD_CHECK_ARG(a->ln_mode == 1 || (a->ln_stats && a->N % 4 == 0), "LayerNorm fold, mode 2: the column statistics ln_stats[N][2] are required");
+        ASD_CHECK_ARG(a->ln_mode == 2 || !a->conv, "LayerNorm fold, mode 1: plain GEMM only (the rows of A are the LayerNorm's rows)");
+        if (a->split_k > 1) { a->split_k = 1; a->tile_cfg = 0; }      // the row statistics (mode 1) and the fold itself need the whole K in one block
+    }
     int cfg = asd_gemm_resolve_cfg(a);
     ASD_CHECK_ARG(a->act != 2 || (!asd_cfg_is_window(cfg) && (asd_gemm_tiles[cfg].bn / asd_gemm_tiles[cfg].wn) % 32 == 0),
                   "GEGLU epilogue needs a tile whose per-wave width is a multiple of 32 columns");
@@ -1159,19 +1229,21 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     if (a->group_m < 1 || a->group_n < 1) asd_pick_group(asd_div_up(a->M, bm), asd_div_up(a->N, bn), bm, bn, lds, &a->group_m, &a->group_n);
     const dim3 grid(8 * asd_div_up(tiles * a->split_k, 8)), block(asd_gemm_tiles[cfg].wm * asd_gemm_tiles[cfg].wn * asd_cfg_kgroups(cfg) * 64);   // asd_xcd_item
     hipStream_t s = (hipStream_t)stream;
-#define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_, NST_, KG_)                                                                \
+#define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_, NST_, KG_, LN_)                                                           \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_>,                \
+            (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_, LN_>,           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, NST_ * KG_ * (BM_ + BN_) * 128);       \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_>), grid, block, lds, s, *a);            \
+        hipLaunchKernelGGL((gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_, LN_>), grid, block, lds, s, *a);       \
     } while (0)
 #define GEMM_CASE_N(IDX_, BM_, BN_, WM_, WN_, NST_, KG_)                                                                 \
     case IDX_:                                                                                                           \
-        if (a->conv) GEMM_LAUNCH(BM_, BN_, WM_, WN_, true, NST_, KG_); else GEMM_LAUNCH(BM_, BN_, WM_, WN_, false, NST_, KG_); \
+        if (a->conv) GEMM_LAUNCH(BM_, BN_, WM_, WN_, true, NST_, KG_, false);                                            \
+        else if (a->ln_mode == 1) GEMM_LAUNCH(BM_, BN_, WM_, WN_, false, NST_, KG_, true);                               \
+        else GEMM_LAUNCH(BM_, BN_, WM_, WN_, false, NST_, KG_, false);                                                   \
         break
 #define GEMM_CASE(IDX_, BM_, BN_, WM_, WN_) GEMM_CASE_N(IDX_, BM_, BN_, WM_, WN_, 2, 1)
     switch (cfg) {

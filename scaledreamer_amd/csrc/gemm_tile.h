@@ -135,6 +135,29 @@ __device__ __forceinline__ void gn_tile_end(const asd_gemm_args& p, const float*
     if (threadIdx.x < 64) p.gn_partials[(size_t)record * 64 + threadIdx.x] = lds64[threadIdx.x];
 }
 
+// LayerNorm folded into its consumer (asd_gemm_args.ln_mode): v <- rstd * (v - mean * s) + c on CNT consecutive columns n.. of row m.
+// mode 1: (mean, rstd) belong to the row (arguments), s / c to the columns; mode 2: s / c belong to the row, the statistics to the columns
+// (read from ln_stats[N][2]).
+template <int CNT>
+__device__ __forceinline__ void ln_fold(const asd_gemm_args& p, float* v, int m, int n, float mean, float rstd) {
+    if (p.ln_mode == 1) {
+#pragma unroll
+        for (int q = 0; q < CNT / 4; ++q) {
+            const floatx4 s = *(const floatx4*)(p.ln_sc + n + 4 * q), c = *(const floatx4*)(p.ln_sc + p.N + n + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaf(rstd, v[4 * q + r] - mean * s[r], c[r]);
+        }
+    } else {
+        const float s = p.ln_sc[m], c = p.ln_sc[p.M + m];
+#pragma unroll
+        for (int q = 0; q < CNT / 2; ++q) {
+            const floatx4 st = *(const floatx4*)(p.ln_stats + 2 * (n + 2 * q));      // {mean, rstd} of columns n + 2q, n + 2q + 1
+            v[2 * q] = fmaf(st[1], v[2 * q] - st[0] * s, c);
+            v[2 * q + 1] = fmaf(st[3], v[2 * q + 1] - st[2] * s, c);
+        }
+    }
+}
+
 // bias + row_bias + SiLU + residual + store of 4 consecutive output channels of row m (shared by all GEMM / conv kernels)
 __device__ __forceinline__ floatx4 gemm_store4(const asd_gemm_args& p, floatx4 v, int m, int n) {
     if (p.bias) {
@@ -208,8 +231,10 @@ __device__ __forceinline__ void gemm_store8(const asd_gemm_args& p, floatx4& lo,
 // Epilogue of a wave's TM x TN fragment tile (all GEMM / conv kernels): split-K partial slabs, or bias / row_bias / SiLU / residual /
 // store, plus the GroupNorm reductions when asked.  nb = first channel of the wave, row(i) = output row of fragment row i (< 0: none),
 // row0 = any row of the tile (the batch element of the GroupNorm constants).
+// ln_mean / ln_rstd: statistics of the lane's row in fragment row i (ln_mode 1; null otherwise)
 template <int TM, int TN, typename RowFn>
-__device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&acc)[TM][TN], int nb, int kz, int row0, RowFn row, bool gn, float* gn_lds) {
+__device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&acc)[TM][TN], int nb, int kz, int row0, RowFn row, bool gn, float* gn_lds,
+                                              const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
     const int g = (threadIdx.x & 63) >> 4;
     if constexpr (TN % 2 == 0) {
         if (p.wide_rows) {
@@ -228,6 +253,11 @@ __device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&
                         *(floatx4*)(dst + 4) = acc[i][2 * s2 + 1];
                     } else {
                         floatx4 lo = acc[i][2 * s2], hi = acc[i][2 * s2 + 1];
+                        if (p.ln_mode) {
+                            float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            ln_fold<8>(p, v8, m, n, ln_mean ? ln_mean[i] : 0.f, ln_rstd ? ln_rstd[i] : 0.f);
+                            lo = floatx4{v8[0], v8[1], v8[2], v8[3]}; hi = floatx4{v8[4], v8[5], v8[6], v8[7]};
+                        }
                         gemm_store8(p, lo, hi, m, n);
                         if (gn) {
 #pragma unroll
@@ -255,7 +285,13 @@ __device__ __forceinline__ void tile_epilogue(const asd_gemm_args& p, floatx4 (&
             if (m < 0 || n >= p.N) continue;
             if (p.split_k > 1) *(floatx4*)(p.workspace + ((size_t)kz * p.M + m) * p.N + n) = acc[i][j];
             else {
-                const floatx4 o = gemm_store4(p, acc[i][j], m, n);
+                floatx4 a4 = acc[i][j];
+                if (p.ln_mode) {
+                    float v4[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    ln_fold<4>(p, v4, m, n, ln_mean ? ln_mean[i] : 0.f, ln_rstd ? ln_rstd[i] : 0.f);
+                    a4 = floatx4{v4[0], v4[1], v4[2], v4[3]};
+                }
+                const floatx4 o = gemm_store4(p, a4, m, n);
                 if (gn) gn_tile_accum(p, gc, o, m, n, cs, cq);
             }
         }

@@ -91,6 +91,9 @@ struct GemmOpt {
     const half_t* gn_x = nullptr; const float* gn_fstats = nullptr; const half_t* gn_gamma = nullptr; const half_t* gn_beta = nullptr;
     int gn_silu = 0;
     bool gn_bwd_form = false;   // set with gn_x (dry passes carry null pointers: the record count must still be the backward form's)
+    // LayerNorm folded into this GEMM (asd_gemm_args.ln_mode): 1 = the rows of A are normalised (statistics reduced in the main loop,
+    // optionally exported to ln_stats), 2 = the rows of the W operand are (statistics read from ln_stats)
+    int ln_mode = 0; const float* ln_sc = nullptr; float* ln_stats = nullptr;
 };
 
 void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
@@ -147,6 +150,7 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     g.bias = o.bias; g.row_bias = o.row_bias; g.rows_per_group = o.row_bias ? o.rows_per_group : 1; g.ld_row_bias = o.ld_row_bias;
     g.residual = o.residual; g.ldr = o.ldr; g.act = o.act; g.out_f32 = o.out_f32;
     g.gn_rows = o.gn_rows;
+    g.ln_mode = o.ln_mode; g.ln_sc = o.ln_sc; g.ln_stats = o.ln_stats; g.ln_eps = 1e-5f;
     if (o.gn_x) set_gn_bwd(g, o);
     if (o.out) *o.out = Act{(const half_t*)C, nullptr, 0};
     launch_gemm(r, g, o.out, o.gn_bwd_form);
@@ -203,6 +207,7 @@ struct UNet : Net {
     int emb_total = 0, ctx_total = 0;
 };
 
+#define ASD_LN_FOLD_MIN_C 1024      // transformer blocks at least this wide fold their LayerNorms (weights.py: LN_FOLD_MIN_C)
 void u_norm(UNet& n, const std::string& p, int c) { n.add(p + ".weight", 1, c); n.add(p + ".bias", 1, c); }
 void u_lin(UNet& n, const std::string& p, int cin, int cout, bool bias = true) { n.add(p + ".weight", cout, cin); if (bias) n.add(p + ".bias", 1, cout); }
 void u_conv(UNet& n, const std::string& p, int cin, int cout) { n.add(p + ".weight", cout, 9 * pad32(cin)); n.add(p + ".bias", 1, cout); }
@@ -221,13 +226,24 @@ void u_attn(UNet& n, const std::string& p, int c) {
     u_lin(n, p + ".proj_in", c, c);
     for (int dd = 0; dd < n.d.transformer_depth; ++dd) {
         const std::string b = p + ".transformer_blocks." + std::to_string(dd);
-        for (const char* nm : {".norm1", ".norm2", ".norm3"}) u_norm(n, b + nm, c);
+        // Blocks of the low-resolution levels (c >= ASD_LN_FOLD_MIN_C: 16x16 and 8x8 tokens, M <= 1280 rows at batch 5) fold norm1 / norm2 /
+        // norm3 into the GEMMs that consume them (asd_gemm_args.ln_mode): their weights are gamma (.) W and every such GEMM has a "ln_sc"
+        // entry = fp32 {rowsum(gamma (.) W), W beta} (stored as 4 halfs per output row; weights.pack_unet applies the same rule).  The fold
+        // re-derives the row statistics in every N tile of a row block; measured on the step: it removes a ~5 us LayerNorm launch per
+        // norm where a row block has few N tiles and the launch is latency bound, and LOSES where M = 20480 / 5120 (the 2560-column GEGLU
+        // projection has 40 N tiles per row block: 64.6 -> 130 us), so the wide levels keep the LayerNorm kernel.
+        const bool fold = c >= ASD_LN_FOLD_MIN_C;
+        if (!fold) for (const char* nm : {".norm1", ".norm2", ".norm3"}) u_norm(n, b + nm, c);
         n.add(b + ".attn1.to_qk.weight", 2 * c, c);            // q | k rows fused
+        if (fold) n.add(b + ".attn1.to_qk.ln_sc", 1, 4 * 2 * c);
         n.add(b + ".attn1.to_v.weight", c, c);
+        if (fold) n.add(b + ".attn1.to_v.ln_sc", 1, 4 * c);
         u_lin(n, b + ".attn1.to_out.0", c, c);
         n.add(b + ".attn2.to_q.weight", c, c);
+        if (fold) n.add(b + ".attn2.to_q.ln_sc", 1, 4 * c);
         u_lin(n, b + ".attn2.to_out.0", c, c);
         u_lin(n, b + ".ff.net.0.proj", c, 8 * c);              // GEGLU rows interleaved [16 value | 16 gate] (asd_gemm_args.act = 2)
+        if (fold) n.add(b + ".ff.net.0.proj.ln_sc", 1, 4 * 8 * c);
         u_lin(n, b + ".ff.net.2", 4 * c, c);
         n.ctx_off[b + ".attn2"] = n.ctx_total;                 // its K / V projections of the context live in ctx_{k,v}_all
         n.ctx_total += c;
@@ -371,11 +387,20 @@ Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, con
     for (int dd = 0; dd < n.d.transformer_depth; ++dd) {
         const std::string b = p + ".transformer_blocks." + std::to_string(dd);
         // self-attention (MVDream: over the F views of a group, attention.py:348-354)
-        half_t* y = layernorm(r, h, M, C, n.w(b + ".norm1.weight"), n.w(b + ".norm1.bias"));
+        // Folded blocks: norm1 lives inside the two projections — the q | k GEMM reduces the row statistics of h in its main loop and
+        // leaves them for the V^T GEMM, whose W operand is the same h (attention.py:262: attn1(norm1(x))).
+        const bool fold = n.has(b + ".attn1.to_qk.ln_sc");
+        GemmOpt oqk, ov;
+        const half_t* y = h;
+        if (fold) {
+            float* lnst = r.mem.floats((size_t)M * 2);
+            oqk.ln_mode = 1; oqk.ln_sc = (const float*)n.w(b + ".attn1.to_qk.ln_sc"); oqk.ln_stats = lnst;
+            ov.ln_mode = 2; ov.ln_sc = (const float*)n.w(b + ".attn1.to_v.ln_sc"); ov.ln_stats = lnst;
+        } else y = layernorm(r, h, M, C, n.w(b + ".norm1.weight"), n.w(b + ".norm1.bias"));
         half_t* qk = r.mem.halfs((size_t)M * 2 * C);
-        gemm(r, y, M, C, n.w(b + ".attn1.to_qk.weight"), 2 * C, C, C, qk, 2 * C);
-        half_t* vT = r.mem.halfs((size_t)C * M);                              // V^T = W_v y^T: operands swapped
-        gemm(r, n.w(b + ".attn1.to_v.weight"), C, C, y, M, C, C, vT, M);
+        gemm(r, y, M, C, n.w(b + ".attn1.to_qk.weight"), 2 * C, C, C, qk, 2 * C, oqk);
+        half_t* vT = r.mem.halfs((size_t)C * M);                              // V^T = W_v norm1(h)^T: operands swapped
+        gemm(r, n.w(b + ".attn1.to_v.weight"), C, C, y, M, C, C, vT, M, ov);
         half_t* o1 = r.mem.halfs((size_t)M * C);
         LEAF(asd_attention_f16(qk, 2 * C, qk + C, 2 * C, vT, M, o1, C, B / F, heads, F * L, F * L, F * L, 0.125f, r.zero_page, r.stream));
         half_t* h1 = r.mem.halfs((size_t)M * C);
@@ -389,9 +414,12 @@ Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, con
         }
         const UState& s = *sp;
         // cross-attention on the text context (K / V^T of every layer were projected once per forward)
-        y = layernorm(r, h1, M, C, n.w(b + ".norm2.weight"), n.w(b + ".norm2.bias"));
         half_t* q = r.mem.halfs((size_t)M * C);
-        gemm(r, y, M, C, n.w(b + ".attn2.to_q.weight"), C, C, C, q, C);
+        { GemmOpt o;                                                                                    // attn2(norm2(x))
+          y = h1;
+          if (fold) { o.ln_mode = 1; o.ln_sc = (const float*)n.w(b + ".attn2.to_q.ln_sc"); }
+          else y = layernorm(r, h1, M, C, n.w(b + ".norm2.weight"), n.w(b + ".norm2.bias"));
+          gemm(r, y, M, C, n.w(b + ".attn2.to_q.weight"), C, C, C, q, C, o); }
         const int coff = n.ctx_off[b + ".attn2"], ldv = B * s.ctx_stride;
         half_t* o2 = r.mem.halfs((size_t)M * C);
         LEAF(asd_attention_f16(q, C, s.k_all + coff, n.ctx_total, s.vT_all + (size_t)coff * ldv, ldv, o2, C, B, heads, L, s.n_ctx, s.ctx_stride,
@@ -400,9 +428,11 @@ Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, con
         { GemmOpt o; o.bias = n.w(b + ".attn2.to_out.0.bias"); o.residual = h1; o.ldr = C;
           gemm(r, o2, M, C, n.w(b + ".attn2.to_out.0.weight"), C, C, C, h2, C, o); }
         // GEGLU feed-forward
-        y = layernorm(r, h2, M, C, n.w(b + ".norm3.weight"), n.w(b + ".norm3.bias"));
         half_t* g = r.mem.halfs((size_t)M * 4 * C);
-        { GemmOpt o; o.bias = n.w(b + ".ff.net.0.proj.bias"); o.act = 2;
+        { GemmOpt o; o.bias = n.w(b + ".ff.net.0.proj.bias"); o.act = 2;                               // ff(norm3(x))
+          y = h2;
+          if (fold) { o.ln_mode = 1; o.ln_sc = (const float*)n.w(b + ".ff.net.0.proj.ln_sc"); }
+          else y = layernorm(r, h2, M, C, n.w(b + ".norm3.weight"), n.w(b + ".norm3.bias"));
           gemm(r, y, M, C, n.w(b + ".ff.net.0.proj.weight"), 8 * C, C, C, g, 4 * C, o); }
         half_t* h3 = r.mem.halfs((size_t)M * C);
         { GemmOpt o; o.bias = n.w(b + ".ff.net.2.bias"); o.residual = h2; o.ldr = C;

@@ -114,11 +114,14 @@ if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none" and os.path.exists(L.LIB_P
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
-         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0, gn_bwd: Optional[dict] = None):
+         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0, gn_bwd: Optional[dict] = None, ln: Optional[dict] = None):
     """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv.
     gn_rows > 0: also ask the epilogue for the GroupNorm statistics records of C (rows per batch element = gn_rows); returns
     (C, records | None, records_per_batch_element).  gn_bwd = dict(x, fstats, gamma, beta, eps, silu): C is the gradient reaching
-    GroupNorm(x)[+SiLU] and the records carry that layer's two backward reductions instead (asd_gemm_args.gn_bwd_x)."""
+    GroupNorm(x)[+SiLU] and the records carry that layer's two backward reductions instead (asd_gemm_args.gn_bwd_x).
+    ln = dict(mode, sc, stats=None, eps=1e-5): a LayerNorm folded into this GEMM (asd_gemm_args.ln_mode; w = gamma (.) W and sc = fp32
+    [2, rows] {rowsum(w), W beta} from weights._ln_fold): mode 1 normalises the rows of a (stats, if given, receives {mean, rstd} per
+    row), mode 2 the rows of w with the statistics read from stats."""
     dev = a.device
     N, K = w.shape
     if conv is not None and int(conv.get("upsample", 0)) == 3:     # parity form: w = [4 parities][Cout][4 * Cin]
@@ -150,6 +153,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
             setattr(g, k, int(conv[k]))
     g.zero_page = zero_page(dev).data_ptr()
     g.tile_cfg = tile_cfg
+    if ln is not None:
+        g.ln_mode, g.ln_eps, g.ln_sc = int(ln["mode"]), float(ln.get("eps", 1e-5)), ln["sc"].data_ptr()
+        g.ln_stats = None if ln.get("stats") is None else ln["stats"].data_ptr()
     if split_k is not None:
         g.split_k = split_k
     else:

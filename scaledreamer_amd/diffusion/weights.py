@@ -282,6 +282,21 @@ def _geglu_rows(c: int) -> torch.Tensor:
     return torch.stack([torch.arange(c).view(-1, 16), torch.arange(c, 2 * c).view(-1, 16)], dim=1).reshape(-1)
 
 
+LN_FOLD_MIN_C = 1024      # transformer blocks at least this wide fold their LayerNorms into the consuming GEMMs (csrc/net.hip: ASD_LN_FOLD_MIN_C)
+
+
+def _ln_fold(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm folded into the Linear that consumes it (asd_gemm_args.ln_mode, csrc/gemm_tile.h: ln_fold):
+        LN(x) W^T = rstd * (x W'^T - mean * s) + c,   W' = gamma (.) W,  s = rowsum(W'),  c = W beta.
+    W' is rounded to fp16 here and s is summed from the ROUNDED values (the kernel's accumulator holds exactly mean * s plus the
+    centred part, the subtraction must cancel the same numbers).  Returns (W' fp16, {s, c} fp32 [2, N] viewed as fp16 [4 N] — the weight
+    table of csrc/net.hip carries fp16 matrices only)."""
+    wf = w.float()
+    w2 = (wf * gamma.float()[None, :]).half()
+    sc = torch.stack([w2.float().sum(1), wf @ beta.float()]).contiguous()
+    return w2, sc.view(torch.float16).reshape(1, -1)
+
+
 def pack_unet(p: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Tensor]:
     """name-keyed LDM UNet state dict -> the packed fp32/fp16-agnostic matrices of the C table (names as csrc/net.hip: unet_build)."""
     _, inputs, middle, outputs = unet_layout(cfg)
@@ -306,12 +321,22 @@ def pack_unet(p: Dict[str, torch.Tensor], cfg: UNetConfig) -> Dict[str, torch.Te
             elif kind == "attn":
                 for d in range(cfg.transformer_depth):
                     b = f"{name}.transformer_blocks.{d}"
-                    out[b + ".attn1.to_qk.weight"] = torch.cat([p[b + ".attn1.to_q.weight"], p[b + ".attn1.to_k.weight"]], 0)
                     ck.append(p[b + ".attn2.to_k.weight"])
                     cv.append(p[b + ".attn2.to_v.weight"])
                     perm = _geglu_rows(4 * cout).to(p[b + ".ff.net.0.proj.weight"].device)
-                    out[b + ".ff.net.0.proj.weight"] = p[b + ".ff.net.0.proj.weight"][perm]
                     out[b + ".ff.net.0.proj.bias"] = p[b + ".ff.net.0.proj.bias"][perm]
+                    if cout < LN_FOLD_MIN_C:      # the wide levels keep their LayerNorm kernels (csrc/net.hip: u_attn)
+                        out[b + ".attn1.to_qk.weight"] = torch.cat([p[b + ".attn1.to_q.weight"], p[b + ".attn1.to_k.weight"]], 0)
+                        out[b + ".ff.net.0.proj.weight"] = p[b + ".ff.net.0.proj.weight"][perm]
+                        continue
+                    # norm1 -> (q | k, v), norm2 -> cross-attention q, norm3 -> GEGLU projection: folded into those weights
+                    for dst, wmat, nm in ((b + ".attn1.to_qk", torch.cat([p[b + ".attn1.to_q.weight"], p[b + ".attn1.to_k.weight"]], 0), ".norm1"),
+                                          (b + ".attn1.to_v", p[b + ".attn1.to_v.weight"], ".norm1"),
+                                          (b + ".attn2.to_q", p[b + ".attn2.to_q.weight"], ".norm2"),
+                                          (b + ".ff.net.0.proj", p[b + ".ff.net.0.proj.weight"][perm], ".norm3")):
+                        out[dst + ".weight"], out[dst + ".ln_sc"] = _ln_fold(wmat, p[b + nm + ".weight"], p[b + nm + ".bias"])
+                    for nm in (".norm1", ".norm2", ".norm3"):          # no longer read: the table of csrc/net.hip does not list them
+                        out.pop(b + nm + ".weight", None), out.pop(b + nm + ".bias", None)
     out["emb_all.weight"], out["emb_all.bias"] = torch.cat(emb_w, 0), torch.cat(emb_b, 0)
     out["ctx_k_all.weight"], out["ctx_v_all.weight"] = torch.cat(ck, 0), torch.cat(cv, 0)
     return out

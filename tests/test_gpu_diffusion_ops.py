@@ -363,3 +363,42 @@ def test_groupnorm_backward_reductions_from_the_dgrad_epilogue(B, hw, c, tile, s
     ref = ref.reshape(B, hw * hw, c) + dx_add.float()
     assert float((got.float() - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
     assert float((got.float() - want.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,C_,N,tile", [(20480, 320, 640, 2), (5120, 640, 640, 12), (1280, 1280, 1280, 16), (320, 1280, 2560, 17), (333, 320, 320, 15),
+                                          (1280, 1280, 2560, 19), (4096, 640, 1280, 5), (777, 320, 640, 0), (2048, 320, 320, 3)])
+def test_layernorm_folded_into_the_consuming_gemm(M, C_, N, tile):
+    """asd_gemm_args.ln_mode: LN(x) W^T = rstd * (x (gamma . W)^T - mean * rowsum(gamma . W)) + W beta with the row statistics reduced
+    from the A fragments in the main loop (mode 1, every tile family incl. the k-group and ring variants) or read from the statistics
+    a mode-1 launch left (mode 2: the V^T = W_v LN(x)^T form) — against torch's LayerNorm + matmul in fp32"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+    from scaledreamer_amd.diffusion.weights import _ln_fold
+
+    if N % H.TILE_BN[tile] and H.TILE_BN[tile] != 64:
+        pytest.skip("tile does not divide N")
+    x = (_rand(M, C_, seed=1).float() * 1.5 + _rand(M, 1, seed=2).float() * 2.0 + 0.7).half()      # rows with their own offsets and scales
+    gamma, beta = (_rand(C_, seed=3).float() * 0.2 + 1.0), _rand(C_, seed=4).float() * 0.3
+    w = _rand(N, C_, scale=C_ ** -0.5, seed=5)
+    bias = _rand(N, seed=6)
+    y = F.layer_norm(x.float(), (C_,), gamma.cuda(), beta.cuda(), 1e-5)
+    ref = y @ w.float().t() + bias.float()
+    w2, sc = _ln_fold(w, gamma.cuda(), beta.cuda())
+    sc32 = sc.view(torch.float32).view(2, N).contiguous()
+    stats = torch.zeros(M, 2, device="cuda")
+    got = H.gemm(x, w2.contiguous(), bias=bias, tile_cfg=tile + 1, split_k=1, ln=dict(mode=1, sc=sc32, stats=stats))
+    _close(got, ref)
+    torch.testing.assert_close(stats[:, 0], x.float().mean(1), rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(stats[:, 1], (x.float().var(1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-3, atol=1e-4)
+    # mode 2: the same product transposed — the normalised rows are the W operand, their statistics come from the launch above
+    if M % 4 == 0:
+        wv = _rand(256, C_, scale=C_ ** -0.5, seed=7)
+        wv2, scv = _ln_fold(wv, gamma.cuda(), beta.cuda())
+        gotT = H.gemm(wv2.contiguous(), x, split_k=1, ln=dict(mode=2, sc=scv.view(torch.float32).view(2, 256).contiguous(), stats=stats))
+        _close(gotT, wv.float() @ y.t())
+    # the GEGLU form (ff.net.0.proj behind norm3)
+    if N % 32 == 0:      # (every tile of this list has whole 32-column groups per wave)
+        wp, bp = H.pack_geglu_weight(w, bias)
+        wp2, scp = _ln_fold(wp, gamma.cuda(), beta.cuda())
+        gg = H.gemm(x, wp2.contiguous(), bias=bp, act=2, tile_cfg=tile + 1, ln=dict(mode=1, sc=scp.view(torch.float32).view(2, N).contiguous()))
+        val, gate = ref[:, :N // 2], ref[:, N // 2:]
+        _close(gg, val * F.gelu(gate))
