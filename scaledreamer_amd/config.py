@@ -57,34 +57,46 @@ def parse_structured(fields: Any, cfg: Optional[dict] = None) -> Any:
 
 
 # ---- scheduled scalars ---------------------------------------------------------------------------
+class Schedule:
+    """A scheduled scalar of the configs (threestudio/utils/misc.py:66-101 defines the list format) as a table of knots.
+    `[v0, v1, s1]` = from (0, v0) to (s1, v1); `[s0, v0, v1, s1]` = from (s0, v0) to (s1, v1); longer lists append further
+    (value, step) pairs: `[s0, v0, v1, s1, v2, s2, ...]`.  The active segment is the last one whose start step has been reached by
+    global_step (segment 0 before that); inside it the value is interpolated on global_step when the segment's end step is an int and
+    on the epoch otherwise, clamped to the segment."""
+
+    __slots__ = ("steps", "values")
+
+    def __init__(self, spec: Any):
+        spec = config_to_primitive(spec)
+        if not isinstance(spec, list):
+            raise TypeError("Scalar specification only supports list, got", type(spec))
+        if len(spec) == 3:
+            spec = [0] + spec
+        assert len(spec) == 4 or len(spec) >= 6, "a schedule is [v0, v1, s1], [s0, v0, v1, s1] or the latter followed by (value, step) pairs"
+        self.steps = [spec[0]] + spec[3::2]
+        self.values = ([spec[1]] + spec[2::2])[:len(self.steps)]
+
+    def segment(self, global_step) -> int:
+        reached = [k for k in range(1, len(self.steps) - 1) if global_step >= self.steps[k]]
+        return reached[-1] if reached else 0
+
+    def at(self, epoch: int, global_step: int, interpolation: str = "linear") -> float:
+        k = self.segment(global_step)
+        (s0, s1), (v0, v1) = self.steps[k:k + 2], self.values[k:k + 2]
+        clock = global_step if isinstance(s1, int) else epoch
+        t = min(max((clock - s0) / (s1 - s0), 0.0), 1.0)
+        if interpolation == "linear":
+            return v0 + (v1 - v0) * t
+        if interpolation == "exp":
+            return math.exp((1.0 - t) * math.log(v0) + t * math.log(v1))
+        raise ValueError(f"Unknown interpolation method: {interpolation}, only support linear and exp")
+
+
 def C(value: Any, epoch: int, global_step: int, interpolation: str = "linear") -> float:
+    """value of a scheduled scalar at (epoch, global_step); plain numbers pass through"""
     if isinstance(value, (int, float)):
         return value
-    value = config_to_primitive(value)
-    if not isinstance(value, list):
-        raise TypeError("Scalar specification only supports list, got", type(value))
-    if len(value) == 3:
-        value = [0] + value
-    if len(value) >= 6:
-        select_i = 3
-        for i in range(3, len(value) - 2, 2):
-            if global_step >= value[i]:
-                select_i = i + 2
-        if select_i != 3:
-            start_value, start_step = value[select_i - 3], value[select_i - 2]
-        else:
-            start_step, start_value = value[:2]
-        end_value, end_step = value[select_i - 1], value[select_i]
-        value = [start_step, start_value, end_value, end_step]
-    assert len(value) == 4
-    start_step, start_value, end_value, end_step = value
-    current_step = global_step if isinstance(end_step, int) else epoch
-    t = max(min(1.0, (current_step - start_step) / (end_step - start_step)), 0.0)
-    if interpolation == "linear":
-        return start_value + (end_value - start_value) * t
-    if interpolation == "exp":
-        return math.exp(math.log(start_value) * (1 - t) + math.log(end_value) * t)
-    raise ValueError(f"Unknown interpolation method: {interpolation}, only support linear and exp")
+    return Schedule(value).at(epoch, global_step, interpolation)
 
 
 # ---- YAML loading with ${...} interpolation --------------------------------------------------------

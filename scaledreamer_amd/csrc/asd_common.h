@@ -246,19 +246,8 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
             // the carrier sits in the head's cell, so it forms the same idx
             const float val = issue ? v[2 * c] : f1_prev;
             float* dst = tab + 2u * (size_t)idx + (issue ? 0 : 1);
-#ifdef ASD_ABLATE_COARSE_BELOW      // tools/field_bwd_ab.py: timing-only builds (wrong results) — no atomics on levels < / >= a bound
-            if (l < ASD_ABLATE_COARSE_BELOW) continue;
-#endif
-#ifdef ASD_ABLATE_COARSE_FROM
-            if (l >= ASD_ABLATE_COARSE_FROM) continue;
-#endif
-#ifndef ASD_ABLATE_COARSE_ATOMICS
             if ((issue || carrier) && val != 0.f) atomicAdd(dst, val);
             if (self_f1 && v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
-#else
-            if ((issue || carrier) && val == 12345.678f) atomicAdd(dst, val);
-            if (self_f1 && v[2 * c + 1] == 12345.678f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
-#endif
         }
     }
     if (NAGG >= L) return;
@@ -286,11 +275,7 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
                 // same product order as the one-lane-per-sample form: (ax * ay) * az
                 const float wt = ax * ((c & 1) ? wy : 1.f - wy) * ((c & 2) ? wz : 1.f - wz);
                 const uint32_t idx = asd_grid_index(m, l, cx, cy + (c & 1), cz + ((c >> 1) & 1));
-#ifndef ASD_ABLATE_FINE_ATOMICS
                 atomicAdd(tab + 2u * (size_t)idx, wt * g);
-#else
-                if (wt * g == 12345.678f) atomicAdd(tab + 2u * (size_t)idx, wt * g);
-#endif
             }
         }
     }

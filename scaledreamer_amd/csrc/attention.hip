@@ -135,9 +135,7 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
-#ifndef ASD_ATTN_ABL_NOLOAD     // ablation: wrong results, tiles are not re-loaded
         if (t + 1 < n_tiles) issue(t + 1, buf ^ 1);
-#endif
         const char* Ks = smem + buf * 2 * TILE_BYTES;
         const char* Vs = Ks + TILE_BYTES;
 
@@ -191,12 +189,8 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
                 // v_pk_fma_f32: two exponents per instruction
                 const float2_ x01 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 0, 1), sl2v, nm);
                 const float2_ x23 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 2, 3), sl2v, nm);
-#ifdef ASD_ATTN_ABL_NOEXP      // ablation (tools/build_variant.sh): what the transcendentals cost
-                const float2_ e01 = x01 * x01, e23 = x23 * x23;
-#else
                 const float2_ e01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
                 const float2_ e23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
-#endif
                 sum2 += e01 + e23;
                 half8& dst = pb[kt >> 1][qs];                              // v_cvt_pk_f16_f32 (RNE) x2, written in place
                 dst[(kt & 1) * 4 + 0] = (half_t)e01[0]; dst[(kt & 1) * 4 + 1] = (half_t)e01[1];
@@ -230,9 +224,7 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
                 for (int qs = 0; qs < QS; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[j][qs], oacc[qs][dt], 0, 0, 0);
             }
         }
-#ifndef ASD_ATTN_ABL_NOBARRIER  // ablation: wrong results, no per-tile block barrier
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done with this buffer
-#endif
     }
 
     // ---- normalise and store: lane owns query (l&15), 4 consecutive d -----------------------------------------

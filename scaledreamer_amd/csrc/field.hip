@@ -393,7 +393,6 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
-#ifndef ASD_ABLATE_WSUM     // timing-only builds (tools/field_bwd_ab.py; wrong dw2)
                 if (ASD_FIELD_W2_COPIES > 1) {
                     const float v = active ? draw * fmaxf(a, 0.f) : 0.f;
                     if (v != 0.f) atomicAdd(&w2_acc[w2c + h], v);
@@ -401,17 +400,12 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                     const float v = asd_wave_sum(active ? draw * fmaxf(a, 0.f) : 0.f);
                     if (lead) atomicAdd(&w2_acc[h], v);
                 }
-#endif
                 const float da = (active && a > 0.f) ? draw * w2d[h] : 0.f;
                 dav[j] = da;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) denc[k] = fmaf(da, w1d[h * NIN + k], denc[k]);
             }
-#ifdef ASD_ABLATE_DA_STORE
-            if (active && dav[0] == 12345.678f)
-#else
             if (active)
-#endif
                 *reinterpret_cast<float4*>(da_row + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
         }
         // ---- feature MLP (centre point only) -------------------------------------------------------------------
@@ -435,7 +429,6 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
 #pragma unroll
                         for (int o = 0; o < C; ++o) {
                             dh = fmaf(df[o], w2f[o * H + h], dh);
-#ifndef ASD_ABLATE_WSUM
                             if (ASD_FIELD_W2_COPIES > 1) {
                                 const float v = df[o] * hv;
                                 if (v != 0.f) atomicAdd(&w2_acc[w2c + H + o * H + h], v);
@@ -443,9 +436,6 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                                 const float v = asd_wave_sum(df[o] * hv);
                                 if (lead) atomicAdd(&w2_acc[H + o * H + h], v);
                             }
-#else
-                            if (df[o] * hv == 12345.678f) w2_acc[H] = 1.f;
-#endif
                         }
                         da = a > 0.f ? dh : 0.f;
 #pragma unroll
@@ -453,11 +443,7 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                     }
                     dav[j] = da;
                 }
-#ifdef ASD_ABLATE_DA_STORE
-                if (active && dav[0] == 12345.678f)
-#else
                 if (active)
-#endif
                     *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }

@@ -295,14 +295,21 @@ class MultipromptNeuralHashgridEnvironmentMapBackground(BaseBackground):
     hypernet_forward = staticmethod(hypernet_forward)
 
     def forward(self, dirs: torch.Tensor, text_embed: Optional[torch.Tensor] = None) -> torch.Tensor:
-        batch_size, height, width, _ = dirs.shape
+        """[B, H, W, 3] unit directions -> [B, H, W, n_output_dims] colours (multiprompt_neural_environment_hashgrid_map_background.py:82-116).
+        Three cases, decided BEFORE any field evaluation:
+          * eval with a fixed colour: a constant image;
+          * training with random_aug, with probability random_aug_prob: one uniform random colour per batch element.  The reference
+            evaluates the whole field and multiplies it by zero, whose only lasting effect is that every parameter receives an all-zero
+            gradient (so AdamW still decays its moments and applies weight decay this step); the same gradient is produced here by a
+            zero-weighted sum over the parameters — no hash-grid gather, no hypernetwork pass, same draws from `random` / torch in the
+            same order;
+          * otherwise: hash-grid encoding of the directions through the per-prompt MLP the hypernetwork emits, then the colour activation."""
+        lead, n_out = dirs.shape[:-1], self.cfg.n_output_dims
         if not self.training and self.cfg.eval_color is not None:
-            return torch.ones(*dirs.shape[:-1], self.cfg.n_output_dims).to(dirs) * torch.as_tensor(self.cfg.eval_color).to(dirs)
-        bg_cache = self.hypernet(text_embed)
-        dirs01 = (dirs + 1.0) / 2.0
-        emb = self.encoding(dirs01.view(-1, 3))
-        color = hypernet_forward(emb.view(batch_size, height * width, -1), bg_cache["bg_weights"]).view(*dirs.shape[:-1], self.cfg.n_output_dims)
-        color = get_activation(self.cfg.color_activation)(color)
+            return torch.as_tensor(self.cfg.eval_color).to(dirs).expand(*lead, n_out).contiguous()
         if self.training and self.cfg.random_aug and random.random() < self.cfg.random_aug_prob:
-            color = color * 0 + self.rand_fn(dirs.shape[0], self.cfg.n_output_dims, dirs).expand(*dirs.shape[:-1], -1)
-        return color
+            zero_grad_anchor = sum(p.sum() for p in self.parameters() if p.requires_grad) * 0.0
+            return self.rand_fn(dirs.shape[0], n_out, dirs).expand(*lead, n_out) + zero_grad_anchor
+        mlp = self.hypernet(text_embed)["bg_weights"]
+        feats = self.encoding(((dirs + 1.0) * 0.5).reshape(-1, 3)).view(dirs.shape[0], -1, self.encoding.n_output_dims)
+        return get_activation(self.cfg.color_activation)(hypernet_forward(feats, mlp).view(*lead, n_out))

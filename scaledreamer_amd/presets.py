@@ -6,6 +6,12 @@ from __future__ import annotations
 import copy
 
 
+# No pretrained checkpoint exists offline.  A preset-driven run therefore FAILS when its checkpoint path does not resolve (a prior of
+# random weights distills nothing); bench.py, __graft_entry__.smoke(), tests/conftest.py and the tools set this switch explicitly to
+# run on the seeded random prior (diffusion/checkpoint.py: resolve_params).
+ALLOW_RANDOM_WEIGHTS = False
+
+
 def asd_sd_nerf(prompt: str = "synthetic", guidance_backend: str = "hip") -> dict:
     """configs/single-prompt_benchmark/asd_sd_nerf.yaml (BASELINE config 2: 64x64 render, SD-2.1 guidance,
     implicit-volume iNGP geometry, occupancy-grid renderer, Perp-Neg, AdamW with 5 parameter groups)."""
@@ -40,7 +46,7 @@ def asd_sd_nerf(prompt: str = "synthetic", guidance_backend: str = "hip") -> dic
             "guidance": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "guidance_scale": 7.5,
                          "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 25000],
                          "max_step_percent": [0, 0.98, 0.5, 25000], "guidance_perp_neg": -0.5,
-                         "backend": guidance_backend, "allow_random_weights": True},
+                         "backend": guidance_backend, "allow_random_weights": ALLOW_RANDOM_WEIGHTS},
             "loggers": {"wandb": {"enable": False, "project": "threestudio", "name": "None"}},
             "loss": {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 30, "lambda_opaque": [10000, 0.0, 100.0, 10001],
                      "lambda_z_variance": 0.0},
@@ -69,7 +75,7 @@ def asd_mv_nerf(prompt: str = "synthetic", guidance_backend: str = "hip-mvdream"
     s["guidance_type"] = "mvdream-asynchronous-score-distillation-guidance"
     s["guidance"] = {"model_name": "sd-v2.1-base-4view", "ckpt_path": "pretrained/sd-v2.1-base-4view.pt", "guidance_scale": 7.5,
                      "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 25000],
-                     "max_step_percent": [0, 0.98, 0.5, 25000], "backend": guidance_backend, "allow_random_weights": True}
+                     "max_step_percent": [0, 0.98, 0.5, 25000], "backend": guidance_backend, "allow_random_weights": ALLOW_RANDOM_WEIGHTS}
     s["loss"] = {"lambda_asd": 1.0, "lambda_orient": [10000, 0.0, 100.0, 10001], "lambda_sparsity": 20,
                  "lambda_opaque": [10000, 0.0, 100.0, 10001], "lambda_z_variance": 0.0}
     s["optimizer"]["params"] = {"geometry.encoding": {"lr": 0.003}, "geometry.density_network": {"lr": 0.003},
@@ -113,7 +119,7 @@ def asd_sd_hyper_ingp(prompts=None, guidance_backend: str = "hip") -> dict:
             "guidance_type": "stable-diffusion-asynchronous-score-distillation-guidance",
             "guidance": {"pretrained_model_name_or_path": "pretrained/stable-diffusion-2-1-base", "guidance_scale": 7.5,
                          "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 50000],
-                         "max_step_percent": [0, 0.98, 0.5, 50000], "guidance_perp_neg": -0.5, "backend": guidance_backend, "allow_random_weights": True},
+                         "max_step_percent": [0, 0.98, 0.5, 50000], "guidance_perp_neg": -0.5, "backend": guidance_backend, "allow_random_weights": ALLOW_RANDOM_WEIGHTS},
             "loggers": {"wandb": {"enable": False, "project": "threestudio", "name": "None"}},
             "loss": {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 20, "lambda_opaque": [40000, 0, 10.0, 50000],
                      "lambda_z_variance": 0.0, "lambda_eikonal": [1, 100.0, 1.0, 5000]},
@@ -166,7 +172,7 @@ def asd_mv_triplane_transformer(prompts=None) -> dict:
     s["guidance_type"] = "mvdream-asynchronous-score-distillation-guidance"
     s["guidance"] = {"model_name": "sd-v2.1-base-4view", "ckpt_path": "pretrained/sd-v2.1-base-4view.pt", "guidance_scale": 7.5,
                      "plus_ratio": 0.1, "plus_random": True, "min_step_percent": [0, 0.5, 0.02, 100000],
-                     "max_step_percent": [0, 0.98, 0.5, 100000], "backend": "hip-mvdream", "allow_random_weights": True}
+                     "max_step_percent": [0, 0.98, 0.5, 100000], "backend": "hip-mvdream", "allow_random_weights": ALLOW_RANDOM_WEIGHTS}
     s["loss"] = {"lambda_asd": 1.0, "lambda_orient": 0.0, "lambda_sparsity": 20, "lambda_opaque": [80000, 0, 1.0, 100000],
                  "lambda_z_variance": 0.0, "lambda_eikonal": 0.01}
     s["optimizer"] = {"name": "Adan", "args": {"betas": [0.98, 0.92, 0.99], "eps": 1.0e-15},

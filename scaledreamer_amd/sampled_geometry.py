@@ -78,29 +78,34 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
         return {k: v.reshape(batch_size * n_points, -1) for k, v in self._forward_points(points, space_cache, output_normal).items()}
 
     def _forward_points(self, points: torch.Tensor, space_cache: Any, output_normal: bool) -> Dict[str, torch.Tensor]:
-        """outputs as [batch, points, k] (the public forward flattens them batch-major, as the reference does)"""
-        batch_size, n_points, _ = points.shape
-        points_unscaled = points
-        pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
-        if output_normal and self.cfg.normal_type == "analytic":
-            raise NotImplementedError("analytic normal is not implemented yet.")
-        enc = self.interpolate_encodings(pts, space_cache)
-        sdf = self.get_shifted_sdf(points_unscaled, self.sdf_network(enc).view(*pts.shape[:-1], 1))
-        out = {"sdf": sdf.view(batch_size, n_points, 1)}
-        if self.cfg.n_feature_dims > 0:
-            out["features"] = self.feature_network(enc).view(batch_size, n_points, self.cfg.n_feature_dims)
+        """SDF / features (/ finite-difference normal) of [batch, points, 3] -> outputs as [batch, points, k]; the public forward flattens
+        them batch-major (triplane_transformer.py:153-200, stylegan_3dconv_net.py forward).  With a normal the centre and its three
+        +eps probes go through the feature sampler and the SDF head as ONE stencil of 4 points per sample — one sampler launch and one
+        head pass over 4 N points instead of one over N plus one over 3 N; per point the arithmetic is that of forward_sdf."""
+        if output_normal and self.cfg.normal_type != "finite_difference":
+            raise NotImplementedError(f"normal_type {self.cfg.normal_type!r}: only the finite-difference normal of the shipped configs is implemented")
+        batch, n = points.shape[:2]
+        query = points
         if output_normal:
-            if self.cfg.normal_type != "finite_difference":
-                raise NotImplementedError(f"normal_type == {self.cfg.normal_type} is not implemented yet.")
-            assert self.finite_difference_normal_eps is not None
             eps = self.finite_difference_normal_eps
-            offsets = torch.as_tensor([[eps, 0.0, 0.0], [0.0, eps, 0.0], [0.0, 0.0, eps]]).to(points_unscaled)
-            po = (points_unscaled[..., None, :] + offsets).clamp(-self.cfg.radius, self.cfg.radius)
-            sdf_offset = self.forward_sdf(po, space_cache)
-            sdf_grad = (sdf_offset[..., 0::1, 0] - sdf) / eps
-            normal = F.normalize(sdf_grad, dim=-1)
-            out.update({"normal": normal.view(batch_size, n_points, 3), "shading_normal": normal.view(batch_size, n_points, 3),
-                        "sdf_grad": sdf_grad.view(batch_size, n_points, 3)})
+            assert eps is not None, "update_step() sets finite_difference_normal_eps before the first forward"
+            probes = (points[:, :, None, :] + eps * torch.eye(3, dtype=points.dtype, device=points.device)).clamp(-self.cfg.radius, self.cfg.radius)
+            query = torch.cat([points[:, :, None, :], probes], dim=2).reshape(batch, 4 * n, 3)         # [centre, +x, +y, +z] per sample
+        enc = self.interpolate_encodings(contract_to_unisphere_custom(query, self.bbox, self.unbounded), space_cache)
+        sdf_all = self.get_shifted_sdf(query, self.sdf_network(enc).view(batch, -1, 1))
+        if not output_normal:
+            out = {"sdf": sdf_all}
+            if self.cfg.n_feature_dims > 0:
+                out["features"] = self.feature_network(enc).view(batch, n, self.cfg.n_feature_dims)
+            return out
+        stencil = sdf_all.view(batch, n, 4)
+        out = {"sdf": stencil[..., :1]}
+        if self.cfg.n_feature_dims > 0:
+            centre_enc = enc.view(batch, n, 4, -1)[:, :, 0]
+            out["features"] = self.feature_network(centre_enc).view(batch, n, self.cfg.n_feature_dims)
+        sdf_grad = (stencil[..., 1:] - stencil[..., :1]) / eps
+        normal = F.normalize(sdf_grad, dim=-1)
+        out.update(normal=normal, shading_normal=normal, sdf_grad=sdf_grad)
         return out
 
     def forward_sdf(self, points: torch.Tensor, space_cache: Any) -> torch.Tensor:

@@ -21,6 +21,7 @@ def build_smoke_system(seed: int = 0, n_batches: int = 2):
     torch.manual_seed(seed)
     random.seed(seed)
     dev = torch.device("cuda", 0)
+    presets.ALLOW_RANDOM_WEIGHTS = True      # smoke test: seeded random prior (no checkpoint offline)
     cfg = presets.asd_sd_nerf()
     backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128), vae_cfg=W.VAEConfig(), seed=3)
     g = torch.Generator().manual_seed(1)

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from scaledreamer_amd import presets
+
+    presets.ALLOW_RANDOM_WEIGHTS = True      # the tests run the presets on the seeded random prior: no checkpoint exists offline
 
 
 @pytest.fixture(scope="session")

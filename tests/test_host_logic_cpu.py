@@ -567,3 +567,48 @@ def test_stride2_input_gradient_parity_packing_matches_autograd():
                     src = dyp[:, :, a + ty:a + ty + hl, b + tx:b + tx + hl]                # rows y - 1 + a + ty of the unpadded image
                     got[:, :, a::2, b::2] += torch.einsum("bohw,io->bihw", src, w4[a, b, :, ty, tx, :])
     torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_scheduled_scalars_match_the_reference_values():
+    """config.C / config.Schedule (knot table) against values of the reference's C() (threestudio/utils/misc.py:66-101) on 3-, 4-, 6- and
+    8-element schedules, int (global step) and float (epoch) clocks, both interpolations — tests/golden/schedule_values.json was written
+    by evaluating the reference function in the build container"""
+    import json
+    import os
+
+    from scaledreamer_amd.config import C, Schedule
+
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "schedule_values.json")))
+    assert len(rows) > 300
+    for spec, epoch, step, interp, want in rows:
+        got = C(spec, epoch, step, interp)
+        assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (spec, epoch, step, interp, got, want)
+    assert C(0.25, 3, 7) == 0.25 and Schedule([0, 1.0, 0.5, 100, 0.1, 200]).segment(150) == 1
+    for bad, err in (([1, 2], AssertionError), ([1, 2, 3, 4, 5], AssertionError), ("x", TypeError)):
+        try:
+            C(bad, 0, 0)
+        except err:
+            continue
+        raise AssertionError(f"{bad!r} must raise {err.__name__}")
+    try:
+        C([0, 1.0, 2.0, 10], 0, 5, "cubic")
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("unknown interpolation must raise ValueError")
+
+
+def test_presets_do_not_allow_a_random_prior_unless_asked():
+    """ADVICE (round 2): a preset-driven run whose checkpoint path does not resolve must fail, not train against random weights;
+    bench / smoke / this test suite switch the synthetic prior on explicitly (presets.ALLOW_RANDOM_WEIGHTS)"""
+    from scaledreamer_amd import presets
+
+    saved = presets.ALLOW_RANDOM_WEIGHTS
+    try:
+        presets.ALLOW_RANDOM_WEIGHTS = False
+        for make in (presets.asd_sd_nerf, presets.asd_mv_nerf, presets.asd_sd_hyper_ingp, presets.asd_mv_triplane_transformer):
+            assert make()["system"]["guidance"]["allow_random_weights"] is False
+        presets.ALLOW_RANDOM_WEIGHTS = True
+        assert presets.asd_sd_nerf()["system"]["guidance"]["allow_random_weights"] is True
+    finally:
+        presets.ALLOW_RANDOM_WEIGHTS = saved

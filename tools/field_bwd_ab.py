@@ -27,6 +27,7 @@ if sys.argv[1] == "dump":
 else:
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
+    presets.ALLOW_RANDOM_WEIGHTS = True
     cfg = presets.asd_sd_nerf(guidance_backend="hip")
     geo = find(cfg["system"]["geometry_type"])(cfg["system"]["geometry"]).to(dev)
     d = torch.load("/tmp/fb.pt")
