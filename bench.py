@@ -128,14 +128,18 @@ def to_device(batch, dev):
 # HBM-side bytes per launch from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under `--pmc FETCH_SIZE` and
 # `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; summaries in
 # profiles/r02_g_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.csv for the current plans, r01_final* for the earlier ones), keyed by (op, autotuned plan).
-PMC_TRAFFIC = {("vae512", (12, 1)): 140.3e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.1e6, ("gemm320", (3, 1)): 37.1e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
+# Round 3 (profiles/r03_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.csv, tools/roofline_pmc.sh): conv3x3_pp_kernel<4,4> on the 512^2 layer 72.4 MB
+# read + 79.6 MB written for 134.5 MB algorithmic; the other two entries re-measured unchanged.
+PMC_TRAFFIC = {("vae512", (24, 1)): 152.0e6, ("vae512", (12, 1)): 140.3e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.1e6, ("unet64", (14, 1)): 50.1e6,
+               ("gemm320", (3, 1)): 37.2e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
 
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
 DOMINANT = "field_bwd"
-DOMINANT_SOURCE = ("profiles/r02_h_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3>; "
-                   "inside the timed steps alone (profiles/r02_h_step_breakdown.txt) conv3x3_win2_kernel<128,8> 1.47 ms, gemm_f16_kernel<256,64> 1.36 ms, "
-                   "attention_fwd_kernel<4> + <2> 1.27 ms and field_bwd_sample_kernel 1.12 ms per step are within 25 % of each other: see roofline_vae_conv / roofline_gemm")
+DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3> (its 23 extra "
+                   "launches in this roofline leg included), second conv3x3_pp_kernel<4,4> 11.7 %; inside the timed steps alone (profiles/r03_step_breakdown.txt) "
+                   "conv3x3_pp_kernel<4,4> is first with 2.0 ms per step (23 launches on six shapes), gemm_f16_kernel<256,64> 1.33 ms, attention 1.2 ms, "
+                   "field_bwd_sample_kernel 1.13 ms: see roofline_vae_conv (the ping-pong window kernel on its heaviest shape) / roofline_gemm")
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
@@ -163,7 +167,11 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     flops = 2.0 * B * hw * hw * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
     plan = tuple(H.plan_table().get((B * hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
-    if plan[0] - 1 in H.WINDOW_TILES:
+    if plan[0] - 1 in H.PP_TILES:
+        t = plan[0] - 1
+        kern = (f"conv3x3_pp_kernel<{H.TILE_BM[t] // 64},{H.TILE_BN[t] // 32}> (ping-pong LDS-window kernel, csrc/gemm_pp.hip: {H.TILE_BM[t] // 16}x16-pixel patch x "
+                f"{H.TILE_BN[t]} channels, eight waves in two groups staggered by a barrier, counted vmcnt, 32-channel k-steps)")
+    elif plan[0] - 1 in H.WINDOW_TILES:
         kname = "conv3x3_win2_kernel" if plan[0] - 1 >= 10 else "conv3x3_win_kernel"
         kern = f"{kname}<{H.TILE_BN[plan[0] - 1]}> (16x16-pixel patch, LDS-resident 18x18 input window{', two blocks per CU' if plan[0] - 1 >= 10 else ''})"
     else:
@@ -283,14 +291,14 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
     # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 20 launches
-    # of the kernel = this leg, 433 172 samples each: profiles/r02_h_pmc_roofline_kernel.txt): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
+    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1067.4 + 69.2 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
     # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
     # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
     # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
-    traffic = n * (1059.38e6 + 69.00e6) / 433172.0
+    traffic = n * (1067.39e6 + 69.15e6) / 433172.0
     return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 20 launches, profiles/r02_h_pmc_roofline_kernel.txt, scaled by samples)",
+            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 20 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
             "atomic_dwords_per_sample": 256, "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1),

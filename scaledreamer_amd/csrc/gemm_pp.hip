@@ -44,6 +44,18 @@ __device__ __forceinline__ void pp_vm_wait_n(int n) {
 __device__ __forceinline__ void pp_mfma(floatx4& c, const half8& w, const half8& x) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
+// A/B switches of tools/pp_variants.sh (results unchanged): -DASD_PP_NO_STAGGER runs the two halves of the block in lockstep (all eight
+// waves read / load together, then multiply together), -DASD_PP_NO_PRIO drops the s_setprio around the MFMA segments
+#ifdef ASD_PP_NO_PRIO
+#define PP_PRIO(x) do { } while (0)
+#else
+#define PP_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifdef ASD_PP_NO_STAGGER
+#define PP_STAGGER 0
+#else
+#define PP_STAGGER 1
+#endif
 #define PP_PIN() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER()                    \
     do {                                \
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
         load_w(c0, 1, 1);
         pp_vm_wait<0>();
         PP_BARRIER();
-        if (grp == 1) PP_BARRIER();                    // the second group runs one barrier behind
+        if (PP_STAGGER && grp == 1) PP_BARRIER();      // the second group runs one barrier behind
         PT_ADD(pt_pro);
 
 #pragma unroll 1
@@ -227,13 +239,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
                 PT_ADD(pt_l);
                 PP_BARRIER();
                 PT_ADD(pt_b1);
-                __builtin_amdgcn_s_setprio(1);
+                PP_PRIO(1);
 #pragma unroll
                 for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         pp_mfma(acc[a][j], B[j], A[a]);
-                __builtin_amdgcn_s_setprio(0);
+                PP_PRIO(0);
                 PT_ADD(pt_m);
                 PP_BARRIER();
                 PT_ADD(pt_b2);
@@ -257,14 +269,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
                     PT_ADD(pt_l);
                     PP_BARRIER();
                     PT_ADD(pt_b1);
-                    __builtin_amdgcn_s_setprio(1);
+                    PP_PRIO(1);
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
 #pragma unroll
                         for (int j = 0; j < NB; ++j) {
                             pp_mfma(SPLIT_N ? acc[a][NB + j] : acc[NA + a][j], B[j], A[a]);
                         }
-                    __builtin_amdgcn_s_setprio(0);
+                    PP_PRIO(0);
                     PT_ADD(pt_m);
                     PP_BARRIER();
                     PT_ADD(pt_b2);
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
                 nwin_prev = nwin;
             }
         }
-        if (grp == 0) PP_BARRIER();                    // the first group waits for the second one's last segment
+        if (PP_STAGGER && grp == 0) PP_BARRIER();      // the first group waits for the second one's last segment
     }
 
     // acc[i][j][r] = C[pixel (y0 + wm*TM + i, x0 + (lane&15))][n0 + wn*TN*16 + j*16 + (lane>>4)*4 + r]
