@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef ASD_PP_PROFILE
-    const unsigned long long pt_start = PT_NOW();
+    const unsigned long long pt_start = PT_NOW(), pt_wall0 = wall_clock64();     // wall_clock64: constant 100 MHz
     unsigned long long pt_last = pt_start, pt_pro = 0, pt_l = 0, pt_b1 = 0, pt_m = 0, pt_b2 = 0, pt_epi = 0;
 #endif
     if (c0 < c1) {
@@ -298,8 +298,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const asd_gemm_args p) 
     if (p.split_k == 1 && p.workspace && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PT_ADD(pt_epi);
-        unsigned long long* o = (unsigned long long*)p.workspace + ((size_t)item * 8 + wave) * 8;
+        unsigned long long* o = (unsigned long long*)p.workspace + ((size_t)item * 8 + wave) * 16;
         o[0] = pt_start; o[1] = pt_last; o[2] = pt_pro; o[3] = pt_l; o[4] = pt_b1; o[5] = pt_m; o[6] = pt_b2; o[7] = pt_epi;
+        o[8] = pt_wall0; o[9] = wall_clock64();
     }
 #endif
 }

@@ -7,3 +7,5 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INS
 tail -3 /tmp/mfma.err
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16; do python $R/tools/pmc_summary.py /tmp/pmc_mfma $c > $O/pmc_${c}_per_kernel.csv; done
 cat $O/counters_available.txt; head -8 $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES_per_kernel.csv | cut -c1-120
+# per (kernel, grid size) averages of the same pass: one row per shape of a kernel
+python $R/tools/pmc_table.py /tmp/pmc_mfma > $O/pmc_mfma_by_kernel_and_grid.txt

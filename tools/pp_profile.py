@@ -24,7 +24,7 @@ for (B, hw, cin, cout, cfg) in shapes:
     y = torch.empty(B * hw * hw, cout, device=dev, dtype=torch.float16)
     bn, bm = H.TILE_BN[cfg], H.TILE_BM[cfg]
     items = (B * hw * hw // bm) * (cout // bn)
-    ws = torch.zeros(items * 8 * 8, device=dev, dtype=torch.int64)
+    ws = torch.zeros(items * 8 * 16, device=dev, dtype=torch.int64)
     g = GemmArgs()
     g.A, g.W, g.C = x.data_ptr(), w.data_ptr(), y.data_ptr()
     g.M, g.N, g.K = B * hw * hw, cout, 9 * cin
@@ -40,12 +40,17 @@ for (B, hw, cin, cout, cfg) in shapes:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); check(lib().asd_gemm_f16(C.byref(g), stream())); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    t = ws.cpu().numpy().reshape(items, 8, 8).astype(np.float64)
-    t = t[t[:, 0, 0] > 0]
+    t = ws.cpu().numpy().reshape(items, 8, 16).astype(np.float64)
+    wall0, wall1 = t[..., 8], t[..., 9]
     start, end, pro, tl, b1, tm, b2, epi = (t[..., i] for i in range(8))
-    span = end.max() - start.min()
+    # wall_clock64 is a chip-wide constant 100 MHz counter: shader clock during the kernel = s_memtime ticks per wall tick, kernel span
+    # and the number of blocks alive at a time from the wall stamps
+    mhz = float(np.median((end - start)[:, 0] / np.maximum(wall1 - wall0, 1)[:, 0])) * 100.0
+    span = (wall1.max() - wall0.min()) * (mhz / 100.0)
+    conc = float((wall1 - wall0)[:, 0].sum() / (wall1.max() - wall0.min()))
     nph = (cin // 32) * 9 * (2 if (bm // 64) * (bn // 32) >= 24 else 1)
     for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
-        print(f"{B}x{hw}^2 {cin}->{cout} cfg{cfg} {grp}: {us:.1f} us, span {span:.0f} ticks ({span / us:.0f}/us), {len(t)} blocks; per wave: life {(end - start)[:, sl].mean():.0f} "
+        print(f"{B}x{hw}^2 {cin}->{cout} cfg{cfg} {grp}: {us:.1f} us, span {span:.0f} shader cycles at {mhz:.0f} MHz (s_memtime ticks per wall_clock64 tick), "
+              f"{len(t)} blocks, {conc:.0f} alive on average; per wave: life {(end - start)[:, sl].mean():.0f} "
               f"prologue {pro[:, sl].mean():.0f} epilogue {epi[:, sl].mean():.0f}; per phase ({nph}): load/read {tl[:, sl].mean() / nph:.0f}  barrier1 {b1[:, sl].mean() / nph:.0f}  "
               f"mfma {tm[:, sl].mean() / nph:.0f}  barrier2 {b2[:, sl].mean() / nph:.0f}", flush=True)
