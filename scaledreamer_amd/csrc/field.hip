@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #ifndef ASD_FIELD_PRIV_CAP
 #define ASD_FIELD_PRIV_CAP (1 << 17)   // floats per copy reserved in the workspace (levels 0-2 of the 16-level grid: 106 034)
 #endif
-#define WG_ROWS 2048   // rows per wgrad block
+#ifndef WG_ROWS
+#define WG_ROWS 512    // rows per wgrad block.  2048 (rounds 1-2) gave the headline step 212 blocks of four waves for 256 CUs — one wave per
+                       // SIMD with nobody to hide the LDS latency; 512: 846 blocks, three to four per CU, wgrad + slab reduction 0.24 -> 0.09 ms
+                       // (tools/wgrad_ab.sh, same box: 1024 -> 0.13, 256 -> 0.10)
+#endif
 #define WG_TILE 64     // rows per LDS tile
 
 template <int L, int H, int C>
