@@ -166,6 +166,23 @@ def load_ldm_checkpoint(path: str, unet_cfg: W.UNetConfig, vae_cfg: W.VAEConfig)
     return _check(unet, W.unet_layout(unet_cfg)[0], "LDM UNet"), _check(vae, vshapes, "LDM first stage")
 
 
+def hub_cache_snapshot(repo_id: str) -> Optional[str]:
+    """A hub id ("org/name", the reference's default `pretrained_model_name_or_path`) resolved OFFLINE against the local Hugging Face
+    cache layout: $HF_HUB_CACHE | $HF_HOME/hub | ~/.cache/huggingface/hub / models--org--name / snapshots / <revision> — the newest
+    snapshot that holds a unet/ directory.  None when the model was never downloaded to this machine."""
+    if not repo_id or repo_id.count("/") != 1 or repo_id.startswith(("/", ".", "~")):
+        return None
+    roots = [os.environ.get("HF_HUB_CACHE"), os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+             os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub")]
+    for root in roots:
+        snaps = os.path.join(root, "models--" + repo_id.replace("/", "--"), "snapshots") if root else None
+        if snaps and os.path.isdir(snaps):
+            cands = [os.path.join(snaps, d) for d in os.listdir(snaps) if os.path.isdir(os.path.join(snaps, d, "unet"))]
+            if cands:
+                return max(cands, key=os.path.getmtime)
+    return None
+
+
 def resolve_params(cfg, unet_cfg: W.UNetConfig, vae_cfg: W.VAEConfig):
     """(unet_params, vae_params, description) for a guidance config: `ckpt_path` (MVDream) or `pretrained_model_name_or_path`
     (SD, a local diffusers directory) when they exist on disk; seeded random weights only behind `allow_random_weights`."""
@@ -177,6 +194,9 @@ def resolve_params(cfg, unet_cfg: W.UNetConfig, vae_cfg: W.VAEConfig):
         return (*load_diffusers_pipeline(name, unet_cfg, vae_cfg), f"diffusers pipeline {name}")
     if name and os.path.isfile(name):
         return (*load_ldm_checkpoint(name, unet_cfg, vae_cfg), f"LDM checkpoint {name}")
+    snap = hub_cache_snapshot(name) if name else None
+    if snap:
+        return (*load_diffusers_pipeline(snap, unet_cfg, vae_cfg), f"diffusers pipeline {name} (local hub cache: {snap})")
     wanted = ckpt or name or getattr(cfg, "model_name", None)
     if not getattr(cfg, "allow_random_weights", False):
         raise MissingWeightsError(

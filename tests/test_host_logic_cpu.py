@@ -473,6 +473,23 @@ def test_diffusers_and_ldm_checkpoints_map_onto_the_engine_layout(tmp_path):
     save_file(vae_d, str(tmp_path / "sd" / "vae" / "diffusion_pytorch_model.safetensors"))
     gu, gv, what = CK.resolve_params(ConfigDict(pretrained_model_name_or_path=str(tmp_path / "sd")), ucfg, vcfg)
     assert all(torch.equal(gu[k], up[k]) for k in up) and all(torch.equal(gv[k], vp[k]) for k in vp) and "diffusers" in what
+    # a hub id is resolved offline against the local Hugging Face cache layout
+    import os
+    import shutil
+
+    snap = tmp_path / "hub" / "models--stabilityai--stable-diffusion-2-1-base" / "snapshots" / "abc123"
+    shutil.copytree(tmp_path / "sd", snap)
+    old = os.environ.get("HF_HUB_CACHE")
+    os.environ["HF_HUB_CACHE"] = str(tmp_path / "hub")
+    try:
+        hu, hv, what = CK.resolve_params(ConfigDict(pretrained_model_name_or_path="stabilityai/stable-diffusion-2-1-base"), ucfg, vcfg)
+        assert all(torch.equal(hu[k], up[k]) for k in up) and "local hub cache" in what
+    finally:
+        if old is None:
+            del os.environ["HF_HUB_CACHE"]
+        else:
+            os.environ["HF_HUB_CACHE"] = old
+    shutil.rmtree(tmp_path / "hub")
     # nothing on disk: an error unless random weights were asked for explicitly
     with pytest.raises(CK.MissingWeightsError):
         CK.resolve_params(ConfigDict(pretrained_model_name_or_path="stabilityai/stable-diffusion-2-1-base"), ucfg, vcfg)
