@@ -5,7 +5,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
 
-cfg, system, data = bench.build_system("hip", seed=10, workload="asd_sd_nerf")
+cfg, system, data = bench.build_system("hip", seed=10, workload=(sys.argv[1] if len(sys.argv) > 1 else "asd_sd_nerf"))
 dev = torch.device("cuda", 0)
 for _ in range(6):
     system.train_one_step(bench.to_device(data.collate(), dev))
