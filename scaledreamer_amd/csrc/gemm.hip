@@ -936,8 +936,9 @@ static bool asd_conv_window_ok(const asd_gemm_args* a) {
 // 256 blocks at a time at full aggregate rate (fewer blocks run up to ~1.5x faster each), padding is wasted work, and
 // every block pays a fixed prologue/epilogue.  Returns the cheapest configuration for the given split.
 // ping-pong window kernel: whole patches (rows of the image divisible by the patch rows), whole N tiles
-static bool asd_conv_pp_ok(const asd_gemm_args* a, int cfg) {
-    return asd_conv_window_ok(a) && a->Hout % (asd_gemm_tiles[cfg].bm / 16) == 0 && a->N % asd_gemm_tiles[cfg].bn == 0;
+static bool asd_conv_pp_ok(const asd_gemm_args* a, int cfg) {   // 32-channel chunks: Cin = 32 (the padded RGB input of the VAE) qualifies too
+    return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Cin % 32 == 0 && a->Hin == a->Hout && a->Win == a->Wout &&
+           a->Hout % 16 == 0 && a->Wout % 16 == 0 && a->Hout % (asd_gemm_tiles[cfg].bm / 16) == 0 && a->N % asd_gemm_tiles[cfg].bn == 0;
 }
 static int g_force_tile = -1;   // tuning hook (asd_gemm_force_tile, tools/gemm_sweep.py); -1 = cost model
 
@@ -1163,8 +1164,9 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
                 a->Win, a->Cin, a->Hout, a->Wout, a->stride, a->pad, a->upsample, cfg, a->split_k, a->act, a->residual != nullptr, a->out_f32,
                 a->gn_partials ? (a->gn_bwd_x ? 2 : 1) : 0);
     if (asd_cfg_is_window(cfg)) {
-        ASD_CHECK_ARG(asd_conv_window_ok(a), "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 and H, W % 16 == 0");
-        ASD_CHECK_ARG(a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
+        ASD_CHECK_ARG(asd_cfg_is_pp(cfg) ? asd_conv_pp_ok(a, cfg) : asd_conv_window_ok(a),
+                      "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 (ping-pong: % 32) and H, W % 16 == 0");
+        ASD_CHECK_ARG(a->split_k == 1 || a->split_k <= a->Cin / 64, "window convolution: split_k exceeds the channel chunks");
         if (asd_cfg_is_pp(cfg)) {
             ASD_CHECK_ARG(asd_conv_pp_ok(a, cfg), "ping-pong window convolution: image rows % patch rows == 0 and N % tile == 0");
             const int tiles_mp = a->M / bm, tiles_np = a->N / bn;
@@ -1284,8 +1286,7 @@ static int asd_tune_candidates(const asd_gemm_args* a, int (*out)[2], int max_ou
     for (int t = 0; t < ASD_GEMM_NCFG && n < max_out; ++t) {
         const int bm = asd_gemm_tiles[t].bm, bn = asd_gemm_tiles[t].bn;
         if (asd_cfg_is_window(t)) {
-            if (!window_ok || (bn != 64 && a->N % bn != 0)) continue;
-            if (asd_cfg_is_pp(t) && !asd_conv_pp_ok(a, t)) continue;
+            if (asd_cfg_is_pp(t) ? !asd_conv_pp_ok(a, t) : (!window_ok || (bn != 64 && a->N % bn != 0))) continue;
             const int tiles = (a->M / bm) * asd_div_up(a->N, bn);
             for (int sk : sk_win) {
                 if (sk > 1 && (a->Cin / 64 < 2 * sk || tiles * sk > 1536)) continue;

@@ -55,8 +55,12 @@ for key, cnt in calls.items():
     def run(i):
         H.gemm(a[i % pool], w[i % pool], bias=bias, residual=resid, act=act, out=out, out_f32=bool(f32), conv=cv, M=M, tile_cfg=cfg + 1, split_k=split)
 
-    for i in range(3):
-        run(i)
+    try:
+        for i in range(3):
+            run(i)
+    except Exception as e:      # a form this tool cannot rebuild from the trace line (parity-form weights): listed, not timed
+        print("skipped", key, str(e)[-80:], file=sys.stderr)
+        continue
     n = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
