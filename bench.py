@@ -134,12 +134,73 @@ PMC_TRAFFIC = {("vae512", (24, 1)): 152.0e6, ("vae512", (12, 1)): 140.3e6, ("vae
                ("gemm320", (3, 1)): 37.2e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
 
 
-# the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV)
-DOMINANT = "field_bwd"
-DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row field_bwd_sample_kernel<16,64,3> (its 23 extra "
-                   "launches in this roofline leg included), second conv3x3_pp_kernel<4,4> 11.7 %; inside the timed steps alone (profiles/r03_step_breakdown.txt) "
-                   "conv3x3_pp_kernel<4,4> is first with 2.0 ms per step (23 launches on six shapes), gemm_f16_kernel<256,64> 1.33 ms, attention 1.2 ms, "
-                   "field_bwd_sample_kernel 1.13 ms: see roofline_vae_conv (the ping-pong window kernel on its heaviest shape) / roofline_gemm")
+# the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV) and inside
+# the timed steps (profiles/r03_step_breakdown.txt: 2.0 ms of every 15.5 ms step)
+DOMINANT = "pp_conv"
+DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row conv3x3_pp_kernel<4,4>; inside the timed steps "
+                   "(profiles/r03_step_breakdown.txt) it is first too with 2.0 ms per step (24 launches on seven shapes, all in the VAE encoder's forward and "
+                   "input-gradient pass), then gemm_f16_kernel<256,64> 1.33 ms, attention 1.2 ms, field_bwd_sample_kernel 1.13 ms (round 2's `roofline` kernel, now "
+                   "`roofline_field_bwd`: 0.047 of HBM, bound by the L2's atomic request rate)")
+
+# every launch of conv3x3_pp_kernel<4,4> in one step (tools/gemm_shapes.py trace of the step, gpurun_out/gemm_shapes.txt): (H = W, Cin, Cout,
+# residual, GroupNorm records in the epilogue: 1 forward statistics / 2 the backward reductions of the GroupNorm in front, launches per step)
+PP44_LAUNCHES = [(512, 128, 128, 0, 2, 4), (512, 128, 128, 1, 1, 2), (512, 128, 128, 0, 1, 2), (128, 512, 512, 0, 2, 3), (128, 512, 512, 1, 1, 2),
+                 (128, 512, 512, 0, 1, 1), (256, 256, 256, 0, 2, 3), (256, 256, 256, 1, 1, 2), (256, 256, 256, 0, 1, 1), (128, 256, 512, 0, 1, 1),
+                 (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 2, 1), (512, 32, 128, 0, 1, 1)]
+# HBM bytes per launch of that kernel, averaged over the launches of `python bench.py` (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+# profiles/r03_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)
+PP44_PMC_BYTES = 120.62e6 + 52.52e6
+
+
+def roofline_pp_kernel(reps: int = 3):
+    """conv3x3_pp_kernel<4,4> (csrc/gemm_pp.hip) over ALL its launches of one step, each with the epilogue it has in the step (residual,
+    GroupNorm statistics / backward reductions), back to back on the launch stream between HIP events.  achieved = algorithmic flops of
+    the 24 launches (2 M N K each) / their summed duration; avg_launch_ms is what the rocprofv3 summary's average for
+    this kernel has to agree with."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    flops = secs = launches = 0.0
+    alg_bytes = 0.0
+    skipped = []
+    for hw, cin, cout, res, gn, count in PP44_LAUNCHES:
+        plan = tuple(H.plan_table().get((hw * hw, cout, 9 * cin, (hw, cin, 1, 0, 1)), (0, 1)))
+        if plan != (24, 1):
+            skipped.append((hw, cin, cout))
+            continue
+        x = torch.randn(1, hw, hw, cin, device="cuda").half()
+        w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * (9 * cin) ** -0.5)
+        kw = dict(gn_rows=hw * hw)
+        if res:
+            kw["residual"] = torch.randn(hw * hw, cout, device="cuda").half()
+        if gn == 2:
+            xg = torch.randn(1, hw * hw, cout, device="cuda").half()
+            gamma, beta = torch.ones(cout, device="cuda").half(), torch.zeros(cout, device="cuda").half()
+            _, fstats = H.groupnorm(xg, gamma, beta, 1e-6, True, return_stats=True)
+            kw["gn_bwd"] = dict(x=xg, fstats=fstats, gamma=gamma, beta=beta, eps=1e-6, silu=True)
+        for _ in range(2):
+            H.conv3x3(x, w, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps * count):
+            H.conv3x3(x, w, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        secs += e0.elapsed_time(e1) * 1e-3 / reps
+        flops += count * 2.0 * hw * hw * cout * 9 * cin
+        alg_bytes += count * 2.0 * hw * hw * (cin + cout * (1 + (1 if res or gn == 2 else 0)))
+        launches += count
+        del x, w, kw
+    if launches == 0:
+        return None
+    achieved = flops / secs / 1e12
+    return {"kernel": "conv3x3_pp_kernel<4,4> (ping-pong LDS-window 3x3 convolution, csrc/gemm_pp.hip: 16x16-pixel patch x 128 channels, eight waves in two groups "
+                      "staggered by a barrier, counted vmcnt, 32-channel k-steps); all its launches of one step (VAE encoder forward + input gradient), each with its "
+                      "step epilogue", "bound": "mfma",
+            "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
+            "traffic": PP44_PMC_BYTES, "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_*_per_kernel.csv)",
+            "launches_per_step": int(launches), "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "avg_launch_ms": round(secs / launches * 1e3, 4), "ms_per_step": round(secs * 1e3, 3),
+            "shapes_not_on_this_kernel_under_the_loaded_plans": skipped}
 
 
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
@@ -290,15 +351,15 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     ms_call = t0_.elapsed_time(t1_) / reps
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
-    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 20 launches
-    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1067.4 + 69.2 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
+    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 10 launches
+    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1096.6 + 69.0 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
     # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
     # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
     # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
-    traffic = n * (1067.39e6 + 69.15e6) / 433172.0
+    traffic = n * (1096.62e6 + 69.04e6) / 433172.0
     return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 20 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
+            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 10 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
             "atomic_dwords_per_sample": 256, "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1),
@@ -522,10 +583,12 @@ def main():
             out.pop("kept_samples_last_step", None)
         if phases:
             out["phases_ms"] = phases
-        # `roofline` = the kernel rocprofv3 ranks first for this step (profiles/: see DOMINANT below); the other families follow
+        # `roofline` = the kernel rocprofv3 ranks first for this step (profiles/: see DOMINANT above); the other families follow
         lines = {"gemm": roofline_gemm_kernel(), "vae_conv": roofline_conv_kernel("vae512"), "unet_conv": roofline_conv_kernel("unet64")}
+        if args.workload == "asd_sd_nerf":
+            lines["pp_conv"] = roofline_pp_kernel()
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
-            lines["field_bwd"] = roofline_field_bwd(system, batch)
+            lines["field_bwd"] = roofline_field_bwd(system, batch, reps=5)
             lines["renderer"] = roofline_field_kernel(system, batch)
         dom = DOMINANT if DOMINANT in lines and lines[DOMINANT] is not None else "gemm"     # secondary workloads: no implicit-volume scatter
         out["roofline"] = lines.pop(dom)
