@@ -143,10 +143,11 @@ DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --st
                    "`roofline_field_bwd`: 0.047 of HBM, bound by the L2's atomic request rate)")
 
 # every launch of conv3x3_pp_kernel<4,4> in one step (tools/gemm_shapes.py trace of the step, gpurun_out/gemm_shapes.txt): (H = W, Cin, Cout,
-# residual, GroupNorm records in the epilogue: 1 forward statistics / 2 the backward reductions of the GroupNorm in front, launches per step)
-PP44_LAUNCHES = [(512, 128, 128, 0, 2, 4), (512, 128, 128, 1, 1, 2), (512, 128, 128, 0, 1, 2), (128, 512, 512, 0, 2, 3), (128, 512, 512, 1, 1, 2),
-                 (128, 512, 512, 0, 1, 1), (256, 256, 256, 0, 2, 3), (256, 256, 256, 1, 1, 2), (256, 256, 256, 0, 1, 1), (128, 256, 512, 0, 1, 1),
-                 (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 2, 1), (512, 32, 128, 0, 1, 1)]
+# residual, GroupNorm records in the epilogue: 0 none (the input-gradient launches) / 1 forward statistics / 2 the backward reductions of the
+# GroupNorm in front (off by default since round 3, csrc/net.hip), launches per step)
+PP44_LAUNCHES = [(512, 128, 128, 0, 0, 4), (512, 128, 128, 1, 1, 2), (512, 128, 128, 0, 1, 2), (128, 512, 512, 0, 0, 3), (128, 512, 512, 1, 1, 2),
+                 (128, 512, 512, 0, 1, 1), (256, 256, 256, 0, 0, 3), (256, 256, 256, 1, 1, 2), (256, 256, 256, 0, 1, 1), (128, 256, 512, 0, 1, 1),
+                 (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 0, 1), (512, 32, 128, 0, 1, 1)]
 # HBM bytes per launch of that kernel, averaged over the launches of `python bench.py` (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
 # profiles/r03_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)
 PP44_PMC_BYTES = 120.62e6 + 52.52e6
@@ -169,7 +170,7 @@ def roofline_pp_kernel(reps: int = 3):
             continue
         x = torch.randn(1, hw, hw, cin, device="cuda").half()
         w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * (9 * cin) ** -0.5)
-        kw = dict(gn_rows=hw * hw)
+        kw = dict(gn_rows=hw * hw) if gn else {}
         if res:
             kw["residual"] = torch.randn(hw * hw, cout, device="cuda").half()
         if gn == 2:

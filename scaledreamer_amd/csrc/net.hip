@@ -114,6 +114,12 @@ void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr, bool gn_bwd_fo
     const size_t need = (size_t)asd_gemm_workspace_bytes(&g);
     if (need > r.scratch_need) r.scratch_need = need;
     static const bool gn_epilogue = !(getenv("ASD_GN_EPILOGUE") && getenv("ASD_GN_EPILOGUE")[0] == '0');    // A/B switch (tools)
+    // The backward form of the records (the two reductions of the GroupNorm input gradient from the dgrad launch's epilogue) is OFF by
+    // default since round 3: on the ping-pong kernel the epilogue's silu'(z) over the whole tile is not hidden behind another block's
+    // main loop — the VAE's eleven dgrad launches grew by 22-53 us each (0.39 ms per step) for 0.33 ms of statistics passes saved; same-box
+    // A/B 15.58 vs 15.64 ms per step (gpurun_out/gnb).  ASD_GN_BWD_EPILOGUE=1 switches it back on.
+    static const bool gn_bwd_epilogue = getenv("ASD_GN_BWD_EPILOGUE") && getenv("ASD_GN_BWD_EPILOGUE")[0] == '1';
+    if (gn_bwd_form && !gn_bwd_epilogue) { gn_out = nullptr; g.gn_bwd_x = nullptr; g.gn_bwd_fstats = nullptr; g.gn_bwd_gamma = nullptr; g.gn_bwd_beta = nullptr; }
     if (gn_epilogue && gn_out && g.gn_rows > 0 && g.N % 32 == 0) {     // statistics records of the output, produced in the epilogue when the plan allows
         g.gn_cg = g.N / 32;
         const int batch = g.M / g.gn_rows;
