@@ -55,11 +55,11 @@ if "--gaps" in sys.argv:     # idle gaps above a threshold (us) inside the last 
     print(f"idle total {tot_idle / 1e6:.3f} ms")
 
 if "--list" in sys.argv:     # durations (us) of the launches of one kernel name inside the last analysed steps, in program order, averaged over the steps
-    pat = sys.argv[sys.argv.index("--list") + 1]
+    pat = sys.argv[sys.argv.index("--list") + 1]      # regular expression on the kernel name
     per = []
     for k in range(nlast):
         st = rows[starts[-nlast - 1 - skip + k]:starts[-nlast - skip + k]]
-        per.append([(e_ - s_) / 1e3 for s_, e_, nm in st if pat in nm])
+        per.append([(e_ - s_) / 1e3 for s_, e_, nm in st if re.search(pat, nm)])
     m = min(len(p_) for p_ in per)
     print(f"{pat}: {m} launches per step; mean us per position over {nlast} steps:")
     print(" ".join(f"{sum(p_[i] for p_ in per) / nlast:.1f}" for i in range(m)))

@@ -27,7 +27,12 @@ env = dict(os.environ, ASD_GEMM_TRACE="1", ASD_GEMM_TRACE_CHILD="1", ASD_UNET_GR
 err = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True).stderr
 body = err.split("ASD_STEP_BEGIN")[-1].split("ASD_STEP_END")[0]
 pat = re.compile(r"ASD_GEMM (\d+) (\d+) (\d+) conv=(\d) (\d+) (\d+) (\d+) (\d+) (\d+) s=(\d+) p=(\d+) u=(\d+) cfg=(\d+) split=(\d+) act=(\d) res=(\d) f32=(\d) gn=(\d)")
-calls = collections.Counter(tuple(int(v) for v in m.groups()) for m in pat.finditer(body))
+order = [tuple(int(v) for v in m.groups()) for m in pat.finditer(body)]
+calls = collections.Counter(order)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "gemm_order.txt"), "w") as f:      # launch order of the step (tools/gemm_in_step.py joins it with the step's kernel trace)
+    for k in order:
+        f.write(" ".join(str(v) for v in k) + "\n")
 print(len(calls), "distinct launches,", sum(calls.values()), "per step", file=sys.stderr)
 
 import torch
@@ -39,7 +44,7 @@ rows = []
 for key, cnt in calls.items():
     M, N, K, conv, Hin, Win, Cin, Hout, Wout, stride, pad, ups, cfg, split, act, res, f32, gn = key
     pool = 4
-    w = [torch.randn(N, K, device=dev, dtype=torch.float16) * K ** -0.5 for _ in range(pool)]
+    w = [torch.randn(N * (4 if conv and ups == 3 else 1), K, device=dev, dtype=torch.float16) * K ** -0.5 for _ in range(pool)]     # parity form: [4][N][K]
     if conv:
         B = M // (Hout * Wout)
         a = [torch.randn(B, Hin, Win, Cin, device=dev, dtype=torch.float16) for _ in range(pool)]
