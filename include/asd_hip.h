@@ -374,6 +374,8 @@ int asd_gemm_plan_set(int32_t M, int32_t N, int32_t K, int32_t conv, int32_t s0,
 /* plan of args' shape -> (*tile_cfg, *split_k); returns 0 when tuned, 1 when the defaults (cost model, heuristic split) are given */
 int asd_gemm_plan_get(const asd_gemm_args* args, int32_t* tile_cfg, int32_t* split_k);
 int asd_gemm_plan_count(void);
+/* changes whenever the plan table (or the forced tile) changes: lets a caller cache what it derived from the plans (workspace layouts) */
+uint64_t asd_gemm_plan_generation(void);
 int asd_gemm_plan_entry(int32_t i, int32_t* out11 /* {M,N,K,conv,s0..s4,tile_cfg,split_k} */);
 /* bytes of split-K workspace asd_gemm_f16 needs for args (split_k == 0: under the current plan) */
 int64_t asd_gemm_workspace_bytes(const asd_gemm_args* args);

@@ -19,6 +19,7 @@
 
 #include "asd_common.h"
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <cstring>
 #include <iterator>
@@ -971,6 +972,7 @@ struct asd_plan_key {
 struct asd_plan_val { int32_t tile, split; };
 static std::map<asd_plan_key, asd_plan_val> g_plans;
 static std::mutex g_plans_mu;
+static std::atomic<uint64_t> g_plan_gen{1};     // bumped by everything that can change what a launch resolves to (asd_gemm_plan_generation)
 
 static asd_plan_key asd_plan_key_of(const asd_gemm_args* a) {
     asd_plan_key k;
@@ -1051,6 +1053,7 @@ extern "C" {
 
 int asd_gemm_force_tile(int32_t cfg) {
     g_force_tile = cfg;
+    ++g_plan_gen;
     return ASD_OK;
 }
 
@@ -1062,6 +1065,7 @@ int asd_gemm_plan_set(int32_t M, int32_t N, int32_t K, int32_t conv, int32_t s0,
     k.M = M; k.N = N; k.K = K; k.conv = conv ? 1 : 0; k.a = s0; k.b = s1; k.c = s2; k.d = s3; k.e = s4;
     std::lock_guard<std::mutex> lk(g_plans_mu);
     g_plans[k] = asd_plan_val{tile_cfg, split_k};
+    ++g_plan_gen;
     return ASD_OK;
 }
 
@@ -1380,8 +1384,11 @@ int asd_gemm_tune(const asd_gemm_args* a_in, void* scratch, int64_t scratch_byte
     const asd_plan_key k = asd_plan_key_of(a_in);
     std::lock_guard<std::mutex> lk(g_plans_mu);
     g_plans[k] = asd_plan_val{cand[pick][0], cand[pick][1]};
+    ++g_plan_gen;
     return ASD_OK;
 }
+
+uint64_t asd_gemm_plan_generation(void) { return g_plan_gen.load(); }
 
 /* enumerate the plan table (persisting what asd_gemm_tune found): entry i -> 11 ints {M,N,K,conv,s0..s4,tile,split} */
 int asd_gemm_plan_entry(int32_t i, int32_t* out11) {

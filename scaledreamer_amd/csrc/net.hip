@@ -577,6 +577,9 @@ struct Vae : Net {
     std::vector<VLayer> plan;
     std::map<const void*, size_t> scratch_of;      // workspace -> split-K scratch size its last forward laid it out with
     std::map<const void*, std::vector<int>> recs_of;   // workspace -> GroupNorm record counts of that forward, in allocation order
+    // the last shape whose forward + backward layout was sized and found to fit (valid while the plan table does not change)
+    struct Sized { int batch = 0, H = 0, W = 0, tune = 0; uint64_t gen = 0; int64_t bytes = 0, need = 0; size_t scratch = 0; } sized;
+    std::map<const void*, uint64_t> gen_of;        // workspace -> plan generation of its last forward
 };
 
 // conv: forward weights [cout, 9*pad32(cin)], input-gradient weights [pad32(cin), 9*pad32(cout)] (roles swapped, taps flipped for
@@ -881,19 +884,26 @@ size_t plan_bytes(F&& pass, bool tune) {
 }
 // *scratch_io: in = scratch size to use (when `given`), out = the size used — the VAE backward must lay the workspace out exactly
 // as its forward did, whatever happened to the plan table in between
+// checked: the caller has already run this very pass on this workspace size under the current plan table (asd_gemm_plan_generation) and
+// passes its scratch size — the sizing walk over the network is skipped (two of them took ~100 us of host time in front of the first
+// launch of every VAE pass, with the GPU idle: the host is not ahead right after the renderer's read-back)
 template <class F>
 int run_pass(F&& pass, void* workspace, size_t workspace_bytes, hipStream_t stream, bool tune, const void* zero_page,
-             size_t* scratch_io = nullptr, bool given = false) {
-    Run dry;
-    dry.dry = true;
-    dry.tune = tune;
-    pass(dry);
-    size_t scratch = ((tune ? TUNE_SCRATCH : dry.scratch_need) + 255) & ~(size_t)255;
-    if (given) scratch = *scratch_io;
-    if (scratch_io) *scratch_io = scratch;
-    if (scratch + dry.mem.off > workspace_bytes) {
-        asd_set_error("workspace of %zu bytes is too small (need %zu)", workspace_bytes, scratch + dry.mem.off);
-        return ASD_ERR_ARG;
+             size_t* scratch_io = nullptr, bool given = false, bool checked = false) {
+    size_t scratch = 0;
+    if (checked && given) scratch = *scratch_io;
+    else {
+        Run dry;
+        dry.dry = true;
+        dry.tune = tune;
+        pass(dry);
+        scratch = ((tune ? TUNE_SCRATCH : dry.scratch_need) + 255) & ~(size_t)255;
+        if (given) scratch = *scratch_io;
+        if (scratch_io) *scratch_io = scratch;
+        if (scratch + dry.mem.off > workspace_bytes) {
+            asd_set_error("workspace of %zu bytes is too small (need %zu)", workspace_bytes, scratch + dry.mem.off);
+            return ASD_ERR_ARG;
+        }
     }
     Run r;
     r.dry = false; r.tune = tune; r.stream = stream; r.zero_page = zero_page;
@@ -1000,6 +1010,10 @@ int asd_vae_enc_bind_weights(asd_vae_enc* h, const void* const* ptrs, int32_t co
 int64_t asd_vae_enc_workspace_bytes(asd_vae_enc* h, int32_t batch, int32_t H, int32_t W, int32_t tune) {
     Vae* n = (Vae*)h;
     if (!n || batch < 1 || H < 8 || W < 8) return -1;
+    {   // the answer of the last forward pass, while shape and plans are the same
+        const Vae::Sized& z = n->sized;
+        if (z.gen != 0 && z.gen == asd_gemm_plan_generation() && z.batch == batch && z.H == H && z.W == W && z.tune == tune) return z.need;
+    }
     return (int64_t)plan_bytes([&](Run& r) {
         std::vector<VSaved> saved;
         vae_forward(*n, r, nullptr, batch, H, W, nullptr, saved, true);
@@ -1014,18 +1028,28 @@ int asd_vae_enc_fwd(asd_vae_enc* h, const void* x_nhwc32, int32_t batch, int32_t
     ASD_CHECK_ARG(H > 0 && W > 0 && H % (1 << (n->d.n_levels - 1)) == 0 && W % (1 << (n->d.n_levels - 1)) == 0,
                   "H and W must be multiples of 2^(levels - 1): every Downsample halves the image exactly (parity-form input gradient)");
     // size check against the forward + backward plan, so that the backward can never overrun what the forward accepted
-    const int64_t need = asd_vae_enc_workspace_bytes(h, batch, H, W, tune);
+    const uint64_t gen = asd_gemm_plan_generation();
+    Vae::Sized& z = n->sized;
+    static const bool cache_on = !(getenv("ASD_VAE_SIZING_CACHE") && getenv("ASD_VAE_SIZING_CACHE")[0] == '0');       // A/B switch (tools)
+    const bool known = cache_on && z.gen == gen && z.batch == batch && z.H == H && z.W == W && z.tune == tune && workspace_bytes >= z.need;
+    const int64_t need = known ? z.need : asd_vae_enc_workspace_bytes(h, batch, H, W, tune);
     if (need < 0 || need > workspace_bytes) { asd_set_error("workspace of %lld bytes is too small (need %lld)", (long long)workspace_bytes, (long long)need); return ASD_ERR_ARG; }
     // the scratch region is sized for both passes (the dry pass walks the backward as well) and remembered per workspace
-    size_t scratch = 0;
+    size_t scratch = known ? z.scratch : 0;
     std::vector<int> log;
     const int st = run_pass([&](Run& r) {
         std::vector<VSaved> saved;
         if (!r.dry) r.rec_log = &log;
         vae_forward(*n, r, (const half_t*)x_nhwc32, batch, H, W, moments_nhwc, saved, true);
         if (r.dry) vae_backward(*n, r, saved, nullptr, batch, nullptr);
-    }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch);
-    if (st == ASD_OK) { n->scratch_of[workspace] = scratch; n->recs_of[workspace] = log; }
+    }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch, known, known);
+    if (st == ASD_OK) {
+        n->scratch_of[workspace] = scratch; n->recs_of[workspace] = log;
+        const uint64_t after = asd_gemm_plan_generation();          // tuning inside the pass changes the plans: nothing to remember then
+        n->gen_of[workspace] = after == gen ? gen : 0;
+        if (after == gen) { z.batch = batch; z.H = H; z.W = W; z.tune = tune; z.gen = gen; z.need = need; z.scratch = scratch; }
+        else z.gen = 0;
+    }
     return st;
 }
 int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, int32_t H, int32_t W, void* workspace, int64_t workspace_bytes,
@@ -1044,7 +1068,10 @@ int asd_vae_enc_bwd(asd_vae_enc* h, const float* d_moments_nhwc, int32_t batch, 
         vae_forward(*n, r, nullptr, batch, H, W, nullptr, saved, false);     // replays the forward's allocation sequence: same addresses
         r.rec_replay = nullptr;                                              // the backward's own launches size their records from the plans
         vae_backward(*n, r, saved, d_moments_nhwc, batch, (half_t*)dx_nhwc32);
-    }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch, true);
+    }, workspace, (size_t)workspace_bytes, (hipStream_t)stream, tune != 0, n->zero_page, &scratch, true,
+       /* checked: the forward on this workspace sized both passes under the same plans and shape */
+       n->gen_of[workspace] != 0 && n->gen_of[workspace] == asd_gemm_plan_generation() && n->sized.gen == n->gen_of[workspace] &&
+           n->sized.batch == batch && n->sized.H == H && n->sized.W == W && n->sized.tune == tune && workspace_bytes >= n->sized.need);
 }
 
 }  // extern "C"
