@@ -22,7 +22,7 @@ def timeit(fn, reps=24):
 
 def main():
     torch.manual_seed(0)
-    for B, hw, cin, cout in [(5, 8, 1280, 1280), (5, 16, 1280, 1280), (5, 8, 2560, 1280), (1, 64, 512, 512)]:
+    for B, hw, cin, cout in ([(5, 8, 1280, 1280), (5, 8, 2560, 1280)] if len(sys.argv) > 1 else [(5, 8, 1280, 1280), (5, 16, 1280, 1280), (5, 8, 2560, 1280), (1, 64, 512, 512)]):
         pool = max(2, int(400e6 // (cout * 9 * cin * 2)) + 1)
         x = torch.randn(B, hw, hw, cin, device="cuda").half()
         ws = [H.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5).half()) for _ in range(pool)]
@@ -32,12 +32,14 @@ def main():
         plan = timeit(lambda i: H.conv3x3(x, ws[i % pool], residual=res))
         print(f"{(B, hw, cin, cout)}: weights {cout * 9 * cin * 2 / 1e6:.1f} MB, pool {pool}; reduction read {rd:.1f} us; plan {plan:.1f} us", flush=True)
         rows = []
-        for t in range(25):
+        for t in range(len(H.TILE_BN)):
             bn, bm = H.TILE_BN[t], H.TILE_BM[t]
-            if (cout % bn and bn != 64) or (t in H.PP_TILES and hw % (bm // 16)) or (t in H.WINDOW_TILES and hw % 16):
+            if (cout % bn and bn != 64) or (t in H.PP_TILES and hw % (bm // 16)) or (t in H.WINDOW_TILES and t not in getattr(H, 'PP8_TILES', ()) and hw % 16):
                 continue
-            for sk in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-                if t in H.WINDOW_TILES and sk > cin // 128:
+            if t in getattr(H, 'PP8_TILES', ()) and (hw != 8 or (B * 64) % bm):
+                continue
+            for sk in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+                if t in H.WINDOW_TILES and sk > cin // (64 if t in getattr(H, 'PP8_TILES', ()) else 128):
                     continue
                 try:
                     us = timeit(lambda i: H.conv3x3(x, ws[i % pool], residual=res, tile_cfg=t + 1, split_k=sk), reps=12)
