@@ -199,7 +199,11 @@ __device__ __forceinline__ float silu_grad(float z) {
     return sg * (1.f + z * (1.f - sg));
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
+// NT threads per block: 256, or 512 for the large tensors — the grid is capped at 256 blocks (every apply block sums all their
+// partials), and with four waves per CU the silu' arithmetic of a wave was not hidden behind anybody's loads: 2.6 TB/s on the VAE's
+// 512^2 x 128 tensors.  Eight waves per CU: 51 -> 34.5 us there, 28 -> 20 us at 256^2 x 256 (sixteen: 36.5 / 23 us, 128 registers, spills)
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy, int C,
                                                            int hw, int rows_per_block, const half_t* __restrict__ gamma,
                                                            const half_t* __restrict__ beta, float eps, int silu,
                                                            const float* __restrict__ fstats, float* __restrict__ bstats) {
@@ -210,13 +214,13 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const half_t* __restr
     __syncthreads();
     const float inv_cnt = 1.f / ((float)hw * (float)cg);
     const int r0 = blockIdx.y * rows_per_block, r1 = min(hw, r0 + rows_per_block);
-    const int rows_in_flight = slots >= 256 ? 1 : 256 / slots;
-    const int rsub = slots >= 256 ? 0 : tid / slots;
-    const int slot0 = slots >= 256 ? tid : tid % slots;
+    const int rows_in_flight = slots >= NT ? 1 : NT / slots;
+    const int rsub = slots >= NT ? 0 : tid / slots;
+    const int slot0 = slots >= NT ? tid : tid % slots;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int slot = slot0 + j * 256;
-        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= 256)) continue;
+        const int slot = slot0 + j * NT;
+        if (slot >= slots || rsub >= rows_in_flight || (j == 1 && slots <= NT)) continue;
         const int c = slot * 8;
         float mean[8], rstd[8], gm[8], bt[8], s[8], q[8];
 #pragma unroll
@@ -690,8 +694,12 @@ int asd_groupnorm_bwd_f16(const void* x, const void* dy, int32_t c, int32_t batc
     // (apply blocks) x (statistics chunks) small — with 515 x 1280 blocks the prologue read 2.6x the tensor itself
     const int cap_s = asd_div_up(256, batch), cap_a = asd_div_up(GN_CAP_A, batch);
     const int chunks_s = chunks > cap_s ? cap_s : chunks, chunks_a = chunks > cap_a ? cap_a : chunks;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
-                       asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
+    if ((size_t)asd_div_up(hw, chunks_s) * c >= 32768 && c % 8 == 0 && 512 % (c / 8) == 0)      // >= 64 KB of each tensor per block
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<512>, dim3(batch, chunks_s), dim3(512), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                           asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
+    else
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<256>, dim3(batch, chunks_s), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
+                           asd_div_up(hw, chunks_s), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(batch, chunks_a), dim3(256), 0, s, (const half_t*)x, (const half_t*)dy, c, hw,
                        asd_div_up(hw, chunks_a), (const half_t*)gamma, (const half_t*)beta, eps, silu, fwd_stats, bwd_stats, chunks_s,
                        (const half_t*)dx_add, (half_t*)dx);
