@@ -135,11 +135,11 @@ PMC_TRAFFIC = {("vae512", (24, 1)): 152.0e6, ("vae512", (12, 1)): 140.3e6, ("vae
 
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV) and inside
-# the timed steps (profiles/r03_step_breakdown.txt: 2.0 ms of every 15.5 ms step)
+# the timed steps (profiles/r03_step_breakdown.txt: 1.67 ms of every 15.1 ms step)
 DOMINANT = "pp_conv"
 DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row conv3x3_pp_kernel<4,4>; inside the timed steps "
-                   "(profiles/r03_step_breakdown.txt) it is first too with 2.0 ms per step (24 launches on seven shapes, all in the VAE encoder's forward and "
-                   "input-gradient pass), then gemm_f16_kernel<256,64> 1.33 ms, attention 1.2 ms, field_bwd_sample_kernel 1.13 ms (round 2's `roofline` kernel, now "
+                   "(profiles/r03_step_breakdown.txt) it is first too with 1.67 ms per step (24 launches on seven shapes, all in the VAE encoder's forward and "
+                   "input-gradient pass), then gemm_f16_kernel<256,64> 1.35 ms, attention 1.2 ms, field_bwd_sample_kernel 1.13 ms (round 2's `roofline` kernel, now "
                    "`roofline_field_bwd`: 0.047 of HBM, bound by the L2's atomic request rate)")
 
 # every launch of conv3x3_pp_kernel<4,4> in one step (tools/gemm_shapes.py trace of the step, gpurun_out/gemm_shapes.txt): (H = W, Cin, Cout,
@@ -150,7 +150,7 @@ PP44_LAUNCHES = [(512, 128, 128, 0, 0, 4), (512, 128, 128, 1, 1, 2), (512, 128, 
                  (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 0, 1), (512, 32, 128, 0, 1, 1)]
 # HBM bytes per launch of that kernel, averaged over the launches of `python bench.py` (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
 # profiles/r03_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)
-PP44_PMC_BYTES = 120.62e6 + 52.52e6
+PP44_PMC_BYTES = 70.21e6 + 49.47e6
 
 
 def roofline_pp_kernel(reps: int = 3):
@@ -353,11 +353,11 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
     # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 10 launches
-    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1096.6 + 69.0 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
+    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1076.0 + 69.0 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
     # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
     # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
     # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
-    traffic = n * (1096.62e6 + 69.04e6) / 433172.0
+    traffic = n * (1076.01e6 + 68.97e6) / 433172.0
     return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 10 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
