@@ -280,7 +280,7 @@ def roofline_field_kernel(system, batch, reps: int = 20):
 
     ren, geo = system.renderer, system.geometry
     with torch.no_grad():
-        ri, t0, t1, pts, dirs, off, cnt = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
+        ri, t0, t1, pts, dirs, off, cnt, _ = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
     n = int(pts.shape[0])
     if n == 0:
         return None
@@ -313,7 +313,7 @@ def roofline_field_bwd(system, batch, reps: int = 10):
 
     ren, geo = system.renderer, system.geometry
     with torch.no_grad():
-        ri, t0, t1, pts, dirs, off, cnt = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
+        ri, t0, t1, pts, dirs, off, cnt, _ = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
         n = int(pts.shape[0])
         if n == 0:
             return None

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
     __shared__ float w2_acc[ASD_FIELD_W2_COPIES * W2S];
     const int w2c = ASD_FIELD_W2_COPIES > 1 ? (threadIdx.x & (ASD_FIELD_W2_COPIES - 1)) * W2S : 0;
     const int nn = n_dev ? min(*n_dev, n) : n;
+    if (n_dev && (int)blockIdx.x * 256 >= nn) return;       // capacity-sized launch (device-side count): nothing lives in this block
     const int tid = threadIdx.x;
     for (int q = tid; q < ASD_FIELD_W2_COPIES * W2S; q += 256) w2_acc[q] = 0.f;
     __syncthreads();
@@ -502,6 +503,13 @@ __global__ __launch_bounds__(256) void field_wgrad_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     const int r_begin = blockIdx.x * WG_ROWS, r_end = min(rows_total, r_begin + WG_ROWS);
+    if (r_begin >= live_a && r_end <= rows_a) {      // a chunk of dead centre rows (capacity-sized launch)
+        if (rows_total == rows_a) return;            // ... whose slab slab_reduce_kernel does not read either
+        float* slab0 = slabs + (size_t)blockIdx.x * HH * NIN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(slab0 + (h0 + i) * NIN + k0) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     for (int r0 = r_begin; r0 < r_end; r0 += WG_TILE) {
         __syncthreads();
         // stage 64 rows of DA (512 B each) and ENC (128 B each), zero-filling dead rows
@@ -541,9 +549,12 @@ __global__ __launch_bounds__(256) void field_wgrad_kernel(const float* __restric
 // sum the per-block slabs: out[j] += sum_b slabs[b][j]   (fixed order: reproducible).  A block owns 32 consecutive outputs x 32 slab
 // lanes, four loads in flight per thread: the one-thread-per-output loop was a chain of n_blocks dependent round trips (503 us for
 // the 1543 slabs of a Hyper-iNGP step, 42 us for the 211 of the headline step).
+// live (optional): device-side count of the rows behind the slabs when they are all centre rows — only the slabs of live chunks are summed
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_blocks, int stride,
-                                                           int len, float* __restrict__ out) {
+                                                           int len, float* __restrict__ out, const int* __restrict__ live = nullptr,
+                                                           int rows_per_slab = 1) {
     __shared__ float part[32][33];
+    if (live) n_blocks = min(n_blocks, (max(*live, 0) + rows_per_slab - 1) / rows_per_slab);
     const int jl = threadIdx.x & 31, lane = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + jl;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -862,11 +873,12 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);
     // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks
+    const int* live = (n_dev && rows == (int64_t)n) ? n_dev : nullptr;      // every slab row is a centre row: dead chunks are skipped
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, chunks, 128 * 32, 64 * 32,
-                       dw1_density);
+                       dw1_density, live, WG_ROWS);
     if (cfg->n_feature_dims == 3)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, chunks, 128 * 32,
-                           64 * 32, dw1_feature);
+                           64 * 32, dw1_feature, live, WG_ROWS);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -70,10 +70,10 @@ class _FieldFn(torch.autograd.Function):
     """sigma, features, normal = field(points); backward scatters into the table and reduces MLP grads."""
 
     @staticmethod
-    def forward(ctx, points, grid, w1d, w2d, w1f, w2f, geom, want_normal):
-        sigma, feats, normal, enc = ops.field_fwd(geom._meta, geom._fcfg, grid, w1d, w2d, w1f, w2f, points, want_normal)
+    def forward(ctx, points, grid, w1d, w2d, w1f, w2f, geom, want_normal, n_dev=None):
+        sigma, feats, normal, enc = ops.field_fwd(geom._meta, geom._fcfg, grid, w1d, w2d, w1f, w2f, points, want_normal, n_dev=n_dev)
         ctx.save_for_backward(points, grid, w1d, w2d, w1f, w2f, enc, sigma)
-        ctx.geom = geom
+        ctx.geom, ctx.n_dev = geom, n_dev
         ctx.set_materialize_grads(False)
         if normal is None:
             normal = sigma.new_zeros(0)
@@ -86,12 +86,12 @@ class _FieldFn(torch.autograd.Function):
         g = ctx.geom
         d_grid = torch.zeros_like(grid)
         if d_sigma is None and d_feats is None and d_normal is None:
-            return None, d_grid, torch.zeros_like(w1d), torch.zeros_like(w2d), torch.zeros_like(w1f), torch.zeros_like(w2f), None, None
+            return None, d_grid, torch.zeros_like(w1d), torch.zeros_like(w2d), torch.zeros_like(w1f), torch.zeros_like(w2f), None, None, None
         dw = ops.field_bwd(g._meta, g._fcfg, grid, w1d, w2d, w1f, w2f, points, enc, sigma,
                            None if d_sigma is None else d_sigma.contiguous(),
                            None if d_feats is None else d_feats.contiguous(),
-                           None if d_normal is None else d_normal.contiguous(), d_grid)
-        return None, d_grid, dw[0], dw[1], dw[2], dw[3], None, None
+                           None if d_normal is None else d_normal.contiguous(), d_grid, n_dev=ctx.n_dev)
+        return None, d_grid, dw[0], dw[1], dw[2], dw[3], None, None, None
 
 
 @register("implicit-volume")
@@ -186,12 +186,16 @@ class ImplicitVolume(BaseImplicitGeometry):
         raw = density + bias
         return raw, get_activation(c.density_activation)(raw)
 
-    def forward(self, points: torch.Tensor, output_normal: bool = False) -> Dict[str, torch.Tensor]:
+    def forward(self, points: torch.Tensor, output_normal: bool = False, n_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """n_dev (extension of the reference signature, fused path only): int32 device scalar — only the first n_dev points are valid,
+        the rows behind them are neither read nor written (the renderer's capacity-sized sample buffers, no host read of the count)"""
         if self.fused and points.is_cuda:
-            return self._forward_fused(points, output_normal)
+            return self._forward_fused(points, output_normal, n_dev)
+        if n_dev is not None:
+            raise ValueError("n_dev needs the fused field kernels")
         return self._forward_composed(points, output_normal)
 
-    def _forward_fused(self, points, output_normal):
+    def _forward_fused(self, points, output_normal, n_dev=None):
         if output_normal and self.cfg.normal_type is None:
             raise AttributeError(f"Unknown normal type {self.cfg.normal_type}")
         shape = points.shape[:-1]
@@ -199,10 +203,10 @@ class ImplicitVolume(BaseImplicitGeometry):
         w1d, w2d, w1f, w2f = self._weights()
         grid = self.encoding.encoding.encoding.params
         if torch.is_grad_enabled() and grid.requires_grad:
-            sigma, feats, normal = _FieldFn.apply(flat, grid, w1d, w2d, w1f, w2f, self, bool(output_normal))
+            sigma, feats, normal = _FieldFn.apply(flat, grid, w1d, w2d, w1f, w2f, self, bool(output_normal), n_dev)
         else:
             sigma, feats, normal, _ = ops.field_fwd(self._meta, self._fcfg, grid.detach(), w1d.detach(), w2d.detach(),
-                                                    w1f.detach(), w2f.detach(), flat, bool(output_normal))
+                                                    w1f.detach(), w2f.detach(), flat, bool(output_normal), n_dev=n_dev)
         out = {"density": sigma.view(*shape, 1)}
         if self.cfg.n_feature_dims > 0:
             out["features"] = feats.view(*shape, self.cfg.n_feature_dims)

@@ -41,6 +41,13 @@ class NoMaterial(BaseMaterial):
     cfg: Config
     reads_normal = False           # colour = activation(features): the normals are never looked at (no_material.py:41-54)
 
+    @property
+    def elementwise(self) -> bool:
+        """colour rows are independent functions of feature rows with no parameters behind them: the renderer may hand over
+        capacity-sized buffers whose tail rows are garbage (a colour MLP would sum its weight gradient over those rows too)"""
+        return not self.use_network
+
+
     def configure(self) -> None:
         self.use_network = False
         if self.cfg.input_feature_dims is not None and self.cfg.mlp_network_config is not None:

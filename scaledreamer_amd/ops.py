@@ -171,9 +171,11 @@ def prune(sigma, t0, t1, offset, count, early_stop_eps: float, alpha_thre: float
     return keep, kept
 
 
-def compact(rays_o, rays_d, offset, count, keep, t0, t1, kept_offset, n_out: int):
+def compact(rays_o, rays_d, offset, count, keep, t0, t1, kept_offset, n_out: int, zero_ray_idx: bool = False):
+    """n_out may be an upper bound of the kept count (rows behind the kept ones stay unwritten); zero_ray_idx: those rows of ray_idx
+    then read 0, so the buffer stays a valid index tensor"""
     nr, dev = count.shape[0], t0.device
-    ray_idx = torch.empty(n_out, device=dev, dtype=torch.int64)
+    ray_idx = (torch.zeros if zero_ray_idx else torch.empty)(n_out, device=dev, dtype=torch.int64)
     t0o = torch.empty(n_out, device=dev, dtype=torch.float32)
     t1o = torch.empty(n_out, device=dev, dtype=torch.float32)
     pts = torch.empty((n_out, 3), device=dev, dtype=torch.float32)

@@ -8,6 +8,8 @@ with their fused kernels.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Any, Dict, Optional
 
@@ -192,8 +194,11 @@ class NeRFVolumeRenderer(VolumeRenderer):
         self.jitter_fn = lambda n, device: torch.rand(n, device=device)  # injectable
 
     # ------------------------------------------------------------------------------------------
-    def _sample(self, rays_o_flatten, rays_d_flatten):
-        """(ray_indices int64, t_starts, t_ends, offset int32, count int32) of the kept samples."""
+    def _sample(self, rays_o_flatten, rays_d_flatten, sync_free: bool = False):
+        """(ray_indices int64, t_starts, t_ends, points, dirs, offset int32, count int32, total) of the kept samples.  `total` is None
+        and the sample tensors have exactly the kept length — or, with sync_free (and the fused candidate path), `total` is the kept
+        count as an int32 DEVICE scalar and the sample tensors have the candidates' capacity: only their first `total` rows are
+        written (ray_indices reads 0 behind them), and no device->host read happens in here at all."""
         n_rays = rays_o_flatten.shape[0]
         est = self.estimator
         jitter = self.jitter_fn(n_rays, rays_o_flatten.device) if self.randomized else None
@@ -229,12 +234,16 @@ class NeRFVolumeRenderer(VolumeRenderer):
                 sigma = t0.new_zeros(0)
             keep, kept = ops.prune(sigma, t0, t1, offset, count, early_stop_eps, alpha_thre)
             koff, ktot = ops.scan_i32(kept)
+            if sync_free and fused_density and n_cap is not None and ray_idx.shape[0] > 0:
+                ri, k0, k1, kp, kd = ops.compact(rays_o_flatten, rays_d_flatten, offset, count, keep, t0, t1, koff, ray_idx.shape[0],
+                                                 zero_ray_idx=True)
+                return ri, k0, k1, kp, kd, koff, kept, ktot.reshape(1)
             n_out = int(ktot.item())
             ri, k0, k1, kp, kd = ops.compact(rays_o_flatten, rays_d_flatten, offset, count, keep, t0, t1, koff, n_out)
-            return ri, k0, k1, kp, kd, koff, kept
+            return ri, k0, k1, kp, kd, koff, kept, None
         n_out = ray_idx.shape[0]
         ri, k0, k1, kp, kd = ops.compact(rays_o_flatten, rays_d_flatten, offset, count, None, t0, t1, offset, n_out)
-        return ri, k0, k1, kp, kd, offset, count
+        return ri, k0, k1, kp, kd, offset, count, None
 
     def forward(self, rays_o: torch.Tensor, rays_d: torch.Tensor, light_positions: torch.Tensor,
                 bg_color: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, torch.Tensor]:
@@ -244,8 +253,20 @@ class NeRFVolumeRenderer(VolumeRenderer):
         light_positions_flatten = light_positions.reshape(-1, 1, 1, 3).expand(-1, height, width, -1).reshape(-1, 3)
         n_rays = rays_o_flatten.shape[0]
 
+        # Sync-free training path: the kept-sample count stays on the device (the field kernels take it as `n_dev`, compositing is per
+        # ray), the per-sample tensors are capacity-sized, and the per-sample entries of the output dictionary are cut to their exact
+        # length only if somebody reads them (LazyOutputs) — the host never waits for the GPU inside a step, so it runs ahead of it and
+        # its launch latencies disappear from the step (the read-back cost 0.1 ms of GPU idle time plus a host-bound renderer forward).
+        # Needs: fused field kernels, a material that is a row-wise function of the features, no consumer of the normal in here.
+        sync_free = (self.training and os.environ.get("ASD_SYNC_FREE", "1") != "0" and getattr(self.geometry, "fused", False)
+                     and rays_o_flatten.is_cuda and getattr(self.material, "elementwise", False) and not self.cfg.return_comp_normal
+                     and not self.cfg.return_normal_perturb
+                     and not (self.material.requires_normal and getattr(self.material, "reads_normal", True)))
         with torch.no_grad():
-            ray_indices, t_starts_, t_ends_, positions, t_dirs, offset, count = self._sample(rays_o_flatten, rays_d_flatten)
+            ray_indices, t_starts_, t_ends_, positions, t_dirs, offset, count, n_dev = self._sample(rays_o_flatten, rays_d_flatten, sync_free)
+        if n_dev is not None:
+            return self._forward_sync_free(batch_size, height, width, rays_d, bg_color, ray_indices, t_starts_, t_ends_, positions, t_dirs,
+                                           offset, count, n_dev, kwargs)
         if ray_indices.nelement() == 0:
             ray_indices, t_starts_, t_ends_ = validate_empty_rays(ray_indices, t_starts_, t_ends_)
             positions = rays_o_flatten[ray_indices] + rays_d_flatten[ray_indices] * 0.0
@@ -254,7 +275,7 @@ class NeRFVolumeRenderer(VolumeRenderer):
             count[0] = 1
             offset = torch.ones(n_rays, dtype=torch.int32, device=rays_o.device)
             offset[0] = 0
-        self.last_n_samples = int(ray_indices.shape[0])
+        self._last_n = int(ray_indices.shape[0])
         t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
         t_light_positions = light_positions_flatten[ray_indices]
         t_positions = (t_starts + t_ends) / 2.0
@@ -323,6 +344,63 @@ class NeRFVolumeRenderer(VolumeRenderer):
                                                           output_normal=self.material.requires_normal)["normal"]
         elif "normal" in geo_out:
             out["comp_normal"] = comp_normal_of(geo_out["normal"])
+        return out
+
+    @property
+    def last_n_samples(self) -> int:
+        """kept samples of the last forward pass (reads the device count of a sync-free pass when asked)"""
+        n = getattr(self, "_last_n", 0)
+        return int(n.item()) if torch.is_tensor(n) else int(n)
+
+    def _forward_sync_free(self, batch_size, height, width, rays_d, bg_color, ray_indices, t_starts_, t_ends_, positions, t_dirs,
+                           offset, count, n_dev, kwargs):
+        """forward() behind the sampler with the kept count on the device (see there): same arithmetic on the first n_dev rows"""
+        n_rays = batch_size * height * width
+        self._last_n = n_dev
+        geo_out = self.geometry(positions, output_normal=False, n_dev=n_dev)
+        rgb_fg_all = self.material(viewdirs=t_dirs, positions=positions, light_positions=None, **geo_out, **kwargs)
+        comp_rgb_bg = self.background(dirs=rays_d)
+        if bg_color is None:
+            bg_color = comp_rgb_bg
+        elif bg_color.shape[:-1] == (batch_size,):
+            bg_color = bg_color.unsqueeze(1).unsqueeze(1).expand(-1, height, width, -1)
+        if bg_color.shape[:-1] == (batch_size, height, width):
+            bg_color = bg_color.reshape(n_rays, -1)
+        weights_, opacity_, depth_, comp_rgb_fg, z_variance_, comp_rgb = nerfacc_api.composite(
+            geo_out["density"][..., 0], rgb_fg_all, bg_color.float(), t_starts_, t_ends_, offset, count, 0
+        )
+        out = LazyOutputs({
+            "comp_rgb": comp_rgb.view(batch_size, height, width, -1),
+            "comp_rgb_fg": comp_rgb_fg.view(batch_size, height, width, -1),
+            "comp_rgb_bg": comp_rgb_bg.view(batch_size, height, width, -1),
+            "opacity": opacity_[..., None].view(batch_size, height, width, 1),
+            "depth": depth_[..., None].view(batch_size, height, width, 1),
+            "z_variance": z_variance_[..., None].view(batch_size, height, width, 1),
+        })
+        geo_keys = tuple(geo_out)
+
+        def per_sample():                       # exact-length views, made (with ONE read of the count) when first asked for
+            n = int(n_dev.item())
+            if n == 0:                          # the reference's dummy sample of an empty batch (validate_empty_rays)
+                z = t_starts_.new_zeros(1)
+                o = {"weights": z[..., None], "t_points": z[..., None], "t_intervals": z[..., None], "t_dirs": rays_d.reshape(-1, 3)[:1],
+                     "ray_indices": torch.zeros(1, dtype=torch.long, device=z.device), "points": positions[:1] * 0.0}
+                o.update({k: geo_out[k][:1] * 0.0 for k in geo_keys})
+                return o
+            t0, t1 = t_starts_[:n, None], t_ends_[:n, None]
+            o = {"weights": weights_[:n, None], "t_points": (t0 + t1) / 2.0, "t_intervals": t1 - t0, "t_dirs": t_dirs[:n],
+                 "ray_indices": ray_indices[:n], "points": positions[:n]}
+            o.update({k: geo_out[k][:n] for k in geo_keys})
+            return o
+
+        sample_keys = ("weights", "t_points", "t_intervals", "t_dirs", "ray_indices", "points") + geo_keys
+        out.defer(sample_keys, per_sample)
+        if self.material.requires_normal:
+            def lazy_normal(geometry=self.geometry, pts=positions):
+                n = int(n_dev.item())
+                g = geometry(pts[:max(n, 1)], output_normal=True)
+                return {"normal": g["normal"], "shading_normal": g["shading_normal"]}
+            out.defer(("normal", "shading_normal"), lazy_normal)
         return out
 
     # ------------------------------------------------------------------------------------------

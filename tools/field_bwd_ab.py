@@ -21,7 +21,7 @@ if sys.argv[1] == "dump":
     batch = bench.to_device(data.collate(), dev)
     ren, geo = system.renderer, system.geometry
     with torch.no_grad():
-        ri, t0, t1, pts, dirs, off, cnt = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
+        ri, t0, t1, pts, dirs, off, cnt, _ = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
     torch.save({"pts": pts.cpu(), "geo": {k: v.cpu() for k, v in geo.state_dict().items()}}, "/tmp/fb.pt")
     print("dumped", pts.shape[0], "samples")
 else:

@@ -12,7 +12,7 @@ for _ in range(12):
 batch = bench.to_device(data.collate(), dev)
 ren, geo = system.renderer, system.geometry
 with torch.no_grad():
-    ri, t0, t1, pts, dirs, off, cnt = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
+    ri, t0, t1, pts, dirs, off, cnt, _ = ren._sample(batch["rays_o"].reshape(-1, 3).contiguous(), batch["rays_d"].reshape(-1, 3).contiguous())
 grid = geo.encoding.encoding.encoding.params.detach()
 w = [t.detach() for t in geo._weights()]
 print("samples", pts.shape[0])
