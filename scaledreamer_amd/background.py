@@ -91,5 +91,10 @@ class NeuralEnvironmentMapBackground(BaseBackground):
             color = get_activation(self.cfg.color_activation)(color)
         if self.training and self.cfg.random_aug and self.rand_fn() < self.cfg.random_aug_prob:
             # random solid colour; `color * 0 +` keeps every parameter in the autograd graph (DDP)
-            color = color * 0 + self.rand_color_fn(dirs.shape[0], self.cfg.n_output_dims).to(dirs).expand(*dirs.shape[:-1], -1)
+            rc = self.rand_color_fn(dirs.shape[0], self.cfg.n_output_dims)      # host RNG, as in the reference (its draw order is the contract)
+            if dirs.is_cuda and not rc.is_cuda:
+                # through pinned memory, asynchronously: a pageable .to(device) blocks the host until the stream reaches the copy —
+                # every second step (random_aug_prob = 0.5) the host lost the lead it has over the GPU
+                rc = rc.pin_memory().to(dirs.device, non_blocking=True)
+            color = color * 0 + rc.to(dirs).expand(*dirs.shape[:-1], -1)
         return color

@@ -290,7 +290,7 @@ class MultipromptNeuralHashgridEnvironmentMapBackground(BaseBackground):
         self.encoding = get_encoding(3, self.cfg.pos_encoding_config)
         self.hypernet = LinearHyperNetwork(self.encoding.n_output_dims, self.cfg.hypernet_config)
         self.enabling_hypernet = True
-        self.rand_fn = lambda b, c, like: torch.rand(b, 1, 1, c).to(like)   # injectable for tests
+        self.rand_fn = lambda b, c, like: (lambda r: r.pin_memory().to(like.device, non_blocking=True) if like.is_cuda else r)(torch.rand(b, 1, 1, c)).to(like)   # injectable for tests; pinned + asynchronous: no host stall
 
     hypernet_forward = staticmethod(hypernet_forward)
 

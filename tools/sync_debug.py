@@ -11,7 +11,9 @@ torch.cuda.synchronize()
 seen = {}
 def show(message, category, filename, lineno, file=None, line=None):
     st = [f for f in traceback.extract_stack() if "/root/repo" in f.filename or "scaledreamer_amd" in f.filename]
-    key = tuple((f.filename.split("/")[-1], f.lineno) for f in st[-4:])
+    if not st:                                  # no frame of this repository on the stack: show where it comes from anyway
+        st = traceback.extract_stack()[:-1]
+    key = tuple((f.filename.split("/")[-1], f.lineno) for f in st[-5:])
     seen[key] = seen.get(key, 0) + 1
 warnings.showwarning = show
 warnings.simplefilter("always")
