@@ -353,11 +353,11 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
     # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 10 launches
-    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1076.0 + 69.0 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
+    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1089.6 + 69.2 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
     # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
     # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
     # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
-    traffic = n * (1076.01e6 + 68.97e6) / 433172.0
+    traffic = n * (1089.63e6 + 69.21e6) / 433172.0
     return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 10 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
