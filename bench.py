@@ -33,7 +33,6 @@ def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     from scaledreamer_amd import presets
     from scaledreamer_amd.data import RandomCameraIterableDataset, RandomMultiviewCameraIterableDataset
 
-    presets.ALLOW_RANDOM_WEIGHTS = True      # synthetic prior: no checkpoint exists offline (the JSON line says "data": "synthetic")
     from scaledreamer_amd.guidance import PromptUtils
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
@@ -43,7 +42,8 @@ def build_system(backend: str, seed: int, workload: str = "asd_sd_nerf"):
     mv = workload == "asd_mv_nerf"
     if workload in ("asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"):
         return build_hyper_system(backend, seed, workload)
-    cfg = presets.asd_mv_nerf() if mv else presets.asd_sd_nerf(guidance_backend=backend)
+    with presets.random_weights_allowed():   # synthetic prior: no checkpoint exists offline (the JSON line says "data": "synthetic")
+        cfg = presets.asd_mv_nerf() if mv else presets.asd_sd_nerf(guidance_backend=backend)
     torch.manual_seed(seed)
     random.seed(seed)
     pp = cfg["system"]["prompt_processor"]
@@ -61,13 +61,13 @@ def build_hyper_system(backend: str, seed: int, workload: str = "asd_sd_hyper_in
     from scaledreamer_amd import presets
     from scaledreamer_amd.multiprompt import SyntheticMultiPromptProcessor
 
-    presets.ALLOW_RANDOM_WEIGHTS = True
     from scaledreamer_amd.registry import find
     import scaledreamer_amd.plugins  # noqa: F401
 
-    cfg = {"asd_sd_hyper_ingp": lambda: presets.asd_sd_hyper_ingp(guidance_backend=backend),
-           "asd_sd_3dconv_net": lambda: presets.asd_sd_3dconv_net(guidance_backend=backend),
-           "asd_mv_triplane": presets.asd_mv_triplane_transformer}[workload]()
+    with presets.random_weights_allowed():
+        cfg = {"asd_sd_hyper_ingp": lambda: presets.asd_sd_hyper_ingp(guidance_backend=backend),
+               "asd_sd_3dconv_net": lambda: presets.asd_sd_3dconv_net(guidance_backend=backend),
+               "asd_mv_triplane": presets.asd_mv_triplane_transformer}[workload]()
     torch.manual_seed(seed)
     random.seed(seed)
     dev = torch.device("cuda", torch.cuda.current_device())

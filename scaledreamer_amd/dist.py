@@ -112,7 +112,13 @@ class GradientExchange:
         # rank touched keeps `.grad = None`, so the optimizer skips it exactly as the single-process path does (no weight decay, no
         # moment decay, no step count for an unused branch)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self._touched_host = torch.zeros(len(self.params), dtype=torch.int32, pin_memory=dev.type == "cuda")
+        # two pinned flag buffers used alternately, each with the event behind its asynchronous upload: the host runs a step ahead of
+        # the stream (nothing in a step synchronises), so the buffer of step i may still be waiting for its copy while the hooks of
+        # step i + 1 write flags — into the other buffer; before a buffer is reused its own event is waited for
+        self._touched_bufs = [torch.zeros(len(self.params), dtype=torch.int32, pin_memory=dev.type == "cuda") for _ in range(2)]
+        self._touched_events = [None, None]
+        self._touched_slot = 0
+        self._touched_host = self._touched_bufs[0]
         self._touched_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self.order = list(range(len(self.units)))      # launch order (positions into self.units)
         self._order_learned = False
@@ -171,6 +177,11 @@ class GradientExchange:
         self._launched = 0                              # number of positions of self.order already launched
         self._works = []
         self._seen_order = []
+        self._touched_slot ^= 1
+        if self._touched_events[self._touched_slot] is not None:     # uploaded two steps ago: normally long complete
+            self._touched_events[self._touched_slot].synchronize()
+            self._touched_events[self._touched_slot] = None
+        self._touched_host = self._touched_bufs[self._touched_slot]
         self._touched_host.zero_()
         self._armed = True
         self.prepare_called += 1
@@ -218,6 +229,9 @@ class GradientExchange:
             e0.record()
         self._launch_ready(force=True)
         self._touched_dev.copy_(self._touched_host, non_blocking=True)
+        if on_gpu:
+            self._touched_events[self._touched_slot] = torch.cuda.Event()
+            self._touched_events[self._touched_slot].record()
         self._works.append(dist.all_reduce(self._touched_dev, op=dist.ReduceOp.MAX, async_op=True))
         for w in self._works:
             w.wait()

@@ -3,6 +3,7 @@
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 
 
@@ -10,6 +11,17 @@ import copy
 # random weights distills nothing); bench.py, __graft_entry__.smoke(), tests/conftest.py and the tools set this switch explicitly to
 # run on the seeded random prior (diffusion/checkpoint.py: resolve_params).
 ALLOW_RANDOM_WEIGHTS = False
+
+
+@contextlib.contextmanager
+def random_weights_allowed(allow: bool = True):
+    """scoped form of the switch: presets built inside the block accept a missing checkpoint, anything built after it fails closed again"""
+    global ALLOW_RANDOM_WEIGHTS
+    saved, ALLOW_RANDOM_WEIGHTS = ALLOW_RANDOM_WEIGHTS, allow
+    try:
+        yield
+    finally:
+        ALLOW_RANDOM_WEIGHTS = saved
 
 
 def asd_sd_nerf(prompt: str = "synthetic", guidance_backend: str = "hip") -> dict:

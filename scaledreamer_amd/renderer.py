@@ -105,8 +105,9 @@ class LazyOutputs(dict):
         if cell is not None:
             vals = cell["fn"]()
             for k in cell["keys"]:
-                self._deferred.pop(k, None)
-                dict.__setitem__(self, k, vals[k])
+                if self._deferred.get(k) is cell:          # (a key written or deleted by the user meanwhile stays as the user left it)
+                    del self._deferred[k]
+                    dict.__setitem__(self, k, vals[k])
 
     def __getitem__(self, key):
         self._force(key)
@@ -118,9 +119,37 @@ class LazyOutputs(dict):
     def __contains__(self, key):
         return dict.__contains__(self, key) or key in self._deferred
 
-    def __iter__(self):                    # (also sends `{**out}` / dict(out) down the keys() + __getitem__ path)
-        yield from dict.__iter__(self)
-        yield from list(self._deferred)
+    # writes replace a deferred entry instead of being overwritten by it on the next read
+    def __setitem__(self, key, value):
+        self._deferred.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        if self._deferred.pop(key, None) is None or dict.__contains__(self, key):
+            dict.__delitem__(self, key)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+    _MISSING = object()
+
+    def pop(self, key, default=_MISSING):
+        if key in self:
+            v = self[key]
+            dict.__delitem__(self, key)
+            return v
+        if default is LazyOutputs._MISSING:
+            raise KeyError(key)
+        return default
+
+    def __iter__(self):                    # (also sends `{**out}` / dict(out) down the keys() + __getitem__ path); iterates over a
+        yield from list(dict.__iter__(self)) + list(self._deferred)     # snapshot: forcing an entry inside the loop moves its key
 
     def __len__(self):
         return dict.__len__(self) + len(self._deferred)

@@ -21,8 +21,8 @@ def build_smoke_system(seed: int = 0, n_batches: int = 2):
     torch.manual_seed(seed)
     random.seed(seed)
     dev = torch.device("cuda", 0)
-    presets.ALLOW_RANDOM_WEIGHTS = True      # smoke test: seeded random prior (no checkpoint offline)
-    cfg = presets.asd_sd_nerf()
+    with presets.random_weights_allowed():   # smoke test: seeded random prior (no checkpoint offline); scoped, not a process-wide switch
+        cfg = presets.asd_sd_nerf()
     backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128), vae_cfg=W.VAEConfig(), seed=3)
     g = torch.Generator().manual_seed(1)
     pu = PromptUtils(torch.randn(4, 77, 128, generator=g).to(dev), torch.randn(1, 77, 128, generator=g).expand(4, -1, -1).contiguous().to(dev),
