@@ -303,6 +303,13 @@ typedef struct asd_gemm_args {
     float   ln_eps;
     const float* ln_sc;
     float*  ln_stats;
+    /* Segmented rows (plain GEMM, K % 64 == 0): row r of A lives at A + a_seg_off[r / a_seg_rows] bytes + (r % a_seg_rows) * lda halfs
+     * (likewise W with w_seg_*), instead of A + r * lda.  Lets ONE matrix serve several row blocks that are the same rows read at
+     * different (also odd: 2-byte aligned) offsets along K — the 27 taps of the 3-D convolution's weight gradient are the same
+     * channel-major plane shifted along the voxel axis (csrc/conv3d.hip).  0 rows = off.  Offsets must be >= 0. */
+    int32_t a_seg_rows, w_seg_rows;
+    int32_t a_seg_off[9], w_seg_off[3];
+    int32_t partials_only;  /* split_k > 1: leave the fp32 slabs workspace[split_k, M, N] unreduced (no epilogue launch; the caller sums them) */
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
 int32_t asd_gemm_gn_records(const asd_gemm_args* args);
@@ -513,6 +520,42 @@ int asd_adamw_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1,
 /* Adan step with the gradient scaled by `clip` first (global-norm clipping factor computed by the caller) */
 int asd_adan_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float beta3, float eps, float clip,
                  int32_t no_prox, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generator backbone of the multi-prompt configs: the StyleGAN-3D synthesis network's 3x3x3 convolutions
+ * (custom/amortized/extern/stylegan_3dconv_modules.py:64-82 modulated_conv3d -> F.conv3d(groups = batch), :117-171) with forward,
+ * input gradient and weight gradient, and the layer tail around them (:56-62 SmoothUpsample, :301-313 noise + bias + lrelu + clamp).
+ * Every volume is fp32 CHANNEL-LAST [N][D][H][W][C]; weights are fp32 in torch's layout [Cout][Cin][3][3][3], one set per sample
+ * (stride w_sample_stride floats; 0 = shared).  Arithmetic: each fp32 operand is split into two fp16 planes and a product is three
+ * fp16 MFMA products accumulated in fp32 (csrc/conv3d.hip) - ~22 significant bits per operand.  H, W multiples of 16 (pad smaller
+ * volumes), Cin, Cout multiples of 64.  Workspace: asd_conv3d_workspace_bytes(desc, pass), pass 0 forward / 1 input gradient /
+ * 2 weight gradient; the caller owns it.
+ * ---------------------------------------------------------------------------------------------- */
+#define ASD_CONV3D_WGRAD_MAX_SPLIT 64
+typedef struct asd_conv3d_desc { int32_t N, D, H, W, Cin, Cout; } asd_conv3d_desc;
+typedef struct asd_conv3d_epilogue {      /* y = act(conv + noise[voxel] * *noise_strength + bias[c]) */
+    const float* bias;            /* [C] or NULL */
+    const float* noise;           /* [N*D*H*W] or NULL */
+    const float* noise_strength;  /* device scalar (the layer's parameter); required with noise */
+    int32_t act;                  /* 0: none; 1: clamp(leaky_relu(v, 0.2) * gain, -clamp, clamp)  (clamp_gain, :5-7) */
+    float gain, clamp;
+} asd_conv3d_epilogue;
+int64_t asd_conv3d_workspace_bytes(const asd_conv3d_desc* desc, int32_t pass);
+int asd_conv3d_fwd(const asd_conv3d_desc* desc, const float* x, const float* w, int64_t w_sample_stride, float* y,
+                   const asd_conv3d_epilogue* ep /* or NULL */, void* ws, int64_t ws_bytes, void* stream);
+int asd_conv3d_dgrad(const asd_conv3d_desc* desc, const float* dy, const float* w, int64_t w_sample_stride, float* dx, void* ws,
+                     int64_t ws_bytes, void* stream);
+int asd_conv3d_wgrad(const asd_conv3d_desc* desc, const float* x, const float* dy, float* dw /* [N][Cout][Cin][27] */,
+                     int64_t dw_sample_stride, void* ws, int64_t ws_bytes, void* zero_page /* >= 16 B of zeros */, void* stream);
+/* gradient through the layer tail, read off the OUTPUT y: dz = dy * act'(y); d_bias[C] = sum over rows of dz (optional);
+ * d_rowsum[rows] = sum over channels of dz (optional: the gradient of the per-voxel noise term) */
+int asd_layer_act_bwd(const float* dy, const float* y, int64_t rows, int32_t C, float gain, float clamp, float* dz, float* d_bias,
+                      float* d_rowsum, void* stream);
+/* y[N][2r][2r][2r][C] = act(trilinear_2x(x[N][r][r][r][C], align_corners) + noise * ns + bias) + add   (ep and add optional) */
+int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const asd_conv3d_epilogue* ep, const float* add, float* y,
+                       void* stream);
+/* dx = transpose of the upsampling applied to dy; ws: 6 * N * r^3 * C floats */
+int asd_upsample3d_bwd(const float* dy, int32_t N, int32_t r, int32_t C, float* dx, float* ws, void* stream);
 
 /* library info */
 const char* asd_version(void);

@@ -81,7 +81,18 @@ class GemmArgs(C.Structure):
         ("gn_bwd_x", C.c_void_p), ("gn_bwd_fstats", C.c_void_p), ("gn_bwd_gamma", C.c_void_p), ("gn_bwd_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("gn_silu", C.c_int32), ("wide_rows", C.c_int32),
         ("ln_mode", C.c_int32), ("ln_eps", C.c_float), ("ln_sc", C.c_void_p), ("ln_stats", C.c_void_p),
+        ("a_seg_rows", C.c_int32), ("w_seg_rows", C.c_int32), ("a_seg_off", C.c_int32 * 9), ("w_seg_off", C.c_int32 * 3),
+        ("partials_only", C.c_int32),
     ]
+
+
+class Conv3dDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32)]
+
+
+class Conv3dEpilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_strength", C.c_void_p), ("act", C.c_int32), ("gain", C.c_float),
+                ("clamp", C.c_float)]
 
 
 class OptTensor(C.Structure):
@@ -126,6 +137,7 @@ SYMBOLS = [
     "asd_vae_enc_create", "asd_vae_enc_destroy", "asd_vae_enc_num_weights", "asd_vae_enc_weight_info", "asd_vae_enc_bind_weights",
     "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
     "asd_adamw_f32", "asd_adan_f32",
+    "asd_conv3d_workspace_bytes", "asd_conv3d_fwd", "asd_conv3d_dgrad", "asd_conv3d_wgrad", "asd_layer_act_bwd", "asd_upsample3d_fwd", "asd_upsample3d_bwd",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 
@@ -144,7 +156,8 @@ def lib() -> C.CDLL:
         l.asd_version.restype = C.c_char_p
         l.asd_grid_meta_init.restype = C.c_uint32
         l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
-        for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_unet_workspace_bytes_shared", "asd_vae_enc_workspace_bytes"):
+        for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_unet_workspace_bytes_shared", "asd_vae_enc_workspace_bytes",
+                   "asd_conv3d_workspace_bytes"):
             getattr(l, fn).restype = C.c_int64
         l.asd_unet_destroy.restype = None
         l.asd_vae_enc_destroy.restype = None

@@ -130,8 +130,21 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void gemm_f16_kernel(const asd_g
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
         const int slab = wave + j * NW;
-        if (slab >= ASLABS) roff[j] = (unsigned)min(n0 + w_slab_rows(slab - ASLABS) + wl, p.N - 1) * (unsigned)(p.ldw * 2) + lch * 16 + (ks0 + kg) * 128;
-        else roff[j] = CONV ? 0u : (unsigned)min(m0 + slab * 8 + lrow, p.M - 1) * (unsigned)(p.lda * 2) + lch * 16 + (ks0 + kg) * 128;
+        if (slab >= ASLABS) {
+            const int row = min(n0 + w_slab_rows(slab - ASLABS) + wl, p.N - 1);
+            roff[j] = (unsigned)row * (unsigned)(p.ldw * 2) + lch * 16 + (ks0 + kg) * 128;
+            if (!CONV && p.w_seg_rows > 0) {      // segmented rows (asd_gemm_args.w_seg_*): the same rows at another offset along K
+                const int seg = row / p.w_seg_rows;
+                roff[j] = (unsigned)(row - seg * p.w_seg_rows) * (unsigned)(p.ldw * 2) + (unsigned)p.w_seg_off[seg] + lch * 16 + (ks0 + kg) * 128;
+            }
+        } else {
+            const int row = min(m0 + slab * 8 + lrow, p.M - 1);
+            roff[j] = CONV ? 0u : (unsigned)row * (unsigned)(p.lda * 2) + lch * 16 + (ks0 + kg) * 128;
+            if (!CONV && p.a_seg_rows > 0) {
+                const int seg = row / p.a_seg_rows;
+                roff[j] = (unsigned)(row - seg * p.a_seg_rows) * (unsigned)(p.lda * 2) + (unsigned)p.a_seg_off[seg] + lch * 16 + (ks0 + kg) * 128;
+            }
+        }
     }
 
     auto issue_rows = [&](int stage) __attribute__((always_inline)) {
@@ -1136,6 +1149,10 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         ASD_CHECK_ARG(a->Hout > 0 && a->Wout > 0 && a->M % (a->Hout * a->Wout) == 0, "conv: M must be B*Hout*Wout");
     }
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
+    if (a->a_seg_rows > 0 || a->w_seg_rows > 0 || a->partials_only)
+        ASD_CHECK_ARG(!a->conv && a->K % 64 == 0 && a->a_seg_rows >= 0 && a->w_seg_rows >= 0 && (!a->partials_only || a->split_k > 1) &&
+                      (a->a_seg_rows == 0 || (a->M + a->a_seg_rows - 1) / a->a_seg_rows <= 9) && (a->w_seg_rows == 0 || (a->N + a->w_seg_rows - 1) / a->w_seg_rows <= 3),
+                      "segmented rows / partials_only: plain GEMM, K % 64 == 0, at most 9 (A) and 3 (W) segments, split_k > 1 for partials_only");
     ASD_CHECK_ARG((size_t)a->N * a->ldw * 2 < ((size_t)1 << 32) && (a->conv || (size_t)a->M * a->lda * 2 < ((size_t)1 << 32)),
                   "row-major operands are addressed with 32-bit byte offsets (< 4 GiB each)");
     if (a->act == 2)
@@ -1272,7 +1289,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
 #undef GEMM_CASE
 #undef GEMM_CASE_N
 #undef GEMM_LAUNCH
-    if (a->split_k > 1) {
+    if (a->split_k > 1 && !a->partials_only) {
         const size_t total4 = (size_t)a->M * a->N / 4;
         if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, s, *a, a->split_k);
         else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);

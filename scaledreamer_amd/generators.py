@@ -1,6 +1,12 @@
-"""Generator backbones of the multi-prompt configs, stated with library tensor ops — they are dense fp32
-training graphs (forward + weight gradients) whose GEMM / conv3d work belongs to rocBLAS / MIOpen; what this repository
-hand-writes is what CONSUMES their output every sample (samplers.py, the SDF field, the VolSDF renderer).
+"""Generator backbones of the multi-prompt configs.
+
+Generator3D's synthesis network runs on the HIP path (`backend = "hip"`, the default; csrc/conv3d.hip): every 3x3x3 modulated convolution
+— forward, input gradient, weight gradient — is a split-fp16 MFMA kernel (each fp32 operand = two fp16 planes, three products, fp32
+accumulation), the layer tail (noise + bias + leaky-ReLU + clamp) rides in the convolution's epilogue or in the trilinear upsampling
+kernel, and the volumes stay channel-last [N, D, H, W, C] from the constant input to the voxel sampler that consumes the result.  What
+remains library code are the per-sample style / demodulation arithmetic on the weights (a few MB), the mapping network and the
+1x1x1 toRGB projections (plain matrix products on the channel-last view).  `backend = "library"` is the torch-op restatement (depth-sliced
+conv2d through MIOpen): the A/B arm of tools/ and what the CPU golden test runs; it is never selected silently.
 
   Generator3D            custom/amortized/extern/stylegan_3dconv_modules.py:85-344   (StyleGAN2-style 3-D synthesis: mapping
                          network -> modulated 3x3x3 convolutions 4^3 ... 128^3, trilinear upsampling, skip "toRGB" volumes)
@@ -97,6 +103,80 @@ def _upsample2(x):
     return torch.einsum("ad,ncdhw->ncahw", m, x)               # D axis
 
 
+# ---- HIP path: autograd nodes over the C ABI (channel-last fp32 volumes) ------------------------------------------------------------
+def _ops():
+    from . import ops
+    return ops
+
+
+class _Conv3dFn(torch.autograd.Function):
+    """y = act(conv3d(x, w) + noise * ns + bias) with per-sample weights w [N, Cout, Cin, 3, 3, 3]; x, y channel-last [N, D, H, W, C]
+    (include/asd_hip.h: asd_conv3d_fwd / _dgrad / _wgrad, asd_layer_act_bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, noise, ns, act, gain, clamp):
+        y = _ops().conv3d_fwd(x, w, bias, noise, ns, act, gain, clamp)
+        ctx.save_for_backward(x, w, y if act else None, noise)
+        ctx.act, ctx.gain, ctx.clamp, ctx.has_bias, ctx.has_noise = act, gain, clamp, bias is not None, noise is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, noise = ctx.saved_tensors
+        ops = _ops()
+        d_bias = d_ns = None
+        if ctx.act:
+            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise)
+            if ctx.has_noise:
+                d_ns = torch.dot(d_rows, noise.reshape(-1)).reshape(1)
+        else:
+            dz = dy.contiguous()
+        dx = ops.conv3d_dgrad(dz, w, x.shape[4]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv3d_wgrad(x, dz) if ctx.needs_input_grad[1] else None
+        return dx, dw, d_bias, None, d_ns, None, None, None
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """y = act(trilinear_2x(x) + noise * ns + bias) + add on channel-last volumes (asd_upsample3d_fwd / _bwd); `add` (the skip volume's
+    other summand) only without an activation"""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, ns, act, gain, clamp, add):
+        assert not (act and add is not None)
+        y = _ops().upsample3d_fwd(x, bias, noise, ns, act, gain, clamp, add)
+        ctx.save_for_backward(y if act else None, noise)
+        ctx.act, ctx.gain, ctx.clamp, ctx.has_bias, ctx.has_noise, ctx.has_add = act, gain, clamp, bias is not None, noise is not None, add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, noise = ctx.saved_tensors
+        ops = _ops()
+        d_bias = d_ns = None
+        if ctx.act:
+            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise)
+            if ctx.has_noise:
+                d_ns = torch.dot(d_rows, noise.reshape(-1)).reshape(1)
+        else:
+            dz = dy.contiguous()
+        dx = ops.upsample3d_bwd(dz) if ctx.needs_input_grad[0] else None
+        return dx, d_bias, None, d_ns, None, None, None, (dy if ctx.has_add else None)
+
+
+def _conv3d_cl(x, w, bias=None, noise=None, ns=None, act=False, gain=1.0, clamp=0.0):
+    """the convolution node; volumes below 16 x 16 in-plane (the 4^3 and 8^3 levels: 0.1 % of the generator's flops) are zero-padded to the
+    kernel's 16 x 16 patch and cropped, with their layer tail as tensor ops on the cropped volume"""
+    H, W = x.shape[2], x.shape[3]
+    if H % 16 == 0 and W % 16 == 0:
+        return _Conv3dFn.apply(x, w, bias, noise, ns, act, gain, clamp)
+    y = _Conv3dFn.apply(F.pad(x, (0, 0, 0, -W % 16, 0, -H % 16)), w, None, None, None, False, 1.0, 0.0)[:, :, :H, :W]
+    if noise is not None:
+        y = y + (noise * ns)[..., None]
+    if bias is not None:
+        y = y + bias
+    return torch.clamp(F.leaky_relu(y, 0.2) * gain, -clamp, clamp) if act else y
+
+
 class SynthesisLayer(nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, upsample=False):
         super().__init__()
@@ -121,6 +201,25 @@ class SynthesisLayer(nn.Module):
         act_gain = math.sqrt(2) * gain
         return torch.clamp(F.leaky_relu(x + self.bias[None, :, None, None, None], 0.2) * act_gain, -256 * gain, 256 * gain)
 
+    def forward_cl(self, x, w, noise_mode, gain=1):
+        """the same layer on a channel-last volume x [N, D, H, W, Cin] through the HIP nodes"""
+        n, cin = x.shape[0], x.shape[4]
+        styles = self.affine(w)
+        wm = self.weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1, 1)
+        wm = wm * (wm.square().sum(dim=[2, 3, 4, 5]) + 1e-8).rsqrt().reshape(n, -1, 1, 1, 1, 1)
+        r = self.resolution
+        if noise_mode == "random":
+            noise = torch.randn([n, 1, r, r, r], device=x.device).reshape(n, r, r, r)       # (the reference's draw: same shape, same stream position)
+        elif noise_mode == "const":
+            noise = self.noise_const.expand(n, r, r, r).contiguous()
+        else:
+            raise TypeError(f"noise_mode {noise_mode!r}: the reference adds `None` here; only 'random' and 'const' are usable")
+        act_gain, clamp = math.sqrt(2) * gain, 256.0 * gain
+        if self.upsample:
+            y0 = _conv3d_cl(x, wm)
+            return _UpsampleFn.apply(y0, self.bias, noise, self.noise_strength, True, act_gain, clamp, None)
+        return _conv3d_cl(x, wm, self.bias, noise, self.noise_strength, True, act_gain, clamp)
+
 
 class ToRGBLayer(nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1):
@@ -132,6 +231,13 @@ class ToRGBLayer(nn.Module):
 
     def forward(self, x, w):
         return modulated_conv3d(x, self.weight, self.affine(w) * self.weight_gain, demodulate=False) + self.bias[None, :, None, None, None]
+
+    def forward_cl(self, x, w):
+        """channel-last: the 1x1x1 modulated convolution (no demodulation) is a per-sample matrix product on the [voxels, C] view"""
+        n, cin = x.shape[0], x.shape[4]
+        wm = self.weight.reshape(1, -1, cin) * (self.affine(w) * self.weight_gain).reshape(n, 1, cin)      # [N, Cout, Cin]
+        y = torch.baddbmm(self.bias.reshape(1, 1, -1), x.reshape(n, -1, cin), wm.transpose(1, 2))
+        return y.reshape(*x.shape[:4], -1)
 
 
 class SynthesisPrologue(nn.Module):
@@ -146,6 +252,11 @@ class SynthesisPrologue(nn.Module):
         x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1, 1])
         x = self.conv1(x, ws[:, 0], noise_mode=noise_mode)
         return x, self.torgb(x, ws[:, 1])
+
+    def forward_cl(self, ws, noise_mode="random"):
+        x = self.const.permute(1, 2, 3, 0).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1, 1])
+        x = self.conv1.forward_cl(x, ws[:, 0], noise_mode=noise_mode)
+        return x, self.torgb.forward_cl(x, ws[:, 1])
 
 
 class SynthesisBlock(nn.Module):
@@ -165,12 +276,22 @@ class SynthesisBlock(nn.Module):
         x = self.conv1(x, ws[:, 1], noise_mode=noise_mode)
         return x, _upsample2(img) + self.torgb(x, ws[:, 2])
 
+    def forward_cl(self, x, img, ws, noise_mode="random"):
+        x = self.conv0.forward_cl(x, ws[:, 0], noise_mode=noise_mode)
+        if self.const_bias is not None:
+            x = x + self.const_bias.permute(1, 2, 3, 0)
+        x = self.conv1.forward_cl(x, ws[:, 1], noise_mode=noise_mode)
+        return x, _UpsampleFn.apply(img, None, None, None, False, 1.0, 0.0, self.torgb.forward_cl(x, ws[:, 2]))
+
 
 class SynthesisNetwork3D(nn.Module):
     CHANNELS = {4: 512, 8: 512, 16: 512, 32: 256, 64: 128, 128: 64, 256: 32}
 
-    def __init__(self, w_dim, img_resolution, img_channels, channel_multiplier=1, bias_resolution=64):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_multiplier=1, bias_resolution=64, backend="hip"):
         super().__init__()
+        if backend not in ("hip", "library"):
+            raise ValueError(f"unknown generator backend {backend!r}")
+        self.backend = backend
         log2 = int(math.log2(img_resolution))
         self.block_resolutions = [2 ** i for i in range(2, log2 + 1)]
         ch = {r: (c if r <= 16 else c * channel_multiplier) for r, c in self.CHANNELS.items()}
@@ -184,6 +305,14 @@ class SynthesisNetwork3D(nn.Module):
 
     def forward(self, ws, noise_mode="random"):
         # style slices overlap by one (the toRGB style of a block is the first conv style of the next), as in StyleGAN2 (:161)
+        if self.backend == "hip":
+            if not ws.is_cuda:
+                raise RuntimeError("Generator3D(backend='hip') needs device tensors: the HIP path has no CPU fallback "
+                                   "(backend='library' is the explicit torch-op restatement)")
+            x, img = self.first_block.forward_cl(ws[:, 0:2], noise_mode=noise_mode)
+            for i, blk in enumerate(self.blocks):
+                x, img = blk.forward_cl(x, img, ws[:, 2 * (i + 1) + 1: 2 * (i + 1) + 4], noise_mode)
+            return img.permute(0, 4, 1, 2, 3)          # [N, C, D, H, W] view of the channel-last volume (what the voxel sampler reads as is)
         x, img = self.first_block(ws[:, 0:2], noise_mode=noise_mode)
         for i, blk in enumerate(self.blocks):
             x, img = blk(x, img, ws[:, 2 * (i + 1) + 1: 2 * (i + 1) + 4], noise_mode)
@@ -215,11 +344,12 @@ class MappingNetwork(nn.Module):
 
 
 class Generator3D(nn.Module):
-    def __init__(self, z_dim, w_dim, num_layers, img_resolution, img_channels, c_dim=0, channel_multiplier=1, bias_resolution=64, **unused):
+    def __init__(self, z_dim, w_dim, num_layers, img_resolution, img_channels, c_dim=0, channel_multiplier=1, bias_resolution=64,
+                 backend="hip", **unused):
         super().__init__()
         self.z_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, w_dim, img_resolution, img_channels
         self.synthesis = SynthesisNetwork3D(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
-                                            channel_multiplier=channel_multiplier, bias_resolution=bias_resolution)
+                                            channel_multiplier=channel_multiplier, bias_resolution=bias_resolution, backend=backend)
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, num_layers=num_layers)
 

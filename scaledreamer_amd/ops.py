@@ -327,3 +327,116 @@ def triplane_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape, coord_
     check(lib().asd_triplane_sample_bwd(k(d_out), i32(B), i32(H), i32(W), i32(Cc), ptr(points), i32(points.shape[1]),
                                         f32(coord_scale), ptr(d_planes), stream()))
     return d_planes
+
+
+# ---- generator backbone: split-fp16 3x3x3 convolution + layer tail on channel-last fp32 volumes (csrc/conv3d.hip) ----------------------
+_conv3d_ws = {}     # device -> grow-only workspace (uint8); one conv runs at a time on a stream, so the passes share it
+_zero_pages = {}
+
+
+def _ws(device, nbytes: int) -> torch.Tensor:
+    cur = _conv3d_ws.get(device)
+    if cur is None or cur.numel() < nbytes:
+        cur = None
+        _conv3d_ws.pop(device, None)
+        cur = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        _conv3d_ws[device] = cur
+    return cur
+
+
+def _zero_page(device) -> torch.Tensor:
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(64, device=device, dtype=torch.float32)
+    return z
+
+
+def _conv3d_desc(x_shape, cout: int) -> L.Conv3dDesc:
+    N, D, H, W, Cin = x_shape
+    return L.Conv3dDesc(int(N), int(D), int(H), int(W), int(Cin), int(cout))
+
+
+def _epilogue(bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0):
+    """-> (Conv3dEpilogue, tensors to keep alive)"""
+    keep = [_c(t) for t in (bias, noise, noise_strength)]
+    ep = L.Conv3dEpilogue(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), int(bool(act)), float(gain), float(clamp))
+    return ep, keep
+
+
+def conv3d_fwd(x: torch.Tensor, w: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0,
+               clamp: float = 0.0) -> torch.Tensor:
+    """x [N,D,H,W,Cin] fp32 channel-last, w [N,Cout,Cin,3,3,3] (per sample) or [Cout,Cin,3,3,3] -> act(conv + noise * ns + bias) [N,D,H,W,Cout]"""
+    _need_cuda(x, w)
+    x, w = _c(x), _c(w)
+    cout = w.shape[-5]
+    d = _conv3d_desc(x.shape, cout)
+    y = torch.empty((*x.shape[:4], cout), device=x.device, dtype=torch.float32)
+    nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(0))
+    ws = _ws(x.device, nb)
+    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp)
+    stride = cout * x.shape[4] * 27 if w.dim() == 6 else 0
+    check(lib().asd_conv3d_fwd(C.byref(d), ptr(x), ptr(w), C.c_int64(stride), ptr(y), C.byref(ep), ptr(ws), C.c_int64(nb), stream()))
+    return y
+
+
+def conv3d_dgrad(dy: torch.Tensor, w: torch.Tensor, cin: int) -> torch.Tensor:
+    _need_cuda(dy, w)
+    dy, w = _c(dy), _c(w)
+    N, D, H, W, cout = dy.shape
+    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout))
+    dx = torch.empty((N, D, H, W, cin), device=dy.device, dtype=torch.float32)
+    nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(1))
+    ws = _ws(dy.device, nb)
+    stride = cout * cin * 27 if w.dim() == 6 else 0
+    check(lib().asd_conv3d_dgrad(C.byref(d), ptr(dy), ptr(w), C.c_int64(stride), ptr(dx), ptr(ws), C.c_int64(nb), stream()))
+    return dx
+
+
+def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """-> dw [N,Cout,Cin,3,3,3] (one gradient per sample: the modulated convolution has per-sample weights)"""
+    _need_cuda(x, dy)
+    x, dy = _c(x), _c(dy)
+    N, D, H, W, cin = x.shape
+    cout = dy.shape[4]
+    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout))
+    dw = torch.empty((N, cout, cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(2))
+    ws = _ws(x.device, nb)
+    check(lib().asd_conv3d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), C.c_int64(cout * cin * 27), ptr(ws), C.c_int64(nb),
+                                 ptr(_zero_page(x.device)), stream()))
+    return dw
+
+
+def layer_act_bwd(dy: torch.Tensor, y: torch.Tensor, gain: float, clamp: float, want_bias: bool = True, want_rowsum: bool = True):
+    """dz = dy * act'(y) on [..., C]; -> (dz, d_bias [C] | None, d_rowsum [rows] | None)"""
+    dy, y = _c(dy), _c(y)
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    dz = torch.empty_like(y)
+    d_bias = torch.empty(Cc, device=y.device, dtype=torch.float32) if want_bias else None
+    d_rowsum = torch.empty(rows, device=y.device, dtype=torch.float32) if want_rowsum else None
+    check(lib().asd_layer_act_bwd(ptr(dy), ptr(y), C.c_int64(rows), i32(Cc), f32(gain), f32(clamp), ptr(dz), ptr(d_bias), ptr(d_rowsum), stream()))
+    return dz, d_bias, d_rowsum
+
+
+def upsample3d_fwd(x: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0,
+                   add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,r,r,r,C] -> act(trilinear 2x (align_corners) + noise * ns + bias) + add, [N,2r,2r,2r,C]"""
+    _need_cuda(x)
+    x, add = _c(x), _c(add)
+    N, r, r2, r3, Cc = x.shape
+    assert r == r2 == r3, "cubic volumes"
+    y = torch.empty((N, 2 * r, 2 * r, 2 * r, Cc), device=x.device, dtype=torch.float32)
+    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp)
+    check(lib().asd_upsample3d_fwd(ptr(x), i32(N), i32(r), i32(Cc), C.byref(ep), ptr(add), ptr(y), stream()))
+    return y
+
+
+def upsample3d_bwd(dy: torch.Tensor) -> torch.Tensor:
+    dy = _c(dy)
+    N, R, _, _, Cc = dy.shape
+    r = R // 2
+    dx = torch.empty((N, r, r, r, Cc), device=dy.device, dtype=torch.float32)
+    ws = torch.empty(6 * N * r * r * r * Cc, device=dy.device, dtype=torch.float32)
+    check(lib().asd_upsample3d_bwd(ptr(dy), i32(N), i32(r), i32(Cc), ptr(dx), ptr(ws), stream()))
+    return dx

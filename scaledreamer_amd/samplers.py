@@ -56,7 +56,11 @@ def _cached(x: torch.Tensor, make):
 
 
 def channels_last(x: torch.Tensor) -> torch.Tensor:
-    """[B, C, *S] -> [B, *S, C], cached per tensor version (one step samples the same volume several times)."""
+    """[B, C, *S] -> [B, *S, C], cached per tensor version (one step samples the same volume several times).  A tensor that already
+    is channel-last in memory (the HIP generator's output: a permuted view) is handed on as that view — no kernel, no copy."""
+    cl = x.movedim(1, -1)
+    if cl.is_contiguous():
+        return cl
     return _cached(x, _ChannelsLast.apply)
 
 

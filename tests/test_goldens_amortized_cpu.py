@@ -139,28 +139,42 @@ def _seed_params(module, tag, seed, scale=1.0):
             p.copy_(seeded(f"{tag}.{k}", tuple(p.shape), seed, scale))
 
 
-def test_generator3d_matches_reference_stylegan3d():
-    """scaledreamer_amd.generators.Generator3D vs the reference's in-tree `Generator` (same state-dict keys, forward, gradients)"""
+def check_generator3d_golden(device="cpu", backend="library", tol=1.0):
+    """scaledreamer_amd.generators.Generator3D vs the reference's in-tree `Generator` (same state-dict keys, forward, gradients); shared with
+    the GPU test of the HIP backend (tests/test_gpu_conv3d.py)"""
     from scaledreamer_amd.generators import Generator3D
 
     g = _load("amortized_generator3d_16")
     seed = int(g["seed"])
-    gen = Generator3D(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
+    gen = Generator3D(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1, backend=backend)
     assert list(gen.state_dict().keys()) == g["keys"].tolist()
     _seed_params(gen, "gen3d", seed, 0.3)
     with torch.no_grad():
         for m in gen.modules():
             if hasattr(m, "noise_const"):
                 m.noise_const.copy_(seeded("gen3d.noise." + str(tuple(m.noise_const.shape)), tuple(m.noise_const.shape), seed))
-    img = gen(seeded("gen3d.z", (2, 64), seed), seeded("gen3d.c", (2, 1024), seed), noise_mode="const")["image"]
-    np.testing.assert_allclose(img.detach()[:, ::4, ::2, ::2, ::2].numpy(), g["image_sub"], rtol=1e-4, atol=1e-4 * np.abs(g["image_sub"]).max())
-    assert abs(img.double().norm().item() / float(g["image_l2"]) - 1) < 1e-5
-    (img * seeded("gen3d.g", tuple(img.shape), seed)).sum().backward()
+    gen = gen.to(device)
+    img = gen(seeded("gen3d.z", (2, 64), seed).to(device), seeded("gen3d.c", (2, 1024), seed).to(device), noise_mode="const")["image"]
+    np.testing.assert_allclose(img.detach()[:, ::4, ::2, ::2, ::2].cpu().numpy(), g["image_sub"], rtol=1e-4 * tol, atol=1e-4 * tol * np.abs(g["image_sub"]).max())
+    assert abs(img.double().norm().item() / float(g["image_l2"]) - 1) < 1e-5 * tol
+    (img * seeded("gen3d.g", tuple(img.shape), seed).to(device)).sum().backward()
     gr = {k: p.grad for k, p in gen.named_parameters()}
     ref = g["g_affine"]
-    np.testing.assert_allclose(gr["synthesis.blocks.1.conv0.affine.weight"].numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(gr["synthesis.blocks.1.conv0.affine.weight"].cpu().numpy(), ref, rtol=1e-3 * tol, atol=1e-4 * tol * np.abs(ref).max())
     for key, name in (("g_conv_l2", "synthesis.blocks.0.conv1.weight"), ("g_embed_l2", "mapping.embed.weight"), ("g_const_l2", "synthesis.first_block.const")):
-        assert abs(gr[name].double().norm().item() / float(g[key]) - 1) < 1e-4, name
+        assert abs(gr[name].double().norm().item() / float(g[key]) - 1) < 1e-4 * tol, name
+    return gen, gr
+
+
+def test_generator3d_matches_reference_stylegan3d():
+    """the torch-op restatement (backend="library", explicit) against the reference golden; the HIP backend refuses CPU tensors"""
+    check_generator3d_golden("cpu", "library")
+    from scaledreamer_amd.generators import Generator3D
+
+    gen = Generator3D(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32)
+    assert gen.synthesis.backend == "hip"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gen(torch.zeros(1, 64), torch.zeros(1, 1024), noise_mode="const")
 
 
 @pytest.mark.parametrize("local", [1, 0])

@@ -1,0 +1,153 @@
+"""GPU parity of the generator backbone's HIP path (csrc/conv3d.hip), through the C ABI: the split-fp16 3x3x3 convolution
+— forward, input gradient, weight gradient — against float64 F.conv3d (and next to the fp32 library path's own error), the layer tail and
+the trilinear upsampling against torch autograd, and the whole Generator3D against the golden of the reference's own `Generator`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):          # [N, C, D, H, W] -> channel-last [N, D, H, W, C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+@pytest.mark.parametrize("N,D,H,W,cin,cout", [(1, 6, 32, 32, 64, 64), (2, 5, 16, 32, 128, 64), (1, 4, 16, 16, 64, 128), (1, 3, 16, 16, 192, 256)])
+def test_conv3d_forward_input_gradient_weight_gradient_vs_float64(N, D, H, W, cin, cout):
+    from scaledreamer_amd import ops
+
+    g = torch.Generator().manual_seed(N * 1000 + cin + cout)
+    x = torch.randn(N, cin, D, H, W, generator=g) * torch.rand(N, cin, 1, 1, 1, generator=g) * 3          # uneven channel magnitudes
+    w = torch.randn(N, cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    dy = torch.randn(N, cout, D, H, W, generator=g) * 1e-4                                                  # gradients are small numbers
+    x64, w64, dy64 = x.double().requires_grad_(True), w.double().requires_grad_(True), dy.double()
+    y64 = torch.cat([F.conv3d(x64[n:n + 1], w64[n], padding=1) for n in range(N)])
+    y64.backward(dy64)
+    xd, wd, dyd = _cl(x).cuda(), w.cuda(), _cl(dy).cuda()
+    y = ops.conv3d_fwd(xd, wd)
+    dx = ops.conv3d_dgrad(dyd, wd, cin)
+    dw = ops.conv3d_wgrad(xd, dyd)
+    torch.cuda.synchronize()
+    e_y, e_dx, e_dw = _relerr(_cf(y.cpu()), y64.detach()), _relerr(_cf(dx.cpu()), x64.grad), _relerr(dw.cpu(), w64.grad)
+    # the fp32 library path on the same problem (what the reference runs): its error against float64 is the yardstick
+    y32 = torch.cat([F.conv3d(x[n:n + 1].cuda(), w[n].cuda(), padding=1) for n in range(N)]).cpu()
+    e_lib = _relerr(y32, y64.detach())
+    print(f"conv3d {cin}->{cout} @ {D}x{H}x{W}: rel. error vs float64  fwd {e_y:.2e}  dgrad {e_dx:.2e}  wgrad {e_dw:.2e}   (library fp32 fwd {e_lib:.2e})")
+    # split-fp16: 2^-22 per operand + fp32 accumulation over K = 27 cin terms
+    assert e_y < 3e-6 and e_dx < 3e-6 and e_dw < 3e-6
+    assert e_y < max(4 * e_lib, 1e-6)
+
+
+def test_conv3d_fused_layer_tail_and_its_gradient():
+    from scaledreamer_amd import ops
+    from scaledreamer_amd.generators import _Conv3dFn
+
+    g = torch.Generator().manual_seed(7)
+    N, D, H, W, cin, cout = 1, 4, 16, 16, 64, 64
+    x = (torch.randn(N, D, H, W, cin, generator=g)).cuda().requires_grad_(True)
+    w = (torch.randn(N, cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5 * 150).cuda().requires_grad_(True)     # large: some outputs reach the clamp
+    bias = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    noise = torch.randn(N, D, H, W, generator=g).cuda()
+    ns = torch.tensor([0.7]).cuda().requires_grad_(True)
+    gain, clamp = 2 ** 0.5, 256.0
+    y = _Conv3dFn.apply(x, w, bias, noise, ns, True, gain, clamp)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, w, bias, ns)]
+    for t in (x, w, bias, ns):
+        t.grad = None
+    x64, w64, b64, ns64 = (t.detach().double().requires_grad_(True) for t in (x, w, bias, ns))
+    z = F.conv3d(x64.permute(0, 4, 1, 2, 3), w64[0], padding=1).permute(0, 2, 3, 4, 1) + (noise.double() * ns64)[..., None] + b64
+    ref = torch.clamp(F.leaky_relu(z, 0.2) * gain, -clamp, clamp)
+    assert float((ref.abs() >= clamp).float().mean()) > 1e-4, "the test must exercise the clamp"
+    ref.backward(gy.double())
+    assert _relerr(y, ref.detach()) < 3e-6
+    for a, b, name in zip(got, (x64.grad, w64.grad, b64.grad, ns64.grad), ("dx", "dw", "d_bias", "d_noise_strength")):
+        assert _relerr(a, b) < 2e-5, name        # (elements within 1e-6 of the kink / clamp may take the other branch)
+
+
+@pytest.mark.parametrize("r,C", [(4, 512), (8, 64), (16, 32)])
+def test_upsample_matches_trilinear_align_corners_and_its_transpose(r, C):
+    from scaledreamer_amd.generators import _UpsampleFn
+
+    g = torch.Generator().manual_seed(r)
+    x = torch.randn(2, r, r, r, C, generator=g).cuda().requires_grad_(True)
+    bias = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    noise = torch.randn(2, 2 * r, 2 * r, 2 * r, generator=g).cuda()
+    ns = torch.tensor([0.3]).cuda().requires_grad_(True)
+    add = torch.randn(2, 2 * r, 2 * r, 2 * r, C, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(2, 2 * r, 2 * r, 2 * r, C, generator=g).cuda()
+
+    def ref(x_, bias_, ns_, add_, act):
+        up = F.interpolate(x_.permute(0, 4, 1, 2, 3), scale_factor=2, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
+        if act:
+            return torch.clamp(F.leaky_relu(up + (noise * ns_)[..., None] + bias_, 0.2) * 1.4142135, -256, 256)
+        return up + add_
+
+    for act in (True, False):
+        y = _UpsampleFn.apply(x, bias if act else None, noise if act else None, ns if act else None, act, 1.4142135, 256.0, None if act else add)
+        y.backward(gy)
+        got = {k: t.grad.clone() for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)) if t.grad is not None}
+        for t in (x, bias, ns, add):
+            t.grad = None
+        yr = ref(x, bias, ns, add, act)
+        yr.backward(gy)
+        assert _relerr(y, yr.detach()) < 2e-6
+        for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)):
+            if t.grad is not None:
+                assert _relerr(got[k], t.grad) < 2e-5, (act, k)
+            t.grad = None
+
+
+def test_generator3d_hip_backend_matches_reference_golden():
+    """Generator3D(backend="hip") — every 3x3x3 convolution forward / input gradient / weight gradient through csrc/conv3d.hip, the
+    4^3 and 8^3 levels through the padded-patch path — against the golden of the reference's own `Generator` (forward sub-sampled image,
+    its norm, parameter gradients)"""
+    from test_goldens_amortized_cpu import check_generator3d_golden
+
+    check_generator3d_golden("cuda", "hip", tol=2.0)
+
+
+def test_conv3d_full_size_layer_sampled_against_float64():
+    """the generator's largest layer (64 -> 64 channels at 128^3: 464 GFLOP per pass) at full size: 512 random outputs of the forward and the input
+    gradient and 8 x 27 entries of the weight gradient (each a sum over all 2 M voxels) against float64"""
+    from scaledreamer_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    R, Cc = 128, 64
+    x = torch.randn(1, R, R, R, Cc, device="cuda", generator=g).clamp_(-3, 3) * 5
+    w = torch.randn(1, Cc, Cc, 3, 3, 3, device="cuda", generator=g) / (27 * Cc) ** 0.5
+    dy = torch.randn(1, R, R, R, Cc, device="cuda", generator=g) * 1e-5
+    y = ops.conv3d_fwd(x, w)
+    dx = ops.conv3d_dgrad(dy, w, Cc)
+    dw = ops.conv3d_wgrad(x, dy)
+    xp = F.pad(x[0], (0, 0, 1, 1, 1, 1, 1, 1)).double()            # [R+2, R+2, R+2, C]
+    dyp = F.pad(dy[0], (0, 0, 1, 1, 1, 1, 1, 1)).double()
+    w64 = w[0].double()                                            # [co, ci, kd, ky, kx]
+    idx = torch.randint(0, R, (512, 3), device="cuda", generator=g)
+    idx[:8] = torch.tensor([[0, 0, 0], [R - 1, R - 1, R - 1], [0, R - 1, 5], [7, 0, R - 1], [R - 1, 3, 0], [64, 64, 64], [1, 1, 1], [0, 64, 0]], device="cuda")
+    scale_y, scale_dx = float(y.abs().max()), float(dx.abs().max())
+    for (d, h, ww) in idx.tolist():
+        win = xp[d:d + 3, h:h + 3, ww:ww + 3]                      # [3,3,3,ci]
+        ref = torch.einsum("dhwi,oidhw->o", win, w64)
+        assert float((y[0, d, h, ww].double() - ref).abs().max()) < 3e-6 * scale_y
+        gwin = dyp[d:d + 3, h:h + 3, ww:ww + 3].flip(0, 1, 2)      # dx[v] = sum_tap dy[v - off(tap)] w[:, :, tap]
+        refd = torch.einsum("dhwo,oidhw->i", gwin, w64)
+        assert float((dx[0, d, h, ww].double() - refd).abs().max()) < 3e-6 * scale_dx
+    scale_dw = float(dw.abs().max())
+    for co, ci in [(0, 0), (63, 63), (5, 40), (40, 5), (17, 17), (1, 62), (33, 2), (60, 31)]:
+        gy = dy[0, ..., co].double()
+        for kd in range(3):
+            for ky in range(3):
+                for kx in range(3):
+                    ref = float((gy * xp[kd:kd + R, ky:ky + R, kx:kx + R, ci]).sum())
+                    assert abs(float(dw[0, co, ci, kd, ky, kx]) - ref) < 3e-6 * scale_dw, (co, ci, kd, ky, kx)

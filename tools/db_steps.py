@@ -8,7 +8,10 @@ nlast = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 10
 c = sqlite3.connect(db)
 rows = c.execute("select start, end, name from kernels order by start").fetchall()
 short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "")).replace("at::native::", "")[:64]
-starts = [i for i, r in enumerate(rows) if "march_kernel" in r[2]]
+# --marker NAME: the kernel that opens a step (default the marcher; the amortized workloads have none: use e.g. score_fwd_kernel,
+# which runs once per step — the step boundaries are then shifted, the per-step sums are not)
+marker = sys.argv[sys.argv.index("--marker") + 1] if "--marker" in sys.argv else "march_kernel"
+starts = [i for i, r in enumerate(rows) if marker in r[2]]
 starts = [s for k, s in enumerate(starts) if k == 0 or s - starts[k - 1] > 50]
 # bench.py: the steps are followed by roofline micro-benchmarks that also march; use --skip-last S to stay inside the timed region
 skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0
