@@ -532,13 +532,19 @@ int asd_adan_f32(const asd_opt_tensor* tensors, int32_t n_tensors, float beta1, 
  * 2 weight gradient; the caller owns it.
  * ---------------------------------------------------------------------------------------------- */
 #define ASD_CONV3D_WGRAD_MAX_SPLIT 64
-typedef struct asd_conv3d_desc { int32_t N, D, H, W, Cin, Cout; } asd_conv3d_desc;
+typedef struct asd_conv3d_desc {
+    int32_t N, D, H, W, Cin, Cout;
+    /* optional: bit pattern of max|x| / max|dy| over the whole tensor when its producer already left it (asd_conv3d_epilogue.amax_out,
+     * asd_layer_act_bwd); NULL = one extra pass over the tensor in here.  Only their binary exponent is used (the split scale). */
+    const uint32_t* amax_x; const uint32_t* amax_dy;
+} asd_conv3d_desc;
 typedef struct asd_conv3d_epilogue {      /* y = act(conv + noise[voxel] * *noise_strength + bias[c]) */
     const float* bias;            /* [C] or NULL */
     const float* noise;           /* [N*D*H*W] or NULL */
     const float* noise_strength;  /* device scalar (the layer's parameter); required with noise */
     int32_t act;                  /* 0: none; 1: clamp(leaky_relu(v, 0.2) * gain, -clamp, clamp)  (clamp_gain, :5-7) */
     float gain, clamp;
+    uint32_t* amax_out;           /* optional: receives max|y| as a bit pattern (atomicMax: zero it first) for the consumer's asd_conv3d_desc.amax_x */
 } asd_conv3d_epilogue;
 int64_t asd_conv3d_workspace_bytes(const asd_conv3d_desc* desc, int32_t pass);
 int asd_conv3d_fwd(const asd_conv3d_desc* desc, const float* x, const float* w, int64_t w_sample_stride, float* y,
@@ -547,10 +553,20 @@ int asd_conv3d_dgrad(const asd_conv3d_desc* desc, const float* dy, const float* 
                      int64_t ws_bytes, void* stream);
 int asd_conv3d_wgrad(const asd_conv3d_desc* desc, const float* x, const float* dy, float* dw /* [N][Cout][Cin][27] */,
                      int64_t dw_sample_stride, void* ws, int64_t ws_bytes, void* zero_page /* >= 16 B of zeros */, void* stream);
-/* gradient through the layer tail, read off the OUTPUT y: dz = dy * act'(y); d_bias[C] = sum over rows of dz (optional);
- * d_rowsum[rows] = sum over channels of dz (optional: the gradient of the per-voxel noise term) */
-int asd_layer_act_bwd(const float* dy, const float* y, int64_t rows, int32_t C, float gain, float clamp, float* dz, float* d_bias,
-                      float* d_rowsum, void* stream);
+/* gradient through the layer tail, read off the OUTPUT y (minus `sub` when the layer output was act(.) + sub): dz = dy * act'(y - sub);
+ * d_bias[C] = sum over rows of dz (optional); d_rowsum[rows] = sum over channels of dz (optional: the gradient of the per-voxel noise
+ * term); amax_out (optional, zeroed by the caller): max|dz| for asd_conv3d_desc.amax_dy */
+int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t rows, int32_t C, float gain, float clamp, float* dz,
+                      float* d_bias, float* d_rowsum, uint32_t* amax_out, void* stream);
+/* *amax_out = max(*amax_out, bit pattern of max|x|) over n floats (n % 4 == 0): for tensors whose producer left no such word */
+int asd_absmax_f32(const float* x, int64_t n, uint32_t* amax_out, void* stream);
+/* toRGB (ToRGBLayer, :283-296: 1x1x1 modulated convolution onto the 32-channel skip volume) on channel-last rows, exact fp32:
+ * y[rows][32] = x[rows][Cin] w[32][Cin]^T + bias + add (add optional: the upsampled skip volume); amax_out as above.
+ * bwd: dx = dy w (+ dx_add), dw[32][Cin] = dy^T x, d_bias[32] = column sums of dy — each optional (NULL skips it). */
+int asd_torgb_fwd(const float* x, int64_t rows, int32_t Cin, const float* w, const float* bias, const float* add, float* y,
+                  uint32_t* amax_out, void* stream);
+int asd_torgb_bwd(const float* x, const float* dy, int64_t rows, int32_t Cin, const float* w, const float* dx_add, float* dx, float* dw,
+                  float* d_bias, void* stream);
 /* y[N][2r][2r][2r][C] = act(trilinear_2x(x[N][r][r][r][C], align_corners) + noise * ns + bias) + add   (ep and add optional) */
 int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const asd_conv3d_epilogue* ep, const float* add, float* y,
                        void* stream);

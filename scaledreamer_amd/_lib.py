@@ -87,12 +87,13 @@ class GemmArgs(C.Structure):
 
 
 class Conv3dDesc(C.Structure):
-    _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32)]
+    _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("amax_x", C.c_void_p), ("amax_dy", C.c_void_p)]
 
 
 class Conv3dEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_strength", C.c_void_p), ("act", C.c_int32), ("gain", C.c_float),
-                ("clamp", C.c_float)]
+                ("clamp", C.c_float), ("amax_out", C.c_void_p)]
 
 
 class OptTensor(C.Structure):
@@ -138,6 +139,7 @@ SYMBOLS = [
     "asd_vae_enc_workspace_bytes", "asd_vae_enc_fwd", "asd_vae_enc_bwd",
     "asd_adamw_f32", "asd_adan_f32",
     "asd_conv3d_workspace_bytes", "asd_conv3d_fwd", "asd_conv3d_dgrad", "asd_conv3d_wgrad", "asd_layer_act_bwd", "asd_upsample3d_fwd", "asd_upsample3d_bwd",
+    "asd_torgb_fwd", "asd_torgb_bwd", "asd_absmax_f32",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 

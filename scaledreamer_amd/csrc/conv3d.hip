@@ -38,15 +38,26 @@ __device__ __forceinline__ void split2(float v, half_t& hi, half_t& lo) {
     lo = (half_t)(v - (float)hi);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const floatx4 v = *(const floatx4*)(x + 4 * i);
-        m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
-    }
+__device__ __forceinline__ float abs4max(const floatx4 v, float m) {
+    return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
+}
+// one atomicMax per wave of the bit pattern of max|.| (callers zero *out first)
+__device__ __forceinline__ void wave_amax_commit(float m, unsigned* out) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight
+        const floatx4 a = *(const floatx4*)(x + 4 * i), b = *(const floatx4*)(x + 4 * (i + stride));
+        const floatx4 c = *(const floatx4*)(x + 4 * (i + 2 * stride)), d = *(const floatx4*)(x + 4 * (i + 3 * stride));
+        m = abs4max(a, abs4max(b, abs4max(c, abs4max(d, m))));
+    }
+    for (; i < n4; i += stride) m = abs4max(*(const floatx4*)(x + 4 * i), m);
+    wave_amax_commit(m, out);
 }
 
 // x fp32 [rows][C] -> hi / lo fp16 [rows][C] (channel-last volume: rows = voxels), 8 channels per thread
@@ -144,6 +155,7 @@ struct conv3d_kargs {
     const float* noise_strength;
     int act;                                // 0: none; 1: clamp(lrelu(v, 0.2) * gain, +-clamp)
     float gain, clamp;
+    unsigned* amax_out;                     // optional: max|y| (bit pattern, atomicMax) for the consumer's split
     int group_m, group_n;
 };
 
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(512) void conv3d_pp_kernel(const conv3d_kargs p) {
     // ---- epilogue: acc[i][j][r] = Y[voxel (b, y0 + wm*TM + i, x0 + (lane&15))][n0 + wn*TN*16 + j*16 + (lane>>4)*4 + r] ------------------
     const float inv = 1.f / (split_scale(*p.amax_x) * split_scale(*p.amax_w));
     const float ns = p.noise ? *p.noise_strength : 0.f;
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const size_t m = ((size_t)b * H + y0 + wm * TM + i) * Wd + x0 + fi;
@@ -368,9 +381,11 @@ __global__ __launch_bounds__(512) void conv3d_pp_kernel(const conv3d_kargs p) {
                 }
                 v[r] = u;
             }
+            am = abs4max(v, am);
             *(floatx4*)(p.y + m * p.ldc + n) = v;
         }
     }
+    if (p.amax_out) wave_amax_commit(am, p.amax_out);
 }
 
 // ---- weight gradient: reduction of the split-K slabs of the three products -----------------------------------------------------------
@@ -393,8 +408,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // gradient through the layer's activation: y = clamp(lrelu(z) * gain, +-clamp), z = conv + noise * ns + bias.  dz = dy * act'(y), read off
 // the OUTPUT (sign(y) = sign(z); |y| == clamp where the clamp cut).  Also leaves d_bias[c] = sum_rows dz (atomics of block partials) and
 // d_noise[row] = sum_c dz (the gradient of noise * ns w.r.t. the per-voxel term; the caller contracts it with the noise it drew).
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t rows, int C, float gain, float clamp,
-                                                      float* __restrict__ dz, float* __restrict__ d_bias, float* __restrict__ d_rowsum) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ sub, size_t rows, int C,
+                                                      float gain, float clamp, float* __restrict__ dz, float* __restrict__ d_bias, float* __restrict__ d_rowsum,
+                                                      unsigned* __restrict__ amax_out) {
     extern __shared__ float cb[];                     // [C] block partial of d_bias
     for (int c = threadIdx.x; c < C; c += 256) cb[c] = 0.f;
     __syncthreads();
@@ -402,11 +418,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     const int rpb = 256 / tpr;                        // rows per block pass
     const int c = (threadIdx.x % tpr) * 4, rr = threadIdx.x / tpr;
     floatx4 bs = {0.f, 0.f, 0.f, 0.f};
+    float am = 0.f;
     for (size_t r0 = (size_t)blockIdx.x * rpb; r0 < rows; r0 += (size_t)gridDim.x * rpb) {
         const size_t r = r0 + rr;
         float rs = 0.f;
         if (r < rows) {
-            const floatx4 g = *(const floatx4*)(dy + r * C + c), o = *(const floatx4*)(y + r * C + c);
+            const floatx4 g = *(const floatx4*)(dy + r * C + c);
+            floatx4 o = *(const floatx4*)(y + r * C + c);
+            if (sub) {        // y = act(.) + sub: the activation's own output
+                const floatx4 sb = *(const floatx4*)(sub + r * C + c);
+                o[0] -= sb[0]; o[1] -= sb[1]; o[2] -= sb[2]; o[3] -= sb[3];
+            }
             floatx4 z;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -415,6 +437,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 rs += z[k];
                 bs[k] += z[k];
             }
+            am = abs4max(z, am);
             *(floatx4*)(dz + r * C + c) = z;
         }
         if (d_rowsum) {
@@ -426,6 +449,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             }
         }
     }
+    if (amax_out) wave_amax_commit(am, amax_out);
 #pragma unroll
     for (int k = 0; k < 4; ++k) atomicAdd(&cb[c + k], bs[k]);
     __syncthreads();
@@ -447,11 +471,12 @@ __device__ __forceinline__ float layer_act(float u, int act, float gain, float c
 // source coordinate of output index a: a * (r - 1) / (2 r - 1)
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int N, int r, int C, const float* __restrict__ noise,
                                                            const float* __restrict__ noise_strength, const float* __restrict__ bias, int act, float gain,
-                                                           float clamp, const float* __restrict__ add, float* __restrict__ y) {
+                                                           float clamp, const float* __restrict__ add, float* __restrict__ y, unsigned* __restrict__ amax_out) {
     const int R = 2 * r, c4 = C / 4;
     const size_t total = (size_t)N * R * R * R * c4;
     const float sc = (float)(r - 1) / (float)(R - 1);
     const float ns = noise ? *noise_strength : 0.f;
+    float am = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % c4) * 4;
         size_t v = i / c4;
@@ -481,8 +506,10 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         if (add) ad = *(const floatx4*)(add + row * C + c);
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = layer_act(o[q] + nz + bb[q], act, gain, clamp) + ad[q];
+        am = abs4max(o, am);
         *(floatx4*)(y + row * C + c) = o;
     }
+    if (amax_out) wave_amax_commit(am, amax_out);
 }
 
 // transpose of the 1-D interpolation along one axis: dx [outer][r][inner] from dy [outer][2 r][inner] (three passes undo the upsampling).
@@ -512,6 +539,121 @@ __global__ __launch_bounds__(256) void upsample1d_bwd_kernel(const float* __rest
             }
         }
         *(floatx4*)(dx + ((o * r + i) * inner4 + in) * 4) = acc;
+    }
+}
+
+
+// ---- toRGB: the 1x1x1 modulated convolution onto the 32-channel skip volume (ToRGBLayer, stylegan_3dconv_modules.py:283-296) ---------------
+// y[v][o] = sum_i x[v][i] w[o][i] + b[o] on channel-last rows, exact fp32 (v_fmac chains; HBM-bound: K = Cin <= 512 against 4 (Cin + 32) bytes per
+// voxel).  Block = 64 voxels x 32 outputs: the x tile goes through LDS (coalesced 16-byte loads, conflict-free 16-byte reads at a pitch of
+// 132 floats), wave q owns outputs 8 q .. 8 q + 7 whose weights are wave-uniform (scalar loads), lane = voxel.
+#define TORGB_O 32
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, size_t rows, int Cin, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ add, float* __restrict__ y, unsigned* __restrict__ amax_out) {
+    __shared__ __attribute__((aligned(16))) float xs[64][132];
+    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t v0 = (size_t)blockIdx.x * 64;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = bias ? bias[8 * q + k] : 0.f;
+    for (int k0 = 0; k0 < Cin; k0 += 128) {
+        const int kw = min(128, Cin - k0);                   // Cin % 32 == 0
+        __syncthreads();
+        for (int t = threadIdx.x; t < 64 * (kw / 4); t += 256) {
+            const int r = t / (kw / 4), c = (t - r * (kw / 4)) * 4;
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + r < rows) v = *(const floatx4*)(x + (v0 + r) * Cin + k0 + c);
+            *(floatx4*)&xs[r][c] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < kw; c += 4) {
+            const floatx4 xv = *(const floatx4*)&xs[lane][c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* wr = w + (size_t)(8 * q + k) * Cin + k0 + c;        // wave-uniform
+                acc[k] = fmaf(xv[0], wr[0], acc[k]); acc[k] = fmaf(xv[1], wr[1], acc[k]);
+                acc[k] = fmaf(xv[2], wr[2], acc[k]); acc[k] = fmaf(xv[3], wr[3], acc[k]);
+            }
+        }
+    }
+    float am = 0.f;
+    if (v0 + lane < rows) {
+        float* dst = y + (v0 + lane) * TORGB_O + 8 * q;
+        floatx4 a = {acc[0], acc[1], acc[2], acc[3]}, b = {acc[4], acc[5], acc[6], acc[7]};
+        if (add) {
+            const floatx4 p0 = *(const floatx4*)(add + (v0 + lane) * TORGB_O + 8 * q), p1 = *(const floatx4*)(add + (v0 + lane) * TORGB_O + 8 * q + 4);
+            a[0] += p0[0]; a[1] += p0[1]; a[2] += p0[2]; a[3] += p0[3]; b[0] += p1[0]; b[1] += p1[1]; b[2] += p1[2]; b[3] += p1[3];
+        }
+        am = abs4max(a, abs4max(b, 0.f));
+        *(floatx4*)dst = a; *(floatx4*)(dst + 4) = b;
+    }
+    if (amax_out) wave_amax_commit(am, amax_out);
+}
+// dx[v][i] (+)= sum_o dy[v][o] w[o][i]: lane = voxel, wave q owns 16 input channels per pass; dy row (32 floats) through LDS
+__global__ __launch_bounds__(256) void torgb_dgrad_kernel(const float* __restrict__ dy, size_t rows, int Cin, const float* __restrict__ w, const float* __restrict__ dx_add,
+                                                          float* __restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float gs[64][36];
+    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t v0 = (size_t)blockIdx.x * 64;
+    for (int t = threadIdx.x; t < 64 * 8; t += 256) {
+        const int r = t >> 3, c = (t & 7) * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (v0 + r < rows) v = *(const floatx4*)(dy + (v0 + r) * TORGB_O + c);
+        *(floatx4*)&gs[r][c] = v;
+    }
+    __syncthreads();
+    for (int i0 = 16 * q; i0 < Cin; i0 += 64) {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int o = 0; o < TORGB_O; o += 4) {
+            const floatx4 g = *(const floatx4*)&gs[lane][o];
+#pragma unroll
+            for (int oo = 0; oo < 4; ++oo) {
+                const float* wr = w + (size_t)(o + oo) * Cin + i0;                  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = fmaf(g[oo], wr[k], acc[k]);
+            }
+        }
+        if (v0 + lane < rows) {
+            float* dst = dx + (v0 + lane) * Cin + i0;
+            const float* ad = dx_add ? dx_add + (v0 + lane) * Cin + i0 : nullptr;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                floatx4 o4 = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                if (ad) { const floatx4 p = *(const floatx4*)(ad + k); o4[0] += p[0]; o4[1] += p[1]; o4[2] += p[2]; o4[3] += p[3]; }
+                *(floatx4*)(dst + k) = o4;
+            }
+        }
+    }
+}
+// dw[o][i] += sum_v dy[v][o] x[v][i] over this block's voxels (atomics of the block totals; dw zeroed by the caller); d_bias[o] += sum_v dy[v][o].
+// lane = input channel i0 + lane (coalesced reads of x), wave q owns outputs 8 q .. 8 q + 7 (dy values wave-uniform: scalar loads)
+__global__ __launch_bounds__(256) void torgb_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, size_t rows, int Cin, size_t rows_per_block,
+                                                          float* __restrict__ dw, float* __restrict__ d_bias) {
+    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int i0 = 0; i0 < Cin; i0 += 64) {
+        const int i = i0 + lane;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        if (i < Cin) {
+#pragma unroll 4
+            for (size_t r = r0; r < r1; ++r) {
+                const float xv = x[r * Cin + i];
+                const float* g = dy + r * TORGB_O + 8 * q;                           // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(xv, g[k], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(dw + (size_t)(8 * q + k) * Cin + i, acc[k]);
+        }
+    }
+    if (d_bias && lane < 8) {
+        float sb = 0.f;
+        for (size_t r = r0; r < r1; ++r) sb += dy[r * TORGB_O + 8 * q + lane];
+        atomicAdd(d_bias + 8 * q + lane, sb);
     }
 }
 
@@ -565,8 +707,8 @@ static int c3_check(const asd_conv3d_desc* d) {
 }
 
 // one sample of the forward form: y[D,H,W,cout] = conv(x[D,H,W,cin], w[cout][cin][27] (transpose: w is [cin][cout][27], mirrored))
-static int c3_run(int D, int H, int W, int cin, int cout, const float* x, const float* w, int transpose_w, float* y, const asd_conv3d_epilogue* ep,
-                  size_t noise_off, char* ws, hipStream_t s) {
+static int c3_run(int D, int H, int W, int cin, int cout, const float* x, const unsigned* amax_x, const float* w, int transpose_w, float* y,
+                  const asd_conv3d_epilogue* ep, size_t noise_off, char* ws, hipStream_t s) {
     const size_t vox = (size_t)D * H * W;
     unsigned* amax = (unsigned*)ws;                                   // [0] x, [1] w
     half_t* xh = (half_t*)(ws + 256);
@@ -574,15 +716,19 @@ static int c3_run(int D, int H, int W, int cin, int cout, const float* x, const 
     half_t* wh = (half_t*)((char*)xl + al256(vox * cin * 2));
     half_t* wl = (half_t*)((char*)wh + al256((size_t)cout * 27 * cin * 2));
     (void)hipMemsetAsync(amax, 0, 8, s);
-    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * cin / 4)), dim3(256), 0, s, x, vox * cin / 4, amax);
-    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid((size_t)cout * cin * 27 / 4)), dim3(256), 0, s, w, (size_t)cout * cin * 27 / 4, amax + 1);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(c3_grid(vox * cin / 8)), dim3(256), 0, s, x, vox * cin / 8, amax, xh, xl);
+    if (!amax_x) {
+        hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * cin / 16)), dim3(256), 0, s, x, vox * cin / 4, amax);
+        amax_x = amax;
+    }
+    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid((size_t)cout * cin * 27 / 16)), dim3(256), 0, s, w, (size_t)cout * cin * 27 / 4, amax + 1);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(c3_grid(vox * cin / 8)), dim3(256), 0, s, x, vox * cin / 8, amax_x, xh, xl);
     hipLaunchKernelGGL(pack_w_kernel, dim3(c3_grid((size_t)cout * cin * 27)), dim3(256), 0, s, w, transpose_w ? cin : cout, transpose_w ? cout : cin,
                        transpose_w, amax + 1, wh, wl);
     conv3d_kargs k;
     k.x_hi = (const char*)xh; k.x_lo = (const char*)xl; k.w_hi = (const char*)wh; k.w_lo = (const char*)wl;
     k.y = y; k.N = 1; k.D = D; k.H = H; k.W = W; k.Cin = cin; k.Cout = cout; k.ldc = cout;
-    k.amax_x = amax; k.amax_w = amax + 1;
+    k.amax_x = amax_x; k.amax_w = amax + 1;
+    k.amax_out = ep ? ep->amax_out : nullptr;
     k.bias = ep ? ep->bias : nullptr;
     k.noise = ep && ep->noise ? ep->noise + noise_off : nullptr;
     k.noise_strength = ep ? ep->noise_strength : nullptr;
@@ -617,8 +763,8 @@ int asd_conv3d_fwd(const asd_conv3d_desc* d, const float* x, const float* w, int
     ASD_CHECK_ARG(!ep || (ep->act >= 0 && ep->act <= 1 && (!ep->noise || ep->noise_strength)), "bad epilogue");
     const size_t vox = (size_t)d->D * d->H * d->W;
     for (int n = 0; n < d->N; ++n)
-        c3_run(d->D, d->H, d->W, d->Cin, d->Cout, x + n * vox * d->Cin, w + (size_t)n * w_sample_stride, 0, y + n * vox * d->Cout, ep, n * vox, (char*)ws,
-               (hipStream_t)stream);
+        c3_run(d->D, d->H, d->W, d->Cin, d->Cout, x + n * vox * d->Cin, d->amax_x, w + (size_t)n * w_sample_stride, 0, y + n * vox * d->Cout, ep, n * vox,
+               (char*)ws, (hipStream_t)stream);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -629,8 +775,8 @@ int asd_conv3d_dgrad(const asd_conv3d_desc* d, const float* dy, const float* w, 
     ASD_CHECK_ARG(dy && w && dx && ws && ws_bytes >= asd_conv3d_workspace_bytes(d, 1), "null argument / workspace too small");
     const size_t vox = (size_t)d->D * d->H * d->W;
     for (int n = 0; n < d->N; ++n)
-        c3_run(d->D, d->H, d->W, d->Cout, d->Cin, dy + n * vox * d->Cout, w + (size_t)n * w_sample_stride, 1, dx + n * vox * d->Cin, nullptr, 0, (char*)ws,
-               (hipStream_t)stream);
+        c3_run(d->D, d->H, d->W, d->Cout, d->Cin, dy + n * vox * d->Cout, d->amax_dy, w + (size_t)n * w_sample_stride, 1, dx + n * vox * d->Cin, nullptr, 0,
+               (char*)ws, (hipStream_t)stream);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -657,8 +803,10 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
     const int split = c3_wgrad_split(d, l.ld);
     for (int n = 0; n < d->N; ++n) {
         (void)hipMemsetAsync(amax, 0, 8, s);
-        hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cin / 4)), dim3(256), 0, s, x + n * vox * Cin, vox * Cin / 4, amax);
-        hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cout / 4)), dim3(256), 0, s, dy + n * vox * Cout, vox * Cout / 4, amax + 1);
+        const unsigned* ax = d->amax_x ? d->amax_x : amax;
+        const unsigned* ay = d->amax_dy ? d->amax_dy : amax + 1;
+        if (!d->amax_x) hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cin / 16)), dim3(256), 0, s, x + n * vox * Cin, vox * Cin / 4, amax);
+        if (!d->amax_dy) hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cout / 16)), dim3(256), 0, s, dy + n * vox * Cout, vox * Cout / 4, amax + 1);
         // guards and the K tail of every row read zeros: clear the planes' borders (the kernel writes all Vp positions of every row)
         for (int q = 0; q < 4; ++q) {
             half_t* pl = q == 0 ? xh : (q == 1 ? xl : (q == 2 ? yh : yl));
@@ -667,8 +815,8 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
             (void)hipMemsetAsync(pl + l.guard + (size_t)C * l.ld, 0, l.guard * 2, s);
             if (l.ld > l.Vp) (void)hipMemset2DAsync(pl + l.guard + l.Vp, l.ld * 2, 0, (l.ld - l.Vp) * 2, C, s);
         }
-        hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cin / 32), dim3(256), 0, s, x + n * vox * Cin, D, H, W, Cin, amax, xh, xl, l.ld, (int)l.guard);
-        hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cout / 32), dim3(256), 0, s, dy + n * vox * Cout, D, H, W, Cout, amax + 1, yh, yl, l.ld, (int)l.guard);
+        hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cin / 32), dim3(256), 0, s, x + n * vox * Cin, D, H, W, Cin, ax, xh, xl, l.ld, (int)l.guard);
+        hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cout / 32), dim3(256), 0, s, dy + n * vox * Cout, D, H, W, Cout, ay, yh, yl, l.ld, (int)l.guard);
         // C[(t9, ci)][(kx, co)] = sum_u XT[ci][u + sA(t9)] * dYT[co][u - (kx - 1)]
         asd_gemm_args a;
         memset(&a, 0, sizeof(a));
@@ -689,15 +837,15 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
             if (prod == 0) ASD_PROBE_STOP(s);
             if (rc != ASD_OK) return rc;
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(asd_div_up((size_t)M * N, 256)), dim3(256), 0, s, slabs, 3 * split, Cin, Cout, amax, amax + 1,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(asd_div_up((size_t)M * N, 256)), dim3(256), 0, s, slabs, 3 * split, Cin, Cout, ax, ay,
                            dw + (size_t)n * dw_sample_stride, 0);
     }
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
 
-int asd_layer_act_bwd(const float* dy, const float* y, int64_t rows, int32_t C, float gain, float clamp, float* dz, float* d_bias, float* d_rowsum,
-                      void* stream) {
+int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t rows, int32_t C, float gain, float clamp, float* dz, float* d_bias,
+                      float* d_rowsum, uint32_t* amax_out, void* stream) {
     ASD_CHECK_ARG(dy && y && dz && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0, "C / 4 must divide 256");
     hipStream_t s = (hipStream_t)stream;
     if (d_bias) (void)hipMemsetAsync(d_bias, 0, (size_t)C * 4, s);
@@ -705,7 +853,38 @@ int asd_layer_act_bwd(const float* dy, const float* y, int64_t rows, int32_t C, 
     const int rpb = 256 / (C / 4);
     int grid = asd_div_up(rows, rpb);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), (size_t)C * 4, s, dy, y, (size_t)rows, C, gain, clamp, dz, d_bias, d_rowsum);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), (size_t)C * 4, s, dy, y, sub, (size_t)rows, C, gain, clamp, dz, d_bias, d_rowsum, amax_out);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+
+int asd_absmax_f32(const float* x, int64_t n, uint32_t* amax_out, void* stream) {
+    ASD_CHECK_ARG(x && amax_out && n > 0 && n % 4 == 0, "n must be a positive multiple of 4");
+    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid((size_t)n / 16)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n / 4, amax_out);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_torgb_fwd(const float* x, int64_t rows, int32_t Cin, const float* w, const float* bias, const float* add, float* y, uint32_t* amax_out, void* stream) {
+    ASD_CHECK_ARG(x && w && y && rows > 0 && Cin > 0 && Cin % 32 == 0, "bad argument (Cin % 32 == 0, 32 output channels)");
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(asd_div_up(rows, 64)), dim3(256), 0, (hipStream_t)stream, x, (size_t)rows, Cin, w, bias, add, y, amax_out);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_torgb_bwd(const float* x, const float* dy, int64_t rows, int32_t Cin, const float* w, const float* dx_add, float* dx, float* dw, float* d_bias,
+                  void* stream) {
+    ASD_CHECK_ARG(x && dy && w && rows > 0 && Cin > 0 && Cin % 64 == 0, "bad argument (Cin % 64 == 0, 32 output channels)");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(torgb_dgrad_kernel, dim3(asd_div_up(rows, 64)), dim3(256), 0, s, dy, (size_t)rows, Cin, w, dx_add, dx);
+    if (dw) {
+        (void)hipMemsetAsync(dw, 0, (size_t)TORGB_O * Cin * 4, s);
+        if (d_bias) (void)hipMemsetAsync(d_bias, 0, TORGB_O * 4, s);
+        size_t rpb = (size_t)asd_div_up(rows, 2048);
+        if (rpb < 64) rpb = 64;
+        hipLaunchKernelGGL(torgb_wgrad_kernel, dim3(asd_div_up(rows, rpb)), dim3(256), 0, s, x, dy, (size_t)rows, Cin, rpb, dw, d_bias);
+    }
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -715,7 +894,8 @@ int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const as
     ASD_CHECK_ARG(!ep || (ep->act >= 0 && ep->act <= 1 && (!ep->noise || ep->noise_strength)), "bad epilogue");
     const size_t total = (size_t)N * 8 * r * r * r * (C / 4);
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3(c3_grid(total) * 2), dim3(256), 0, (hipStream_t)stream, x, N, r, C, ep ? ep->noise : nullptr,
-                       ep ? ep->noise_strength : nullptr, ep ? ep->bias : nullptr, ep ? ep->act : 0, ep ? ep->gain : 1.f, ep ? ep->clamp : 0.f, add, y);
+                       ep ? ep->noise_strength : nullptr, ep ? ep->bias : nullptr, ep ? ep->act : 0, ep ? ep->gain : 1.f, ep ? ep->clamp : 0.f, add, y,
+                       ep ? ep->amax_out : nullptr);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

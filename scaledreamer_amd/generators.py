@@ -111,50 +111,60 @@ def _ops():
 
 class _Conv3dFn(torch.autograd.Function):
     """y = act(conv3d(x, w) + noise * ns + bias) with per-sample weights w [N, Cout, Cin, 3, 3, 3]; x, y channel-last [N, D, H, W, C]
-    (include/asd_hip.h: asd_conv3d_fwd / _dgrad / _wgrad, asd_layer_act_bwd)"""
+    (include/asd_hip.h: asd_conv3d_fwd / _dgrad / _wgrad, asd_layer_act_bwd).  ax: the word in which x's producer left max|x| (or None);
+    returns (y, ay) with ay the same for y — the split scales then cost no pass over the volumes."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, noise, ns, act, gain, clamp):
-        y = _ops().conv3d_fwd(x, w, bias, noise, ns, act, gain, clamp)
-        ctx.save_for_backward(x, w, y if act else None, noise)
+    def forward(ctx, x, ax, w, bias, noise, ns, act, gain, clamp):
+        ops = _ops()
+        if ax is None:
+            ax = ops.absmax(x)
+        ay = ops.new_amax(x.device)
+        y = ops.conv3d_fwd(x, w, bias, noise, ns, act, gain, clamp, amax_x=ax, amax_out=ay)
+        ctx.save_for_backward(x, ax, w, y if act else None, noise)
         ctx.act, ctx.gain, ctx.clamp, ctx.has_bias, ctx.has_noise = act, gain, clamp, bias is not None, noise is not None
-        return y
+        ctx.mark_non_differentiable(ay)
+        return y, ay
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, y, noise = ctx.saved_tensors
+    def backward(ctx, dy, _):
+        x, ax, w, y, noise = ctx.saved_tensors
         ops = _ops()
         d_bias = d_ns = None
         if ctx.act:
-            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise)
+            az = ops.new_amax(x.device)
+            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise, amax_out=az)
             if ctx.has_noise:
                 d_ns = torch.dot(d_rows, noise.reshape(-1)).reshape(1)
         else:
             dz = dy.contiguous()
-        dx = ops.conv3d_dgrad(dz, w, x.shape[4]) if ctx.needs_input_grad[0] else None
-        dw = ops.conv3d_wgrad(x, dz) if ctx.needs_input_grad[1] else None
-        return dx, dw, d_bias, None, d_ns, None, None, None
+            az = ops.absmax(dz)
+        dx = ops.conv3d_dgrad(dz, w, x.shape[4], amax_dy=az) if ctx.needs_input_grad[0] else None
+        dw = ops.conv3d_wgrad(x, dz, amax_x=ax, amax_dy=az) if ctx.needs_input_grad[2] else None
+        return dx, None, dw, d_bias, None, d_ns, None, None, None
 
 
 class _UpsampleFn(torch.autograd.Function):
-    """y = act(trilinear_2x(x) + noise * ns + bias) + add on channel-last volumes (asd_upsample3d_fwd / _bwd); `add` (the skip volume's
-    other summand) only without an activation"""
+    """y = act(trilinear_2x(x) + noise * ns + bias) + add on channel-last volumes (asd_upsample3d_fwd / _bwd; the activation's gradient is
+    read off y - add); returns (y, ay) like _Conv3dFn"""
 
     @staticmethod
     def forward(ctx, x, bias, noise, ns, act, gain, clamp, add):
-        assert not (act and add is not None)
-        y = _ops().upsample3d_fwd(x, bias, noise, ns, act, gain, clamp, add)
-        ctx.save_for_backward(y if act else None, noise)
+        ops = _ops()
+        ay = ops.new_amax(x.device)
+        y = ops.upsample3d_fwd(x, bias, noise, ns, act, gain, clamp, add, amax_out=ay)
+        ctx.save_for_backward(y if act else None, noise, add if act else None)
         ctx.act, ctx.gain, ctx.clamp, ctx.has_bias, ctx.has_noise, ctx.has_add = act, gain, clamp, bias is not None, noise is not None, add is not None
-        return y
+        ctx.mark_non_differentiable(ay)
+        return y, ay
 
     @staticmethod
-    def backward(ctx, dy):
-        y, noise = ctx.saved_tensors
+    def backward(ctx, dy, _):
+        y, noise, add = ctx.saved_tensors
         ops = _ops()
         d_bias = d_ns = None
         if ctx.act:
-            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise)
+            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise, sub=add)
             if ctx.has_noise:
                 d_ns = torch.dot(d_rows, noise.reshape(-1)).reshape(1)
         else:
@@ -163,18 +173,34 @@ class _UpsampleFn(torch.autograd.Function):
         return dx, d_bias, None, d_ns, None, None, None, (dy if ctx.has_add else None)
 
 
-def _conv3d_cl(x, w, bias=None, noise=None, ns=None, act=False, gain=1.0, clamp=0.0):
-    """the convolution node; volumes below 16 x 16 in-plane (the 4^3 and 8^3 levels: 0.1 % of the generator's flops) are zero-padded to the
-    kernel's 16 x 16 patch and cropped, with their layer tail as tensor ops on the cropped volume"""
+class _ToRGBFn(torch.autograd.Function):
+    """y = x w^T + bias (+ add) with per-sample w [N, 32, Cin] on channel-last rows, exact fp32 (asd_torgb_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, add):
+        ctx.save_for_backward(x, w)
+        ctx.has_add = add is not None
+        return _ops().torgb_fwd(x, w, bias, add)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = _ops().torgb_bwd(x, dy, w, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, db, (dy if ctx.has_add else None)
+
+
+def _conv3d_cl(x, ax, w, bias=None, noise=None, ns=None, act=False, gain=1.0, clamp=0.0):
+    """the convolution node -> (y, ay); volumes below 16 x 16 in-plane (the 4^3 and 8^3 levels: 0.1 % of the generator's flops) are zero-padded
+    to the kernel's 16 x 16 patch and cropped, with their layer tail as tensor ops on the cropped volume"""
     H, W = x.shape[2], x.shape[3]
     if H % 16 == 0 and W % 16 == 0:
-        return _Conv3dFn.apply(x, w, bias, noise, ns, act, gain, clamp)
-    y = _Conv3dFn.apply(F.pad(x, (0, 0, 0, -W % 16, 0, -H % 16)), w, None, None, None, False, 1.0, 0.0)[:, :, :H, :W]
+        return _Conv3dFn.apply(x, ax, w, bias, noise, ns, act, gain, clamp)
+    y = _Conv3dFn.apply(F.pad(x, (0, 0, 0, -W % 16, 0, -H % 16)), ax, w, None, None, None, False, 1.0, 0.0)[0][:, :, :H, :W]
     if noise is not None:
         y = y + (noise * ns)[..., None]
     if bias is not None:
         y = y + bias
-    return torch.clamp(F.leaky_relu(y, 0.2) * gain, -clamp, clamp) if act else y
+    return (torch.clamp(F.leaky_relu(y, 0.2) * gain, -clamp, clamp) if act else y), None
 
 
 class SynthesisLayer(nn.Module):
@@ -201,8 +227,9 @@ class SynthesisLayer(nn.Module):
         act_gain = math.sqrt(2) * gain
         return torch.clamp(F.leaky_relu(x + self.bias[None, :, None, None, None], 0.2) * act_gain, -256 * gain, 256 * gain)
 
-    def forward_cl(self, x, w, noise_mode, gain=1):
-        """the same layer on a channel-last volume x [N, D, H, W, Cin] through the HIP nodes"""
+    def forward_cl(self, x, ax, w, noise_mode, gain=1, add=None):
+        """the same layer on a channel-last volume x [N, D, H, W, Cin] through the HIP nodes -> (y, ay); ax / ay: max|.| words (or None);
+        add: a volume added to the result (the block's const_bias, which the reference adds right after this layer)"""
         n, cin = x.shape[0], x.shape[4]
         styles = self.affine(w)
         wm = self.weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1, 1)
@@ -216,9 +243,10 @@ class SynthesisLayer(nn.Module):
             raise TypeError(f"noise_mode {noise_mode!r}: the reference adds `None` here; only 'random' and 'const' are usable")
         act_gain, clamp = math.sqrt(2) * gain, 256.0 * gain
         if self.upsample:
-            y0 = _conv3d_cl(x, wm)
-            return _UpsampleFn.apply(y0, self.bias, noise, self.noise_strength, True, act_gain, clamp, None)
-        return _conv3d_cl(x, wm, self.bias, noise, self.noise_strength, True, act_gain, clamp)
+            y0, _ = _conv3d_cl(x, ax, wm)
+            return _UpsampleFn.apply(y0, self.bias, noise, self.noise_strength, True, act_gain, clamp, add)
+        assert add is None
+        return _conv3d_cl(x, ax, wm, self.bias, noise, self.noise_strength, True, act_gain, clamp)
 
 
 class ToRGBLayer(nn.Module):
@@ -236,7 +264,9 @@ class ToRGBLayer(nn.Module):
         """channel-last: the 1x1x1 modulated convolution (no demodulation) is a per-sample matrix product on the [voxels, C] view"""
         n, cin = x.shape[0], x.shape[4]
         wm = self.weight.reshape(1, -1, cin) * (self.affine(w) * self.weight_gain).reshape(n, 1, cin)      # [N, Cout, Cin]
-        y = torch.baddbmm(self.bias.reshape(1, 1, -1), x.reshape(n, -1, cin), wm.transpose(1, 2))
+        if wm.shape[1] == 32 and cin % 64 == 0:
+            return _ToRGBFn.apply(x, wm, self.bias, None)
+        y = torch.baddbmm(self.bias.reshape(1, 1, -1), x.reshape(n, -1, cin), wm.transpose(1, 2))       # other widths: library product
         return y.reshape(*x.shape[:4], -1)
 
 
@@ -255,8 +285,8 @@ class SynthesisPrologue(nn.Module):
 
     def forward_cl(self, ws, noise_mode="random"):
         x = self.const.permute(1, 2, 3, 0).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1, 1])
-        x = self.conv1.forward_cl(x, ws[:, 0], noise_mode=noise_mode)
-        return x, self.torgb.forward_cl(x, ws[:, 1])
+        x, ax = self.conv1.forward_cl(x, None, ws[:, 0], noise_mode=noise_mode)
+        return x, ax, self.torgb.forward_cl(x, ws[:, 1])
 
 
 class SynthesisBlock(nn.Module):
@@ -276,12 +306,11 @@ class SynthesisBlock(nn.Module):
         x = self.conv1(x, ws[:, 1], noise_mode=noise_mode)
         return x, _upsample2(img) + self.torgb(x, ws[:, 2])
 
-    def forward_cl(self, x, img, ws, noise_mode="random"):
-        x = self.conv0.forward_cl(x, ws[:, 0], noise_mode=noise_mode)
-        if self.const_bias is not None:
-            x = x + self.const_bias.permute(1, 2, 3, 0)
-        x = self.conv1.forward_cl(x, ws[:, 1], noise_mode=noise_mode)
-        return x, _UpsampleFn.apply(img, None, None, None, False, 1.0, 0.0, self.torgb.forward_cl(x, ws[:, 2]))
+    def forward_cl(self, x, ax, img, ws, noise_mode="random"):
+        cb = None if self.const_bias is None else self.const_bias.permute(1, 2, 3, 0).contiguous().unsqueeze(0).expand(x.shape[0], -1, -1, -1, -1)
+        x, ax = self.conv0.forward_cl(x, ax, ws[:, 0], noise_mode=noise_mode, add=cb)       # (+ const_bias inside the upsampling kernel)
+        x, ax = self.conv1.forward_cl(x, ax, ws[:, 1], noise_mode=noise_mode)
+        return x, ax, _UpsampleFn.apply(img, None, None, None, False, 1.0, 0.0, self.torgb.forward_cl(x, ws[:, 2]))[0]
 
 
 class SynthesisNetwork3D(nn.Module):
@@ -309,9 +338,9 @@ class SynthesisNetwork3D(nn.Module):
             if not ws.is_cuda:
                 raise RuntimeError("Generator3D(backend='hip') needs device tensors: the HIP path has no CPU fallback "
                                    "(backend='library' is the explicit torch-op restatement)")
-            x, img = self.first_block.forward_cl(ws[:, 0:2], noise_mode=noise_mode)
+            x, ax, img = self.first_block.forward_cl(ws[:, 0:2], noise_mode=noise_mode)
             for i, blk in enumerate(self.blocks):
-                x, img = blk.forward_cl(x, img, ws[:, 2 * (i + 1) + 1: 2 * (i + 1) + 4], noise_mode)
+                x, ax, img = blk.forward_cl(x, ax, img, ws[:, 2 * (i + 1) + 1: 2 * (i + 1) + 4], noise_mode)
             return img.permute(0, 4, 1, 2, 3)          # [N, C, D, H, W] view of the channel-last volume (what the voxel sampler reads as is)
         x, img = self.first_block(ws[:, 0:2], noise_mode=noise_mode)
         for i, blk in enumerate(self.blocks):

@@ -351,39 +351,53 @@ def _zero_page(device) -> torch.Tensor:
     return z
 
 
-def _conv3d_desc(x_shape, cout: int) -> L.Conv3dDesc:
-    N, D, H, W, Cin = x_shape
-    return L.Conv3dDesc(int(N), int(D), int(H), int(W), int(Cin), int(cout))
+def new_amax(device) -> torch.Tensor:
+    """a zeroed device word that a producer kernel fills with the bit pattern of max|output| (include/asd_hip.h: amax_out)"""
+    return torch.zeros(1, device=device, dtype=torch.int32)
 
 
-def _epilogue(bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0):
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """the max|x| word of a tensor whose producer left none (asd_absmax_f32)"""
+    x = _c(x)
+    a = new_amax(x.device)
+    check(lib().asd_absmax_f32(ptr(x), C.c_int64(x.numel()), _ap(a), stream()))
+    return a
+
+
+def _ap(t: Optional[torch.Tensor]):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _epilogue(bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0, amax_out=None):
     """-> (Conv3dEpilogue, tensors to keep alive)"""
     keep = [_c(t) for t in (bias, noise, noise_strength)]
-    ep = L.Conv3dEpilogue(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), int(bool(act)), float(gain), float(clamp))
+    ep = L.Conv3dEpilogue(ptr(keep[0]).value, ptr(keep[1]).value, ptr(keep[2]).value, int(bool(act)), float(gain), float(clamp), _ap(amax_out).value)
     return ep, keep
 
 
 def conv3d_fwd(x: torch.Tensor, w: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0,
-               clamp: float = 0.0) -> torch.Tensor:
-    """x [N,D,H,W,Cin] fp32 channel-last, w [N,Cout,Cin,3,3,3] (per sample) or [Cout,Cin,3,3,3] -> act(conv + noise * ns + bias) [N,D,H,W,Cout]"""
+               clamp: float = 0.0, amax_x=None, amax_out=None) -> torch.Tensor:
+    """x [N,D,H,W,Cin] fp32 channel-last, w [N,Cout,Cin,3,3,3] (per sample) or [Cout,Cin,3,3,3] -> act(conv + noise * ns + bias) [N,D,H,W,Cout].
+    amax_x: the producer's max|x| word if it left one (else one more pass over x); amax_out: a zeroed word that receives max|y|"""
     _need_cuda(x, w)
     x, w = _c(x), _c(w)
     cout = w.shape[-5]
-    d = _conv3d_desc(x.shape, cout)
-    y = torch.empty((*x.shape[:4], cout), device=x.device, dtype=torch.float32)
+    N, D, H, W, Cin = x.shape
+    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(Cin), int(cout), _ap(amax_x).value, None)
+    y = torch.empty((N, D, H, W, cout), device=x.device, dtype=torch.float32)
     nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(0))
     ws = _ws(x.device, nb)
-    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp)
-    stride = cout * x.shape[4] * 27 if w.dim() == 6 else 0
+    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp, amax_out)
+    stride = cout * Cin * 27 if w.dim() == 6 else 0
     check(lib().asd_conv3d_fwd(C.byref(d), ptr(x), ptr(w), C.c_int64(stride), ptr(y), C.byref(ep), ptr(ws), C.c_int64(nb), stream()))
     return y
 
 
-def conv3d_dgrad(dy: torch.Tensor, w: torch.Tensor, cin: int) -> torch.Tensor:
+def conv3d_dgrad(dy: torch.Tensor, w: torch.Tensor, cin: int, amax_dy=None) -> torch.Tensor:
     _need_cuda(dy, w)
     dy, w = _c(dy), _c(w)
     N, D, H, W, cout = dy.shape
-    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout))
+    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout), None, _ap(amax_dy).value)
     dx = torch.empty((N, D, H, W, cin), device=dy.device, dtype=torch.float32)
     nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(1))
     ws = _ws(dy.device, nb)
@@ -392,13 +406,13 @@ def conv3d_dgrad(dy: torch.Tensor, w: torch.Tensor, cin: int) -> torch.Tensor:
     return dx
 
 
-def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor, amax_x=None, amax_dy=None) -> torch.Tensor:
     """-> dw [N,Cout,Cin,3,3,3] (one gradient per sample: the modulated convolution has per-sample weights)"""
     _need_cuda(x, dy)
     x, dy = _c(x), _c(dy)
     N, D, H, W, cin = x.shape
     cout = dy.shape[4]
-    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout))
+    d = L.Conv3dDesc(int(N), int(D), int(H), int(W), int(cin), int(cout), _ap(amax_x).value, _ap(amax_dy).value)
     dw = torch.empty((N, cout, cin, 3, 3, 3), device=x.device, dtype=torch.float32)
     nb = lib().asd_conv3d_workspace_bytes(C.byref(d), i32(2))
     ws = _ws(x.device, nb)
@@ -407,27 +421,29 @@ def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dw
 
 
-def layer_act_bwd(dy: torch.Tensor, y: torch.Tensor, gain: float, clamp: float, want_bias: bool = True, want_rowsum: bool = True):
-    """dz = dy * act'(y) on [..., C]; -> (dz, d_bias [C] | None, d_rowsum [rows] | None)"""
-    dy, y = _c(dy), _c(y)
+def layer_act_bwd(dy: torch.Tensor, y: torch.Tensor, gain: float, clamp: float, want_bias: bool = True, want_rowsum: bool = True,
+                  sub: Optional[torch.Tensor] = None, amax_out=None):
+    """dz = dy * act'(y - sub) on [..., C]; -> (dz, d_bias [C] | None, d_rowsum [rows] | None)"""
+    dy, y, sub = _c(dy), _c(y), _c(sub)
     Cc = y.shape[-1]
     rows = y.numel() // Cc
     dz = torch.empty_like(y)
     d_bias = torch.empty(Cc, device=y.device, dtype=torch.float32) if want_bias else None
     d_rowsum = torch.empty(rows, device=y.device, dtype=torch.float32) if want_rowsum else None
-    check(lib().asd_layer_act_bwd(ptr(dy), ptr(y), C.c_int64(rows), i32(Cc), f32(gain), f32(clamp), ptr(dz), ptr(d_bias), ptr(d_rowsum), stream()))
+    check(lib().asd_layer_act_bwd(ptr(dy), ptr(y), ptr(sub), C.c_int64(rows), i32(Cc), f32(gain), f32(clamp), ptr(dz), ptr(d_bias), ptr(d_rowsum),
+                                  _ap(amax_out), stream()))
     return dz, d_bias, d_rowsum
 
 
 def upsample3d_fwd(x: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0,
-                   add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   add: Optional[torch.Tensor] = None, amax_out=None) -> torch.Tensor:
     """x [N,r,r,r,C] -> act(trilinear 2x (align_corners) + noise * ns + bias) + add, [N,2r,2r,2r,C]"""
     _need_cuda(x)
     x, add = _c(x), _c(add)
     N, r, r2, r3, Cc = x.shape
     assert r == r2 == r3, "cubic volumes"
     y = torch.empty((N, 2 * r, 2 * r, 2 * r, Cc), device=x.device, dtype=torch.float32)
-    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp)
+    ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp, amax_out)
     check(lib().asd_upsample3d_fwd(ptr(x), i32(N), i32(r), i32(Cc), C.byref(ep), ptr(add), ptr(y), stream()))
     return y
 
@@ -440,3 +456,30 @@ def upsample3d_bwd(dy: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(6 * N * r * r * r * Cc, device=dy.device, dtype=torch.float32)
     check(lib().asd_upsample3d_bwd(ptr(dy), i32(N), i32(r), i32(Cc), ptr(dx), ptr(ws), stream()))
     return dx
+
+
+def torgb_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,D,H,W,Cin], w [N,32,Cin] (per-sample modulated weights), bias [32] -> x w^T + bias (+ add) [N,D,H,W,32], exact fp32"""
+    _need_cuda(x, w)
+    x, w, bias, add = _c(x), _c(w), _c(bias), _c(add)
+    N, Cin = x.shape[0], x.shape[-1]
+    rows = x.numel() // Cin // N
+    y = torch.empty((*x.shape[:-1], 32), device=x.device, dtype=torch.float32)
+    for n in range(N):
+        check(lib().asd_torgb_fwd(ptr(x[n]), C.c_int64(rows), i32(Cin), ptr(w[n]), ptr(bias), ptr(None if add is None else add[n]), ptr(y[n]),
+                                  C.c_void_p(0), stream()))
+    return y
+
+
+def torgb_bwd(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, need_dx: bool = True):
+    """-> (dx [N,D,H,W,Cin] | None, dw [N,32,Cin], d_bias [32])"""
+    x, dy, w = _c(x), _c(dy), _c(w)
+    N, Cin = x.shape[0], x.shape[-1]
+    rows = x.numel() // Cin // N
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((N, 32, Cin), device=x.device, dtype=torch.float32)
+    db = torch.empty((N, 32), device=x.device, dtype=torch.float32)
+    for n in range(N):
+        check(lib().asd_torgb_bwd(ptr(x[n]), ptr(dy[n]), C.c_int64(rows), i32(Cin), ptr(w[n]), C.c_void_p(0), ptr(None if dx is None else dx[n]),
+                                  ptr(dw[n]), ptr(db[n]), stream()))
+    return dx, dw, db.sum(0)

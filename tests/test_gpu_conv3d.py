@@ -18,7 +18,13 @@ def _cf(x):
 
 
 def _relerr(a, b):
-    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    return float((a.detach().double() - b.detach().double()).abs().max() / b.detach().double().abs().max())
+
+
+def _rel_l2(a, b):
+    """gradients through the leaky-ReLU / clamp: an output within rounding distance of the kink may take the other branch than the float64
+    reference (the forward values agree to 1e-6, not to the sign of a 1e-7), which moves single elements by 80 % — compare in the L2 norm"""
+    return float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm())
 
 
 @pytest.mark.parametrize("N,D,H,W,cin,cout", [(1, 6, 32, 32, 64, 64), (2, 5, 16, 32, 128, 64), (1, 4, 16, 16, 64, 128), (1, 3, 16, 16, 192, 256)])
@@ -59,7 +65,8 @@ def test_conv3d_fused_layer_tail_and_its_gradient():
     noise = torch.randn(N, D, H, W, generator=g).cuda()
     ns = torch.tensor([0.7]).cuda().requires_grad_(True)
     gain, clamp = 2 ** 0.5, 256.0
-    y = _Conv3dFn.apply(x, w, bias, noise, ns, True, gain, clamp)
+    y, ay = _Conv3dFn.apply(x, None, w, bias, noise, ns, True, gain, clamp)
+    assert float(ay.view(torch.float32)) == float(y.detach().abs().max())          # the max|y| word the next layer's split reads
     gy = torch.randn(y.shape, generator=g).cuda()
     y.backward(gy)
     got = [t.grad.clone() for t in (x, w, bias, ns)]
@@ -72,7 +79,7 @@ def test_conv3d_fused_layer_tail_and_its_gradient():
     ref.backward(gy.double())
     assert _relerr(y, ref.detach()) < 3e-6
     for a, b, name in zip(got, (x64.grad, w64.grad, b64.grad, ns64.grad), ("dx", "dw", "d_bias", "d_noise_strength")):
-        assert _relerr(a, b) < 2e-5, name        # (elements within 1e-6 of the kink / clamp may take the other branch)
+        assert _rel_l2(a, b) < 1e-4, name
 
 
 @pytest.mark.parametrize("r,C", [(4, 512), (8, 64), (16, 32)])
@@ -87,25 +94,48 @@ def test_upsample_matches_trilinear_align_corners_and_its_transpose(r, C):
     add = torch.randn(2, 2 * r, 2 * r, 2 * r, C, generator=g).cuda().requires_grad_(True)
     gy = torch.randn(2, 2 * r, 2 * r, 2 * r, C, generator=g).cuda()
 
-    def ref(x_, bias_, ns_, add_, act):
+    def ref(x_, bias_, ns_, add_, act, with_add):
         up = F.interpolate(x_.permute(0, 4, 1, 2, 3), scale_factor=2, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
         if act:
-            return torch.clamp(F.leaky_relu(up + (noise * ns_)[..., None] + bias_, 0.2) * 1.4142135, -256, 256)
-        return up + add_
+            up = torch.clamp(F.leaky_relu(up + (noise * ns_)[..., None] + bias_, 0.2) * 1.4142135, -256, 256)
+        return up + add_ if with_add else up
 
-    for act in (True, False):
-        y = _UpsampleFn.apply(x, bias if act else None, noise if act else None, ns if act else None, act, 1.4142135, 256.0, None if act else add)
+    for act, with_add in ((True, False), (False, True), (True, True)):          # layer tail / skip volume / layer tail + const_bias
+        y, ay = _UpsampleFn.apply(x, bias if act else None, noise if act else None, ns if act else None, act, 1.4142135, 256.0, add if with_add else None)
+        assert float(ay.view(torch.float32)) == float(y.detach().abs().max())
         y.backward(gy)
         got = {k: t.grad.clone() for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)) if t.grad is not None}
         for t in (x, bias, ns, add):
             t.grad = None
-        yr = ref(x, bias, ns, add, act)
+        yr = ref(x, bias, ns, add, act, with_add)
         yr.backward(gy)
         assert _relerr(y, yr.detach()) < 2e-6
         for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)):
             if t.grad is not None:
-                assert _relerr(got[k], t.grad) < 2e-5, (act, k)
+                assert (_rel_l2 if act else _relerr)(got[k], t.grad) < (1e-4 if act else 2e-5), (act, with_add, k)
             t.grad = None
+
+
+@pytest.mark.parametrize("cin,rows_shape", [(64, (2, 5, 16, 16)), (512, (1, 4, 4, 4)), (128, (1, 3, 8, 40))])
+def test_torgb_matches_float64(cin, rows_shape):
+    from scaledreamer_amd.generators import _ToRGBFn
+
+    g = torch.Generator().manual_seed(cin)
+    N = rows_shape[0]
+    x = torch.randn(*rows_shape, cin, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(N, 32, cin, generator=g) / cin ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(32, generator=g).cuda().requires_grad_(True)
+    add = torch.randn(*rows_shape, 32, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(*rows_shape, 32, generator=g).cuda()
+    y = _ToRGBFn.apply(x, w, b, add)
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, w, b, add)]
+    x64, w64, b64, a64 = (t.detach().double().requires_grad_(True) for t in (x, w, b, add))
+    ref = torch.einsum("n...i,noi->n...o", x64, w64) + b64 + a64
+    ref.backward(gy.double())
+    assert _relerr(y, ref.detach()) < 2e-6
+    for a_, r_, name in zip(got, (x64.grad, w64.grad, b64.grad, a64.grad), ("dx", "dw", "d_bias", "d_add")):
+        assert _relerr(a_, r_) < 5e-6, name
 
 
 def test_generator3d_hip_backend_matches_reference_golden():
