@@ -112,7 +112,7 @@ def test_upsample_matches_trilinear_align_corners_and_its_transpose(r, C):
         assert _relerr(y, yr.detach()) < 2e-6
         for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)):
             if t.grad is not None:
-                assert (_rel_l2 if act else _relerr)(got[k], t.grad) < (1e-4 if act else 2e-5), (act, with_add, k)
+                assert (_rel_l2 if act else _relerr)(got[k], t.grad) < (5e-4 if act else 2e-5), (act, with_add, k)      # (with `add`, act' is read off fl(y) - add: +-1 ulp of |add| around the kink)
             t.grad = None
 
 
