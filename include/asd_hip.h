@@ -115,6 +115,21 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                   const float* d_fd_grad, float* d_grid_params, float* dw1_density, float* dw2_density, float* dw1_feature, float* dw2_feature,
                   float* workspace, void* stream);
 
+/* The same fused field over a SAMPLED feature volume (`3DConv-net`, custom/amortized/models/geometry/stylegan_3dconv_net.py:244-346:
+ * contract -> get_trilinear_feature -> VanillaMLP sdf / feature heads -> sdf + bias -> finite-difference sdf_grad): the encoding of a
+ * point is the trilinear sample (F.grid_sample, zeros, align_corners = False) of voxel_cl [D][H][W][32] instead of the hash grid, the
+ * heads / bias / finite differences are asd_field_fwd's in ASD_FIELD_SDF mode (cfg).  One batch entry per call.  Backward: d_voxel_cl +=
+ * (atomics; the scatter is asd_voxel_sample_bwd's), weight gradients += as asd_field_bwd; workspace: asd_voxfield_bwd_workspace floats. */
+int asd_voxfield_fwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* w1_sdf,
+                     const float* w2_sdf, const float* w1_feature, const float* w2_feature, const float* points, int32_t n, float* sdf,
+                     float* features, float* normal, float* fd_grad, float* enc_save, void* stream);
+int asd_voxfield_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats);
+int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* w1_sdf,
+                     const float* w2_sdf, const float* w1_feature, const float* w2_feature, const float* points, const float* enc_save,
+                     const float* sdf, int32_t n, const float* d_sdf, const float* d_features, const float* d_normal,
+                     const float* d_fd_grad, float* d_voxel_cl, float* dw1_sdf, float* dw2_sdf, float* dw1_feature, float* dw2_feature,
+                     float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Background: (d+1)/2 -> hash grid (L levels) -> VanillaMLP(2L -> H -> H -> 3) -> sigmoid.
  * Replaces NeuralEnvironmentMapBackground.forward

@@ -140,7 +140,41 @@ __device__ __forceinline__ void mlpC(const float* __restrict__ w1, const float* 
     }
 }
 
-template <int L, int H>
+// ENC = 1: the "encoding" of a point is the trilinear sample of a channel-last feature volume [D][H][W][2 L] — the generator-backed
+// geometries (3DConv-net: get_trilinear_feature = F.grid_sample(bilinear, zeros, align_corners = False),
+// custom/amortized/models/geometry/utils.py:95-110) — instead of the hash grid; m.resolution[0..2] = W, H, D; (x, y, z) in [0, 1] are
+// mapped to grid_sample's [-1, 1] (x -> W, y -> H, z -> D).  Everything behind the encoding (MLP heads, bias, finite differences) is shared.
+__device__ __forceinline__ void vox_axis(float x01, int size, int& i0, float& w1) {
+    const float ix = (((2.f * x01 - 1.f) + 1.f) * (float)size - 1.f) * 0.5f;   // align_corners = False
+    const float f = floorf(ix);
+    i0 = (int)f;
+    w1 = ix - f;
+}
+template <int NC>
+__device__ __forceinline__ void vox_encode(const asd_grid_meta& m, const float* __restrict__ vox, float x, float y, float z, float (&enc)[NC]) {
+    const int W = (int)m.resolution[0], Hh = (int)m.resolution[1], D = (int)m.resolution[2];
+    int x0, y0, z0;
+    float fx, fy, fz;
+    vox_axis(x, W, x0, fx); vox_axis(y, Hh, y0, fy); vox_axis(z, D, z0, fz);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) enc[k] = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+        if (xi < 0 || xi >= W || yi < 0 || yi >= Hh || zi < 0 || zi >= D) continue;
+        const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+        const float4* row = reinterpret_cast<const float4*>(vox + (((size_t)zi * Hh + yi) * W + xi) * NC);
+#pragma unroll
+        for (int q = 0; q < NC / 4; ++q) {
+            const float4 v = row[q];
+            enc[4 * q] = fmaf(w, v.x, enc[4 * q]); enc[4 * q + 1] = fmaf(w, v.y, enc[4 * q + 1]);
+            enc[4 * q + 2] = fmaf(w, v.z, enc[4 * q + 2]); enc[4 * q + 3] = fmaf(w, v.w, enc[4 * q + 3]);
+        }
+    }
+}
+
+template <int L, int H, int ENC = 0>
 __device__ __forceinline__ float field_raw(const asd_grid_meta& m, const asd_field_cfg& c,
                                            const float* __restrict__ grid, const float* __restrict__ w1d,
                                            const float* __restrict__ w2d, float px, float py, float pz,
@@ -148,7 +182,8 @@ __device__ __forceinline__ float field_raw(const asd_grid_meta& m, const asd_fie
     const float x = (px - c.bbox_min[0]) / (c.bbox_max[0] - c.bbox_min[0]);
     const float y = (py - c.bbox_min[1]) / (c.bbox_max[1] - c.bbox_min[1]);
     const float z = (pz - c.bbox_min[2]) / (c.bbox_max[2] - c.bbox_min[2]);
-    asd_encode<L>(m, grid, x, y, z, enc);
+    if constexpr (ENC == 1) vox_encode<2 * L>(m, grid, x, y, z, enc);
+    else asd_encode<L>(m, grid, x, y, z, enc);
     return mlp1<2 * L, H>(w1d, w2d, enc) + field_bias(c, px, py, pz);
 }
 
@@ -174,7 +209,7 @@ __global__ __launch_bounds__(256, 4) void field_density_kernel(const asd_grid_me
 // ---------------------------------------------------------------------------------------------------
 // training forward: sigma, features, finite-difference normal; saves the centre encoding
 // ---------------------------------------------------------------------------------------------------
-template <int L, int H, int C>
+template <int L, int H, int C, int ENC = 0>
 __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m, const asd_field_cfg c,
                                                         const float* __restrict__ grid,
                                                         const float* __restrict__ w1d, const float* __restrict__ w2d,
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nn; i += gridDim.x * 256) {
         const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
         float enc[2 * L];
-        const float raw = field_raw<L, H>(m, c, grid, w1d, w2d, px, py, pz, enc);
+        const float raw = field_raw<L, H, ENC>(m, c, grid, w1d, w2d, px, py, pz, enc);
         const float s = field_act(c, raw);
         sigma[i] = s;
         if (enc_save) {
@@ -210,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
                 const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
                 const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
                 float e2[2 * L];
-                const float sk = field_act(c, field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2));
+                const float sk = field_act(c, field_raw<L, H, ENC>(m, c, grid, w1d, w2d, qx, qy, qz, e2));
                 nr[k] = fd_sign * (sk - s) / c.fd_eps;
             }
             if (fd_grad) {
@@ -264,7 +299,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #endif
 #define WG_TILE 64     // rows per LDS tile
 
-template <int L, int H, int C>
+template <int L, int H, int C, int ENC = 0>
 __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_kernel(
     const asd_grid_meta m, const asd_field_cfg c, const float* __restrict__ grid, const float* __restrict__ w1d,
     const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
@@ -273,7 +308,9 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
     const float* __restrict__ d_normal, const float* __restrict__ d_fd_grad, float* __restrict__ d_grid,
     float* __restrict__ da_out /*[rows,2H]*/,
     float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f,
-    float* __restrict__ priv /*[ASD_PRIV_COPIES][priv_stride] per-XCD copies of the gradient of levels < ASD_FIELD_NPRIV*/, uint32_t priv_stride) {
+    float* __restrict__ priv /*[ASD_PRIV_COPIES][priv_stride] per-XCD copies of the gradient of levels < ASD_FIELD_NPRIV*/, uint32_t priv_stride,
+    float* __restrict__ denc_out = nullptr /* ENC == 1: [rows', 2L] gradient w.r.t. the sampled features, row' = 4 i + pt (i with no normal) */,
+    float* __restrict__ pts_out = nullptr /* ENC == 1: [rows', 3] the sampled positions in grid_sample's [-1, 1] */) {
     constexpr int NIN = 2 * L;
     // second-layer weight-gradient sums of the block.  ASD_FIELD_W2_COPIES > 1: no wave-level reduction — every lane adds its own
     // term with an LDS atomic into copy (lane & 15) of the accumulator (row stride W2N + 1: the 16 copies of one h sit in 16 banks, the
@@ -318,7 +355,7 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
             const float qy = asd_clampf(py + (k == 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
             const float qz = asd_clampf(pz + (k == 2 ? c.fd_eps : 0.f), -c.radius, c.radius);
             float e2[NIN];
-            rawk[k] = field_raw<L, H>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
+            rawk[k] = field_raw<L, H, ENC>(m, c, grid, w1d, w2d, qx, qy, qz, e2);
             nr[k] = fd_sign * (field_act(c, rawk[k]) - s) / c.fd_eps;
             // the encoding of the offset point is needed again below (its row of the weight-gradient GEMM and the back-propagation
             // through the density MLP): park it in enc_fd now instead of gathering its 128 corners a second time
@@ -452,8 +489,21 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                     *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
-        asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by,
-                                                             (qz - c.bbox_min[2]) / bz, denc, active, priv, priv_stride);
+        if constexpr (ENC == 1) {
+            // the scatter into the feature volume is asd_voxel_sample_bwd's (run-aggregated, request-coalesced): leave it the rows
+            if (active) {
+                const size_t ro = with_fd ? (size_t)4 * i + pt : (size_t)i;
+                float4* dst = reinterpret_cast<float4*>(denc_out + ro * NIN);
+#pragma unroll
+                for (int q = 0; q < NIN / 4; ++q) dst[q] = make_float4(denc[4 * q], denc[4 * q + 1], denc[4 * q + 2], denc[4 * q + 3]);
+                pts_out[3 * ro] = 2.f * ((qx - c.bbox_min[0]) / bx) - 1.f;
+                pts_out[3 * ro + 1] = 2.f * ((qy - c.bbox_min[1]) / by) - 1.f;
+                pts_out[3 * ro + 2] = 2.f * ((qz - c.bbox_min[2]) / bz) - 1.f;
+            }
+        } else {
+            asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by,
+                                                                 (qz - c.bbox_min[2]) / bz, denc, active, priv, priv_stride);
+        }
     }
     __syncthreads();
     if (ASD_FIELD_W2_COPIES > 1) {
@@ -879,6 +929,83 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     if (cfg->n_feature_dims == 3)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, chunks, 128 * 32,
                            64 * 32, dw1_feature, live, WG_ROWS);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+// ---- the same fused field over a sampled feature volume (3DConv-net: stylegan_3dconv_net.py:244-346) ---------------------------------
+static asd_grid_meta vox_meta(int D, int H, int W) {
+    asd_grid_meta m;
+    memset(&m, 0, sizeof(m));
+    m.n_levels = 16; m.n_features = 2;
+    m.resolution[0] = (uint32_t)W; m.resolution[1] = (uint32_t)H; m.resolution[2] = (uint32_t)D;
+    return m;
+}
+static int voxfield_supported(const asd_field_cfg* c, int C) {
+    if (C != 32 || c->n_hidden != 64 || !(c->n_feature_dims == 3 || c->n_feature_dims == 0)) {
+        asd_set_error("voxel field kernels are built for 32 feature channels, 64 hidden units, 0/3 feature dims (got %d channels, %d hidden, %d feature dims)",
+                      C, c->n_hidden, c->n_feature_dims);
+        return 0;
+    }
+    return 1;
+}
+
+int asd_voxfield_fwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* w1_sdf, const float* w2_sdf,
+                     const float* w1_feature, const float* w2_feature, const float* points, int32_t n, float* sdf, float* features, float* normal,
+                     float* fd_grad, float* enc_save, void* stream) {
+    if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(voxel_cl && cfg && w1_sdf && w2_sdf && points && sdf && n > 0 && D > 0 && H > 0 && W > 0, "null argument");
+    if (!voxfield_supported(cfg, C)) return ASD_ERR_UNSUPPORTED;
+    ASD_CHECK_ARG(cfg->n_feature_dims == 0 || !features || (w1_feature && w2_feature), "feature weights missing");
+    const asd_grid_meta m = vox_meta(D, H, W);
+    hipLaunchKernelGGL((field_fwd_kernel<16, 64, 3, 1>), dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, m, *cfg, voxel_cl, w1_sdf, w2_sdf,
+                       w1_feature, w2_feature, points, n, (const int*)nullptr, sdf, cfg->n_feature_dims == 3 ? features : nullptr, normal, fd_grad, enc_save);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_voxfield_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats) {
+    ASD_CHECK_ARG(cfg && n_floats && n >= 0, "bad argument");
+    const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
+    const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs + feature-gradient rows [rows, 32] + their positions [rows, 3]
+    *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 + rows * 32 + rows * 3 + 16;
+    return ASD_OK;
+}
+
+int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* w1_sdf, const float* w2_sdf,
+                     const float* w1_feature, const float* w2_feature, const float* points, const float* enc_save, const float* sdf, int32_t n,
+                     const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad, float* d_voxel_cl, float* dw1_sdf,
+                     float* dw2_sdf, float* dw1_feature, float* dw2_feature, float* workspace, void* stream) {
+    if (n == 0) return ASD_OK;
+    ASD_CHECK_ARG(voxel_cl && cfg && w1_sdf && w2_sdf && points && enc_save && sdf && d_voxel_cl && dw1_sdf && dw2_sdf && workspace && n > 0, "null argument");
+    if (!voxfield_supported(cfg, C)) return ASD_ERR_UNSUPPORTED;
+    ASD_CHECK_ARG(cfg->n_feature_dims == 3 || !d_features, "d_features given but no feature network");
+    ASD_CHECK_ARG(cfg->n_feature_dims == 0 || (dw1_feature && dw2_feature && w1_feature && w2_feature), "feature gradients missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int with_normal = d_normal != nullptr || d_fd_grad != nullptr;
+    const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
+    const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    float* da = workspace;
+    float* enc_fd = with_normal ? da + rows * 128 : nullptr;
+    float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);
+    float* denc = slabs + (int64_t)chunks * 128 * 32 + 64;
+    float* pts = denc + rows * 32;
+    const asd_grid_meta m = vox_meta(D, H, W);
+    const dim3 grid(asd_div_up(n, 256)), block(256);
+#define ASD_VOXFIELD_BWD_LAUNCH(C_)                                                                                                        \
+    hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, C_, 1>), grid, block, 0, s, m, *cfg, voxel_cl, w1_sdf, w2_sdf, w1_feature, w2_feature, \
+                       points, enc_save, sdf, n, (const int*)nullptr, d_sdf, d_features, d_normal, d_fd_grad, (float*)nullptr, da, enc_fd,  \
+                       dw2_sdf, dw2_feature, (float*)nullptr, 0u, denc, pts)
+    if (cfg->n_feature_dims == 3) ASD_VOXFIELD_BWD_LAUNCH(3); else ASD_VOXFIELD_BWD_LAUNCH(0);
+#undef ASD_VOXFIELD_BWD_LAUNCH
+    const int rc = asd_voxel_sample_bwd(denc, 1, D, H, W, C, pts, (int32_t)rows, d_voxel_cl, stream);     // += (atomics), amortized.hip
+    if (rc != ASD_OK) return rc;
+    hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, (const int*)nullptr, n, slabs);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, chunks, 128 * 32, 64 * 32, dw1_sdf, (const int*)nullptr, WG_ROWS);
+    if (cfg->n_feature_dims == 3)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, chunks, 128 * 32, 64 * 32, dw1_feature,
+                           (const int*)nullptr, WG_ROWS);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

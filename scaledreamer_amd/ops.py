@@ -483,3 +483,40 @@ def torgb_bwd(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, need_dx: bool 
         check(lib().asd_torgb_bwd(ptr(x[n]), ptr(dy[n]), C.c_int64(rows), i32(Cin), ptr(w[n]), C.c_void_p(0), ptr(None if dx is None else dx[n]),
                                   ptr(dw[n]), ptr(db[n]), stream()))
     return dx, dw, db.sum(0)
+
+
+# ---- fused sampled-volume field (3DConv-net): trilinear sample -> MLP heads -> bias -> finite differences in one kernel -----------------
+def voxfield_fwd(voxel_cl: torch.Tensor, cfg: FieldCfg, w1s, w2s, w1f, w2f, points, want_normal: bool, want_features: bool = True,
+                 save_enc: bool = True):
+    """voxel_cl [D,H,W,32] (one batch entry), points [n,3] world coordinates -> (sdf [n], features [n,3] | None, normal, fd_grad, enc [n,32] | None)"""
+    _need_cuda(voxel_cl, points)
+    voxel_cl, points = _c(voxel_cl), _c(points)
+    D, H, W, Cc = voxel_cl.shape
+    n, dev = points.shape[0], points.device
+    sdf = torch.empty(n, device=dev, dtype=torch.float32)
+    feats = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_features and cfg.n_feature_dims == 3 else None
+    normal = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    fdg = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    enc = torch.empty((n, 32), device=dev, dtype=torch.float32) if save_enc else None
+    check(lib().asd_voxfield_fwd(ptr(voxel_cl), i32(D), i32(H), i32(W), i32(Cc), C.byref(cfg), ptr(w1s), ptr(w2s), ptr(w1f), ptr(w2f), ptr(points), i32(n),
+                                 ptr(sdf), ptr(feats), ptr(normal), ptr(fdg), ptr(enc), stream()))
+    return sdf, feats, normal, fdg, enc
+
+
+def voxfield_bwd(voxel_cl, cfg: FieldCfg, w1s, w2s, w1f, w2f, points, enc, sdf, d_sdf, d_features, d_normal, d_fd_grad, d_voxel: torch.Tensor):
+    """accumulates into d_voxel [D,H,W,32]; returns (dw1s, dw2s, dw1f, dw2f)"""
+    voxel_cl, points = _c(voxel_cl), _c(points)
+    D, H, W, Cc = voxel_cl.shape
+    n, dev = points.shape[0], points.device
+    nf = C.c_int64(0)
+    check(lib().asd_voxfield_bwd_workspace(C.byref(cfg), i32(n), i32(int(d_normal is not None or d_fd_grad is not None)), C.byref(nf)))
+    ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
+    dw1s = torch.zeros((64, 32), device=dev, dtype=torch.float32)
+    dw2s = torch.zeros((1, 64), device=dev, dtype=torch.float32)
+    dw1f = torch.zeros((64, 32), device=dev, dtype=torch.float32)
+    dw2f = torch.zeros((3, 64), device=dev, dtype=torch.float32)
+    k = _Keep()
+    check(lib().asd_voxfield_bwd(ptr(voxel_cl), i32(D), i32(H), i32(W), i32(Cc), C.byref(cfg), ptr(w1s), ptr(w2s), ptr(w1f), ptr(w2f), ptr(points),
+                                 ptr(enc), ptr(sdf), i32(n), k(d_sdf), k(d_features), k(d_normal), k(d_fd_grad), ptr(d_voxel), ptr(dw1s), ptr(dw2s),
+                                 ptr(dw1f), ptr(dw2f), ptr(ws), stream()))
+    return dw1s, dw2s, dw1f, dw2f

@@ -9,18 +9,20 @@ samplers.py; the generators (generators.py) and the small MLP heads are library 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, Optional, Union
 
 import torch
 import torch.nn.functional as F
 
+from . import _lib, ops
 from .config import C
 from .generators import Generator3D, TriplaneTransformer
 from .geometry import BaseImplicitGeometry
 from .networks import get_activation, get_mlp
 from .registry import register
-from .samplers import contract_to_unisphere_custom, get_trilinear_feature, sample_from_planes
+from .samplers import channels_last, contract_to_unisphere_custom, get_trilinear_feature, sample_from_planes
 
 _MLP1 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 1}
 _MLP2 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 2}
@@ -138,6 +140,33 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             self.finite_difference_normal_eps = self.cfg.finite_difference_normal_eps
 
 
+class _VoxFieldFn(torch.autograd.Function):
+    """(sdf, features, normal, sdf_grad) of ONE batch entry from its points, its channel-last feature volume and the two MLP heads: trilinear
+    lookup, heads, bias and finite differences in one kernel each way (include/asd_hip.h: asd_voxfield_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, points, voxel_cl, w1s, w2s, w1f, w2f, fcfg, want_normal):
+        sdf, feats, normal, fdg, enc = ops.voxfield_fwd(voxel_cl, fcfg, w1s, w2s, w1f, w2f, points, want_normal)
+        if not want_normal:
+            normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
+            ctx.mark_non_differentiable(normal, fdg)
+        ctx.save_for_backward(points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf)
+        ctx.fcfg, ctx.want_normal = fcfg, want_normal
+        ctx.set_materialize_grads(False)
+        return sdf, feats, normal, fdg
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
+        points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf = ctx.saved_tensors
+        d_vox = torch.zeros_like(voxel_cl)
+        if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
+            return (None, d_vox, *(torch.zeros_like(w) for w in (w1s, w2s, w1f, w2f)), None, None)
+        c = lambda t: None if t is None else t.contiguous()
+        dw = ops.voxfield_bwd(voxel_cl, ctx.fcfg, w1s, w2s, w1f, w2f, points, enc, sdf, c(d_sdf), c(d_feats),
+                              c(d_normal) if ctx.want_normal else None, c(d_fdg) if ctx.want_normal else None, d_vox)
+        return None, d_vox, dw[0], dw[1], dw[2], dw[3], None, None
+
+
 @register("3DConv-net")
 class Voxel_3d_Sdf(_SampledSdfGeometry):
     @dataclass
@@ -192,6 +221,76 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
         super().update_step(epoch, global_step, on_load_weights)
         self.truncation_psi = C(self.cfg.truncation_psi, epoch, global_step)
+        self._fcfg = self._field_cfg()
+
+    # ---- fused path: lookup + heads + bias + finite differences as one kernel (the shipped configuration) -------------------------------
+    def _field_cfg(self) -> Optional[_lib.FieldCfg]:
+        c = self.cfg
+        if c.sdf_bias == "sphere" and isinstance(c.sdf_bias_params, float):
+            bias, value = _lib.ASD_BIAS_SPHERE, float(c.sdf_bias_params)
+        elif isinstance(c.sdf_bias, float):
+            bias, value = _lib.ASD_BIAS_CONST, float(c.sdf_bias)
+        else:
+            return None
+        m = c.mlp_network_config
+        ok = (c.space_generator_config["img_channels"] == 32 and c.n_feature_dims == 3 and m.get("otype") == "VanillaMLP"
+              and m.get("n_neurons") == 64 and m.get("n_hidden_layers") == 1 and m.get("activation") == "ReLU"
+              and m.get("output_activation", "none") in (None, "none") and c.normal_type == "finite_difference"
+              and self.finite_difference_normal_eps is not None and not self.unbounded and not c.isosurface_deformable_grid)
+        if not ok:
+            return None
+        f = _lib.FieldCfg()
+        for d in range(3):
+            f.bbox_min[d], f.bbox_max[d] = -c.radius, c.radius
+        f.radius, f.bias_mode, f.bias_value = c.radius, bias, value
+        f.blob_scale, f.blob_std, f.activation = 0.0, 1.0, _lib.ASD_ACT_NONE
+        f.fd_eps, f.n_hidden, f.n_feature_dims, f.field_mode = float(self.finite_difference_normal_eps), 64, 3, _lib.ASD_FIELD_SDF
+        return f
+
+    def _heads_weights(self):
+        return (self.sdf_network.layers[0].weight, self.sdf_network.layers[2].weight,
+                self.feature_network.layers[0].weight, self.feature_network.layers[2].weight)
+
+    def _use_fused(self, points) -> bool:
+        return getattr(self, "_fcfg", None) is not None and points.is_cuda and os.environ.get("ASD_VOXFIELD", "1") != "0"
+
+    def _forward_points(self, points, space_cache, output_normal):
+        if not self._use_fused(points):
+            return super()._forward_points(points, space_cache, output_normal)
+        vol = channels_last(space_cache)                                  # [B, D, H, W, 32] (the HIP generator's own layout: a view)
+        w = self._heads_weights()
+        need_grad = torch.is_grad_enabled() and (vol.requires_grad or w[0].requires_grad)
+        outs = []
+        for b in range(points.shape[0]):
+            pts = points[b].reshape(-1, 3).contiguous().float()
+            if need_grad:
+                outs.append(_VoxFieldFn.apply(pts, vol[b], *w, self._fcfg, bool(output_normal)))
+            else:
+                with torch.no_grad():
+                    outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, pts, bool(output_normal), save_enc=False)[:4])
+        st = lambda i: torch.stack([o[i] for o in outs], 0)
+        out = {"sdf": st(0)[..., None], "features": st(1)}
+        if output_normal:
+            normal, sdf_grad = st(2), st(3)
+            out.update(normal=normal, shading_normal=normal, sdf_grad=sdf_grad)
+        return out
+
+    def forward_sdf(self, points, space_cache):
+        if not self._use_fused(points):
+            return super().forward_sdf(points, space_cache)
+        vol, w = channels_last(space_cache), self._heads_weights()
+        B = points.shape[0]
+        with torch.set_grad_enabled(torch.is_grad_enabled()):
+            pts = points.reshape(B, -1, 3)
+            need_grad = torch.is_grad_enabled() and (vol.requires_grad or w[0].requires_grad)
+            outs = []
+            for b in range(B):
+                p = pts[b].contiguous().float()
+                if need_grad:
+                    outs.append(_VoxFieldFn.apply(p, vol[b], *w, self._fcfg, False)[0])
+                else:
+                    outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, p, False, want_features=False, save_enc=False)[0])
+        return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)
 
 
 @register("Triplane-transformer-sdf")
