@@ -260,6 +260,44 @@ int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, co
                       float* d_sigma, float* d_rgb, float* d_bg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The renderer's training pass as one entry point each way: NeRFVolumeRenderer.forward (nerf_volume_renderer.py:118-428) with the
+ * occupancy-grid estimator (:139-180), a density field that runs as the fused kernels above (ImplicitVolume, 3 feature dims), a material
+ * that is colour = activation(features) (NoMaterial, no_material.py:41-54) and per-ray background colours — march, candidate densities,
+ * visibility pruning, compaction, field, compositing — and its backward (compositing gradient -> field gradients).  Every launch is
+ * enqueued from the library, every count stays on the device; one caller-owned workspace holds all buffers at `capacity` samples
+ * (>= n_rays * march.max_steps), asd_render_layout_init() gives their byte offsets (per-sample buffers are valid up to *n_kept).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_render_params {
+    asd_march_cfg march;
+    const asd_grid_meta* meta;          /* [host] */
+    const asd_field_cfg* field;         /* [host] */
+    const float* rays_o; const float* rays_d; int32_t n_rays;
+    const uint32_t* occ_bits;
+    const float* jitter;                /* [n_rays] or NULL */
+    const float* grid; const float* w1d; const float* w2d; const float* w1f; const float* w2f;
+    const float* bg;                    /* [n_rays, 3] */
+    float early_stop_eps, alpha_thre;   /* visibility pruning (asd_prune_count) */
+    int32_t prune;                      /* 0: every candidate is kept */
+    int32_t color_act;                  /* 0: features are colours; 1: sigmoid */
+    int32_t capacity;
+} asd_render_params;
+typedef struct asd_render_layout {      /* byte offsets into the workspace */
+    int64_t total_bytes;
+    int64_t count, offset, total;                                   /* candidates per ray [n_rays] int32, exclusive scan, sum [1] */
+    int64_t c_ray_idx, c_t0, c_t1, c_pts, c_sigma, keep;            /* candidates [capacity] */
+    int64_t kept, koff, n_kept;                                     /* kept per ray, exclusive scan, sum [1] */
+    int64_t ray_idx /* int64 */, t0, t1, pts, dirs, sigma, feats /* raw */, enc, weights;   /* kept samples [capacity] */
+    int64_t opacity, depth, z_var, rgb_fg, comp_rgb;                /* per ray */
+} asd_render_layout;
+int asd_render_layout_init(int32_t n_rays, int32_t capacity, asd_render_layout* layout);   /* [host] */
+int asd_render_fwd(const asd_render_params* p, void* workspace, void* stream);
+int asd_render_bwd_workspace(const asd_render_params* p, int64_t* n_floats);
+/* upstream gradients of the per-ray outputs (any may be NULL) -> d_grid / dw* (+=, as asd_field_bwd), d_bg [n_rays, 3] (or NULL) */
+int asd_render_bwd(const asd_render_params* p, void* workspace, const float* d_comp_rgb, const float* d_rgb_fg, const float* d_opacity,
+                   const float* d_depth, const float* d_z_var, float* d_grid, float* dw1d, float* dw2d, float* dw1f, float* dw2f,
+                   float* d_bg, float* bwd_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Frozen diffusion prior (SD-2.1 UNet eps-prediction): replaces the cuDNN / cuBLAS / SDPA kernels behind
  * diffusers' UNet2DConditionModel called at threestudio/models/guidance/stable_diffusion_asd_guidance.py:
  * 319-331 (forward_unet) — layer inventory SURVEY.md Appendix A.1.  Activations are NHWC fp16, accumulation

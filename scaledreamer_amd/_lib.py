@@ -86,6 +86,21 @@ class GemmArgs(C.Structure):
     ]
 
 
+class RenderParams(C.Structure):
+    _fields_ = [("march", MarchCfg), ("meta", C.c_void_p), ("field", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("n_rays", C.c_int32),
+                ("occ_bits", C.c_void_p), ("jitter", C.c_void_p), ("grid", C.c_void_p), ("w1d", C.c_void_p), ("w2d", C.c_void_p), ("w1f", C.c_void_p),
+                ("w2f", C.c_void_p), ("bg", C.c_void_p), ("early_stop_eps", C.c_float), ("alpha_thre", C.c_float), ("prune", C.c_int32),
+                ("color_act", C.c_int32), ("capacity", C.c_int32)]
+
+
+RENDER_LAYOUT_FIELDS = ["total_bytes", "count", "offset", "total", "c_ray_idx", "c_t0", "c_t1", "c_pts", "c_sigma", "keep", "kept", "koff", "n_kept",
+                        "ray_idx", "t0", "t1", "pts", "dirs", "sigma", "feats", "enc", "weights", "opacity", "depth", "z_var", "rgb_fg", "comp_rgb"]
+
+
+class RenderLayout(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in RENDER_LAYOUT_FIELDS]
+
+
 class Conv3dDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
                 ("amax_x", C.c_void_p), ("amax_dy", C.c_void_p)]
@@ -140,6 +155,7 @@ SYMBOLS = [
     "asd_adamw_f32", "asd_adan_f32",
     "asd_conv3d_workspace_bytes", "asd_conv3d_fwd", "asd_conv3d_dgrad", "asd_conv3d_wgrad", "asd_layer_act_bwd", "asd_upsample3d_fwd", "asd_upsample3d_bwd",
     "asd_torgb_fwd", "asd_torgb_bwd", "asd_absmax_f32", "asd_voxfield_fwd", "asd_voxfield_bwd_workspace", "asd_voxfield_bwd",
+    "asd_render_layout_init", "asd_render_fwd", "asd_render_bwd_workspace", "asd_render_bwd",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 

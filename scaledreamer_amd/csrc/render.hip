@@ -204,12 +204,19 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 // compositing
 // ---------------------------------------------------------------------------------------------------
+// colour of sample i, channel k: `rgb` holds activated colours, or — rgb_act == 1 — the raw features of a material that is
+// colour = sigmoid(features) (NoMaterial, no_material.py:41-54): the activation and its gradient then ride in these kernels
+__device__ __forceinline__ float comp_colour(const float* __restrict__ rgb, size_t i, int k, int rgb_act) {
+    const float v = rgb[3 * i + k];
+    return rgb_act == 1 ? 1.f / (1.f + expf(-v)) : v;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ t_start, const float* __restrict__ t_end,
     const float* __restrict__ rgb, const int* __restrict__ offset, const int* __restrict__ count, int n_rays,
     const float* __restrict__ bg, float* __restrict__ weights, float* __restrict__ opacity, float* __restrict__ depth,
-    float* __restrict__ rgb_fg, float* __restrict__ z_var, float* __restrict__ comp_rgb) {
+    float* __restrict__ rgb_fg, float* __restrict__ z_var, float* __restrict__ comp_rgb, int rgb_act = 0) {
     const int r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= n_rays) return;
     const int lane = asd_lane();
@@ -245,9 +252,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             weights[i] = w;
             op += w;
             dp = fmaf(w, t, dp);
-            c0 = fmaf(w, rgb[3 * (size_t)i], c0);
-            c1 = fmaf(w, rgb[3 * (size_t)i + 1], c1);
-            c2 = fmaf(w, rgb[3 * (size_t)i + 2], c2);
+            c0 = fmaf(w, comp_colour(rgb, i, 0, rgb_act), c0);
+            c1 = fmaf(w, comp_colour(rgb, i, 1, rgb_act), c1);
+            c2 = fmaf(w, comp_colour(rgb, i, 2, rgb_act), c2);
         }
     }
     op = asd_wave_sum(op); dp = asd_wave_sum(dp);
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float* __restrict__ depth, const float* __restrict__ d_comp_rgb, const float* __restrict__ d_rgb_fg,
     const float* __restrict__ d_opacity, const float* __restrict__ d_depth, const float* __restrict__ d_z_var,
     const float* __restrict__ d_weights, float* __restrict__ d_sigma, float* __restrict__ d_rgb,
-    float* __restrict__ d_bg) {
+    float* __restrict__ d_bg, int rgb_act = 0) {
     const int r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= n_rays) return;
     const int lane = asd_lane();
@@ -311,9 +318,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         const int i = b + j;
         const float t = (t_start[i] + t_end[i]) * 0.5f;
         float gw = gop + gdp * t + (d_weights ? d_weights[i] : 0.f);
-        gw = fmaf(G[0], rgb[3 * (size_t)i], gw);
-        gw = fmaf(G[1], rgb[3 * (size_t)i + 1], gw);
-        gw = fmaf(G[2], rgb[3 * (size_t)i + 2], gw);
+        gw = fmaf(G[0], comp_colour(rgb, i, 0, rgb_act), gw);
+        gw = fmaf(G[1], comp_colour(rgb, i, 1, rgb_act), gw);
+        gw = fmaf(G[2], comp_colour(rgb, i, 2, rgb_act), gw);
         if (gzv != 0.f) gw += MODE == 2 ? gzv * ((t - zm) * (t - zm) - 2.f * t * zm * (1.f - op)) : gzv * ((t - zm) * (t - zm) - zvu) / m;
         tot = fmaf(weights[i], gw, tot);
     }
@@ -326,15 +333,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         const bool valid = j < cnt;
         const int i = b + j;
         float t = 0.f, dt = 0.f, w = 0.f, gw = 0.f, sv = 0.f;
+        float col[3] = {0.f, 0.f, 0.f};
         if (valid) {
             t = (t_start[i] + t_end[i]) * 0.5f;
             dt = t_end[i] - t_start[i];
             w = weights[i];
             sv = sigma[i];
             gw = gop + gdp * t + (d_weights ? d_weights[i] : 0.f);
-            gw = fmaf(G[0], rgb[3 * (size_t)i], gw);
-            gw = fmaf(G[1], rgb[3 * (size_t)i + 1], gw);
-            gw = fmaf(G[2], rgb[3 * (size_t)i + 2], gw);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { col[k] = comp_colour(rgb, i, k, rgb_act); gw = fmaf(G[k], col[k], gw); }
             if (gzv != 0.f) gw += MODE == 2 ? gzv * ((t - zm) * (t - zm) - 2.f * t * zm * (1.f - op)) : gzv * ((t - zm) * (t - zm) - zvu) / m;
         }
         const float wg = w * gw;
@@ -359,9 +366,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         }
         if (valid) {
             d_sigma[i] = ds;
-            d_rgb[3 * (size_t)i] = w * G[0];
-            d_rgb[3 * (size_t)i + 1] = w * G[1];
-            d_rgb[3 * (size_t)i + 2] = w * G[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d_rgb[3 * (size_t)i + k] = w * G[k] * (rgb_act == 1 ? col[k] * (1.f - col[k]) : 1.f);
         }
     }
 }
@@ -524,6 +530,109 @@ int asd_composite_bwd(int32_t mode, const float* sigma, const float* t_start, co
 #undef COMPOSITE_BWD
     ASD_LAUNCH_CHECK();
     return ASD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The renderer's training pass as ONE entry point each way (NeRFVolumeRenderer.forward, nerf_volume_renderer.py:118-428, with the
+// occupancy-grid estimator, a fused ImplicitVolume field and a colour = activation(features) material): march -> candidate densities ->
+// visibility pruning -> compaction -> field at the kept samples -> compositing, enqueued from here with every count left on the device.
+// All buffers live in one caller-owned workspace (asd_render_layout_init gives the offsets), sized by `capacity` >= n_rays * max_steps.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static inline int64_t rl_al(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+int asd_render_layout_init(int32_t n_rays, int32_t capacity, asd_render_layout* L) {
+    ASD_CHECK_ARG(L && n_rays > 0 && capacity > 0, "bad argument");
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += rl_al(bytes); return at; };
+    const int64_t nr = n_rays, cap = capacity;
+    L->count = take(nr * 4); L->offset = take(nr * 4); L->total = take(4);
+    L->c_ray_idx = take(cap * 4); L->c_t0 = take(cap * 4); L->c_t1 = take(cap * 4); L->c_pts = take(cap * 12); L->c_sigma = take(cap * 4);
+    L->keep = take(cap); L->kept = take(nr * 4); L->koff = take(nr * 4); L->n_kept = take(4);
+    L->ray_idx = take(cap * 8); L->t0 = take(cap * 4); L->t1 = take(cap * 4); L->pts = take(cap * 12); L->dirs = take(cap * 12);
+    L->sigma = take(cap * 4); L->feats = take(cap * 12); L->enc = take(cap * 128); L->weights = take(cap * 4);
+    L->opacity = take(nr * 4); L->depth = take(nr * 4); L->z_var = take(nr * 4); L->rgb_fg = take(nr * 12); L->comp_rgb = take(nr * 12);
+    L->total_bytes = o;
+    return ASD_OK;
+}
+
+static int render_check(const asd_render_params* p) {
+    ASD_CHECK_ARG(p && p->meta && p->field && p->rays_o && p->rays_d && p->occ_bits && p->grid && p->w1d && p->w2d && p->w1f && p->w2f && p->bg, "null argument");
+    ASD_CHECK_ARG(p->n_rays > 0 && (int64_t)p->capacity >= (int64_t)p->n_rays * p->march.max_steps, "capacity must cover n_rays * max_steps candidates");
+    ASD_CHECK_ARG(p->field->n_feature_dims == 3 && p->field->field_mode == ASD_FIELD_DENSITY, "the fused pass renders a density field with 3 feature dims");
+    ASD_CHECK_ARG(p->color_act == 0 || p->color_act == 1, "color_act: 0 (features are colours) or 1 (sigmoid)");
+    return ASD_OK;
+}
+
+int asd_render_fwd(const asd_render_params* p, void* workspace, void* stream) {
+    if (render_check(p) != ASD_OK) return ASD_ERR_ARG;
+    ASD_CHECK_ARG(workspace, "null workspace");
+    asd_render_layout L;
+    asd_render_layout_init(p->n_rays, p->capacity, &L);
+    char* w = (char*)workspace;
+#define AT(T, f) ((T*)(w + L.f))
+    const int nr = p->n_rays, cap = p->capacity;
+    int rc;
+#define STEP(call) do { rc = (call); if (rc != ASD_OK) return rc; } while (0)
+    STEP(asd_march_count(&p->march, p->rays_o, p->rays_d, nr, p->occ_bits, p->jitter, AT(int32_t, count), stream));
+    STEP(asd_scan_i32(AT(int32_t, count), nr, AT(int32_t, offset), AT(int32_t, total), stream));
+    STEP(asd_march_write(&p->march, p->rays_o, p->rays_d, nr, p->occ_bits, p->jitter, AT(int32_t, offset), AT(int32_t, c_ray_idx), AT(float, c_t0), AT(float, c_t1),
+                         AT(float, c_pts), stream));
+    const int32_t *k_off, *k_cnt, *n_kept;
+    if (p->prune) {
+        STEP(asd_field_density(p->meta, p->field, p->grid, p->w1d, p->w2d, AT(float, c_pts), cap, AT(int32_t, total), AT(float, c_sigma), stream));
+        STEP(asd_prune_count(AT(float, c_sigma), AT(float, c_t0), AT(float, c_t1), AT(int32_t, offset), AT(int32_t, count), nr, p->early_stop_eps, p->alpha_thre,
+                             AT(uint8_t, keep), AT(int32_t, kept), stream));
+        STEP(asd_scan_i32(AT(int32_t, kept), nr, AT(int32_t, koff), AT(int32_t, n_kept), stream));
+        STEP(asd_compact(p->rays_o, p->rays_d, nr, AT(int32_t, offset), AT(int32_t, count), AT(uint8_t, keep), AT(float, c_t0), AT(float, c_t1), AT(int32_t, koff),
+                         AT(int64_t, ray_idx), AT(float, t0), AT(float, t1), AT(float, pts), AT(float, dirs), stream));
+        k_off = AT(int32_t, koff); k_cnt = AT(int32_t, kept); n_kept = AT(int32_t, n_kept);
+    } else {
+        STEP(asd_compact(p->rays_o, p->rays_d, nr, AT(int32_t, offset), AT(int32_t, count), nullptr, AT(float, c_t0), AT(float, c_t1), AT(int32_t, offset),
+                         AT(int64_t, ray_idx), AT(float, t0), AT(float, t1), AT(float, pts), AT(float, dirs), stream));
+        (void)hipMemcpyAsync(AT(int32_t, koff), AT(int32_t, offset), (size_t)nr * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        (void)hipMemcpyAsync(AT(int32_t, kept), AT(int32_t, count), (size_t)nr * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        (void)hipMemcpyAsync(AT(int32_t, n_kept), AT(int32_t, total), 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        k_off = AT(int32_t, koff); k_cnt = AT(int32_t, kept); n_kept = AT(int32_t, n_kept);
+    }
+    STEP(asd_field_fwd(p->meta, p->field, p->grid, p->w1d, p->w2d, p->w1f, p->w2f, AT(float, pts), cap, n_kept, AT(float, sigma), AT(float, feats), nullptr, nullptr,
+                       AT(float, enc), stream));
+    hipLaunchKernelGGL((composite_fwd_kernel<0>), dim3(asd_div_up(nr, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, AT(float, sigma), AT(float, t0), AT(float, t1),
+                       AT(float, feats), k_off, k_cnt, nr, p->bg, AT(float, weights), AT(float, opacity), AT(float, depth), AT(float, rgb_fg), AT(float, z_var),
+                       AT(float, comp_rgb), p->color_act);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_render_bwd_workspace(const asd_render_params* p, int64_t* n_floats) {
+    ASD_CHECK_ARG(p && p->field && n_floats, "null argument");
+    int64_t nf = 0;
+    const int rc = asd_field_bwd_workspace(p->field, p->capacity, 0, &nf);
+    if (rc != ASD_OK) return rc;
+    *n_floats = nf + (int64_t)4 * p->capacity + 64;
+    return ASD_OK;
+}
+
+int asd_render_bwd(const asd_render_params* p, void* workspace, const float* d_comp_rgb, const float* d_rgb_fg, const float* d_opacity, const float* d_depth,
+                   const float* d_z_var, float* d_grid, float* dw1d, float* dw2d, float* dw1f, float* dw2f, float* d_bg, float* bwd_workspace, void* stream) {
+    if (render_check(p) != ASD_OK) return ASD_ERR_ARG;
+    ASD_CHECK_ARG(workspace && bwd_workspace && d_grid && dw1d && dw2d && dw1f && dw2f, "null argument");
+    asd_render_layout L;
+    asd_render_layout_init(p->n_rays, p->capacity, &L);
+    char* w = (char*)workspace;
+    const int nr = p->n_rays, cap = p->capacity;
+    float* d_sigma = bwd_workspace;
+    float* d_feats = d_sigma + cap;
+    float* fws = d_feats + (int64_t)3 * cap + 32;
+    hipLaunchKernelGGL((composite_bwd_kernel<0>), dim3(asd_div_up(nr, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, AT(float, sigma), AT(float, t0), AT(float, t1),
+                       AT(float, feats), AT(int32_t, koff), AT(int32_t, kept), nr, p->bg, AT(float, weights), AT(float, opacity), AT(float, depth), d_comp_rgb, d_rgb_fg,
+                       d_opacity, d_depth, d_z_var, (const float*)nullptr, d_sigma, d_feats, d_bg, p->color_act);
+    const int rc = asd_field_bwd(p->meta, p->field, p->grid, p->w1d, p->w2d, p->w1f, p->w2f, AT(float, pts), AT(float, enc), AT(float, sigma), cap, AT(int32_t, n_kept),
+                                 d_sigma, d_feats, nullptr, nullptr, d_grid, dw1d, dw2d, dw1f, dw2f, fws, stream);
+    if (rc != ASD_OK) return rc;
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+#undef AT
+#undef STEP
 }
 
 int asd_occgrid_update(float* occs, int32_t n_cells, const int32_t* cell_idx, const float* occ_new, int32_t n_update,

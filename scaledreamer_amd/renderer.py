@@ -16,7 +16,9 @@ from typing import Any, Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from . import nerfacc_api, ops
+import ctypes as C
+
+from . import _lib, nerfacc_api, ops
 from .base import BaseModule
 from .registry import register, warn
 
@@ -168,6 +170,81 @@ class LazyOutputs(dict):
         return set(self._deferred)
 
 
+class _RenderPass:
+    """state of one fused training pass (include/asd_hip.h: asd_render_fwd / asd_render_bwd): the parameter block, the tensors its
+    pointers refer to (kept alive until the backward pass) and typed views into the workspace"""
+
+    _DT = {"count": torch.int32, "offset": torch.int32, "total": torch.int32, "kept": torch.int32, "koff": torch.int32, "n_kept": torch.int32,
+           "ray_idx": torch.int64, "keep": torch.uint8, "c_ray_idx": torch.int32}
+
+    def __init__(self, march_cfg, meta, fcfg, rays_o, rays_d, bits, jitter, early_stop_eps, alpha_thre, prune, color_act, capacity):
+        self.march_cfg, self.meta, self.fcfg = march_cfg, meta, fcfg
+        self.rays_o, self.rays_d, self.bits, self.jitter = rays_o, rays_d, bits, jitter
+        self.n_rays, self.capacity = rays_o.shape[0], int(capacity)
+        self.early_stop_eps, self.alpha_thre, self.prune, self.color_act = float(early_stop_eps), float(alpha_thre), int(prune), int(color_act)
+        self.layout = _lib.RenderLayout()
+        _lib.check(_lib.lib().asd_render_layout_init(_lib.i32(self.n_rays), _lib.i32(self.capacity), C.byref(self.layout)))
+        self.ws = None
+
+    def params(self, grid, w1d, w2d, w1f, w2f, bg) -> "_lib.RenderParams":
+        p = _lib.RenderParams()
+        p.march = self.march_cfg
+        p.meta, p.field = C.addressof(self.meta), C.addressof(self.fcfg)
+        p.rays_o, p.rays_d, p.n_rays = self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.n_rays
+        p.occ_bits, p.jitter = self.bits.data_ptr(), (None if self.jitter is None else self.jitter.data_ptr())
+        p.grid, p.w1d, p.w2d, p.w1f, p.w2f, p.bg = (t.data_ptr() for t in (grid, w1d, w2d, w1f, w2f, bg))
+        p.early_stop_eps, p.alpha_thre, p.prune, p.color_act, p.capacity = self.early_stop_eps, self.alpha_thre, self.prune, self.color_act, self.capacity
+        return p
+
+    def view(self, name: str, cols: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+        """typed view of a workspace buffer: per-ray buffers have n_rays rows, per-sample ones `capacity` (or the first `rows`)"""
+        dt = self._DT.get(name, torch.float32)
+        per_ray = name in ("count", "offset", "kept", "koff", "opacity", "depth", "z_var", "rgb_fg", "comp_rgb")
+        n = 1 if name in ("total", "n_kept") else (self.n_rays if per_ray else self.capacity)
+        if rows is not None:
+            n = rows
+        width = max(cols, 1)
+        off = getattr(self.layout, name)
+        nbytes = n * width * torch.empty(0, dtype=dt).element_size()
+        t = self.ws[off:off + nbytes].view(dt)
+        return t.view(n, cols) if cols else t
+
+
+class _RenderFn(torch.autograd.Function):
+    """the whole training pass of the renderer as one autograd node: (hash table, four MLP weights, per-ray background) -> (comp_rgb,
+    comp_rgb_fg, opacity, depth, z_variance); nothing in between is a Python-issued launch"""
+
+    @staticmethod
+    def forward(ctx, grid, w1d, w2d, w1f, w2f, bg, st):
+        st.ws = torch.empty(st.layout.total_bytes, dtype=torch.uint8, device=grid.device)
+        p = st.params(grid, w1d, w2d, w1f, w2f, bg)
+        _lib.check(_lib.lib().asd_render_fwd(C.byref(p), _lib.ptr(st.ws), _lib.stream()))
+        ctx.st = st
+        ctx.save_for_backward(grid, w1d, w2d, w1f, w2f, bg)
+        ctx.set_materialize_grads(False)
+        return st.view("comp_rgb", 3), st.view("rgb_fg", 3), st.view("opacity"), st.view("depth"), st.view("z_var")
+
+    @staticmethod
+    def backward(ctx, d_comp, d_fg, d_op, d_dp, d_zv):
+        grid, w1d, w2d, w1f, w2f, bg = ctx.saved_tensors
+        st = ctx.st
+        d_grid = torch.zeros_like(grid)
+        dws = [torch.zeros_like(w) for w in (w1d, w2d, w1f, w2f)]
+        if all(g is None for g in (d_comp, d_fg, d_op, d_dp, d_zv)):
+            return (d_grid, *dws, None, None)
+        p = st.params(grid, w1d, w2d, w1f, w2f, bg)
+        nf = C.c_int64(0)
+        _lib.check(_lib.lib().asd_render_bwd_workspace(C.byref(p), C.byref(nf)))
+        bws = torch.empty(nf.value, device=grid.device, dtype=torch.float32)
+        d_bg = torch.empty_like(bg) if ctx.needs_input_grad[5] else None
+        k = ops._Keep()
+        _lib.check(_lib.lib().asd_render_bwd(C.byref(p), _lib.ptr(st.ws), k(d_comp), k(d_fg), k(d_op), k(d_dp), k(d_zv), _lib.ptr(d_grid),
+                                             *(_lib.ptr(t) for t in dws), _lib.ptr(d_bg), _lib.ptr(bws), _lib.stream()))
+        if d_bg is not None and d_comp is None:
+            d_bg.zero_()
+        return (d_grid, *dws, d_bg, None)
+
+
 def validate_empty_rays(ray_indices, t_start, t_end):
     """threestudio/utils/ops.py:514-520: substitute one dummy sample when nothing was sampled."""
     if ray_indices.nelement() == 0:
@@ -291,6 +368,8 @@ class NeRFVolumeRenderer(VolumeRenderer):
                      and rays_o_flatten.is_cuda and getattr(self.material, "elementwise", False) and not self.cfg.return_comp_normal
                      and not self.cfg.return_normal_perturb
                      and not (self.material.requires_normal and getattr(self.material, "reads_normal", True)))
+        if sync_free and self._fused_pass_ok(n_rays):
+            return self._forward_fused_pass(batch_size, height, width, rays_o_flatten, rays_d_flatten, rays_d, bg_color, kwargs)
         with torch.no_grad():
             ray_indices, t_starts_, t_ends_, positions, t_dirs, offset, count, n_dev = self._sample(rays_o_flatten, rays_d_flatten, sync_free)
         if n_dev is not None:
@@ -373,6 +452,85 @@ class NeRFVolumeRenderer(VolumeRenderer):
                                                           output_normal=self.material.requires_normal)["normal"]
         elif "normal" in geo_out:
             out["comp_normal"] = comp_normal_of(geo_out["normal"])
+        return out
+
+    # ---- the training pass as one C-ABI entry each way ---------------------------------------------------------------------------
+    _COLOR_ACTS = {"sigmoid": 1, "none": 0, None: 0}
+
+    def _fused_pass_ok(self, n_rays: int) -> bool:
+        """asd_render_fwd covers: occupancy-grid sampling, a density field on the fused kernels with 3 feature dims, colour =
+        sigmoid(features) | features, no normal consumer inside the call (the conditions of the sync-free path, narrowed)"""
+        geo, mat = self.geometry, self.material
+        fc = getattr(geo, "_fcfg", None)
+        return (os.environ.get("ASD_RENDER_ENTRY", "1") != "0" and fc is not None and hasattr(geo, "_weights") and hasattr(geo, "_meta")
+                and getattr(geo.cfg, "n_feature_dims", 0) == 3 and fc.field_mode == _lib.ASD_FIELD_DENSITY
+                and getattr(mat.cfg, "color_activation", "?") in self._COLOR_ACTS and torch.is_grad_enabled()
+                and geo.encoding.encoding.encoding.params.requires_grad
+                and n_rays * int(self.estimator.march_cfg(self.cfg.near_plane, self.cfg.far_plane, self.render_step_size).max_steps) <= self.MAX_CANDIDATE_CAPACITY)
+
+    def _forward_fused_pass(self, batch_size, height, width, rays_o_flatten, rays_d_flatten, rays_d, bg_color, kwargs):
+        n_rays = rays_o_flatten.shape[0]
+        est, geo = self.estimator, self.geometry
+        jitter = self.jitter_fn(n_rays, rays_o_flatten.device) if self.randomized else None
+        if jitter is not None:
+            jitter = jitter.contiguous().float()
+        mcfg = est.march_cfg(self.cfg.near_plane, self.cfg.far_plane, self.render_step_size)
+        bits = est._bits()                       # (also refreshes the host mirror of the mean occupancy read below)
+        prune = self.cfg.grid_prune and self.cfg.prune_alpha_threshold
+        early_stop_eps, alpha_thre = (1e-4, min(0.01, est._occ_mean)) if prune else (0.0, 0.0)
+        st = _RenderPass(mcfg, geo._meta, geo._fcfg, rays_o_flatten, rays_d_flatten, bits, jitter, early_stop_eps, alpha_thre, prune,
+                         self._COLOR_ACTS[self.material.cfg.color_activation], n_rays * int(mcfg.max_steps))
+        comp_rgb_bg = self.background(dirs=rays_d)
+        if bg_color is None:
+            bg_color = comp_rgb_bg
+        elif bg_color.shape[:-1] == (batch_size,):
+            bg_color = bg_color.unsqueeze(1).unsqueeze(1).expand(-1, height, width, -1)
+        if bg_color.shape[:-1] == (batch_size, height, width):
+            bg_color = bg_color.reshape(n_rays, -1)
+        grid = geo.encoding.encoding.encoding.params
+        comp_rgb, comp_rgb_fg, opacity, depth, z_var = _RenderFn.apply(grid, *geo._weights(), bg_color.float().contiguous(), st)
+        n_dev = st.view("n_kept")
+        self._last_n = n_dev
+        out = LazyOutputs({
+            "comp_rgb": comp_rgb.view(batch_size, height, width, -1),
+            "comp_rgb_fg": comp_rgb_fg.view(batch_size, height, width, -1),
+            "comp_rgb_bg": comp_rgb_bg.view(batch_size, height, width, -1),
+            "opacity": opacity.view(batch_size, height, width, 1),
+            "depth": depth.view(batch_size, height, width, 1),
+            "z_variance": z_var.view(batch_size, height, width, 1),
+        })
+        material, bg_flat = self.material, bg_color
+
+        def per_sample():
+            """the per-sample entries, when somebody reads them: ONE read of the kept count, then the composed (differentiable) evaluation of
+            the same samples — field, material, compositing weights — so that a loss on them reaches the parameters as in the reference"""
+            n = int(n_dev.item())
+            if n == 0:                          # the reference's dummy sample of an empty batch (validate_empty_rays)
+                z = rays_o_flatten.new_zeros(1)
+                pts0 = rays_o_flatten[:1].detach()
+                g = geo(pts0, output_normal=False)
+                o = {"weights": z[..., None], "t_points": z[..., None], "t_intervals": z[..., None], "t_dirs": rays_d_flatten[:1],
+                     "ray_indices": torch.zeros(1, dtype=torch.long, device=z.device), "points": pts0}
+                o.update({k: v * 0.0 for k, v in g.items()})
+                return o
+            t0, t1, pts = st.view("t0", rows=n), st.view("t1", rows=n), st.view("pts", 3, rows=n)
+            g = geo(pts, output_normal=False)
+            rgb = material(viewdirs=st.view("dirs", 3, rows=n), positions=pts, light_positions=None, **g, **kwargs)
+            w = nerfacc_api.composite(g["density"][..., 0], rgb, bg_flat.float().detach(), t0, t1, st.view("koff"), st.view("kept"), 0)[0]
+            o = {"weights": w[..., None], "t_points": ((t0 + t1) / 2.0)[..., None], "t_intervals": (t1 - t0)[..., None],
+                 "t_dirs": st.view("dirs", 3, rows=n), "ray_indices": st.view("ray_idx", rows=n), "points": pts}
+            o.update(g)
+            return o
+
+        geo_keys = ("density", "features")
+        out.defer(("weights", "t_points", "t_intervals", "t_dirs", "ray_indices", "points") + geo_keys, per_sample)
+        if self.material.requires_normal:
+            def lazy_normal():
+                n = int(n_dev.item())
+                pts = st.view("pts", 3, rows=n) if n > 0 else rays_o_flatten[:1].detach()
+                g = geo(pts, output_normal=True)
+                return {"normal": g["normal"], "shading_normal": g["shading_normal"]}
+            out.defer(("normal", "shading_normal"), lazy_normal)
         return out
 
     @property
