@@ -150,7 +150,33 @@ PP44_LAUNCHES = [(512, 128, 128, 0, 0, 4), (512, 128, 128, 1, 1, 2), (512, 128, 
                  (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 0, 1), (512, 32, 128, 0, 1, 1)]
 # HBM bytes per launch of that kernel, averaged over the launches of `python bench.py` (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
 # profiles/r03_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)
-PP44_PMC_BYTES = 70.21e6 + 49.47e6
+PP44_PMC_BYTES = 70.21e6 + 49.47e6      # (round 3's figure: used only when the committed CSVs below are missing)
+
+
+def pmc_traffic_of(kernel_substr: str):
+    """HBM bytes per launch of a kernel from the COMMITTED per-kernel PMC summaries (profiles/r04_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv, falling back to
+    round 3's; separate rocprofv3 --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950) — read at run
+    time, so the figure follows the profile that is committed next to the code instead of a constant pasted into this file"""
+    import csv
+
+    tot = 0.0
+    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+        val = None
+        for rnd in ("r04", "r03"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cnt}_per_kernel.csv")
+            if not os.path.exists(path):
+                continue
+            with open(path) as fh:
+                for row in csv.reader(fh):          # kernel, dispatches, sum KB, avg KB, avg MB per dispatch (FETCH_SIZE already doubled there)
+                    if len(row) >= 5 and kernel_substr in row[0]:
+                        val = float(row[4]) * 1e6
+                        break
+            if val is not None:
+                break
+        if val is None:
+            return None
+        tot += val
+    return tot
 
 
 def roofline_pp_kernel(reps: int = 3):
@@ -168,21 +194,29 @@ def roofline_pp_kernel(reps: int = 3):
         if plan != (24, 1):
             skipped.append((hw, cin, cout))
             continue
-        x = torch.randn(1, hw, hw, cin, device="cuda").half()
-        w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * (9 * cin) ** -0.5)
-        kw = dict(gn_rows=hw * hw) if gn else {}
-        if res:
-            kw["residual"] = torch.randn(hw * hw, cout, device="cuda").half()
-        if gn == 2:
-            xg = torch.randn(1, hw * hw, cout, device="cuda").half()
-            gamma, beta = torch.ones(cout, device="cuda").half(), torch.zeros(cout, device="cuda").half()
-            _, fstats = H.groupnorm(xg, gamma, beta, 1e-6, True, return_stats=True)
-            kw["gn_bwd"] = dict(x=xg, fstats=fstats, gamma=gamma, beta=beta, eps=1e-6, silu=True)
-        for _ in range(2):
+        # HBM-cold operands, as inside the step (the review of round 3: replaying ONE operand set back to back keeps <= 67 MB resident in
+        # the 256 MB Infinity Cache and reads 6 % fast): rotate through enough distinct sets to exceed the cache twice over
+        set_bytes = 2.0 * hw * hw * (cin + cout * (1 + (1 if res else 0) + (1 if gn == 2 else 0)))
+        nsets = int(min(12, max(2, -(-600e6 // set_bytes))))
+        sets = []
+        for _ in range(nsets):
+            x = torch.randn(1, hw, hw, cin, device="cuda").half()
+            w = H.pack_conv3x3_weight(torch.randn(cout, cin, 3, 3, device="cuda").half() * (9 * cin) ** -0.5)
+            kw = dict(gn_rows=hw * hw) if gn else {}
+            if res:
+                kw["residual"] = torch.randn(hw * hw, cout, device="cuda").half()
+            if gn == 2:
+                xg = torch.randn(1, hw * hw, cout, device="cuda").half()
+                gamma, beta = torch.ones(cout, device="cuda").half(), torch.zeros(cout, device="cuda").half()
+                _, fstats = H.groupnorm(xg, gamma, beta, 1e-6, True, return_stats=True)
+                kw["gn_bwd"] = dict(x=xg, fstats=fstats, gamma=gamma, beta=beta, eps=1e-6, silu=True)
+            sets.append((x, w, kw))
+        for x, w, kw in sets[:2]:
             H.conv3x3(x, w, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps * count):
+        for i in range(reps * count):
+            x, w, kw = sets[i % nsets]
             H.conv3x3(x, w, **kw)
         e1.record()
         torch.cuda.synchronize()
@@ -190,7 +224,7 @@ def roofline_pp_kernel(reps: int = 3):
         flops += count * 2.0 * hw * hw * cout * 9 * cin
         alg_bytes += count * 2.0 * hw * hw * (cin + cout * (1 + (1 if res or gn == 2 else 0)))
         launches += count
-        del x, w, kw
+        del sets
     if launches == 0:
         return None
     achieved = flops / secs / 1e12
@@ -198,7 +232,9 @@ def roofline_pp_kernel(reps: int = 3):
                       "staggered by a barrier, counted vmcnt, 32-channel k-steps); all its launches of one step (VAE encoder forward + input gradient), each with its "
                       "step epilogue", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": PP44_PMC_BYTES, "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_*_per_kernel.csv)",
+            "traffic": pmc_traffic_of("conv3x3_pp_kernel<4, 4>") or PP44_PMC_BYTES,
+            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r0N_pmc_*_per_kernel.csv at run time)",
+            "operands": "HBM-cold: >= 600 MB of distinct operand sets rotated per shape (as inside the step)",
             "launches_per_step": int(launches), "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
             "avg_launch_ms": round(secs / launches * 1e3, 4), "ms_per_step": round(secs * 1e3, 3),
             "shapes_not_on_this_kernel_under_the_loaded_plans": skipped}
