@@ -240,6 +240,39 @@ def roofline_pp_kernel(reps: int = 3):
             "shapes_not_on_this_kernel_under_the_loaded_plans": skipped}
 
 
+def roofline_conv3d(reps: int = 6):
+    """conv3d_pp_kernel<2> (csrc/conv3d.hip) on the generator's heaviest layer, 64 -> 64 channels at 128^3 (forward and input gradient of
+    SynthesisBlock(128).conv1: 2 launches per C4 step): duration of the kernel alone between HIP events on the launch stream (asd_probe_events;
+    the split / pack passes of the call stay outside), fresh operands every launch.  Flops: 2 M N K fp32-equivalent, x 3 fp16 MFMA products."""
+    import ctypes as C
+    from scaledreamer_amd import ops
+    from scaledreamer_amd._lib import lib
+
+    R, Cc = 128, 64
+    sets = [(torch.randn(1, R, R, R, Cc, device="cuda"), torch.randn(1, Cc, Cc, 3, 3, 3, device="cuda") * (27 * Cc) ** -0.5) for _ in range(2)]
+    ops.conv3d_fwd(*sets[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    torch.cuda.synchronize()
+    lib().asd_probe_events(C.c_void_p(e0.cuda_event), C.c_void_p(e1.cuda_event))
+    ms = []
+    try:
+        for i in range(reps):
+            ops.conv3d_fwd(*sets[i % 2])
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+    finally:
+        lib().asd_probe_events(None, None)
+    t = sum(ms) / len(ms)
+    f32_flops = 2.0 * R ** 3 * Cc * 27 * Cc
+    achieved = 3 * f32_flops / (t * 1e-3) / 1e12
+    return {"kernel": "conv3d_pp_kernel<2> (split-fp16 3x3x3 convolution, csrc/conv3d.hip: 16x16-voxel patch x 64 channels, both fp16 planes of the 18x18 window "
+                      "LDS-resident per (depth tap, 32-channel chunk), three MFMA products per fragment pair) on 64->64 @128^3", "bound": "mfma",
+            "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s (fp16 products)", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
+            "fp32_equivalent_tflops": round(achieved / 3, 1), "traffic": None, "flops_per_launch": 3 * f32_flops, "avg_launch_ms": round(t, 4),
+            "algorithmic_bytes_per_launch": R ** 3 * Cc * (4 + 4)}
+
+
 def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     """The dominant kernel family of the step is the fp16 MFMA convolution (rocprofv3, profiles/r01_final7_kernel_stats_top70.csv:
     conv3x3_win2_kernel<128> + conv3x3_win_kernel<128> + conv3x3_win2_kernel<64> + conv3x3_win_kernel<64> 19.4 % of the kernel
@@ -604,8 +637,9 @@ def main():
                                   "views_per_gpu": 4})
         if args.workload in ("asd_sd_3dconv_net", "asd_mv_triplane"):
             out.update({"metric": f"ASD train steps/sec ({args.workload}, amortized)"})
-            out["config"].update({"workload": {"asd_sd_3dconv_net": "asd_sd_3dconv_net: StyleGAN-3D generator (fp32 library conv3d) -> [32,128^3] volume, "
-                                                                       "HIP trilinear samplers, VolSDF renderer, SD-2.1 guidance, 1 prompt+view/GPU",
+            out["config"].update({"workload": {"asd_sd_3dconv_net": "asd_sd_3dconv_net: StyleGAN-3D generator on the HIP path (split-fp16 3x3x3 convolutions fwd / dgrad / wgrad, "
+                                                                       "csrc/conv3d.hip) -> [32,128^3] volume, fused trilinear lookup + MLP heads, VolSDF renderer, SD-2.1 guidance, "
+                                                                       "1 prompt+view/GPU",
                                                "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer (fp32 library ops) -> 3x[32,64,64] "
                                                                   "planes, HIP tri-plane samplers, VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
             out.pop("kept_samples_last_step", None)
@@ -627,9 +661,13 @@ def main():
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
             lines["field_bwd"] = roofline_field_bwd(system, batch, reps=5)
             lines["renderer"] = roofline_field_kernel(system, batch)
-        dom = DOMINANT if DOMINANT in lines and lines[DOMINANT] is not None else "gemm"     # secondary workloads: no implicit-volume scatter
+        if args.workload == "asd_sd_3dconv_net":
+            lines["conv3d"] = roofline_conv3d()
+        dom = DOMINANT if DOMINANT in lines and lines[DOMINANT] is not None else ("conv3d" if "conv3d" in lines else "gemm")
         out["roofline"] = lines.pop(dom)
-        out["roofline"]["rank_source"] = DOMINANT_SOURCE if dom == DOMINANT else "secondary workload: most frequent GEMM of the diffusion prior"
+        out["roofline"]["rank_source"] = (DOMINANT_SOURCE if dom == DOMINANT else
+                                          "profiles/r04_c4_3dconv_step_breakdown.txt: the generator's convolution kernels lead this workload's step" if dom == "conv3d"
+                                          else "secondary workload: most frequent GEMM of the diffusion prior")
         for k, v in lines.items():
             out["roofline_" + k] = v
         if world == 1 and not args.no_cpu_baseline and args.workload == "asd_sd_nerf":

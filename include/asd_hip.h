@@ -361,7 +361,7 @@ typedef struct asd_gemm_args {
      * different (also odd: 2-byte aligned) offsets along K — the 27 taps of the 3-D convolution's weight gradient are the same
      * channel-major plane shifted along the voxel axis (csrc/conv3d.hip).  0 rows = off.  Offsets must be >= 0. */
     int32_t a_seg_rows, w_seg_rows;
-    int32_t a_seg_off[9], w_seg_off[3];
+    int32_t a_seg_off[9], w_seg_off[6];
     int32_t partials_only;  /* split_k > 1: leave the fp32 slabs workspace[split_k, M, N] unreduced (no epilogue launch; the caller sums them) */
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */

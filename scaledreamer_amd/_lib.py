@@ -81,7 +81,7 @@ class GemmArgs(C.Structure):
         ("gn_bwd_x", C.c_void_p), ("gn_bwd_fstats", C.c_void_p), ("gn_bwd_gamma", C.c_void_p), ("gn_bwd_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("gn_silu", C.c_int32), ("wide_rows", C.c_int32),
         ("ln_mode", C.c_int32), ("ln_eps", C.c_float), ("ln_sc", C.c_void_p), ("ln_stats", C.c_void_p),
-        ("a_seg_rows", C.c_int32), ("w_seg_rows", C.c_int32), ("a_seg_off", C.c_int32 * 9), ("w_seg_off", C.c_int32 * 3),
+        ("a_seg_rows", C.c_int32), ("w_seg_rows", C.c_int32), ("a_seg_off", C.c_int32 * 9), ("w_seg_off", C.c_int32 * 6),
         ("partials_only", C.c_int32),
     ]
 

@@ -388,20 +388,25 @@ __global__ __launch_bounds__(512) void conv3d_pp_kernel(const conv3d_kargs p) {
     if (p.amax_out) wave_amax_commit(am, p.amax_out);
 }
 
-// ---- weight gradient: reduction of the split-K slabs of the three products -----------------------------------------------------------
-// slabs fp32 [n_slabs][M = 9 Cin][N = 3 Cout]: row (t9 = kd * 3 + ky, ci), column (kx, co)  ->  dw fp32 [Cout][Cin][27], times 1 / (s_x s_dy)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int Cin, int Cout, const unsigned* __restrict__ amax_x,
-                                                           const unsigned* __restrict__ amax_dy, float* __restrict__ dw, int accumulate) {
-    const size_t MN = (size_t)9 * Cin * 3 * Cout;
+// ---- weight gradient: reduction of the split-K slabs of the two launches -------------------------------------------------------------
+// s1 fp32 [n1][M = 9 Cin][6 Cout]: X_hi against [dY_hi | dY_lo] (column (plane, kx, co)); s2 fp32 [n2][M][3 Cout]: X_lo against dY_hi.
+// row (t9 = kd * 3 + ky, ci)  ->  dw fp32 [Cout][Cin][27], times 1 / (s_x s_dy)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ s1, int n1, const float* __restrict__ s2, int n2, int Cin, int Cout,
+                                                           const unsigned* __restrict__ amax_x, const unsigned* __restrict__ amax_dy, float* __restrict__ dw) {
+    const int N = 3 * Cout;
+    const size_t MN = (size_t)9 * Cin * N;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
+    const int n = (int)(i % N), m = (int)(i / N);
     float v = 0.f;
-    for (int s = 0; s < n_slabs; ++s) v += slabs[(size_t)s * MN + i];
-    const int n = (int)(i % (3 * Cout)), m = (int)(i / (3 * Cout));
+    for (int s = 0; s < n1; ++s) {
+        const float* row = s1 + ((size_t)s * 9 * Cin + m) * (2 * N);
+        v += row[n] + row[N + n];
+    }
+    for (int s = 0; s < n2; ++s) v += s2[(size_t)s * MN + i];
     const int kx = n / Cout, co = n - kx * Cout, t9 = m / Cin, ci = m - t9 * Cin;
     v *= 1.f / (split_scale(*amax_x) * split_scale(*amax_dy));
-    float* dst = dw + ((size_t)co * Cin + ci) * 27 + t9 * 3 + kx;
-    *dst = accumulate ? *dst + v : v;
+    dw[((size_t)co * Cin + ci) * 27 + t9 * 3 + kx] = v;
 }
 
 // ---- layer glue on channel-last fp32 volumes -----------------------------------------------------------------------------------------
@@ -477,13 +482,25 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
     const float sc = (float)(r - 1) / (float)(R - 1);
     const float ns = noise ? *noise_strength : 0.f;
     float am = 0.f;
+    // R and C / 4 are powers of two on every level of the generator: index arithmetic in shifts (the general form is 64-bit div / mod
+    // five times per output quad — more instructions than the eight gathers)
+    const bool pow2 = (R & (R - 1)) == 0 && (c4 & (c4 - 1)) == 0;
+    const int lr = 31 - __builtin_clz(R), lc = 31 - __builtin_clz(c4);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % c4) * 4;
-        size_t v = i / c4;
-        const int ox = (int)(v % R); v /= R;
-        const int oy = (int)(v % R); v /= R;
-        const int oz = (int)(v % R);
-        const int n = (int)(v / R);
+        int c, ox, oy, oz, n;
+        if (pow2) {
+            c = (int)(i & (size_t)(c4 - 1)) * 4;
+            const size_t v = i >> lc;
+            ox = (int)(v & (size_t)(R - 1)); oy = (int)((v >> lr) & (size_t)(R - 1)); oz = (int)((v >> (2 * lr)) & (size_t)(R - 1));
+            n = (int)(v >> (3 * lr));
+        } else {
+            c = (int)(i % c4) * 4;
+            size_t v = i / c4;
+            ox = (int)(v % R); v /= R;
+            oy = (int)(v % R); v /= R;
+            oz = (int)(v % R);
+            n = (int)(v / R);
+        }
         const float fx = ox * sc, fy = oy * sc, fz = oz * sc;
         const int x0 = min((int)fx, r - 1), y0 = min((int)fy, r - 1), z0 = min((int)fz, r - 1);
         const int x1 = min(x0 + 1, r - 1), y1 = min(y0 + 1, r - 1), z1 = min(z0 + 1, r - 1);
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = fmaf(wt, t[q], o[q]);
         }
-        const size_t row = i / c4;
+        const size_t row = pow2 ? i >> lc : i / c4;
         const float nz = noise ? noise[row] * ns : 0.f;
         floatx4 bb = {0.f, 0.f, 0.f, 0.f};
         if (bias) bb = *(const floatx4*)(bias + c);
@@ -628,33 +645,40 @@ __global__ __launch_bounds__(256) void torgb_dgrad_kernel(const float* __restric
     }
 }
 // dw[o][i] += sum_v dy[v][o] x[v][i] over this block's voxels (atomics of the block totals; dw zeroed by the caller); d_bias[o] += sum_v dy[v][o].
-// lane = input channel i0 + lane (coalesced reads of x), wave q owns outputs 8 q .. 8 q + 7 (dy values wave-uniform: scalar loads)
+// lane = input channel i0 + lane (coalesced reads of x), every thread accumulates ALL 32 outputs (the dy row is wave-uniform: scalar loads,
+// 32 FMAs per loaded x), the block's four waves take every fourth row and are summed through LDS
 __global__ __launch_bounds__(256) void torgb_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, size_t rows, int Cin, size_t rows_per_block,
                                                           float* __restrict__ dw, float* __restrict__ d_bias) {
+    __shared__ float red[4][TORGB_O][64];
     const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float sb = 0.f;                                   // lanes 0..31: column sum of dy over this wave's rows (first channel pass only)
     for (int i0 = 0; i0 < Cin; i0 += 64) {
         const int i = i0 + lane;
-        float acc[8];
+        float acc[TORGB_O];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int k = 0; k < TORGB_O; ++k) acc[k] = 0.f;
         if (i < Cin) {
-#pragma unroll 4
-            for (size_t r = r0; r < r1; ++r) {
+#pragma unroll 2
+            for (size_t r = r0 + q; r < r1; r += 4) {
                 const float xv = x[r * Cin + i];
-                const float* g = dy + r * TORGB_O + 8 * q;                           // wave-uniform
+                const float* g = dy + r * TORGB_O;                                   // wave-uniform
+                if (i0 == 0 && lane < TORGB_O) sb += g[lane];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = fmaf(xv, g[k], acc[k]);
+                for (int k = 0; k < TORGB_O; ++k) acc[k] = fmaf(xv, g[k], acc[k]);
             }
+        }
+        __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(dw + (size_t)(8 * q + k) * Cin + i, acc[k]);
+        for (int k = 0; k < TORGB_O; ++k) red[q][k][lane] = acc[k];
+        __syncthreads();
+        // 32 x 64 sums of four waves: thread t -> outputs t >> 6 + 4 j, channel t & 63
+        for (int k = q; k < TORGB_O; k += 4) {
+            const float t = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+            if (i < Cin) atomicAdd(dw + (size_t)k * Cin + i, t);
         }
     }
-    if (d_bias && lane < 8) {
-        float sb = 0.f;
-        for (size_t r = r0; r < r1; ++r) sb += dy[r * TORGB_O + 8 * q + lane];
-        atomicAdd(d_bias + 8 * q + lane, sb);
-    }
+    if (d_bias && lane < TORGB_O) atomicAdd(d_bias + lane, sb);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
@@ -672,8 +696,8 @@ static c3_cm_layout c3_cm(int D, int H, int W) {
 }
 
 // split-K of the weight-gradient GEMM (M = 9 Cin, N = 3 Cout, 128-row tiles): about two blocks per CU
-static int c3_wgrad_split(const asd_conv3d_desc* d, size_t ld) {
-    const int M = 9 * d->Cin, N = 3 * d->Cout;
+static int c3_wgrad_split(const asd_conv3d_desc* d, size_t ld, int planes) {
+    const int M = 9 * d->Cin, N = 3 * d->Cout * planes;
     const int bn = N % 128 == 0 ? 128 : 64, tiles = asd_div_up(M, 128) * (N / bn);
     int split = 512 / tiles;
     split = split < 2 ? 2 : (split > ASD_CONV3D_WGRAD_MAX_SPLIT ? ASD_CONV3D_WGRAD_MAX_SPLIT : split);
@@ -690,7 +714,7 @@ int64_t asd_conv3d_workspace_bytes(const asd_conv3d_desc* d, int32_t pass) {
     if (pass == 2) {      // weight gradient: four channel-major planes + slabs + scalars
         const c3_cm_layout l = c3_cm(d->D, d->H, d->W);
         const size_t plane_x = ((size_t)d->Cin * l.ld + 2 * l.guard) * 2, plane_y = ((size_t)d->Cout * l.ld + 2 * l.guard) * 2;
-        const size_t slabs = (size_t)3 * c3_wgrad_split(d, l.ld) * 9 * d->Cin * 3 * d->Cout * 4;
+        const size_t slabs = ((size_t)2 * c3_wgrad_split(d, l.ld, 2) + c3_wgrad_split(d, l.ld, 1)) * 9 * d->Cin * 3 * d->Cout * 4;
         return (int64_t)(256 + 2 * al256(plane_x) + 2 * al256(plane_y) + al256(slabs));
     }
     const int cin = pass == 1 ? d->Cout : d->Cin, cout = pass == 1 ? d->Cin : d->Cout;
@@ -799,8 +823,8 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
     half_t* yl = (half_t*)((char*)yh + al256(plane_y));
     float* slabs = (float*)((char*)yl + al256(plane_y));
     const int M = 9 * Cin, N = 3 * Cout;
-    const int bn = N % 128 == 0 ? 128 : 64;
-    const int split = c3_wgrad_split(d, l.ld);
+    const int split1 = c3_wgrad_split(d, l.ld, 2), split2 = c3_wgrad_split(d, l.ld, 1);
+    ASD_CHECK_ARG((char*)yl - (char*)yh < ((ptrdiff_t)1 << 30), "the two gradient planes must lie within 1 GiB of each other");
     for (int n = 0; n < d->N; ++n) {
         (void)hipMemsetAsync(amax, 0, 8, s);
         const unsigned* ax = d->amax_x ? d->amax_x : amax;
@@ -817,28 +841,32 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
         }
         hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cin / 32), dim3(256), 0, s, x + n * vox * Cin, D, H, W, Cin, ax, xh, xl, l.ld, (int)l.guard);
         hipLaunchKernelGGL(split_cm_kernel, dim3((D + 2) * l.Hp, Cout / 32), dim3(256), 0, s, dy + n * vox * Cout, D, H, W, Cout, ay, yh, yl, l.ld, (int)l.guard);
-        // C[(t9, ci)][(kx, co)] = sum_u XT[ci][u + sA(t9)] * dYT[co][u - (kx - 1)]
+        // C[(t9, ci)][(plane, kx, co)] = sum_u XT[ci][u + sA(t9)] * dYT_plane[co][u - (kx - 1)].  Two launches for the three products: X_hi against
+        // BOTH planes of dY (the hi and lo rows are six segments of one W operand: the X_hi tile is loaded once for two products), then X_lo
+        // against dY_hi
         asd_gemm_args a;
         memset(&a, 0, sizeof(a));
-        a.M = M; a.N = N; a.K = (int)l.ld; a.lda = (int)l.ld; a.ldw = (int)l.ld; a.ldc = N;
-        a.zero_page = zero_page; a.split_k = split; a.partials_only = 1;
-        a.tile_cfg = bn == 128 ? 2 : 1;            // 128 x 128 / 128 x 64
+        a.M = M; a.K = (int)l.ld; a.lda = (int)l.ld; a.ldw = (int)l.ld;
+        a.zero_page = zero_page; a.partials_only = 1;
         a.a_seg_rows = Cin; a.w_seg_rows = Cout;
         for (int t9 = 0; t9 < 9; ++t9) a.a_seg_off[t9] = (int)(((long long)l.guard + (long long)(t9 / 3 - 1) * l.Hp * l.Wp + (long long)(t9 % 3 - 1) * l.Wp) * 2);
-        for (int kx = 0; kx < 3; ++kx) a.w_seg_off[kx] = (int)(((long long)l.guard - (kx - 1)) * 2);
+        const long long lo_off = (long long)((char*)yl - (char*)yh);
+        for (int q = 0; q < 6; ++q) a.w_seg_off[q] = (int)((q / 3) * lo_off + ((long long)l.guard - (q % 3 - 1)) * 2);
+        float* slabs2 = slabs + (size_t)split1 * M * 2 * N;
         a.C = slabs;        // unused (partials_only) but must be non-null
-        const size_t slab3 = (size_t)split * M * N;
-        for (int prod = 0; prod < 3; ++prod) {      // hi.hi, hi.lo, lo.hi
-            a.A = prod == 2 ? (const void*)xl : (const void*)xh;
-            a.W = prod == 1 ? (const void*)yl : (const void*)yh;
-            a.workspace = slabs + prod * slab3;
-            if (prod == 0) ASD_PROBE_START(s);
-            const int rc = asd_gemm_f16(&a, stream);
-            if (prod == 0) ASD_PROBE_STOP(s);
-            if (rc != ASD_OK) return rc;
-        }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(asd_div_up((size_t)M * N, 256)), dim3(256), 0, s, slabs, 3 * split, Cin, Cout, ax, ay,
-                           dw + (size_t)n * dw_sample_stride, 0);
+        a.W = yh;
+        // launch 1: X_hi . [dY_hi | dY_lo]
+        a.A = xh; a.N = 2 * N; a.ldc = 2 * N; a.split_k = split1; a.workspace = slabs; a.tile_cfg = 2;      // 128 x 128 (6 Cout % 128 == 0)
+        ASD_PROBE_START(s);
+        int rc = asd_gemm_f16(&a, stream);
+        ASD_PROBE_STOP(s);
+        if (rc != ASD_OK) return rc;
+        // launch 2: X_lo . dY_hi
+        a.A = xl; a.N = N; a.ldc = N; a.split_k = split2; a.workspace = slabs2; a.tile_cfg = N % 128 == 0 ? 2 : 1;
+        rc = asd_gemm_f16(&a, stream);
+        if (rc != ASD_OK) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(asd_div_up((size_t)M * N, 256)), dim3(256), 0, s, slabs, split1, slabs2, split2, Cin, Cout, ax, ay,
+                           dw + (size_t)n * dw_sample_stride);
     }
     ASD_LAUNCH_CHECK();
     return ASD_OK;

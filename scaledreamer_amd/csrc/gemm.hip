@@ -1151,8 +1151,8 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     ASD_CHECK_ARG(a->split_k >= 1 && (a->split_k == 1 || a->workspace), "split-K needs a workspace");
     if (a->a_seg_rows > 0 || a->w_seg_rows > 0 || a->partials_only)
         ASD_CHECK_ARG(!a->conv && a->K % 64 == 0 && a->a_seg_rows >= 0 && a->w_seg_rows >= 0 && (!a->partials_only || a->split_k > 1) &&
-                      (a->a_seg_rows == 0 || (a->M + a->a_seg_rows - 1) / a->a_seg_rows <= 9) && (a->w_seg_rows == 0 || (a->N + a->w_seg_rows - 1) / a->w_seg_rows <= 3),
-                      "segmented rows / partials_only: plain GEMM, K % 64 == 0, at most 9 (A) and 3 (W) segments, split_k > 1 for partials_only");
+                      (a->a_seg_rows == 0 || (a->M + a->a_seg_rows - 1) / a->a_seg_rows <= 9) && (a->w_seg_rows == 0 || (a->N + a->w_seg_rows - 1) / a->w_seg_rows <= 6),
+                      "segmented rows / partials_only: plain GEMM, K % 64 == 0, at most 9 (A) and 6 (W) segments, split_k > 1 for partials_only");
     ASD_CHECK_ARG((size_t)a->N * a->ldw * 2 < ((size_t)1 << 32) && (a->conv || (size_t)a->M * a->lda * 2 < ((size_t)1 << 32)),
                   "row-major operands are addressed with 32-bit byte offsets (< 4 GiB each)");
     if (a->act == 2)
