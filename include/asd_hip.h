@@ -130,6 +130,20 @@ int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int
                      const float* d_fd_grad, float* d_voxel_cl, float* dw1_sdf, float* dw2_sdf, float* dw1_feature, float* dw2_feature,
                      float* workspace, void* stream);
 
+/* The fused field of `Triplane-transformer-sdf` (custom/amortized/models/geometry/triplane_transformer.py:139-240): contract -> three
+ * bilinear plane lookups (sample_from_planes, geometry/utils.py:81-93; planes_cl [3][H][W][32] of ONE batch entry) -> two VanillaMLP heads
+ * 96 -> 64 -> 64 -> 1 | 3 -> sdf + bias -> finite-difference sdf_grad.  cfg: ASD_FIELD_SDF with sphere / constant bias.
+ * weights [host array of 6 device pointers]: sdf head W1^T [96][64] (the first layer TRANSPOSED), W2 [64][64], W3 [1][64]; feature head
+ * W1^T, W2, W3 [3][64].  Backward: nothing but the points and the sdf is kept from the forward pass; d_planes_cl += (atomics),
+ * d_weights [host array of 6 device pointers] += with the FIRST-layer gradients in the NATIVE layout [64][96]; workspace:
+ * asd_trifield_bwd_workspace floats (the pass walks the samples in chunks). */
+int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights,
+                     const float* points, int32_t n, float* sdf, float* features /* or NULL */, float* normal, float* fd_grad, void* stream);
+int asd_trifield_bwd_workspace(int32_t n, int32_t with_normal, int64_t* n_floats);
+int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights,
+                     const float* points, const float* sdf, int32_t n, const float* d_sdf, const float* d_features, const float* d_normal,
+                     const float* d_fd_grad, float* d_planes_cl, float* const* d_weights, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Background: (d+1)/2 -> hash grid (L levels) -> VanillaMLP(2L -> H -> H -> 3) -> sigmoid.
  * Replaces NeuralEnvironmentMapBackground.forward

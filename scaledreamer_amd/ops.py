@@ -520,3 +520,39 @@ def voxfield_bwd(voxel_cl, cfg: FieldCfg, w1s, w2s, w1f, w2f, points, enc, sdf, 
                                  ptr(enc), ptr(sdf), i32(n), k(d_sdf), k(d_features), k(d_normal), k(d_fd_grad), ptr(d_voxel), ptr(dw1s), ptr(dw2s),
                                  ptr(dw1f), ptr(dw2f), ptr(ws), stream()))
     return dw1s, dw2s, dw1f, dw2f
+
+
+# ---- fused tri-plane field (Triplane-transformer-sdf): three plane lookups -> 96 -> 64 -> 64 -> 1 | 3 heads -> bias -> finite differences ------
+def _ptr6(ts):
+    return (C.c_void_p * 6)(*[t.data_ptr() for t in ts])
+
+
+def trifield_fwd(planes_cl: torch.Tensor, cfg: FieldCfg, weights6, points, want_normal: bool, want_features: bool = True):
+    """planes_cl [3,H,W,32] (one batch entry); weights6 = (sdf W1^T [96,64], W2 [64,64], W3 [1,64], feature W1^T, W2, W3 [3,64]) contiguous fp32;
+    points [n,3] world coordinates -> (sdf [n], features [n,3] | None, normal, fd_grad)"""
+    _need_cuda(planes_cl, points)
+    planes_cl, points = _c(planes_cl), _c(points)
+    _, H, W, Cc = planes_cl.shape
+    n, dev = points.shape[0], points.device
+    sdf = torch.empty(n, device=dev, dtype=torch.float32)
+    feats = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_features else None
+    normal = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    fdg = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
+    check(lib().asd_trifield_fwd(ptr(planes_cl), i32(H), i32(W), i32(Cc), C.byref(cfg), _ptr6(weights6), ptr(points), i32(n), ptr(sdf), ptr(feats),
+                                 ptr(normal), ptr(fdg), stream()))
+    return sdf, feats, normal, fdg
+
+
+def trifield_bwd(planes_cl, cfg: FieldCfg, weights6, points, sdf, d_sdf, d_features, d_normal, d_fd_grad, d_planes: torch.Tensor):
+    """accumulates into d_planes [3,H,W,32]; returns the six weight gradients (first layers in the NATIVE [64,96] layout)"""
+    planes_cl, points = _c(planes_cl), _c(points)
+    _, H, W, Cc = planes_cl.shape
+    n, dev = points.shape[0], points.device
+    nf = C.c_int64(0)
+    check(lib().asd_trifield_bwd_workspace(i32(n), i32(int(d_normal is not None or d_fd_grad is not None)), C.byref(nf)))
+    ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
+    dws = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))]
+    k = _Keep()
+    check(lib().asd_trifield_bwd(ptr(planes_cl), i32(H), i32(W), i32(Cc), C.byref(cfg), _ptr6(weights6), ptr(points), ptr(sdf), i32(n), k(d_sdf),
+                                 k(d_features), k(d_normal), k(d_fd_grad), ptr(d_planes), _ptr6(dws), ptr(ws), stream()))
+    return dws

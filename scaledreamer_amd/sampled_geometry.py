@@ -22,7 +22,7 @@ from .generators import Generator3D, TriplaneTransformer
 from .geometry import BaseImplicitGeometry
 from .networks import get_activation, get_mlp
 from .registry import register
-from .samplers import channels_last, contract_to_unisphere_custom, get_trilinear_feature, sample_from_planes
+from .samplers import channels_last, contract_to_unisphere_custom, get_trilinear_feature, planes_channels_last, sample_from_planes
 
 _MLP1 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 1}
 _MLP2 = {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 2}
@@ -293,6 +293,34 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
         return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)
 
 
+class _TriFieldFn(torch.autograd.Function):
+    """(sdf, features, normal, sdf_grad) of ONE batch entry from its points, its channel-last planes [3, H, W, 32] and the two 96 -> 64 -> 64 -> 1 | 3
+    heads (include/asd_hip.h: asd_trifield_fwd / _bwd); nothing but the points and the sdf is kept for the backward pass"""
+
+    @staticmethod
+    def forward(ctx, points, planes_cl, s1, s2, s3, f1, f2, f3, fcfg, want_normal):
+        w6 = (s1.t().contiguous(), s2.contiguous(), s3.contiguous(), f1.t().contiguous(), f2.contiguous(), f3.contiguous())
+        sdf, feats, normal, fdg = ops.trifield_fwd(planes_cl, fcfg, w6, points, want_normal)
+        if not want_normal:
+            normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
+            ctx.mark_non_differentiable(normal, fdg)
+        ctx.save_for_backward(points, planes_cl, sdf, *w6)
+        ctx.fcfg, ctx.want_normal = fcfg, want_normal
+        ctx.set_materialize_grads(False)
+        return sdf, feats, normal, fdg
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
+        points, planes_cl, sdf, *w6 = ctx.saved_tensors
+        d_pl = torch.zeros_like(planes_cl)
+        if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
+            return (None, d_pl, *(torch.zeros(sh, device=sdf.device) for sh in ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))), None, None)
+        c = lambda t: None if t is None else t.contiguous()
+        dws = ops.trifield_bwd(planes_cl, ctx.fcfg, w6, points, sdf, c(d_sdf), c(d_feats), c(d_normal) if ctx.want_normal else None,
+                               c(d_fdg) if ctx.want_normal else None, d_pl)
+        return (None, d_pl, *dws, None, None)
+
+
 @register("Triplane-transformer-sdf")
 class TriplaneTransformerSDF(_SampledSdfGeometry):
     @dataclass
@@ -327,3 +355,83 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
 
     def interpolate_encodings(self, points, space_cache):
         return sample_from_planes(plane_features=space_cache, coordinates=points).view(*points.shape[:-1], -1)
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        super().update_step(epoch, global_step, on_load_weights)
+        self._fcfg = self._field_cfg()
+
+    # ---- fused path: three lookups + both heads + bias + finite differences as one kernel each way (the shipped configuration) -----------
+    def _field_cfg(self) -> Optional[_lib.FieldCfg]:
+        c = self.cfg
+        if c.sdf_bias == "sphere" and isinstance(c.sdf_bias_params, float):
+            bias, value = _lib.ASD_BIAS_SPHERE, float(c.sdf_bias_params)
+        elif isinstance(c.sdf_bias, float):
+            bias, value = _lib.ASD_BIAS_CONST, float(c.sdf_bias)
+        else:
+            return None
+        m = c.mlp_network_config
+        ok = (c.space_generator_config["triplane_dim"] == 32 and c.n_feature_dims == 3 and m.get("otype") == "VanillaMLP"
+              and m.get("n_neurons") == 64 and m.get("n_hidden_layers") == 2 and m.get("activation") == "ReLU"
+              and m.get("output_activation", "none") in (None, "none") and c.normal_type == "finite_difference"
+              and self.finite_difference_normal_eps is not None and not self.unbounded and not c.isosurface_deformable_grid)
+        if not ok:
+            return None
+        f = _lib.FieldCfg()
+        for d in range(3):
+            f.bbox_min[d], f.bbox_max[d] = -c.radius, c.radius
+        f.radius, f.bias_mode, f.bias_value = c.radius, bias, value
+        f.blob_scale, f.blob_std, f.activation = 0.0, 1.0, _lib.ASD_ACT_NONE
+        f.fd_eps, f.n_hidden, f.n_feature_dims, f.field_mode = float(self.finite_difference_normal_eps), 64, 3, _lib.ASD_FIELD_SDF
+        return f
+
+    def _heads_weights(self):
+        s, f = self.sdf_network.layers, self.feature_network.layers
+        return (s[0].weight, s[2].weight, s[4].weight, f[0].weight, f[2].weight, f[4].weight)
+
+    def _use_fused(self, points) -> bool:
+        return getattr(self, "_fcfg", None) is not None and points.is_cuda and os.environ.get("ASD_TRIFIELD", "1") != "0"
+
+    def forward(self, points, space_cache, output_normal: bool = False):
+        if self._use_fused(points):       # no autograd state per point beyond the points themselves: no chunking / checkpointing at any size
+            batch_size, n_points, _ = points.shape
+            return {k: v.reshape(batch_size * n_points, -1) for k, v in self._forward_points(points, space_cache, output_normal).items()}
+        return super().forward(points, space_cache, output_normal)
+
+    def _forward_points(self, points, space_cache, output_normal):
+        if not self._use_fused(points):
+            return super()._forward_points(points, space_cache, output_normal)
+        planes = planes_channels_last(space_cache)                        # [B, 3, H, W, 32]
+        w = self._heads_weights()
+        need_grad = torch.is_grad_enabled() and (planes.requires_grad or w[0].requires_grad)
+        outs = []
+        for b in range(points.shape[0]):
+            pts = points[b].reshape(-1, 3).contiguous().float()
+            if need_grad:
+                outs.append(_TriFieldFn.apply(pts, planes[b], *w, self._fcfg, bool(output_normal)))
+            else:
+                with torch.no_grad():
+                    w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
+                    outs.append(ops.trifield_fwd(planes[b], self._fcfg, w6, pts, bool(output_normal)))
+        st = lambda i: torch.stack([o[i] for o in outs], 0)
+        out = {"sdf": st(0)[..., None], "features": st(1)}
+        if output_normal:
+            normal, sdf_grad = st(2), st(3)
+            out.update(normal=normal, shading_normal=normal, sdf_grad=sdf_grad)
+        return out
+
+    def forward_sdf(self, points, space_cache):
+        if not self._use_fused(points):
+            return super().forward_sdf(points, space_cache)
+        planes, w = planes_channels_last(space_cache), self._heads_weights()
+        B = points.shape[0]
+        pts = points.reshape(B, -1, 3)
+        need_grad = torch.is_grad_enabled() and (planes.requires_grad or w[0].requires_grad)
+        outs = []
+        for b in range(B):
+            p = pts[b].contiguous().float()
+            if need_grad:
+                outs.append(_TriFieldFn.apply(p, planes[b], *w, self._fcfg, False)[0])
+            else:
+                w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
+                outs.append(ops.trifield_fwd(planes[b], self._fcfg, w6, p, False, want_features=False)[0])
+        return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)

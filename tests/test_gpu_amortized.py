@@ -290,3 +290,119 @@ def test_generator_backed_amortized_step_runs(kind):
         loss = system.train_one_step(batch)
     assert torch.isfinite(loss).item()
     assert (gen_w.detach() != before).any().item(), "no gradient reached the generator"
+
+
+def _triplane_field_float64(geo, pts, cache, gs, keys):
+    """float64 restatement of Triplane-transformer-sdf.forward (F.grid_sample lookups + double heads + sphere bias + finite differences) and its
+    gradients w.r.t. the planes and the six head weights"""
+    import torch.nn.functional as F
+
+    c = cache.double().requires_grad_(True)
+    ws = [p.detach().double().requires_grad_(True) for p in geo._heads_weights()]
+    B, n = pts.shape[:2]
+
+    def enc(p):
+        u = p.double() / 2.0
+        proj = [u[..., [0, 1]], u[..., [0, 2]], u[..., [2, 1]]]
+        return torch.cat([F.grid_sample(c[:, k], proj[k][:, None], mode="bilinear", padding_mode="zeros", align_corners=False)[:, :, 0].permute(0, 2, 1)
+                          for k in range(3)], -1)
+
+    def sdf_of(p):
+        return torch.relu(torch.relu(enc(p) @ ws[0].t()) @ ws[1].t()) @ ws[2].t() + (p.double().pow(2).sum(-1, keepdim=True).sqrt() - 0.8)
+
+    s = sdf_of(pts)
+    f = torch.relu(torch.relu(enc(pts) @ ws[3].t()) @ ws[4].t()) @ ws[5].t()
+    sg = torch.cat([(sdf_of((pts + 0.01 * torch.eye(3, device=pts.device)[k]).clamp(-2.0, 2.0)) - s) / 0.01 for k in range(3)], -1)
+    out = {"sdf": s.reshape(B * n, 1), "features": f.reshape(B * n, 3), "sdf_grad": sg.reshape(B * n, 3), "normal": F.normalize(sg, dim=-1).reshape(B * n, 3)}
+    sum((out[k] * gs[k].double()).sum() for k in keys).backward()
+    return {k: v.detach() for k, v in out.items()}, c.grad, [w.grad for w in ws]
+
+
+_SAMPLED_COMMON = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere", "sdf_bias_params": 0.8}
+_TRI_GEN = dict(inner_dim=64, condition_dim=128, triplane_low_res=32, triplane_high_res=64, triplane_dim=32, num_layers=1, num_heads=4, local_text=True, mlp_ratio=4)
+
+
+@pytest.mark.parametrize("kind", ["voxel", "triplane"])
+def test_fused_sampled_field_matches_the_composed_path(kind, monkeypatch):
+    """`3DConv-net` / `Triplane-transformer-sdf` with lookup + MLP heads + bias + finite differences as ONE kernel each way (asd_voxfield_* /
+    asd_trifield_*) against the composed path of the same module (HIP sampler + library heads, itself pinned by the reference goldens above):
+    outputs and every gradient - feature volume / planes, all head weights."""
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = torch.Generator().manual_seed(5)
+    if kind == "voxel":
+        geo = find("3DConv-net")(dict(_SAMPLED_COMMON, space_generator_config=dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16,
+                                                                                  img_channels=32, channel_multiplier=1)))
+        cache = (torch.randn(2, 32, 16, 16, 16, generator=g) * 0.5)
+    else:
+        geo = find("Triplane-transformer-sdf")(dict(_SAMPLED_COMMON, space_generator_config=dict(_TRI_GEN)))
+        cache = torch.randn(2, 3, 32, 64, 64, generator=g) * 0.5
+    n = 3001
+    geo = geo.cuda()
+    geo.do_update_step(0, 0)
+    assert geo._fcfg is not None
+    pts = (torch.rand(2, n, 3, generator=g) * 4.4 - 2.2).cuda()          # some points outside the box: zero padding of the lookup
+    gs = {k: torch.randn(2 * n, d, generator=g).cuda() for k, d in (("sdf", 1), ("features", 3), ("normal", 3), ("sdf_grad", 3))}
+
+    def run(fused):
+        monkeypatch.setenv("ASD_VOXFIELD", "1" if fused else "0")
+        monkeypatch.setenv("ASD_TRIFIELD", "1" if fused else "0")
+        for p in geo.parameters():
+            p.grad = None
+        c = cache.clone().cuda().requires_grad_(True)
+        out = geo(pts, c, output_normal=True)
+        sum((out[k] * gs[k]).sum() for k in gs).backward()
+        heads = {k: p.grad.clone() for k, p in geo.named_parameters() if p.grad is not None and ("sdf_network" in k or "feature_network" in k)}
+        return {k: out[k].detach() for k in gs}, c.grad, heads
+
+    o1, c1, h1 = run(True)
+    o0, c0, h0 = run(False)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    for k in gs:
+        tol = 2e-3 if k in ("normal", "sdf_grad") else 2e-5          # (finite differences divide 1e-7 rounding differences by eps = 0.01)
+        assert rel(o1[k], o0[k]) < tol, k
+    assert rel(c1, c0) < 2e-3
+    assert set(h1) == set(h0) and len(h1) == (4 if kind == "voxel" else 6)
+    for k in h0:
+        assert rel(h1[k], h0[k]) < 2e-3, k
+
+
+def test_fused_triplane_field_across_backward_chunks_against_float64(monkeypatch):
+    """270 001 samples per batch entry (the backward pass walks 262 144-sample chunks) with random upstream gradients: at this size the fp32 sums
+    (600 k contributions into 12 k plane cells through atomics, weight gradients over 2.2 M rows) differ between ANY two summation orders by
+    1e-4 .. 1e-2 of the largest entry, so the fused path and the composed path are each compared with a float64 restatement and the fused one
+    must not be further from it than the composed one (tools/tri_dbg.py prints both)."""
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = torch.Generator().manual_seed(6)
+    geo = find("Triplane-transformer-sdf")(dict(_SAMPLED_COMMON, space_generator_config=dict(_TRI_GEN))).cuda()
+    geo.do_update_step(0, 0)
+    cache = (torch.randn(2, 3, 32, 64, 64, generator=g) * 0.5).cuda()
+    n = 270_001
+    pts = (torch.rand(2, n, 3, generator=g) * 4.4 - 2.2).cuda()
+    keys = ("sdf", "features", "normal", "sdf_grad")
+    gs = {k: torch.randn(2 * n, d, generator=g).cuda() for k, d in (("sdf", 1), ("features", 3), ("normal", 3), ("sdf_grad", 3))}
+
+    def run(fused):
+        monkeypatch.setenv("ASD_TRIFIELD", "1" if fused else "0")
+        for p in geo.parameters():
+            p.grad = None
+        c = cache.clone().requires_grad_(True)
+        out = geo(pts, c, output_normal=True)
+        sum((out[k] * gs[k]).sum() for k in keys).backward()
+        return {k: out[k].detach() for k in keys}, c.grad, [p.grad.clone() for p in geo._heads_weights()]
+
+    o1, c1, h1 = run(True)
+    o0, c0, h0 = run(False)
+    oref, cref, href = _triplane_field_float64(geo, pts, cache, gs, keys)
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    for k in ("sdf", "features"):
+        assert l2(o1[k], oref[k]) < 1e-5, k
+    assert l2(o1["sdf_grad"], oref["sdf_grad"]) < max(2 * l2(o0["sdf_grad"], oref["sdf_grad"]), 1e-4)
+    e1, e0 = l2(c1, cref), l2(c0, cref)
+    print(f"planes gradient vs float64: fused {e1:.2e}, composed {e0:.2e}")
+    assert e1 < max(2 * e0, 1e-4)
+    for a, b, r in zip(h1, h0, href):
+        assert l2(a, r) < max(2 * l2(b, r), 1e-4)
