@@ -21,6 +21,7 @@
 //                              (asd_gemm_args.a_seg_*; LDS-DMA loads take 2-byte aligned sources at full rate, tools/lds_dma_align_probe.hip), three
 //                              launches (hi.hi, hi.lo, lo.hi) into the split-K slabs and one reduction that also restores the weight layout.
 // Activations and gradients cross this file as fp32 channel-last volumes [N][D][H][W][C] (what the voxel sampler of amortized.hip reads).
+#include <cstdlib>
 #include <cstring>
 
 #include "gemm_tile.h"
@@ -856,7 +857,8 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
         a.C = slabs;        // unused (partials_only) but must be non-null
         a.W = yh;
         // launch 1: X_hi . [dY_hi | dY_lo]
-        a.A = xh; a.N = 2 * N; a.ldc = 2 * N; a.split_k = split1; a.workspace = slabs; a.tile_cfg = 2;      // 128 x 128 (6 Cout % 128 == 0)
+        static const int tile_env = getenv("ASD_C3_WGRAD_TILE") ? atoi(getenv("ASD_C3_WGRAD_TILE")) : 0;       // A/B hook (tools): 1-based tile configuration
+        a.A = xh; a.N = 2 * N; a.ldc = 2 * N; a.split_k = split1; a.workspace = slabs; a.tile_cfg = tile_env ? tile_env : 8;      // 320 x 128 (6 Cout % 128 == 0): 4.24 vs 4.49 ms with 128 x 128 on 64 -> 64 @128^3 (tools/c3_wgrad_ab.py)
         ASD_PROBE_START(s);
         int rc = asd_gemm_f16(&a, stream);
         ASD_PROBE_STOP(s);
