@@ -155,7 +155,7 @@ SYMBOLS = [
     "asd_adamw_f32", "asd_adan_f32",
     "asd_conv3d_workspace_bytes", "asd_conv3d_fwd", "asd_conv3d_dgrad", "asd_conv3d_wgrad", "asd_layer_act_bwd", "asd_upsample3d_fwd", "asd_upsample3d_bwd",
     "asd_torgb_fwd", "asd_torgb_bwd", "asd_absmax_f32", "asd_voxfield_fwd", "asd_voxfield_bwd_workspace", "asd_voxfield_bwd",
-    "asd_trifield_fwd", "asd_trifield_bwd_workspace", "asd_trifield_bwd",
+    "asd_trifield_fwd_workspace", "asd_trifield_fwd", "asd_trifield_bwd_workspace", "asd_trifield_bwd",
     "asd_render_layout_init", "asd_render_fwd", "asd_render_bwd_workspace", "asd_render_bwd",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]

@@ -16,43 +16,9 @@
 
 #include <type_traits>
 
-#include "asd_common.h"
+#include "trifield_common.h"
+#include "trifield_mfma.h"
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-#define TF_H 64
-#define TF_NIN 96
-
-struct tf_geom { int H, W; };
-
-__device__ __forceinline__ void tf_axis(float x, int size, int& i0, float& w1) {
-    const float ix = ((x + 1.f) * (float)size - 1.f) * 0.5f;   // grid_sample, align_corners = False
-    const float f = floorf(ix);
-    i0 = (int)f;
-    w1 = ix - f;
-}
-__device__ __forceinline__ void tf_plane_uv(float x, float y, float z, int plane, float& u, float& v) {    // (x,y), (x,z), (z,y); first -> W
-    if (plane == 0) { u = x; v = y; } else if (plane == 1) { u = x; v = z; } else { u = z; v = y; }
-}
-__device__ __forceinline__ float tf_bias(const asd_field_cfg& c, float px, float py, float pz) {
-    if (c.bias_mode == ASD_BIAS_SPHERE) return sqrtf(px * px + py * py + pz * pz) - c.bias_value;
-    return c.bias_value;
-}
-// the bilinear setup of one plane for a point in grid_sample coordinates
-struct tf_tap { int off[4]; float w[4]; };
-__device__ __forceinline__ void tf_setup(const tf_geom& g, int plane, float nx, float ny, float nz, tf_tap& t) {
-    float u, v, fx, fy;
-    int x0, y0;
-    tf_plane_uv(nx, ny, nz, plane, u, v);
-    tf_axis(u, g.W, x0, fx); tf_axis(v, g.H, y0, fy);
-#pragma unroll
-    for (int corner = 0; corner < 4; ++corner) {
-        const int dx = corner & 1, dy = corner >> 1;
-        const int x = x0 + dx, y = y0 + dy;
-        const bool ok = x >= 0 && x < g.W && y >= 0 && y < g.H;
-        t.off[corner] = ok ? ((plane * g.H + y) * g.W + x) * 32 : -1;
-        t.w[corner] = ok ? (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) : 0.f;
-    }
-}
 __device__ __forceinline__ floatx4 tf_quad(const float* __restrict__ planes, const tf_tap& t, int q) {     // channels 4 q .. 4 q + 3 of the plane
     floatx4 e = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -168,12 +134,6 @@ struct tf_weights {            // device pointers; w1t = W1^T [96][64], w2 [64][
     const float* s1t; const float* s2; const float* s3;      // sdf head (O = 1)
     const float* f1t; const float* f2; const float* f3;      // feature head (O = 3)
 };
-
-__device__ __forceinline__ void tf_norm(const asd_field_cfg& c, float px, float py, float pz, float& nx, float& ny, float& nz) {
-    nx = 2.f * ((px - c.bbox_min[0]) / (c.bbox_max[0] - c.bbox_min[0])) - 1.f;
-    ny = 2.f * ((py - c.bbox_min[1]) / (c.bbox_max[1] - c.bbox_min[1])) - 1.f;
-    nz = 2.f * ((pz - c.bbox_min[2]) / (c.bbox_max[2] - c.bbox_min[2])) - 1.f;
-}
 
 // sdf of one point (one head): the features are streamed, nothing is kept
 __device__ __forceinline__ float tf_sdf(const tf_geom& g, const asd_field_cfg& c, const float* __restrict__ planes, const tf_weights& w, float px, float py,
@@ -547,15 +507,34 @@ static tf_weights tf_w(const float* const* w6) { return tf_weights{w6[0], w6[1],
 
 extern "C" {
 
+// ASD_TRI_MFMA=0 selects the one-thread-per-sample kernels of this file (the first form of the field, kept as the A/B partner); the default is
+// the matrix-pipe chain of trifield_mfma.hip
+static bool tf_use_mfma() {
+    static const bool on = !(getenv("ASD_TRI_MFMA") && getenv("ASD_TRI_MFMA")[0] == '0');
+    return on;
+}
+
+int asd_trifield_fwd_workspace(int64_t* n_floats) {
+    ASD_CHECK_ARG(n_floats, "null argument");
+    *n_floats = TFM_PREP_FLOATS;
+    return ASD_OK;
+}
+
 int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights /* [host] 6 device pointers:
                      sdf W1^T [96][64], W2 [64][64], W3 [1][64], feature W1^T, W2, W3 [3][64] */, const float* points, int32_t n, float* sdf, float* features,
-                     float* normal, float* fd_grad, void* stream) {
+                     float* normal, float* fd_grad, float* workspace, void* stream) {
     if (n == 0) return ASD_OK;
-    ASD_CHECK_ARG(planes_cl && weights && points && sdf && n > 0, "null argument");
+    ASD_CHECK_ARG(planes_cl && weights && points && sdf && workspace && n > 0, "null argument");
     const int rc = tf_check(cfg, H, W, C);
     if (rc != ASD_OK) return rc;
-    hipLaunchKernelGGL(trifield_fwd_kernel, dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, tf_geom{H, W}, *cfg, planes_cl, tf_w(weights), points, n,
-                       sdf, features, normal, fd_grad);
+    if (tf_use_mfma()) {
+        const int rp = tfm_prepare(planes_cl, H, W, weights, workspace, (hipStream_t)stream);
+        if (rp != ASD_OK) return rp;
+        tfm_forward(tf_geom{H, W}, cfg, planes_cl, weights, workspace, points, n, sdf, features, normal, fd_grad, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(trifield_fwd_kernel, dim3(asd_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, tf_geom{H, W}, *cfg, planes_cl, tf_w(weights), points,
+                           n, sdf, features, normal, fd_grad);
+    }
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -1,0 +1,368 @@
+// trifield_mfma.hip — the tri-plane field of `Triplane-transformer-sdf` (custom/amortized/models/geometry/triplane_transformer.py:139-240) with
+// the two VanillaMLP heads (threestudio/models/networks.py:139-191: 96 -> 64 -> 64 -> 1 | 3, ReLU, no biases) on the MATRIX pipe.
+// trifield.hip evaluates one sample per thread with fp32 multiply-adds (one v_fmac per weight and sample); here a wave owns a tile of
+// 64 rows (16 samples x {centre, +x, +y, +z} with a finite-difference normal, 64 samples without) and every layer is a product
+//        Z^T [units x rows] = W [units x k] * X^T [k x rows]           (v_mfma_f32_16x16x32_f16, A = weight fragment, B = activation fragment)
+// evaluated in split-fp16 arithmetic: x * s = hi + lo (s a power of two), W * sW = hi + lo, product = hi*hi + hi*lo + lo*hi accumulated
+// in fp32 (~22 bits; the scheme of conv3d.hip).  Scales are powers of two taken on the device from max|planes|, max|W| and from norm
+// bounds of the weights (|h1| <= max_j sum_c |W1[j][c]| * max|planes|: interpolation is convex), so nothing overflows fp16 by
+// construction and no pass over activations is needed.
+//
+// Register-resident chain.  The B fragment of a 16x16x32 product holds, in lane (n = l & 15, g = l >> 4), eight k-values of row n; the
+// accumulator holds, in the same lane, units 4g .. 4g+3 of row n for every 16-unit block.  Two unit blocks (2t, 2t+1) therefore ARE the
+// B fragment of k-step t of the next layer once ReLU-ed, scaled and split — in the k ORDER (e < 4: unit 32t + 4g + e, e >= 4: unit
+// 32t + 16 + 4g + e - 4); the weight image of the next layer is packed in that order (tfm_prep_kernel).  Layer 1's B fragment comes from
+// the lookup itself: lane (n, g) gathers channels 8g .. 8g+7 of plane ks for its row — k-step = plane.  The last layer (1 | 3 outputs)
+// is a dot product on the vector pipe in the accumulator layout plus a sum over the four lane groups.  Nothing goes through LDS but the
+// weight images (40 KB per head for the forward chain).
+#include <stdlib.h>
+
+#include "trifield_common.h"
+#include "trifield_mfma.h"
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float tfm_scale_for(float amax) {          // 2^(14 - floor(log2 amax)): amax * scale in [2^14, 2^15)
+    const unsigned b = __float_as_uint(amax);
+    if (b == 0u || b >= 0x7f800000u) return 1.f;
+    int se = 14 - ((int)((b >> 23) & 0xffu) - 127);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    return __uint_as_float((unsigned)(se + 127) << 23);
+}
+__device__ __forceinline__ void tfm_split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const half_t h = (half_t)x[e];
+        hi[e] = h;
+        lo[e] = (half_t)(x[e] - (float)h);
+    }
+}
+__device__ __forceinline__ floatx4 tfm_mma3(const half8 ah, const half8 al, const half8 bh, const half8 bl, floatx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    return acc;
+}
+// sum over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48 hold the same row of the tile)
+__device__ __forceinline__ float tfm_rows_sum(float v) {
+    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// k order of a fragment built from two accumulator blocks
+__host__ __device__ __forceinline__ int tfm_perm(int t, int g, int e) { return 32 * t + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4); }
+
+// ---- weights -> scales + fragment images (one block per head) ----------------------------------------------------------------------------
+// prep (floats): [0] bit pattern of max|planes| (written by asd_absmax_f32 before this kernel) | [16 + 16 head ..] scales | [64 ..] images
+__global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__ w1t_s, const float* __restrict__ w2_s, const float* __restrict__ w3_s,
+                                                       const float* __restrict__ w1t_f, const float* __restrict__ w2_f, const float* __restrict__ w3_f,
+                                                       float* __restrict__ prep) {
+    const int head = blockIdx.x, O = head ? 3 : 1, tid = threadIdx.x;
+    const float* w1t = head ? w1t_f : w1t_s;       // [96][64] = W1^T
+    const float* w2 = head ? w2_f : w2_s;          // [64][64]
+    const float* w3 = head ? w3_f : w3_s;          // [O][64]
+    __shared__ float red[256], row1[TF_H], bj[TF_H], col2[TF_H], sc[8];
+    float m1 = 0.f, m2 = 0.f;
+    for (int q = tid; q < TF_NIN * TF_H; q += 256) m1 = fmaxf(m1, fabsf(w1t[q]));
+    for (int q = tid; q < TF_H * TF_H; q += 256) m2 = fmaxf(m2, fabsf(w2[q]));
+    red[tid] = m1;
+    __syncthreads();
+    if (tid == 0) { float m = 0.f; for (int q = 0; q < 256; ++q) m = fmaxf(m, red[q]); sc[1] = m; }
+    __syncthreads();
+    red[tid] = m2;
+    __syncthreads();
+    if (tid == 0) { float m = 0.f; for (int q = 0; q < 256; ++q) m = fmaxf(m, red[q]); sc[2] = m; }
+    if (tid < TF_H) {
+        float a = 0.f;
+        for (int c = 0; c < TF_NIN; ++c) a += fabsf(w1t[c * TF_H + tid]);
+        row1[tid] = a;                                                       // sum_c |W1[j][c]|
+        float b = 0.f;
+        for (int o = 0; o < O; ++o) b += fabsf(w3[o * TF_H + tid]);
+        bj[tid] = b;                                                         // |v2[j]| <= sum_o |W3[o][j]|  (output gradient normalised to max 1)
+    }
+    __syncthreads();
+    if (tid < TF_H) {
+        float a = 0.f;
+        for (int j = 0; j < TF_H; ++j) a += fabsf(w2[j * TF_H + tid]) * bj[j];
+        col2[tid] = a;                                                       // |u1[i]| <= sum_j |W2[j][i]| |v2[j]|
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float r1 = 0.f, b = 0.f, c2 = 0.f;
+        for (int j = 0; j < TF_H; ++j) { r1 = fmaxf(r1, row1[j]); b = fmaxf(b, bj[j]); c2 = fmaxf(c2, col2[j]); }
+        const float amax_planes = __uint_as_float(((const unsigned*)prep)[0]);
+        float* s = prep + 16 + 16 * head;
+        s[TFM_S_E] = tfm_scale_for(amax_planes);
+        s[TFM_S_W1] = tfm_scale_for(sc[1]);
+        s[TFM_S_W2] = tfm_scale_for(sc[2]);
+        s[TFM_S_H1] = tfm_scale_for(r1 * amax_planes * 1.0001f);
+        s[TFM_S_V2] = tfm_scale_for(b * 1.0001f);
+        s[TFM_S_U1] = tfm_scale_for(c2 * 1.0001f);
+        sc[1] = s[TFM_S_W1]; sc[2] = s[TFM_S_W2];
+    }
+    __syncthreads();
+    const float s1 = sc[1], s2 = sc[2];
+    half_t* img = (half_t*)(prep + 64) + (size_t)head * TFM_HEAD_HALVES;
+    auto put = [&](half_t* hi, half_t* lo, int q, float v) {
+        const half_t h = (half_t)v;
+        hi[q] = h; lo[q] = (half_t)(v - (float)h);
+    };
+    for (int q = tid; q < TFM_A1; q += 256) {                    // [4 mb][3 ks][64 lanes][8]: W1[16 mb + (l & 15)][32 ks + 8 (l >> 4) + e]
+        const int e = q & 7, l = (q >> 3) & 63, ks = (q >> 9) % 3, mb = q / (3 * 512);
+        const int m = 16 * mb + (l & 15), k = 32 * ks + 8 * (l >> 4) + e;
+        put(img + TFM_OFF_A1H, img + TFM_OFF_A1L, q, w1t[k * TF_H + m] * s1);
+    }
+    for (int q = tid; q < TFM_A2; q += 256) {                    // [4 mb][2 t][64][8]: W2[16 mb + (l & 15)][perm(t, l >> 4, e)]; transposed: W2[perm][16 mb + (l & 15)]
+        const int e = q & 7, l = (q >> 3) & 63, t = (q >> 9) & 1, mb = q >> 10;
+        const int m = 16 * mb + (l & 15), k = tfm_perm(t, l >> 4, e);
+        put(img + TFM_OFF_A2H, img + TFM_OFF_A2L, q, w2[m * TF_H + k] * s2);
+        put(img + TFM_OFF_A2TH, img + TFM_OFF_A2TL, q, w2[k * TF_H + m] * s2);
+    }
+    for (int q = tid; q < TFM_A1T; q += 256) {                   // [6 mb][2 t][64][8]: W1^T[16 mb + (l & 15)][perm] = W1[perm][channel]
+        const int e = q & 7, l = (q >> 3) & 63, t = (q >> 9) & 1, mb = q >> 10;
+        const int m = 16 * mb + (l & 15), k = tfm_perm(t, l >> 4, e);
+        put(img + TFM_OFF_A1TH, img + TFM_OFF_A1TL, q, w1t[m * TF_H + k] * s1);
+    }
+}
+
+// ---- pieces of the chain ---------------------------------------------------------------------------------------------------------------
+// B fragment of layer 1: channels ch .. ch + 7 of the plane under the taps `t`, times s (a power of two: folding it into the tap weights is exact)
+__device__ __forceinline__ void tfm_gather8(const float* __restrict__ planes, const tf_tap& t, int ch, float s, half8& hi, half8& lo) {
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int corner = 0; corner < 4; ++corner) {
+        const float w = t.w[corner] * s;                                     // 0 outside the plane
+        const float* src = planes + (t.off[corner] < 0 ? 0 : t.off[corner]) + ch;
+        const floatx4 a = *(const floatx4*)src, b = *(const floatx4*)(src + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = fmaf(w, a[r], e[r]); e[4 + r] = fmaf(w, b[r], e[4 + r]); }
+    }
+    tfm_split8(e, hi, lo);
+}
+// accumulator blocks (2t, 2t+1) of NB row blocks -> ReLU, * c -> B fragments of k-step t
+template <int NB>
+__device__ __forceinline__ void tfm_relu_frags(const floatx4 (&acc)[4][NB], float c, half8 (&bh)[2][NB], half8 (&bl)[2][NB]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float x[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x[r] = fmaxf(acc[2 * t][nb][r], 0.f) * c; x[4 + r] = fmaxf(acc[2 * t + 1][nb][r], 0.f) * c; }
+            tfm_split8(x, bh[t][nb], bl[t][nb]);
+            __builtin_amdgcn_sched_barrier(0);        // one fragment at a time: left alone the scheduler interleaves all of them (400+ registers)
+        }
+}
+// Z^T = W2 * H1^T for NB row blocks: a2h / a2l = LDS images [4 mb][2 t][64 lanes] of half8
+template <int NB>
+__device__ __forceinline__ void tfm_layer2(const half8* a2h, const half8* a2l, int lane, const half8 (&bh)[2][NB], const half8 (&bl)[2][NB], floatx4 (&z)[4][NB]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) z[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const half8 ah = a2h[(mb * 2 + t) * 64 + lane], al = a2l[(mb * 2 + t) * 64 + lane];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) z[mb][nb] = tfm_mma3(ah, al, bh[t][nb], bl[t][nb], z[mb][nb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// out[nb][o] = c * sum_j W3[o][j] relu(z[j][row]): the lane's 16 units, then the four lane groups
+template <int NB, int O>
+__device__ __forceinline__ void tfm_layer3(const floatx4 (&z)[4][NB], const float* __restrict__ w3, int g, float c, float (&out)[NB][O]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int o = 0; o < O; ++o) out[nb][o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const floatx4 w = *(const floatx4*)(w3 + o * TF_H + 16 * mb + 4 * g);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[nb][o] = fmaf(w[r], fmaxf(z[mb][nb][r], 0.f), out[nb][o]);
+        }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int o = 0; o < O; ++o) out[nb][o] = tfm_rows_sum(out[nb][o]) * c;
+}
+
+// the point of row block nb of the lane's sample: FD: the centre and its three clamped probes; else the centre of sample block nb
+template <bool FD>
+__device__ __forceinline__ void tfm_point(const asd_field_cfg& c, const float* __restrict__ points, int n, int tile, int q16, int nb, int& i, float (&p)[3]) {
+    i = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
+    const int ic = i < n ? i : n - 1;
+    p[0] = points[3 * (size_t)ic]; p[1] = points[3 * (size_t)ic + 1]; p[2] = points[3 * (size_t)ic + 2];
+    if (FD && nb > 0) {                                                      // as trifield.hip: every coordinate of a probe is clamped
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = asd_clampf(p[k] + (k == nb - 1 ? c.fd_eps : 0.f), -c.radius, c.radius);
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------------------
+// MODE 0: finite-difference normal — a tile is 16 samples x {centre, +x, +y, +z}: the sdf head on all four row blocks, the feature head
+//         (if wanted) on the centres; the four sdf values of a sample meet in one lane.
+// MODE 1: 64 samples per tile, sdf head only.   MODE 2: 64 samples per tile, feature head only (features without a normal: two launches).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const asd_field_cfg c, const float* __restrict__ planes, const float* __restrict__ prep,
+                                                          const float* __restrict__ w3s, const float* __restrict__ w3f, const float* __restrict__ points, int n,
+                                                          float* __restrict__ sdf, float* __restrict__ features, float* __restrict__ normal,
+                                                          float* __restrict__ fd_grad) {
+    constexpr bool FD = MODE == 0;
+    constexpr int OP = MODE == 2 ? 3 : 1;                                    // outputs of the head that runs on all four row blocks
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // [sdf head: a1h a1l a2h a2l | feature head: same]  2 x 40 KB
+    {
+        const uint4* src0 = (const uint4*)((const half_t*)(prep + 64));
+        const uint4* src1 = (const uint4*)((const half_t*)(prep + 64) + TFM_HEAD_HALVES);
+        uint4* dst = (uint4*)smem;
+        constexpr int N16 = TFM_FWD_HALVES * 2 / 16;
+        for (int q = threadIdx.x; q < N16; q += 256) {
+            if (MODE != 2) dst[q] = src0[q];
+            if (MODE != 1) dst[N16 + q] = src1[q];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
+    const half8* img_s = (const half8*)smem;
+    const half8* img_f = (const half8*)(smem + TFM_FWD_HALVES * 2);
+    const float* ss = prep + 16;
+    const float* sf = prep + 32;
+    const float sE = ss[TFM_S_E];
+    const float c1s = ss[TFM_S_H1] / (ss[TFM_S_W1] * sE), c2s = 1.f / (ss[TFM_S_W2] * ss[TFM_S_H1]);
+    const float c1f = sf[TFM_S_H1] / (sf[TFM_S_W1] * sE), c2f = 1.f / (sf[TFM_S_W2] * sf[TFM_S_H1]);
+    const half8* img_p = MODE == 2 ? img_f : img_s;
+    const float c1p = MODE == 2 ? c1f : c1s, c2p = MODE == 2 ? c2f : c2s;
+    const float* w3p = MODE == 2 ? w3f : w3s;
+    const bool feat = FD && features != nullptr;
+    const int n_tiles = (n + (FD ? 16 : 64) - 1) / (FD ? 16 : 64);
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        int idx[4];
+        float P[4][3], N[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            tfm_point<FD>(c, points, n, tile, q16, nb, idx[nb], P[nb]);
+            tf_norm(c, P[nb][0], P[nb][1], P[nb][2], N[nb][0], N[nb][1], N[nb][2]);
+        }
+        floatx4 acc[4][4], accf[4][1];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+            accf[mb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- layer 1: k-step = plane
+#pragma unroll 1
+        for (int plane = 0; plane < 3; ++plane) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                tf_tap t;
+                tf_setup(g, plane, N[nb][0], N[nb][1], N[nb][2], t);
+                tfm_gather8(planes, t, 8 * lg, sE, bh[nb], bl[nb]);
+                __builtin_amdgcn_sched_barrier(0);    // the loads of one row block in flight at a time (32 registers)
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const half8 ah = img_p[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img_p[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], acc[mb][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (feat) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const half8 ah = img_f[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img_f[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+                    accf[mb][0] = tfm_mma3(ah, al, bh[0], bl[0], accf[mb][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- layers 2, 3 of the head on all row blocks
+        float o[4][OP];
+        {
+            half8 bh[2][4], bl[2][4];
+            tfm_relu_frags<4>(acc, c1p, bh, bl);
+            tfm_layer2<4>(img_p + TFM_OFF_A2H / 8, img_p + TFM_OFF_A2L / 8, lane, bh, bl, acc);
+            tfm_layer3<4, OP>(acc, w3p, lg, c2p, o);
+        }
+        float of[1][3];
+        if (feat) {
+            half8 bh[2][1], bl[2][1];
+            tfm_relu_frags<1>(accf, c1f, bh, bl);
+            tfm_layer2<1>(img_f + TFM_OFF_A2H / 8, img_f + TFM_OFF_A2L / 8, lane, bh, bl, accf);
+            tfm_layer3<1, 3>(accf, w3f, lg, c2f, of);
+        }
+        // ---- outputs: lane group 0 writes its 16 rows
+        if (lg == 0) {
+            if (FD) {
+                const int i = idx[0];
+                if (i < n) {
+                    float s[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) s[nb] = o[nb][0] + tf_bias(c, P[nb][0], P[nb][1], P[nb][2]);
+                    sdf[i] = s[0];
+                    if (feat) { features[3 * (size_t)i] = of[0][0]; features[3 * (size_t)i + 1] = of[0][1]; features[3 * (size_t)i + 2] = of[0][2]; }
+                    float nr[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nr[k] = (s[k + 1] - s[0]) / c.fd_eps;
+                    if (fd_grad) { fd_grad[3 * (size_t)i] = nr[0]; fd_grad[3 * (size_t)i + 1] = nr[1]; fd_grad[3 * (size_t)i + 2] = nr[2]; }
+                    if (normal) {
+                        const float inv = 1.f / fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+                        normal[3 * (size_t)i] = nr[0] * inv; normal[3 * (size_t)i + 1] = nr[1] * inv; normal[3 * (size_t)i + 2] = nr[2] * inv;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int i = idx[nb];
+                    if (i >= n) continue;
+                    if (MODE == 1) sdf[i] = o[nb][0] + tf_bias(c, P[nb][0], P[nb][1], P[nb][2]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < OP; ++k) features[OP * (size_t)i + k] = o[nb][k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------
+int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s) {
+    (void)hipMemsetAsync(prep, 0, 64 * sizeof(float), s);
+    const int rc = asd_absmax_f32(planes_cl, (int64_t)3 * H * W * 32, (uint32_t*)prep, (void*)s);
+    if (rc != ASD_OK) return rc;
+    hipLaunchKernelGGL(tfm_prep_kernel, dim3(2), dim3(256), 0, s, w6[0], w6[1], w6[2], w6[3], w6[4], w6[5], prep);
+    return ASD_OK;
+}
+
+int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,
+                float* features, float* normal, float* fd_grad, hipStream_t s) {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * TFM_FWD_HALVES * 2;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const bool fd = normal || fd_grad;
+    const int tiles = asd_div_up(n, fd ? 16 : 64);
+    int blocks = asd_div_up(tiles, 4);
+    if (blocks > 512) blocks = 512;
+    if (fd) {
+        hipLaunchKernelGGL(tfm_fwd_kernel<0>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+    } else {
+        hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+        if (features)
+            hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+    }
+    return ASD_OK;
+}
