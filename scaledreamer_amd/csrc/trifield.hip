@@ -542,7 +542,7 @@ int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
 int asd_trifield_bwd_workspace(int32_t n, int32_t with_normal, int64_t* n_floats) {
     ASD_CHECK_ARG(n_floats && n >= 0, "bad argument");
     const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs = ch * (with_normal ? 4 : 1);
-    *n_floats = rs * (TF_NIN + 3 * TF_H + TF_NIN + 4) + ch * 3 * TF_H + 1024;
+    *n_floats = rs * (TF_NIN + 3 * TF_H + TF_NIN + 4) + ch * 3 * TF_H + 1024 + TFM_PREP_FLOATS;
     return ASD_OK;
 }
 
@@ -567,7 +567,14 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     R.h1f = p; p += ch * TF_H;
     R.da1f = p; p += ch * TF_H;
     R.da2f = p; p += ch * TF_H;
+    p += 1024;
+    float* const prep = p;
     const tf_weights w = tf_w(weights);
+    const bool mfma = tf_use_mfma();
+    if (mfma) {
+        const int rp = tfm_prepare(planes_cl, H, W, weights, prep, s);
+        if (rp != ASD_OK) return rp;
+    }
     // the LDS-image scatter (tf_scatter_kernel) measured 2.0 ms per 1 M rows against 0.68 ms for the run-aggregated global atomics of
     // asd_triplane_sample_bwd (LDS float atomics retire ~0.4 lane-ops per clock and CU): kept for reference, off
     static const bool want_lds = getenv("ASD_TRI_LDS_SCATTER") && getenv("ASD_TRI_LDS_SCATTER")[0] == '1';
@@ -579,8 +586,13 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     for (int64_t i0 = 0; i0 < n; i0 += ch) {
         const int nc = (int)((n - i0) < ch ? (n - i0) : ch);
         const size_t rows_s = (size_t)nc * npt;
-        hipLaunchKernelGGL(trifield_bwd_kernel, dim3(asd_div_up(nc, 256)), dim3(256), 0, s, tf_geom{H, W}, *cfg, planes_cl, w, points, sdf, (int)i0, nc, d_sdf, d_features,
-                           d_normal, d_fd_grad, R, d_weights[2], d_weights[5]);
+        if (mfma) {
+            tfm_backward_chunk(tf_geom{H, W}, cfg, planes_cl, weights, prep, points, sdf, (int)i0, nc, npt, d_sdf, d_features, d_normal, d_fd_grad, R.denc, R.pts,
+                               d_weights, s);
+        } else {
+            hipLaunchKernelGGL(trifield_bwd_kernel, dim3(asd_div_up(nc, 256)), dim3(256), 0, s, tf_geom{H, W}, *cfg, planes_cl, w, points, sdf, (int)i0, nc, d_sdf,
+                               d_features, d_normal, d_fd_grad, R, d_weights[2], d_weights[5]);
+        }
         // feature gradient -> planes
         if (lds_scatter) {
             const int slices = 20;
@@ -591,6 +603,7 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
         }
         // weight gradients: dW1^T [96][64] = ENC^T DA1 is accumulated as out[64][96]^T — the kernel's `out` is [64][NB] = DA1^T ENC; the W1 gradient is
         // handed back in that ([64][96]) layout for the first layer, see the header
+        if (mfma) continue;                     // (the matrix-pipe pass has accumulated the weight gradients itself)
         const int gb = 1024;
         hipLaunchKernelGGL((tf_outer_kernel<TF_NIN>), dim3(gb), dim3(256), 0, s, R.da1s, R.enc, (size_t)TF_NIN, rows_s, d_weights[0]);
         hipLaunchKernelGGL((tf_outer_kernel<TF_H>), dim3(gb), dim3(256), 0, s, R.da2s, R.h1s, (size_t)TF_H, rows_s, d_weights[1]);

@@ -24,3 +24,6 @@ enum { TFM_S_E = 0, TFM_S_W1, TFM_S_W2, TFM_S_H1, TFM_S_V2, TFM_S_U1 };
 int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s);
 int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,
                 float* features, float* normal, float* fd_grad, hipStream_t s);
+int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points,
+                       const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
+                       float* denc, float* pts, float* const* dw6, hipStream_t s);

@@ -334,6 +334,256 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
     }
 }
 
+// ---- backward, data path ----------------------------------------------------------------------------------------------------------------
+// One head per launch: forward chain again (nothing but the points is kept from the forward pass), then the chain of TRANSPOSED weight images
+//   v2 = W3^T dn (.) [z2 > 0]  ->  u1 = W2^T v2 (.) [z1 > 0]  ->  denc = W1^T u1
+// for the output gradient NORMALISED per row (dn = d_out / G, G a power of two >= max|d_out|; the sdf head has one output: dn = 1), so every
+// operand is bounded by a norm of the weights and the static scales of tfm_prep_kernel hold; the row's G multiplies the result.  Leaves the feature
+// gradient rows for the scatter (sdf head: =, feature head: += into the centre rows) and the head's dW3.
+struct tfm_bwd_args {
+    tf_geom g; asd_field_cfg c;
+    const float* planes; const float* prep; const float* w3;          // this head's W3 [O][64]
+    const float* points; const float* sdf;
+    int i0, n_chunk, npt;                                             // row of (sample li of the chunk, point pt) = npt * li + pt
+    const float* d_sdf; const float* d_features; const float* d_normal; const float* d_fd_grad;
+    float* denc; float* pts;                                          // [rows][96], [rows][3]
+    float* dw1; float* dw2; float* dw3;                               // [64][96], [64][64], [O][64]  (+=)
+};
+
+// power of two >= |x| (x finite): exact divisor for the row normalisation
+__device__ __forceinline__ float tfm_pow2_above(float x) {
+    const unsigned b = __float_as_uint(x) & 0x7f800000u;
+    return b == 0u ? 0.f : __uint_as_float(b + 0x00800000u);
+}
+
+// the per-row output gradient of a tile in the lane that owns the row: G[nb] (multiplier) and dn[nb][o] (|dn| <= 1)
+template <int O, bool FD>
+__device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (&li)[4], const float (&s4)[4], float (&G)[4], float (&dn)[4][O]) {
+    if (O == 1 && FD) {
+        const bool active = li[0] < a.n_chunk;
+        const size_t i = (size_t)a.i0 + (active ? li[0] : 0);
+        float ds = (active && a.d_sdf) ? a.d_sdf[i] : 0.f;
+        float dsk[3] = {0.f, 0.f, 0.f};
+        if (active) {
+            float dnr[3] = {0.f, 0.f, 0.f};
+            if (a.d_normal) {
+                const float s = a.sdf[i];
+                float nr[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nr[k] = (s4[k + 1] - s) / a.c.fd_eps;
+                const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+                const float g0 = a.d_normal[3 * i], g1 = a.d_normal[3 * i + 1], g2 = a.d_normal[3 * i + 2];
+                if (len > 1e-12f) {
+                    const float inv = 1.f / len;
+                    const float n0 = nr[0] * inv, n1 = nr[1] * inv, n2 = nr[2] * inv;
+                    const float dot = n0 * g0 + n1 * g1 + n2 * g2;
+                    dnr[0] = (g0 - n0 * dot) * inv; dnr[1] = (g1 - n1 * dot) * inv; dnr[2] = (g2 - n2 * dot) * inv;
+                } else {
+                    dnr[0] = g0 * 1e12f; dnr[1] = g1 * 1e12f; dnr[2] = g2 * 1e12f;
+                }
+            }
+            if (a.d_fd_grad) { dnr[0] += a.d_fd_grad[3 * i]; dnr[1] += a.d_fd_grad[3 * i + 1]; dnr[2] += a.d_fd_grad[3 * i + 2]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { dsk[k] = dnr[k] / a.c.fd_eps; ds -= dnr[k] / a.c.fd_eps; }
+        }
+        G[0] = ds; G[1] = dsk[0]; G[2] = dsk[1]; G[3] = dsk[2];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) dn[nb][0] = 1.f;
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const bool active = li[nb] < a.n_chunk;
+            const size_t i = (size_t)a.i0 + (active ? li[nb] : 0);
+            if (O == 1) {
+                G[nb] = (active && a.d_sdf) ? a.d_sdf[i] : 0.f;
+                dn[nb][0] = 1.f;
+            } else {
+                float df[O], m = 0.f;
+#pragma unroll
+                for (int o = 0; o < O; ++o) { df[o] = active ? a.d_features[O * i + o] : 0.f; m = fmaxf(m, fabsf(df[o])); }
+                m = tfm_pow2_above(m);
+                const float inv = m > 0.f ? 1.f / m : 0.f;
+                G[nb] = m;
+#pragma unroll
+                for (int o = 0; o < O; ++o) dn[nb][o] = df[o] * inv;
+            }
+        }
+    }
+}
+
+template <int O, bool FD>
+__global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // the head's eight images: 80 KB
+    constexpr int head = O == 3;
+    {
+        const uint4* src = (const uint4*)((const half_t*)(a.prep + 64) + (size_t)head * TFM_HEAD_HALVES);
+        uint4* dst = (uint4*)smem;
+        for (int q = threadIdx.x; q < TFM_HEAD_HALVES * 2 / 16; q += 256) dst[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
+    const half8* img = (const half8*)smem;
+    const float* sc = a.prep + 16 + 16 * head;
+    const float sE = sc[TFM_S_E], sV2 = sc[TFM_S_V2];
+    const float c1 = sc[TFM_S_H1] / (sc[TFM_S_W1] * sE), c2 = 1.f / (sc[TFM_S_W2] * sc[TFM_S_H1]);
+    const float cU = sc[TFM_S_U1] / (sc[TFM_S_W2] * sV2), cD = 1.f / (sc[TFM_S_W1] * sc[TFM_S_U1]);
+    float w3r[O][4][4], w3acc[O][4][4];                                      // the lane's 16 units: 16 mb + 4 lg + r
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const floatx4 w = *(const floatx4*)(a.w3 + o * TF_H + 16 * mb + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { w3r[o][mb][r] = w[r]; w3acc[o][mb][r] = 0.f; }
+        }
+    const int n_tiles = (a.n_chunk + (FD ? 16 : 64) - 1) / (FD ? 16 : 64);
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        int li[4];
+        float P[4][3], N[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            int i;
+            li[nb] = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
+            tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P[nb]);
+            tf_norm(a.c, P[nb][0], P[nb][1], P[nb][2], N[nb][0], N[nb][1], N[nb][2]);
+        }
+        floatx4 acc[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int plane = 0; plane < 3; ++plane) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                tf_tap t;
+                tf_setup(a.g, plane, N[nb][0], N[nb][1], N[nb][2], t);
+                tfm_gather8(a.planes, t, 8 * lg, sE, bh[nb], bl[nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], acc[mb][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        unsigned long long m1 = 0ull, m2 = 0ull;                             // bit (mb * 4 + nb) * 4 + r: pre-activation > 0
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m1 |= (unsigned long long)(acc[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
+        {
+            half8 bh[2][4], bl[2][4];
+            tfm_relu_frags<4>(acc, c1, bh, bl);
+            tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, bh, bl, acc);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m2 |= (unsigned long long)(acc[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
+        // ---- the rows' output gradients (the probes' sdf values feed the normalisation of the finite-difference normal)
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (O == 1 && FD) {
+            float o[4][1];
+            tfm_layer3<4, 1>(acc, a.w3, lg, c2, o);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + tf_bias(a.c, P[nb][0], P[nb][1], P[nb][2]);
+        }
+        float G[4], dn[4][O];
+        tfm_row_grads<O, FD>(a, li, s4, G, dn);
+        // ---- dW3 += G dn (x) h2, and v2 = W3^T dn under the ReLU mask as the B fragments of the transposed chain
+        half8 vh[2][4], vl[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int mb = 2 * t + hb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h2 = fmaxf(acc[mb][nb][r], 0.f) * c2;
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < O; ++o) {
+                            w3acc[o][mb][r] = fmaf(G[nb] * dn[nb][o], h2, w3acc[o][mb][r]);
+                            v = fmaf(dn[nb][o], w3r[o][mb][r], v);
+                        }
+                        x[4 * hb + r] = ((m2 >> ((mb * 4 + nb) * 4 + r)) & 1ull) ? v * sV2 : 0.f;
+                    }
+                }
+                tfm_split8(x, vh[t][nb], vl[t][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- u1 = W2^T v2, masked by layer 1's ReLU
+        tfm_layer2<4>(img + TFM_OFF_A2TH / 8, img + TFM_OFF_A2TL / 8, lane, vh, vl, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[4 * hb + r] = ((m1 >> (((2 * t + hb) * 4 + nb) * 4 + r)) & 1ull) ? acc[2 * t + hb][nb][r] * cU : 0.f;
+                tfm_split8(x, vh[t][nb], vl[t][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- denc = W1^T u1 (six 16-channel blocks), times the row's G; lane (n, g) holds channels 16 mb + 4 g .. + 3 of row n
+#pragma unroll
+        for (int mb = 0; mb < 6; ++mb) {
+            floatx4 d[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) d[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const half8 ah = img[TFM_OFF_A1TH / 8 + (mb * 2 + t) * 64 + lane], al = img[TFM_OFF_A1TL / 8 + (mb * 2 + t) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) d[nb] = tfm_mma3(ah, al, vh[t][nb], vl[t][nb], d[nb]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                if (li[nb] >= a.n_chunk) continue;
+                const size_t row = (size_t)a.npt * li[nb] + (FD ? nb : 0);
+                float* dst = a.denc + row * TF_NIN + 16 * mb + 4 * lg;
+                const float k = G[nb] * cD;
+                floatx4 v = {d[nb][0] * k, d[nb][1] * k, d[nb][2] * k, d[nb][3] * k};
+                if (O == 3) { const floatx4 old = *(const floatx4*)dst; v += old; }
+                *(floatx4*)dst = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (O == 1 && lg == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                if (li[nb] >= a.n_chunk) continue;
+                const size_t row = (size_t)a.npt * li[nb] + (FD ? nb : 0);
+                a.pts[3 * row] = N[nb][0]; a.pts[3 * row + 1] = N[nb][1]; a.pts[3 * row + 2] = N[nb][2];
+            }
+        }
+    }
+    // ---- dW3: the 16 rows of a lane group, then one atomic per unit and wave
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = w3acc[o][mb][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (q16 == 0 && v != 0.f) atomicAdd(a.dw3 + o * TF_H + 16 * mb + 4 * lg + r, v);
+            }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s) {
     (void)hipMemsetAsync(prep, 0, 64 * sizeof(float), s);
@@ -363,6 +613,343 @@ int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_c
         hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
         if (features)
             hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+    }
+    return ASD_OK;
+}
+
+// ---- backward, weight gradients --------------------------------------------------------------------------------------------------------
+// dW2 = sum_rows (G v2) (x) h1 and dW1 = sum_rows (G u1) (x) enc contract over ROWS: both operands of those products must hold a unit (or channel)
+// per lane and rows along k — the TRANSPOSE of the chain's fragments.  Every product of the chain is therefore evaluated a second time with the
+// operands swapped (Z = X W^T instead of Z^T = W X^T: same fragments, same images), whose accumulator holds, in lane (unit = l & 15, g), rows
+// 4g .. 4g+3 of every row block: two row blocks are one k-step of the contraction (the k order of tfm_perm, the same for both operands).
+// The lookup is transposed by a product with an identity fragment (exact: 1 * hi and 1 * lo are fp16 numbers).  The rows' G spans many orders
+// of magnitude across a chunk: a wave keeps a RUNNING power-of-two scale S >= every |G| it has seen (operands carry G / S, the accumulators
+// are rescaled when S grows — exact), so the fp16 operands stay in range without a pass over the gradients.
+// One wave per SIMD (160 accumulator registers + the chain); per-wave LDS: the lookup fragments of the tile (24 KB) and the rows' G.
+template <int O, bool FD>
+__global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_args a) {
+    constexpr int head = O == 3;
+    constexpr int IMG_HALVES = TFM_OFF_A1TH;                                 // a1 a2 a2t (hi, lo): 56 KB
+    constexpr int ENC_BYTES = 3 * 4 * 2 * 64 * 16;                           // per wave: [plane][nb][hi | lo][lane] half8
+    constexpr int GBUF_FLOATS = (1 + O) * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    {
+        const uint4* src = (const uint4*)((const half_t*)(a.prep + 64) + (size_t)head * TFM_HEAD_HALVES);
+        uint4* dst = (uint4*)smem;
+        for (int q = threadIdx.x; q < IMG_HALVES * 2 / 16; q += 256) dst[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
+    const half8* img = (const half8*)smem;
+    half8* encbuf = (half8*)(smem + IMG_HALVES * 2 + wave * ENC_BYTES);
+    float* gbuf = (float*)(smem + IMG_HALVES * 2 + 4 * ENC_BYTES) + wave * GBUF_FLOATS;
+    const float* sc = a.prep + 16 + 16 * head;
+    const float sE = sc[TFM_S_E], sV2 = sc[TFM_S_V2];
+    const float c1 = sc[TFM_S_H1] / (sc[TFM_S_W1] * sE), c2 = 1.f / (sc[TFM_S_W2] * sc[TFM_S_H1]);
+    const float cU = sc[TFM_S_U1] / (sc[TFM_S_W2] * sV2);
+    float w3r[O][4][4], w3n[O][4];                       // W3 at the lane's units of the chain layout (16 mb + 4 lg + r) and of the swapped layout (16 mb + q16)
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const floatx4 w = *(const floatx4*)(a.w3 + o * TF_H + 16 * mb + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w3r[o][mb][r] = w[r];
+            w3n[o][mb] = a.w3[o * TF_H + 16 * mb + q16];
+        }
+    // identity fragments: B operand with a one at k == 16 half + (l & 15)
+    half8 ident[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ident[hf][e] = (half_t)((8 * lg + e == 16 * hf + q16) ? 1.f : 0.f);
+    floatx4 dw2[4][4], dw1[4][6];                        // [unit block of the gradient operand][unit / channel block of the activation operand]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw2[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dw1[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    float S = 0.f;                                       // running scale of G (power of two, wave-uniform)
+    const int n_tiles = (a.n_chunk + (FD ? 16 : 64) - 1) / (FD ? 16 : 64);
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        int li[4];
+        float P[4][3], N[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            int i;
+            li[nb] = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
+            tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P[nb]);
+            tf_norm(a.c, P[nb][0], P[nb][1], P[nb][2], N[nb][0], N[nb][1], N[nb][2]);
+        }
+        // ---- layer 1 (chain orientation); the lookup fragments go to LDS: the swapped products and the last step read them back
+        floatx4 zt[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int plane = 0; plane < 3; ++plane) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                tf_tap t;
+                tf_setup(a.g, plane, N[nb][0], N[nb][1], N[nb][2], t);
+                tfm_gather8(a.planes, t, 8 * lg, sE, bh[nb], bl[nb]);
+                encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = bh[nb];
+                encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = bl[nb];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], zt[mb][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- layer 2 (chain orientation): zt <- Z2^T; h1's fragments stay for the swapped product below
+        half8 h1h[2][4], h1l[2][4];
+        tfm_relu_frags<4>(zt, c1, h1h, h1l);
+        tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, h1h, h1l, zt);
+        // ---- the rows' output gradients, in the lanes that own the rows, and their exchange to the swapped layout
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (O == 1 && FD) {
+            float o[4][1];
+            tfm_layer3<4, 1>(zt, a.w3, lg, c2, o);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + tf_bias(a.c, P[nb][0], P[nb][1], P[nb][2]);
+        }
+        float G[4], dn[4][O];
+        tfm_row_grads<O, FD>(a, li, s4, G, dn);
+        float gm = fmaxf(fmaxf(fabsf(G[0]), fabsf(G[1])), fmaxf(fabsf(G[2]), fabsf(G[3])));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+        gm = tfm_pow2_above(gm);
+        if (gm > S) {                                    // wave-uniform, rare: the accumulators move to the new scale
+            const float f = S / gm;                      // 0 for the first tile (the accumulators are zero)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dw2[i][j] *= f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) dw1[i][j] *= f;
+            }
+            S = gm;
+        }
+        const float invS = S > 0.f ? 1.f / S : 0.f;
+        if (lg == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                gbuf[nb * 16 + q16] = G[nb] * invS;
+#pragma unroll
+                for (int o = 0; o < O; ++o) gbuf[(1 + o) * 64 + nb * 16 + q16] = dn[nb][o];
+            }
+        }
+        // v2 in the chain layout: the row operand of u1 = v2 W2 in the swapped orientation
+        half8 vh[2][4], vl[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int mb = 2 * t + hb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3r[o][mb][r], v);
+                        x[4 * hb + r] = zt[mb][nb][r] > 0.f ? v * sV2 : 0.f;
+                    }
+                }
+                tfm_split8(x, vh[t][nb], vl[t][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- Z2 in the swapped orientation, one unit block at a time -> (G / S) v2 with a unit per lane: the gradient operand of dW2
+        floatx4 gq[4], dq[4][O];                         // G / S and dn of rows 4 lg .. 4 lg + 3 of every row block
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            gq[nb] = *(const floatx4*)(gbuf + nb * 16 + 4 * lg);
+#pragma unroll
+            for (int o = 0; o < O; ++o) dq[nb][o] = *(const floatx4*)(gbuf + (1 + o) * 64 + nb * 16 + 4 * lg);
+        }
+        half8 gvh[4][2], gvl[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            floatx4 zn[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) zn[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const half8 ah = img[TFM_OFF_A2H / 8 + (mb * 2 + t) * 64 + lane], al = img[TFM_OFF_A2L / 8 + (mb * 2 + t) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) zn[nb] = tfm_mma3(h1h[t][nb], h1l[t][nb], ah, al, zn[nb]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < O; ++o) v = fmaf(dq[2 * kk + hb][o][r], w3n[o][mb], v);
+                        x[4 * hb + r] = zn[2 * kk + hb][r] > 0.f ? gq[2 * kk + hb][r] * v * sV2 : 0.f;
+                    }
+                tfm_split8(x, gvh[mb][kk], gvl[mb][kk]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- Z1 in the swapped orientation, one unit block at a time (lookup fragments from LDS) -> h1 with a unit per lane; dW2 += (G v2)^T h1
+        unsigned long long m1n = 0ull;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            floatx4 zn[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) zn[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int plane = 0; plane < 3; ++plane) {
+                const half8 ah = img[TFM_OFF_A1H / 8 + (mi * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mi * 3 + plane) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const half8 bh = encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane], bl = encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane];
+                    zn[nb] = tfm_mma3(bh, bl, ah, al, zn[nb]);
+                }
+            }
+            half8 hh[2], hl[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = zn[2 * kk + hb][r];
+                        m1n |= (unsigned long long)(z > 0.f) << ((mi * 4 + 2 * kk + hb) * 4 + r);
+                        x[4 * hb + r] = fmaxf(z, 0.f) * c1;
+                    }
+                tfm_split8(x, hh[kk], hl[kk]);
+            }
+#pragma unroll
+            for (int mj = 0; mj < 4; ++mj)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) dw2[mj][mi] = tfm_mma3(gvh[mj][kk], gvl[mj][kk], hh[kk], hl[kk], dw2[mj][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- u1 = v2 W2 in the swapped orientation, masked by layer 1's ReLU, times G / S: the gradient operand of dW1
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            floatx4 zn[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) zn[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const half8 ah = img[TFM_OFF_A2TH / 8 + (mb * 2 + t) * 64 + lane], al = img[TFM_OFF_A2TL / 8 + (mb * 2 + t) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) zn[nb] = tfm_mma3(vh[t][nb], vl[t][nb], ah, al, zn[nb]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x[4 * hb + r] = ((m1n >> ((mb * 4 + 2 * kk + hb) * 4 + r)) & 1ull) ? gq[2 * kk + hb][r] * zn[2 * kk + hb][r] * cU : 0.f;
+                tfm_split8(x, gvh[mb][kk], gvl[mb][kk]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- dW1 += (G u1)^T enc: the lookup fragments come back from LDS and are transposed by identity products
+#pragma unroll 1
+        for (int plane = 0; plane < 3; ++plane) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                half8 eh[2], el[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float xh[8], xl[8];
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int nb = 2 * kk + hb;
+                        const half8 bh = encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane], bl = encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane];
+                        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+                        const floatx4 th = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ident[hf], z, 0, 0, 0);
+                        const floatx4 tl = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ident[hf], z, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { xh[4 * hb + r] = th[r]; xl[4 * hb + r] = tl[r]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { eh[kk][e] = (half_t)xh[e]; el[kk][e] = (half_t)xl[e]; }
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        if (plane == 0) dw1[mi][hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][hf]);
+                        else if (plane == 1) dw1[mi][2 + hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][2 + hf]);
+                        else dw1[mi][4 + hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][4 + hf]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- accumulators -> global: lane (q16, lg) of dw2[mj][mi] holds dW2[16 mj + 4 lg + r][16 mi + q16]; dw1[mi][cb]: dW1[16 mi + 4 lg + r][16 cb + q16]
+    const float k2 = S / (sV2 * sc[TFM_S_H1]), k1 = S / (sc[TFM_S_U1] * sE);
+#pragma unroll
+    for (int mj = 0; mj < 4; ++mj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float v = dw2[mj][mi][r] * k2;
+                if (v != 0.f) atomicAdd(a.dw2 + (16 * mj + 4 * lg + r) * TF_H + 16 * mi + q16, v);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 6; ++cb) {
+                const float v = dw1[mj][cb][r] * k1;
+                if (v != 0.f) atomicAdd(a.dw1 + (16 * mj + 4 * lg + r) * TF_NIN + 16 * cb + q16, v);
+            }
+        }
+}
+
+// one chunk of the backward pass: feature-gradient rows (denc, pts) for the scatter and the heads' weight gradients
+int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points,
+                       const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
+                       float* denc, float* pts, float* const* dw6, hipStream_t s) {
+    static bool attr = false;
+    const size_t lds = (size_t)TFM_HEAD_HALVES * 2;
+    auto ldsw = [](int O) { return (size_t)TFM_OFF_A1TH * 2 + 4 * (3 * 4 * 2 * 64 * 16) + 4 * (1 + O) * 64 * sizeof(float); };
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(1));
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(1));
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(3));
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    tfm_bwd_args a;
+    a.g = g; a.c = *cfg; a.planes = planes_cl; a.prep = prep; a.points = points; a.sdf = sdf; a.i0 = i0; a.n_chunk = nc; a.npt = npt;
+    a.d_sdf = d_sdf; a.d_features = d_features; a.d_normal = d_normal; a.d_fd_grad = d_fd_grad; a.denc = denc; a.pts = pts;
+    auto grid = [&](int per_tile) { int b = asd_div_up(asd_div_up(nc, per_tile), 4); return b > 512 ? 512 : b; };
+    auto gridw = [&](int per_tile) { int b = asd_div_up(asd_div_up(nc, per_tile), 4); return b > 256 ? 256 : b; };
+    a.w3 = w6[2]; a.dw1 = dw6[0]; a.dw2 = dw6[1]; a.dw3 = dw6[2];
+    if (npt == 4) {
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, true>), dim3(grid(16)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_weights_kernel<1, true>), dim3(gridw(16)), dim3(256), ldsw(1), s, a);
+    } else {
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, false>), dim3(grid(64)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_weights_kernel<1, false>), dim3(gridw(64)), dim3(256), ldsw(1), s, a);
+    }
+    if (d_features) {
+        a.w3 = w6[5]; a.dw1 = dw6[3]; a.dw2 = dw6[4]; a.dw3 = dw6[5];
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<3, false>), dim3(grid(64)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_weights_kernel<3, false>), dim3(gridw(64)), dim3(256), ldsw(3), s, a);
     }
     return ASD_OK;
 }
