@@ -193,6 +193,9 @@ int asd_triplane_sample_fwd(const float* planes_cl, int32_t B, int32_t H, int32_
                             float coord_scale /* 2 / box_warp */, float* out /*[B,M,3C]*/, void* stream);
 int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
                             float coord_scale, float* d_planes_cl, void* stream);
+/* the same scatter for rows in ray order with `run` consecutive rows per lane group (the fused tri-plane field's backward pass) */
+int asd_triplane_sample_bwd_rows(const float* d_out, int32_t H, int32_t W, int32_t C, const float* points, int32_t rows, float* d_planes_cl,
+                                 int32_t run, void* stream);
 int asd_relayout_f32(const float* x, int32_t batch, int32_t rows, int32_t cols, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

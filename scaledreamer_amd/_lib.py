@@ -140,7 +140,7 @@ SYMBOLS = [
     "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd",
     "asd_envmap_fwd", "asd_envmap_bwd",
     "asd_importance_resample", "asd_transmittance_cdf", "asd_merge_sorted", "asd_voxel_sample_fwd", "asd_voxel_sample_bwd",
-    "asd_triplane_sample_fwd", "asd_triplane_sample_bwd", "asd_relayout_f32",
+    "asd_triplane_sample_fwd", "asd_triplane_sample_bwd", "asd_triplane_sample_bwd_rows", "asd_relayout_f32",
     "asd_generate_rays", "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
     "asd_gemm_f16", "asd_gemm_force_tile", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",

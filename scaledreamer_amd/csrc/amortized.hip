@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) void triplane_sample_kernel(const float* __res
 template <int LPP, int CPL>
 __global__ __launch_bounds__(256) void triplane_sample_bwd_kernel(const float* __restrict__ d_out, int B, int H, int W,
                                                                   const float* __restrict__ points, int M, float coord_scale,
-                                                                  float* __restrict__ d_planes) {
+                                                                  float* __restrict__ d_planes, int run) {
     constexpr int C = LPP * CPL;     // lane `sub` of a group owns channels sub + k * LPP (request-coalesced scatter, see voxel_sample_bwd_kernel)
     const long long total = (long long)B * M;
-    const long long chunks = (total + SCATTER_RUN - 1) / SCATTER_RUN;
+    const long long chunks = (total + run - 1) / run;
     const int sub = threadIdx.x % LPP;
     for (long long t = ((long long)blockIdx.x * 256 + threadIdx.x) / LPP; t < chunks * 3; t += (long long)gridDim.x * 256 / LPP) {
         const long long ch = t / 3;
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void triplane_sample_bwd_kernel(const float* _
                 for (int k = 0; k < CPL; ++k) atomicAdd(dst + k * LPP, acc[corner][k]);
             }
         };
-        const long long q_end = min(total, (ch + 1) * SCATTER_RUN);
-        for (long long q = ch * SCATTER_RUN; q < q_end; ++q) {
+        const long long q_end = min(total, (ch + 1) * run);
+        for (long long q = ch * run; q < q_end; ++q) {
             const int b = (int)(q / M);
             float u, v, fx, fy;
             int x0, y0;
@@ -379,15 +379,27 @@ int asd_triplane_sample_fwd(const float* planes_cl, int32_t B, int32_t H, int32_
     return ASD_OK;
 }
 
-int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
-                            float coord_scale, float* d_planes_cl, void* stream) {
+// `run`: consecutive rows one lane group walks, accumulating in registers while they stay in one cell of its plane (atomics only when the cell changes)
+static int triplane_sample_bwd_run(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M, float coord_scale,
+                                   float* d_planes_cl, int run, void* stream) {
     if ((int64_t)B * M == 0) return ASD_OK;
-    ASD_CHECK_ARG(d_out && points && d_planes_cl && B > 0 && H > 0 && W > 0 && M > 0, "bad argument");
+    ASD_CHECK_ARG(d_out && points && d_planes_cl && B > 0 && H > 0 && W > 0 && M > 0 && run > 0, "bad argument");
     hipStream_t s = (hipStream_t)stream;
-    ASD_SCATTER_DISPATCH(C, hipLaunchKernelGGL((triplane_sample_bwd_kernel<LPP, CPL>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, SCATTER_RUN) * 3 * LPP, 256)),
-                                           dim3(256), 0, s, d_out, B, H, W, points, M, coord_scale, d_planes_cl));
+    ASD_SCATTER_DISPATCH(C, hipLaunchKernelGGL((triplane_sample_bwd_kernel<LPP, CPL>), dim3(asd_grid_for(asd_div_up((int64_t)B * M, run) * 3 * LPP, 256)),
+                                           dim3(256), 0, s, d_out, B, H, W, points, M, coord_scale, d_planes_cl, run));
     ASD_LAUNCH_CHECK();
     return ASD_OK;
+}
+
+int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
+                            float coord_scale, float* d_planes_cl, void* stream) {
+    return triplane_sample_bwd_run(d_out, B, H, W, C, points, M, coord_scale, d_planes_cl, SCATTER_RUN, stream);
+}
+
+// rows in ray order (the fused tri-plane field's feature-gradient rows: four stencil points per sample, samples along a ray): long runs
+int asd_triplane_sample_bwd_rows(const float* d_out, int32_t H, int32_t W, int32_t C, const float* points, int32_t rows, float* d_planes_cl, int32_t run,
+                                 void* stream) {
+    return triplane_sample_bwd_run(d_out, 1, H, W, C, points, rows, 1.f, d_planes_cl, run, stream);
 }
 
 int asd_relayout_f32(const float* x, int32_t batch, int32_t rows, int32_t cols, float* y, void* stream) {

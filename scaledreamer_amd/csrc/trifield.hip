@@ -542,7 +542,9 @@ int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
 int asd_trifield_bwd_workspace(int32_t n, int32_t with_normal, int64_t* n_floats) {
     ASD_CHECK_ARG(n_floats && n >= 0, "bad argument");
     const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs = ch * (with_normal ? 4 : 1);
-    *n_floats = rs * (TF_NIN + 3 * TF_H + TF_NIN + 4) + ch * 3 * TF_H + 1024 + TFM_PREP_FLOATS;
+    // matrix-pipe pass: feature-gradient rows + points for the scatter, scales / weight images; the vector-pipe pass adds the rows of its four
+    // weight-gradient products
+    *n_floats = rs * (TF_NIN + 4) + 1024 + TFM_PREP_FLOATS + (tf_use_mfma() ? 0 : rs * (TF_NIN + 3 * TF_H) + ch * 3 * TF_H);
     return ASD_OK;
 }
 
@@ -558,19 +560,19 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs_max = ch * npt;
     tf_rows R;
     float* p = workspace;
-    R.enc = p; p += rs_max * TF_NIN;
+    R.denc = p; p += rs_max * TF_NIN;
+    R.pts = p; p += rs_max * 4;
+    p += 1024;
+    float* const prep = p; p += TFM_PREP_FLOATS;
+    const bool mfma = tf_use_mfma();
+    R.enc = p; p += rs_max * TF_NIN;           // (vector-pipe pass only: not part of the workspace otherwise, and never touched)
     R.h1s = p; p += rs_max * TF_H;
     R.da1s = p; p += rs_max * TF_H;
     R.da2s = p; p += rs_max * TF_H;
-    R.denc = p; p += rs_max * TF_NIN;
-    R.pts = p; p += rs_max * 4;
     R.h1f = p; p += ch * TF_H;
     R.da1f = p; p += ch * TF_H;
     R.da2f = p; p += ch * TF_H;
-    p += 1024;
-    float* const prep = p;
     const tf_weights w = tf_w(weights);
-    const bool mfma = tf_use_mfma();
     if (mfma) {
         const int rp = tfm_prepare(planes_cl, H, W, weights, prep, s);
         if (rp != ASD_OK) return rp;
@@ -598,7 +600,8 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
             const int slices = 20;
             hipLaunchKernelGGL(tf_scatter_kernel, dim3(slices, 3, 4), dim3(512), (size_t)H * W * 8 * 4, s, R.denc, R.pts, rows_s, H, W, slices, d_planes_cl);
         } else {
-            const int rc2 = asd_triplane_sample_bwd(R.denc, 1, H, W, 32, R.pts, (int32_t)rows_s, 1.f, d_planes_cl, stream);
+            static const int run = getenv("ASD_TRI_RUN") ? atoi(getenv("ASD_TRI_RUN")) : 8;
+            const int rc2 = asd_triplane_sample_bwd_rows(R.denc, H, W, 32, R.pts, (int32_t)rows_s, d_planes_cl, run, stream);
             if (rc2 != ASD_OK) return rc2;
         }
         // weight gradients: dW1^T [96][64] = ENC^T DA1 is accumulated as out[64][96]^T — the kernel's `out` is [64][NB] = DA1^T ENC; the W1 gradient is

@@ -19,7 +19,7 @@
 #define TFM_HEAD_HALVES (TFM_OFF_A1TL + TFM_A1T)              // 40960
 // prep buffer (floats): [0] bits of max|planes| | [16 + 16 head + TFM_S_*] scales | [64 ..] two head images
 #define TFM_PREP_FLOATS (64 + 2 * TFM_HEAD_HALVES / 2)
-enum { TFM_S_E = 0, TFM_S_W1, TFM_S_W2, TFM_S_H1, TFM_S_V2, TFM_S_U1 };
+enum { TFM_S_E = 0, TFM_S_W1, TFM_S_W2, TFM_S_H1, TFM_S_V2, TFM_S_U1, TFM_S_H2 };
 
 int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s);
 int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,

@@ -30,13 +30,49 @@ __device__ __forceinline__ float tfm_scale_for(float amax) {          // 2^(14 -
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     return __uint_as_float((unsigned)(se + 127) << 23);
 }
+// x = hi + lo: hi = fp16(x) (v_cvt_pk_f16_f32, two per instruction), lo = fp16(x - hi) as ONE mixed-precision fma per element (v_fma_mix{lo,hi}_f16:
+// fp16 hi * -1 + fp32 x, rounded once to fp16) — the compiler's form is cvt back + subtract + cvt: 2.5 instructions per element instead of 1.5
+typedef half_t half2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tfm_split2(float x0, float x1, half2_& hi, half2_& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(x0), "v"(x1));
+}
 __device__ __forceinline__ void tfm_split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const half_t h = (half_t)x[e];
-        hi[e] = h;
-        lo[e] = (half_t)(x[e] - (float)h);
+    for (int e = 0; e < 8; e += 2) {
+        half2_ h, l;
+        tfm_split2(x[e], x[e + 1], h, l);
+        hi[e] = h[0]; hi[e + 1] = h[1];
+        lo[e] = l[0]; lo[e + 1] = l[1];
     }
+}
+// three pieces (33 bits: an fp32 number exactly, short of fp16 underflow) for the one product whose rows cancel (dW3 under a finite-difference normal)
+__device__ __forceinline__ void tfm_split8x3(const float (&x)[8], half8& p0, half8& p1, half8& p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const half_t a = (half_t)x[e];
+        const float r1 = x[e] - (float)a;
+        const half_t b = (half_t)r1;
+        p0[e] = a; p1[e] = b; p2[e] = (half_t)(r1 - (float)b);
+    }
+}
+// a * b to ~2^-33: the six leading products of (a0 + a1 + a2)(b0 + b1 + b2), smallest first
+__device__ __forceinline__ floatx4 tfm_mma6(const half8 (&a)[3], const half8 (&b)[3], floatx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+// max(x, 0) as one instruction (fmaxf() canonicalises operands that come out of an MFMA with an extra v_max x, x)
+__device__ __forceinline__ float tfm_relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ floatx4 tfm_mma3(const half8 ah, const half8 al, const half8 bh, const half8 bl, floatx4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
@@ -63,7 +99,7 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
     const float* w1t = head ? w1t_f : w1t_s;       // [96][64] = W1^T
     const float* w2 = head ? w2_f : w2_s;          // [64][64]
     const float* w3 = head ? w3_f : w3_s;          // [O][64]
-    __shared__ float red[256], row1[TF_H], bj[TF_H], col2[TF_H], sc[8];
+    __shared__ float red[256], row1[TF_H], row2[TF_H], bj[TF_H], col2[TF_H], sc[8];
     float m1 = 0.f, m2 = 0.f;
     for (int q = tid; q < TF_NIN * TF_H; q += 256) m1 = fmaxf(m1, fabsf(w1t[q]));
     for (int q = tid; q < TF_H * TF_H; q += 256) m2 = fmaxf(m2, fabsf(w2[q]));
@@ -78,6 +114,9 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
         float a = 0.f;
         for (int c = 0; c < TF_NIN; ++c) a += fabsf(w1t[c * TF_H + tid]);
         row1[tid] = a;                                                       // sum_c |W1[j][c]|
+        float a2 = 0.f;
+        for (int i = 0; i < TF_H; ++i) a2 += fabsf(w2[tid * TF_H + i]);
+        row2[tid] = a2;                                                      // sum_i |W2[j][i]|
         float b = 0.f;
         for (int o = 0; o < O; ++o) b += fabsf(w3[o * TF_H + tid]);
         bj[tid] = b;                                                         // |v2[j]| <= sum_o |W3[o][j]|  (output gradient normalised to max 1)
@@ -90,8 +129,8 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
     }
     __syncthreads();
     if (tid == 0) {
-        float r1 = 0.f, b = 0.f, c2 = 0.f;
-        for (int j = 0; j < TF_H; ++j) { r1 = fmaxf(r1, row1[j]); b = fmaxf(b, bj[j]); c2 = fmaxf(c2, col2[j]); }
+        float r1 = 0.f, r2 = 0.f, b = 0.f, c2 = 0.f;
+        for (int j = 0; j < TF_H; ++j) { r1 = fmaxf(r1, row1[j]); r2 = fmaxf(r2, row2[j]); b = fmaxf(b, bj[j]); c2 = fmaxf(c2, col2[j]); }
         const float amax_planes = __uint_as_float(((const unsigned*)prep)[0]);
         float* s = prep + 16 + 16 * head;
         s[TFM_S_E] = tfm_scale_for(amax_planes);
@@ -100,6 +139,7 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
         s[TFM_S_H1] = tfm_scale_for(r1 * amax_planes * 1.0001f);
         s[TFM_S_V2] = tfm_scale_for(b * 1.0001f);
         s[TFM_S_U1] = tfm_scale_for(c2 * 1.0001f);
+        s[TFM_S_H2] = tfm_scale_for(r2 * r1 * amax_planes * 1.0002f);
         sc[1] = s[TFM_S_W1]; sc[2] = s[TFM_S_W2];
     }
     __syncthreads();
@@ -141,6 +181,48 @@ __device__ __forceinline__ void tfm_gather8(const float* __restrict__ planes, co
     }
     tfm_split8(e, hi, lo);
 }
+// Layer 1 as a software pipeline over its twelve (plane, row block) units: the eight 16-byte loads of unit u + 1 are in flight while unit u is
+// interpolated, split and multiplied (left to the scheduler the loads of a unit are waited for where they are issued: the tile is latency-bound).
+struct tfm_raw { floatx4 v[8]; float w[4]; };
+__device__ __forceinline__ void tfm_issue(const tf_geom& g, const float* __restrict__ planes, int plane, const float (&nrm)[3], int ch, float s, tfm_raw& r) {
+    tf_tap t;
+    tf_setup(g, plane, nrm[0], nrm[1], nrm[2], t);
+#pragma unroll
+    for (int corner = 0; corner < 4; ++corner) {
+        r.w[corner] = t.w[corner] * s;                                       // 0 outside the plane; s a power of two: folding it in here is exact
+        const float* src = planes + (t.off[corner] < 0 ? 0 : t.off[corner]) + ch;
+        r.v[2 * corner] = *(const floatx4*)src;
+        r.v[2 * corner + 1] = *(const floatx4*)(src + 4);
+    }
+}
+__device__ __forceinline__ void tfm_finish(const tfm_raw& r, half8& hi, half8& lo) {
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int corner = 0; corner < 4; ++corner)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = fmaf(r.w[corner], r.v[2 * corner][k], e[k]); e[4 + k] = fmaf(r.w[corner], r.v[2 * corner + 1][k], e[4 + k]); }
+    tfm_split8(e, hi, lo);
+}
+// consume(plane, nb, bh, bl): the unit's B fragment (channels 8 lg .. 8 lg + 7 of `plane` for the lane's row of block nb); plane / nb are constants after unrolling
+template <typename F>
+__device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __restrict__ planes, const float (&N)[4][3], int lg, float sE, F&& consume) {
+    // one scheduling region per unit: the matrix products of unit u next to the interpolation / split of unit u + 1 (loads issued one unit ago) and
+    // the tap setup + loads of unit u + 2 — three independent strands for the scheduler to interleave
+    tfm_raw r[2];
+    half8 bh[2], bl[2];
+    tfm_issue(g, planes, 0, N[0], 8 * lg, sE, r[0]);
+    tfm_issue(g, planes, 0, N[1], 8 * lg, sE, r[1]);
+    tfm_finish(r[0], bh[0], bl[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+        consume(u / 4, u % 4, bh[u & 1], bl[u & 1]);
+        if (u + 1 < 12) tfm_finish(r[(u + 1) & 1], bh[(u + 1) & 1], bl[(u + 1) & 1]);
+        if (u + 2 < 12) tfm_issue(g, planes, (u + 2) / 4, N[(u + 2) % 4], 8 * lg, sE, r[u & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // accumulator blocks (2t, 2t+1) of NB row blocks -> ReLU, * c -> B fragments of k-step t
 template <int NB>
 __device__ __forceinline__ void tfm_relu_frags(const floatx4 (&acc)[4][NB], float c, half8 (&bh)[2][NB], half8 (&bl)[2][NB]) {
@@ -150,7 +232,7 @@ __device__ __forceinline__ void tfm_relu_frags(const floatx4 (&acc)[4][NB], floa
         for (int nb = 0; nb < NB; ++nb) {
             float x[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { x[r] = fmaxf(acc[2 * t][nb][r], 0.f) * c; x[4 + r] = fmaxf(acc[2 * t + 1][nb][r], 0.f) * c; }
+            for (int r = 0; r < 4; ++r) { x[r] = tfm_relu(acc[2 * t][nb][r]) * c; x[4 + r] = tfm_relu(acc[2 * t + 1][nb][r]) * c; }
             tfm_split8(x, bh[t][nb], bl[t][nb]);
             __builtin_amdgcn_sched_barrier(0);        // one fragment at a time: left alone the scheduler interleaves all of them (400+ registers)
         }
@@ -186,7 +268,7 @@ __device__ __forceinline__ void tfm_layer3(const floatx4 (&z)[4][NB], const floa
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[nb][o] = fmaf(w[r], fmaxf(z[mb][nb][r], 0.f), out[nb][o]);
+                for (int r = 0; r < 4; ++r) out[nb][o] = fmaf(w[r], tfm_relu(z[mb][nb][r]), out[nb][o]);
         }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -223,15 +305,15 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
         const uint4* src1 = (const uint4*)((const half_t*)(prep + 64) + TFM_HEAD_HALVES);
         uint4* dst = (uint4*)smem;
         constexpr int N16 = TFM_FWD_HALVES * 2 / 16;
-        for (int q = threadIdx.x; q < N16; q += 256) {
+        for (int q = threadIdx.x; q < N16; q += 256) {          // MODE 1 / 2: one head, 40 KB
             if (MODE != 2) dst[q] = src0[q];
-            if (MODE != 1) dst[N16 + q] = src1[q];
+            if (MODE != 1) dst[(MODE == 2 ? 0 : N16) + q] = src1[q];
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
     const half8* img_s = (const half8*)smem;
-    const half8* img_f = (const half8*)(smem + TFM_FWD_HALVES * 2);
+    const half8* img_f = (const half8*)(smem + (MODE == 2 ? 0 : TFM_FWD_HALVES * 2));
     const float* ss = prep + 16;
     const float* sf = prep + 32;
     const float sE = ss[TFM_S_E];
@@ -258,32 +340,20 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
             accf[mb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
         // ---- layer 1: k-step = plane
-#pragma unroll 1
-        for (int plane = 0; plane < 3; ++plane) {
-            half8 bh[4], bl[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                tf_tap t;
-                tf_setup(g, plane, N[nb][0], N[nb][1], N[nb][2], t);
-                tfm_gather8(planes, t, 8 * lg, sE, bh[nb], bl[nb]);
-                __builtin_amdgcn_sched_barrier(0);    // the loads of one row block in flight at a time (32 registers)
-            }
+        tfm_layer1(g, planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const half8 ah = img_p[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img_p[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], acc[mb][nb]);
-                __builtin_amdgcn_sched_barrier(0);
+                acc[mb][nb] = tfm_mma3(ah, al, bh, bl, acc[mb][nb]);
             }
-            if (feat) {
+            if (nb == 0 && feat) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     const half8 ah = img_f[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img_f[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
-                    accf[mb][0] = tfm_mma3(ah, al, bh[0], bl[0], accf[mb][0]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    accf[mb][0] = tfm_mma3(ah, al, bh, bl, accf[mb][0]);
                 }
             }
-        }
+        });
         // ---- layers 2, 3 of the head on all row blocks
         float o[4][OP];
         {
@@ -411,118 +481,103 @@ __device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (
     }
 }
 
+// W3 of the head at the lane's units of block mb in the chain layout (16 mb + 4 lg + r), from the copy in LDS
+template <int O>
+__device__ __forceinline__ void tfm_w3_chain(const float* w3s, int mb, int lg, floatx4 (&w)[O]) {
+#pragma unroll
+    for (int o = 0; o < O; ++o) w[o] = *(const floatx4*)(w3s + o * TF_H + 16 * mb + 4 * lg);
+}
+
 template <int O, bool FD>
 __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];             // the head's eight images: 80 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // the head's eight images (80 KB) | W3 [O][64] floats
     constexpr int head = O == 3;
     {
         const uint4* src = (const uint4*)((const half_t*)(a.prep + 64) + (size_t)head * TFM_HEAD_HALVES);
         uint4* dst = (uint4*)smem;
         for (int q = threadIdx.x; q < TFM_HEAD_HALVES * 2 / 16; q += 256) dst[q] = src[q];
+        float* w3d = (float*)(smem + TFM_HEAD_HALVES * 2);
+        for (int q = threadIdx.x; q < O * TF_H; q += 256) w3d[q] = a.w3[q];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
     const half8* img = (const half8*)smem;
+    const float* w3s = (const float*)(smem + TFM_HEAD_HALVES * 2);
     const float* sc = a.prep + 16 + 16 * head;
     const float sE = sc[TFM_S_E], sV2 = sc[TFM_S_V2];
     const float c1 = sc[TFM_S_H1] / (sc[TFM_S_W1] * sE), c2 = 1.f / (sc[TFM_S_W2] * sc[TFM_S_H1]);
     const float cU = sc[TFM_S_U1] / (sc[TFM_S_W2] * sV2), cD = 1.f / (sc[TFM_S_W1] * sc[TFM_S_U1]);
-    float w3r[O][4][4], w3acc[O][4][4];                                      // the lane's 16 units: 16 mb + 4 lg + r
-#pragma unroll
-    for (int o = 0; o < O; ++o)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const floatx4 w = *(const floatx4*)(a.w3 + o * TF_H + 16 * mb + 4 * lg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { w3r[o][mb][r] = w[r]; w3acc[o][mb][r] = 0.f; }
-        }
     const int n_tiles = (a.n_chunk + (FD ? 16 : 64) - 1) / (FD ? 16 : 64);
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         int li[4];
-        float P[4][3], N[4][3];
+        float N[4][3], bias4[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             int i;
+            float P[3];
             li[nb] = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
-            tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P[nb]);
-            tf_norm(a.c, P[nb][0], P[nb][1], P[nb][2], N[nb][0], N[nb][1], N[nb][2]);
+            tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P);
+            tf_norm(a.c, P[0], P[1], P[2], N[nb][0], N[nb][1], N[nb][2]);
+            bias4[nb] = (O == 1 && FD) ? tf_bias(a.c, P[0], P[1], P[2]) : 0.f;
+            if (O == 1 && lg == 0 && li[nb] < a.n_chunk) {                   // the rows' points for the scatter
+                const size_t row = (size_t)a.npt * li[nb] + (FD ? nb : 0);
+                a.pts[3 * row] = N[nb][0]; a.pts[3 * row + 1] = N[nb][1]; a.pts[3 * row + 2] = N[nb][2];
+            }
         }
         floatx4 acc[4][4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int plane = 0; plane < 3; ++plane) {
-            half8 bh[4], bl[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                tf_tap t;
-                tf_setup(a.g, plane, N[nb][0], N[nb][1], N[nb][2], t);
-                tfm_gather8(a.planes, t, 8 * lg, sE, bh[nb], bl[nb]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        tfm_layer1(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], acc[mb][nb]);
-                __builtin_amdgcn_sched_barrier(0);
+                acc[mb][nb] = tfm_mma3(ah, al, bh, bl, acc[mb][nb]);
             }
-        }
-        unsigned long long m1 = 0ull, m2 = 0ull;                             // bit (mb * 4 + nb) * 4 + r: pre-activation > 0
+        });
+        unsigned long long m1 = 0ull;                                        // bit (mb * 4 + nb) * 4 + r: layer 1's pre-activation > 0
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m1 |= (unsigned long long)(acc[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
-        {
-            half8 bh[2][4], bl[2][4];
-            tfm_relu_frags<4>(acc, c1, bh, bl);
-            tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, bh, bl, acc);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m2 |= (unsigned long long)(acc[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
+        half8 vh[2][4], vl[2][4];
+        tfm_relu_frags<4>(acc, c1, vh, vl);
+        tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, vh, vl, acc);
         // ---- the rows' output gradients (the probes' sdf values feed the normalisation of the finite-difference normal)
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         if (O == 1 && FD) {
             float o[4][1];
-            tfm_layer3<4, 1>(acc, a.w3, lg, c2, o);
+            tfm_layer3<4, 1>(acc, w3s, lg, c2, o);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + tf_bias(a.c, P[nb][0], P[nb][1], P[nb][2]);
+            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + bias4[nb];
         }
         float G[4], dn[4][O];
         tfm_row_grads<O, FD>(a, li, s4, G, dn);
-        // ---- dW3 += G dn (x) h2, and v2 = W3^T dn under the ReLU mask as the B fragments of the transposed chain
-        half8 vh[2][4], vl[2][4];
+        // ---- v2 = W3^T dn under layer 2's ReLU mask: the B fragments of the transposed chain
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            floatx4 w3v[2][O];
+            tfm_w3_chain<O>(w3s, 2 * t, lg, w3v[0]);
+            tfm_w3_chain<O>(w3s, 2 * t + 1, lg, w3v[1]);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 float x[8];
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    const int mb = 2 * t + hb;
+                for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float h2 = fmaxf(acc[mb][nb][r], 0.f) * c2;
                         float v = 0.f;
 #pragma unroll
-                        for (int o = 0; o < O; ++o) {
-                            w3acc[o][mb][r] = fmaf(G[nb] * dn[nb][o], h2, w3acc[o][mb][r]);
-                            v = fmaf(dn[nb][o], w3r[o][mb][r], v);
-                        }
-                        x[4 * hb + r] = ((m2 >> ((mb * 4 + nb) * 4 + r)) & 1ull) ? v * sV2 : 0.f;
+                        for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3v[hb][o][r], v);
+                        x[4 * hb + r] = acc[2 * t + hb][nb][r] > 0.f ? v * sV2 : 0.f;
                     }
-                }
                 tfm_split8(x, vh[t][nb], vl[t][nb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         // ---- u1 = W2^T v2, masked by layer 1's ReLU
         tfm_layer2<4>(img + TFM_OFF_A2TH / 8, img + TFM_OFF_A2TL / 8, lane, vh, vl, acc);
 #pragma unroll
@@ -561,71 +616,18 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (O == 1 && lg == 0) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                if (li[nb] >= a.n_chunk) continue;
-                const size_t row = (size_t)a.npt * li[nb] + (FD ? nb : 0);
-                a.pts[3 * row] = N[nb][0]; a.pts[3 * row + 1] = N[nb][1]; a.pts[3 * row + 2] = N[nb][2];
-            }
-        }
     }
-    // ---- dW3: the 16 rows of a lane group, then one atomic per unit and wave
-#pragma unroll
-    for (int o = 0; o < O; ++o)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = w3acc[o][mb][r];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-                if (q16 == 0 && v != 0.f) atomicAdd(a.dw3 + o * TF_H + 16 * mb + 4 * lg + r, v);
-            }
-}
-
-// ---- host side ----------------------------------------------------------------------------------------------------------------------
-int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s) {
-    (void)hipMemsetAsync(prep, 0, 64 * sizeof(float), s);
-    const int rc = asd_absmax_f32(planes_cl, (int64_t)3 * H * W * 32, (uint32_t*)prep, (void*)s);
-    if (rc != ASD_OK) return rc;
-    hipLaunchKernelGGL(tfm_prep_kernel, dim3(2), dim3(256), 0, s, w6[0], w6[1], w6[2], w6[3], w6[4], w6[5], prep);
-    return ASD_OK;
-}
-
-int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,
-                float* features, float* normal, float* fd_grad, hipStream_t s) {
-    static bool attr = false;
-    const size_t lds = (size_t)2 * TFM_FWD_HALVES * 2;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    const bool fd = normal || fd_grad;
-    const int tiles = asd_div_up(n, fd ? 16 : 64);
-    int blocks = asd_div_up(tiles, 4);
-    if (blocks > 512) blocks = 512;
-    if (fd) {
-        hipLaunchKernelGGL(tfm_fwd_kernel<0>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
-    } else {
-        hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
-        if (features)
-            hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
-    }
-    return ASD_OK;
 }
 
 // ---- backward, weight gradients --------------------------------------------------------------------------------------------------------
-// dW2 = sum_rows (G v2) (x) h1 and dW1 = sum_rows (G u1) (x) enc contract over ROWS: both operands of those products must hold a unit (or channel)
-// per lane and rows along k — the TRANSPOSE of the chain's fragments.  Every product of the chain is therefore evaluated a second time with the
-// operands swapped (Z = X W^T instead of Z^T = W X^T: same fragments, same images), whose accumulator holds, in lane (unit = l & 15, g), rows
-// 4g .. 4g+3 of every row block: two row blocks are one k-step of the contraction (the k order of tfm_perm, the same for both operands).
-// The lookup is transposed by a product with an identity fragment (exact: 1 * hi and 1 * lo are fp16 numbers).  The rows' G spans many orders
-// of magnitude across a chunk: a wave keeps a RUNNING power-of-two scale S >= every |G| it has seen (operands carry G / S, the accumulators
-// are rescaled when S grows — exact), so the fp16 operands stay in range without a pass over the gradients.
-// One wave per SIMD (160 accumulator registers + the chain); per-wave LDS: the lookup fragments of the tile (24 KB) and the rows' G.
+// dW3 = sum_rows (G dn) (x) h2, dW2 = sum_rows (G v2) (x) h1 and dW1 = sum_rows (G u1) (x) enc contract over ROWS: both operands of those products
+// must hold a unit (or channel, or output) per lane and rows along k — the TRANSPOSE of the chain's fragments.  Every product of the chain is
+// therefore evaluated a second time with the operands swapped (Z = X W^T instead of Z^T = W X^T: same fragments, same images), whose accumulator
+// holds, in lane (unit = l & 15, g), rows 4g .. 4g+3 of every row block: two row blocks are one k-step of the contraction (the k order of
+// tfm_perm, the same for both operands).  The lookup is transposed by a product with an identity fragment (exact: 1 * hi and 1 * lo are fp16
+// numbers).  The rows' G spans many orders of magnitude across a chunk: a wave keeps a RUNNING power-of-two scale S >= every |G| it has seen
+// (operands carry G / S, the accumulators are rescaled when S grows — exact), so the fp16 operands stay in range without a pass over the
+// gradients.  One wave per SIMD (176 accumulator registers + the chain); per-wave LDS: the lookup fragments of the tile (24 KB), the rows' G.
 template <int O, bool FD>
 __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_args a) {
     constexpr int head = O == 3;
@@ -637,35 +639,34 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
         const uint4* src = (const uint4*)((const half_t*)(a.prep + 64) + (size_t)head * TFM_HEAD_HALVES);
         uint4* dst = (uint4*)smem;
         for (int q = threadIdx.x; q < IMG_HALVES * 2 / 16; q += 256) dst[q] = src[q];
+        float* w3d = (float*)(smem + IMG_HALVES * 2 + 4 * ENC_BYTES) + 4 * GBUF_FLOATS;
+        for (int q = threadIdx.x; q < O * TF_H; q += 256) w3d[q] = a.w3[q];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
     const half8* img = (const half8*)smem;
     half8* encbuf = (half8*)(smem + IMG_HALVES * 2 + wave * ENC_BYTES);
     float* gbuf = (float*)(smem + IMG_HALVES * 2 + 4 * ENC_BYTES) + wave * GBUF_FLOATS;
+    const float* w3s = (const float*)(smem + IMG_HALVES * 2 + 4 * ENC_BYTES) + 4 * GBUF_FLOATS;
     const float* sc = a.prep + 16 + 16 * head;
     const float sE = sc[TFM_S_E], sV2 = sc[TFM_S_V2];
     const float c1 = sc[TFM_S_H1] / (sc[TFM_S_W1] * sE), c2 = 1.f / (sc[TFM_S_W2] * sc[TFM_S_H1]);
-    const float cU = sc[TFM_S_U1] / (sc[TFM_S_W2] * sV2);
-    float w3r[O][4][4], w3n[O][4];                       // W3 at the lane's units of the chain layout (16 mb + 4 lg + r) and of the swapped layout (16 mb + q16)
+    const float cU = sc[TFM_S_U1] / (sc[TFM_S_W2] * sV2), cH2 = sc[TFM_S_H2] * c2;
+    float w3n[O][4];                                     // W3 at the lane's units of the swapped layout (16 mb + q16)
 #pragma unroll
     for (int o = 0; o < O; ++o)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const floatx4 w = *(const floatx4*)(a.w3 + o * TF_H + 16 * mb + 4 * lg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w3r[o][mb][r] = w[r];
-            w3n[o][mb] = a.w3[o * TF_H + 16 * mb + q16];
-        }
+        for (int mb = 0; mb < 4; ++mb) w3n[o][mb] = w3s[o * TF_H + 16 * mb + q16];
     // identity fragments: B operand with a one at k == 16 half + (l & 15)
     half8 ident[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ident[hf][e] = (half_t)((8 * lg + e == 16 * hf + q16) ? 1.f : 0.f);
-    floatx4 dw2[4][4], dw1[4][6];                        // [unit block of the gradient operand][unit / channel block of the activation operand]
+    floatx4 dw3[4], dw2[4][4], dw1[4][6];                // [block of the gradient operand][block of the activation operand]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        dw3[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) dw2[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -675,39 +676,33 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
     const int n_tiles = (a.n_chunk + (FD ? 16 : 64) - 1) / (FD ? 16 : 64);
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         int li[4];
-        float P[4][3], N[4][3];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            int i;
-            li[nb] = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
-            tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P[nb]);
-            tf_norm(a.c, P[nb][0], P[nb][1], P[nb][2], N[nb][0], N[nb][1], N[nb][2]);
-        }
-        // ---- layer 1 (chain orientation); the lookup fragments go to LDS: the swapped products and the last step read them back
+        float bias4[4];
         floatx4 zt[4][4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int plane = 0; plane < 3; ++plane) {
-            half8 bh[4], bl[4];
+        {
+            float N[4][3];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                tf_tap t;
-                tf_setup(a.g, plane, N[nb][0], N[nb][1], N[nb][2], t);
-                tfm_gather8(a.planes, t, 8 * lg, sE, bh[nb], bl[nb]);
-                encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = bh[nb];
-                encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = bl[nb];
-                __builtin_amdgcn_sched_barrier(0);
+                int i;
+                float P[3];
+                li[nb] = FD ? tile * 16 + q16 : tile * 64 + nb * 16 + q16;
+                tfm_point<FD>(a.c, a.points + 3 * (size_t)a.i0, a.n_chunk, tile, q16, nb, i, P);
+                tf_norm(a.c, P[0], P[1], P[2], N[nb][0], N[nb][1], N[nb][2]);
+                bias4[nb] = (O == 1 && FD) ? tf_bias(a.c, P[0], P[1], P[2]) : 0.f;
             }
+            // ---- layer 1 (chain orientation); the lookup fragments go to LDS: the swapped products and the last step read them back
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = tfm_mma3(ah, al, bh[nb], bl[nb], zt[mb][nb]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+            tfm_layer1(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
+                encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = bh;
+                encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = bl;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
+                    zt[mb][nb] = tfm_mma3(ah, al, bh, bl, zt[mb][nb]);
+                }
+            });
         }
         // ---- layer 2 (chain orientation): zt <- Z2^T; h1's fragments stay for the swapped product below
         half8 h1h[2][4], h1l[2][4];
@@ -717,12 +712,19 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         if (O == 1 && FD) {
             float o[4][1];
-            tfm_layer3<4, 1>(zt, a.w3, lg, c2, o);
+            tfm_layer3<4, 1>(zt, w3s, lg, c2, o);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + tf_bias(a.c, P[nb][0], P[nb][1], P[nb][2]);
+            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + bias4[nb];
         }
         float G[4], dn[4][O];
         tfm_row_grads<O, FD>(a, li, s4, G, dn);
+        unsigned long long m2t = 0ull;                   // layer 2's ReLU mask in the chain layout (all that is kept of zt)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m2t |= (unsigned long long)(zt[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
         float gm = fmaxf(fmaxf(fabsf(G[0]), fabsf(G[1])), fmaxf(fabsf(G[2]), fabsf(G[3])));
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
@@ -731,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             const float f = S / gm;                      // 0 for the first tile (the accumulators are zero)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                dw3[i] *= f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dw2[i][j] *= f;
 #pragma unroll
@@ -747,35 +750,24 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                 for (int o = 0; o < O; ++o) gbuf[(1 + o) * 64 + nb * 16 + q16] = dn[nb][o];
             }
         }
-        // v2 in the chain layout: the row operand of u1 = v2 W2 in the swapped orientation
-        half8 vh[2][4], vl[2][4];
+        floatx4 gq[4];                                   // G / S of rows 4 lg .. 4 lg + 3 of every row block
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int nb = 0; nb < 4; ++nb) gq[nb] = *(const floatx4*)(gbuf + nb * 16 + 4 * lg);
+        // (G / S) dn with an OUTPUT per lane (lanes >= O carry zeros): the gradient operand of dW3, scaled by 2^14
+        half8 gd[2][3];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float x[8];
+        for (int kk = 0; kk < 2; ++kk) {
+            float x[8];
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    const int mb = 2 * t + hb;
+            for (int hb = 0; hb < 2; ++hb) {
+                floatx4 d = {1.f, 1.f, 1.f, 1.f};
+                if (O > 1) d = *(const floatx4*)(gbuf + (1 + (q16 < O ? q16 : 0)) * 64 + (2 * kk + hb) * 16 + 4 * lg);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3r[o][mb][r], v);
-                        x[4 * hb + r] = zt[mb][nb][r] > 0.f ? v * sV2 : 0.f;
-                    }
-                }
-                tfm_split8(x, vh[t][nb], vl[t][nb]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 4; ++r) x[4 * hb + r] = q16 < O ? gq[2 * kk + hb][r] * d[r] * 16384.f : 0.f;
             }
-        // ---- Z2 in the swapped orientation, one unit block at a time -> (G / S) v2 with a unit per lane: the gradient operand of dW2
-        floatx4 gq[4], dq[4][O];                         // G / S and dn of rows 4 lg .. 4 lg + 3 of every row block
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            gq[nb] = *(const floatx4*)(gbuf + nb * 16 + 4 * lg);
-#pragma unroll
-            for (int o = 0; o < O; ++o) dq[nb][o] = *(const floatx4*)(gbuf + (1 + o) * 64 + nb * 16 + 4 * lg);
+            tfm_split8x3(x, gd[kk][0], gd[kk][1], gd[kk][2]);
         }
+        // ---- Z2 in the swapped orientation, one unit block at a time -> h2 and (G / S) v2 with a unit per lane: dW3, and the gradient operand of dW2
         half8 gvh[4][2], gvl[4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -790,17 +782,30 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                float x[8];
+                float x[8], y[8];
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int nb = 2 * kk + hb;
+                    floatx4 v = {w3n[0][mb], w3n[0][mb], w3n[0][mb], w3n[0][mb]};
+                    if (O > 1) {
+                        v = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int o = 0; o < O; ++o) {
+                            const floatx4 d = *(const floatx4*)(gbuf + (1 + o) * 64 + nb * 16 + 4 * lg);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaf(d[r], w3n[o][mb], v[r]);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int o = 0; o < O; ++o) v = fmaf(dq[2 * kk + hb][o][r], w3n[o][mb], v);
-                        x[4 * hb + r] = zn[2 * kk + hb][r] > 0.f ? gq[2 * kk + hb][r] * v * sV2 : 0.f;
+                        x[4 * hb + r] = zn[nb][r] > 0.f ? gq[nb][r] * v[r] * sV2 : 0.f;
+                        y[4 * hb + r] = tfm_relu(zn[nb][r]) * cH2;
                     }
+                }
                 tfm_split8(x, gvh[mb][kk], gvl[mb][kk]);
+                half8 h2[3];
+                tfm_split8x3(y, h2[0], h2[1], h2[2]);
+                dw3[mb] = tfm_mma6(gd[kk], h2, dw3[mb]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                     for (int r = 0; r < 4; ++r) {
                         const float z = zn[2 * kk + hb][r];
                         m1n |= (unsigned long long)(z > 0.f) << ((mi * 4 + 2 * kk + hb) * 4 + r);
-                        x[4 * hb + r] = fmaxf(z, 0.f) * c1;
+                        x[4 * hb + r] = tfm_relu(z) * c1;
                     }
                 tfm_split8(x, hh[kk], hl[kk]);
             }
@@ -839,6 +844,29 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) dw2[mj][mi] = tfm_mma3(gvh[mj][kk], gvl[mj][kk], hh[kk], hl[kk], dw2[mj][mi]);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- v2 in the chain layout (from the mask): the row operand of u1 = v2 W2 in the swapped orientation
+        half8 vh[2][4], vl[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            floatx4 w3v[2][O];
+            tfm_w3_chain<O>(w3s, 2 * t, lg, w3v[0]);
+            tfm_w3_chain<O>(w3s, 2 * t + 1, lg, w3v[1]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float x[8];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3v[hb][o][r], v);
+                        x[4 * hb + r] = ((m2t >> (((2 * t + hb) * 4 + nb) * 4 + r)) & 1ull) ? v * sV2 : 0.f;
+                    }
+                tfm_split8(x, vh[t][nb], vl[t][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- u1 = v2 W2 in the swapped orientation, masked by layer 1's ReLU, times G / S: the gradient operand of dW1
 #pragma unroll
@@ -865,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- dW1 += (G u1)^T enc: the lookup fragments come back from LDS and are transposed by identity products
-#pragma unroll 1
+#pragma unroll
         for (int plane = 0; plane < 3; ++plane) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -889,21 +917,22 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        if (plane == 0) dw1[mi][hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][hf]);
-                        else if (plane == 1) dw1[mi][2 + hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][2 + hf]);
-                        else dw1[mi][4 + hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][4 + hf]);
-                    }
+                    for (int kk = 0; kk < 2; ++kk) dw1[mi][2 * plane + hf] = tfm_mma3(gvh[mi][kk], gvl[mi][kk], eh[kk], el[kk], dw1[mi][2 * plane + hf]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    // ---- accumulators -> global: lane (q16, lg) of dw2[mj][mi] holds dW2[16 mj + 4 lg + r][16 mi + q16]; dw1[mi][cb]: dW1[16 mi + 4 lg + r][16 cb + q16]
-    const float k2 = S / (sV2 * sc[TFM_S_H1]), k1 = S / (sc[TFM_S_U1] * sE);
+    // ---- accumulators -> global: lane (q16, lg) of dw2[mj][mi] holds dW2[16 mj + 4 lg + r][16 mi + q16]; dw1[mi][cb]: dW1[16 mi + 4 lg + r][16 cb + q16];
+    //      dw3[mb]: dW3[o = 4 lg + r][16 mb + q16] (outputs >= O are zero)
+    const float k3 = S / (16384.f * sc[TFM_S_H2]), k2 = S / (sV2 * sc[TFM_S_H1]), k1 = S / (sc[TFM_S_U1] * sE);
 #pragma unroll
     for (int mj = 0; mj < 4; ++mj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (lg == 0 && r < O) {
+                const float v = dw3[mj][r] * k3;
+                if (v != 0.f) atomicAdd(a.dw3 + r * TF_H + 16 * mj + q16, v);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const float v = dw2[mj][mi][r] * k2;
@@ -917,20 +946,53 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
         }
 }
 
+// ---- host side ----------------------------------------------------------------------------------------------------------------------
+int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s) {
+    (void)hipMemsetAsync(prep, 0, 64 * sizeof(float), s);
+    const int rc = asd_absmax_f32(planes_cl, (int64_t)3 * H * W * 32, (uint32_t*)prep, (void*)s);
+    if (rc != ASD_OK) return rc;
+    hipLaunchKernelGGL(tfm_prep_kernel, dim3(2), dim3(256), 0, s, w6[0], w6[1], w6[2], w6[3], w6[4], w6[5], prep);
+    return ASD_OK;
+}
+
+int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,
+                float* features, float* normal, float* fd_grad, hipStream_t s) {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * TFM_FWD_HALVES * 2;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const bool fd = normal || fd_grad;
+    const int tiles = asd_div_up(n, fd ? 16 : 64);
+    int blocks = asd_div_up(tiles, 4);
+    if (blocks > 512) blocks = 512;
+    if (fd) {
+        hipLaunchKernelGGL(tfm_fwd_kernel<0>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+    } else {
+        hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+        if (features)
+            hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+    }
+    return ASD_OK;
+}
+
 // one chunk of the backward pass: feature-gradient rows (denc, pts) for the scatter and the heads' weight gradients
 int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points,
                        const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
                        float* denc, float* pts, float* const* dw6, hipStream_t s) {
     static bool attr = false;
-    const size_t lds = (size_t)TFM_HEAD_HALVES * 2;
-    auto ldsw = [](int O) { return (size_t)TFM_OFF_A1TH * 2 + 4 * (3 * 4 * 2 * 64 * 16) + 4 * (1 + O) * 64 * sizeof(float); };
+    auto ldsd = [](int O) { return (size_t)TFM_HEAD_HALVES * 2 + (size_t)O * TF_H * sizeof(float); };
+    auto ldsw = [](int O) { return (size_t)TFM_OFF_A1TH * 2 + 4 * (3 * 4 * 2 * 64 * 16) + 4 * (1 + O) * 64 * sizeof(float) + (size_t)O * TF_H * sizeof(float); };
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(1));
         (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(1));
         (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(3));
-        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd(1));
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd(1));
+        (void)hipFuncSetAttribute((const void*)tfm_bwd_data_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd(3));
         attr = true;
     }
     tfm_bwd_args a;
@@ -940,15 +1002,15 @@ int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* p
     auto gridw = [&](int per_tile) { int b = asd_div_up(asd_div_up(nc, per_tile), 4); return b > 256 ? 256 : b; };
     a.w3 = w6[2]; a.dw1 = dw6[0]; a.dw2 = dw6[1]; a.dw3 = dw6[2];
     if (npt == 4) {
-        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, true>), dim3(grid(16)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, true>), dim3(grid(16)), dim3(256), ldsd(1), s, a);
         hipLaunchKernelGGL((tfm_bwd_weights_kernel<1, true>), dim3(gridw(16)), dim3(256), ldsw(1), s, a);
     } else {
-        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, false>), dim3(grid(64)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<1, false>), dim3(grid(64)), dim3(256), ldsd(1), s, a);
         hipLaunchKernelGGL((tfm_bwd_weights_kernel<1, false>), dim3(gridw(64)), dim3(256), ldsw(1), s, a);
     }
     if (d_features) {
         a.w3 = w6[5]; a.dw1 = dw6[3]; a.dw2 = dw6[4]; a.dw3 = dw6[5];
-        hipLaunchKernelGGL((tfm_bwd_data_kernel<3, false>), dim3(grid(64)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((tfm_bwd_data_kernel<3, false>), dim3(grid(64)), dim3(256), ldsd(3), s, a);
         hipLaunchKernelGGL((tfm_bwd_weights_kernel<3, false>), dim3(gridw(64)), dim3(256), ldsw(3), s, a);
     }
     return ASD_OK;
