@@ -168,19 +168,6 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
 }
 
 // ---- pieces of the chain ---------------------------------------------------------------------------------------------------------------
-// B fragment of layer 1: channels ch .. ch + 7 of the plane under the taps `t`, times s (a power of two: folding it into the tap weights is exact)
-__device__ __forceinline__ void tfm_gather8(const float* __restrict__ planes, const tf_tap& t, int ch, float s, half8& hi, half8& lo) {
-    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int corner = 0; corner < 4; ++corner) {
-        const float w = t.w[corner] * s;                                     // 0 outside the plane
-        const float* src = planes + (t.off[corner] < 0 ? 0 : t.off[corner]) + ch;
-        const floatx4 a = *(const floatx4*)src, b = *(const floatx4*)(src + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { e[r] = fmaf(w, a[r], e[r]); e[4 + r] = fmaf(w, b[r], e[4 + r]); }
-    }
-    tfm_split8(e, hi, lo);
-}
 // Layer 1 as a software pipeline over its twelve (plane, row block) units: the eight 16-byte loads of unit u + 1 are in flight while unit u is
 // interpolated, split and multiplied (left to the scheduler the loads of a unit are waited for where they are issued: the tile is latency-bound).
 struct tfm_raw { floatx4 v[8]; float w[4]; };
@@ -195,36 +182,65 @@ __device__ __forceinline__ void tfm_issue(const tf_geom& g, const float* __restr
         r.v[2 * corner + 1] = *(const floatx4*)(src + 4);
     }
 }
-__device__ __forceinline__ void tfm_finish(const tfm_raw& r, half8& hi, half8& lo) {
-    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void tfm_interp(const tfm_raw& r, float (&e)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = 0.f;
 #pragma unroll
     for (int corner = 0; corner < 4; ++corner)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { e[k] = fmaf(r.w[corner], r.v[2 * corner][k], e[k]); e[4 + k] = fmaf(r.w[corner], r.v[2 * corner + 1][k], e[4 + k]); }
-    tfm_split8(e, hi, lo);
 }
-// consume(plane, nb, bh, bl): the unit's B fragment (channels 8 lg .. 8 lg + 7 of `plane` for the lane's row of block nb); plane / nb are constants after unrolling
-template <typename F>
+// consume(plane, nb, bh, bl): the unit's B fragment (channels 8 lg .. 8 lg + 7 of `plane` for the lane's row of block nb); plane / nb are constants after unrolling.
+//
+// FD (row block k = 1..3 of a tile is the probe + eps e_k of the SAME 16 samples as block 0): the probe blocks carry DIFFERENCES to the centre
+// through every linear step — enc_k - enc_0 here, formed in fp32 in the lane that holds both — and are made whole (z_k = z_0 + dz_k) only where
+// a ReLU needs them.  A finite difference (s_k - s_0) / eps and the backward pass's (g_k a_k (x) b_k - g_k a_0 (x) b_0) cancel 2-3 digits; on
+// whole values the 22-bit split products would leave that cancellation 4x the noise of fp32 arithmetic, on differences they leave none.
+template <bool FD, typename F>
 __device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __restrict__ planes, const float (&N)[4][3], int lg, float sE, F&& consume) {
     // one scheduling region per unit: the matrix products of unit u next to the interpolation / split of unit u + 1 (loads issued one unit ago) and
     // the tap setup + loads of unit u + 2 — three independent strands for the scheduler to interleave
     tfm_raw r[2];
     half8 bh[2], bl[2];
+    float e0[8];
     tfm_issue(g, planes, 0, N[0], 8 * lg, sE, r[0]);
     tfm_issue(g, planes, 0, N[1], 8 * lg, sE, r[1]);
-    tfm_finish(r[0], bh[0], bl[0]);
+    tfm_interp(r[0], e0);
+    tfm_split8(e0, bh[0], bl[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
         consume(u / 4, u % 4, bh[u & 1], bl[u & 1]);
-        if (u + 1 < 12) tfm_finish(r[(u + 1) & 1], bh[(u + 1) & 1], bl[(u + 1) & 1]);
+        if (u + 1 < 12) {
+            float e[8];
+            tfm_interp(r[(u + 1) & 1], e);
+            if (FD) {
+                if ((u + 1) % 4 == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e0[k] = e[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] -= e0[k];
+                }
+            }
+            tfm_split8(e, bh[(u + 1) & 1], bl[(u + 1) & 1]);
+        }
         if (u + 2 < 12) tfm_issue(g, planes, (u + 2) / 4, N[(u + 2) % 4], 8 * lg, sE, r[u & 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// FD: probe blocks hold differences after a linear step: make them whole
+template <bool FD, int M>
+__device__ __forceinline__ void tfm_merge(floatx4 (&z)[M][4]) {
+    if (!FD) return;
+#pragma unroll
+    for (int mb = 0; mb < M; ++mb)
+#pragma unroll
+        for (int k = 1; k < 4; ++k) z[mb][k] += z[mb][0];
+}
 
-// accumulator blocks (2t, 2t+1) of NB row blocks -> ReLU, * c -> B fragments of k-step t
-template <int NB>
+// accumulator blocks (2t, 2t+1) of NB row blocks (whole values) -> ReLU, * c -> B fragments of k-step t; FD: the probe blocks as differences to block 0
+template <int NB, bool FD = false>
 __device__ __forceinline__ void tfm_relu_frags(const floatx4 (&acc)[4][NB], float c, half8 (&bh)[2][NB], half8 (&bl)[2][NB]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -233,6 +249,10 @@ __device__ __forceinline__ void tfm_relu_frags(const floatx4 (&acc)[4][NB], floa
             float x[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { x[r] = tfm_relu(acc[2 * t][nb][r]) * c; x[4 + r] = tfm_relu(acc[2 * t + 1][nb][r]) * c; }
+            if (FD && nb > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x[r] -= tfm_relu(acc[2 * t][0][r]) * c; x[4 + r] -= tfm_relu(acc[2 * t + 1][0][r]) * c; }
+            }
             tfm_split8(x, bh[t][nb], bl[t][nb]);
             __builtin_amdgcn_sched_barrier(0);        // one fragment at a time: left alone the scheduler interleaves all of them (400+ registers)
         }
@@ -253,8 +273,8 @@ __device__ __forceinline__ void tfm_layer2(const half8* a2h, const half8* a2l, i
         }
     }
 }
-// out[nb][o] = c * sum_j W3[o][j] relu(z[j][row]): the lane's 16 units, then the four lane groups
-template <int NB, int O>
+// out[nb][o] = c * sum_j W3[o][j] relu(z[j][row]): the lane's 16 units, then the four lane groups; FD: out of a probe block is the DIFFERENCE to block 0
+template <int NB, int O, bool FD = false>
 __device__ __forceinline__ void tfm_layer3(const floatx4 (&z)[4][NB], const float* __restrict__ w3, int g, float c, float (&out)[NB][O]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -268,7 +288,11 @@ __device__ __forceinline__ void tfm_layer3(const floatx4 (&z)[4][NB], const floa
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[nb][o] = fmaf(w[r], tfm_relu(z[mb][nb][r]), out[nb][o]);
+                for (int r = 0; r < 4; ++r) {
+                    float h = tfm_relu(z[mb][nb][r]);
+                    if (FD && nb > 0) h -= tfm_relu(z[mb][0][r]);
+                    out[nb][o] = fmaf(w[r], h, out[nb][o]);
+                }
         }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
             accf[mb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
         // ---- layer 1: k-step = plane
-        tfm_layer1(g, planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
+        tfm_layer1<FD>(g, planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const half8 ah = img_p[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img_p[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
@@ -358,9 +382,11 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
         float o[4][OP];
         {
             half8 bh[2][4], bl[2][4];
-            tfm_relu_frags<4>(acc, c1p, bh, bl);
+            tfm_merge<FD>(acc);
+            tfm_relu_frags<4, FD>(acc, c1p, bh, bl);
             tfm_layer2<4>(img_p + TFM_OFF_A2H / 8, img_p + TFM_OFF_A2L / 8, lane, bh, bl, acc);
-            tfm_layer3<4, OP>(acc, w3p, lg, c2p, o);
+            tfm_merge<FD>(acc);
+            tfm_layer3<4, OP, FD>(acc, w3p, lg, c2p, o);           // FD: o[k] = out_k - out_0 for the probes
         }
         float of[1][3];
         if (feat) {
@@ -374,14 +400,12 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
             if (FD) {
                 const int i = idx[0];
                 if (i < n) {
-                    float s[4];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) s[nb] = o[nb][0] + tf_bias(c, P[nb][0], P[nb][1], P[nb][2]);
-                    sdf[i] = s[0];
+                    const float b0 = tf_bias(c, P[0][0], P[0][1], P[0][2]);
+                    sdf[i] = o[0][0] + b0;
                     if (feat) { features[3 * (size_t)i] = of[0][0]; features[3 * (size_t)i + 1] = of[0][1]; features[3 * (size_t)i + 2] = of[0][2]; }
                     float nr[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) nr[k] = (s[k + 1] - s[0]) / c.fd_eps;
+                    for (int k = 0; k < 3; ++k) nr[k] = (o[k + 1][0] + (tf_bias(c, P[k + 1][0], P[k + 1][1], P[k + 1][2]) - b0)) / c.fd_eps;
                     if (fd_grad) { fd_grad[3 * (size_t)i] = nr[0]; fd_grad[3 * (size_t)i + 1] = nr[1]; fd_grad[3 * (size_t)i + 2] = nr[2]; }
                     if (normal) {
                         const float inv = 1.f / fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
@@ -427,8 +451,10 @@ __device__ __forceinline__ float tfm_pow2_above(float x) {
 }
 
 // the per-row output gradient of a tile in the lane that owns the row: G[nb] (multiplier) and dn[nb][o] (|dn| <= 1)
+// FD: ds4[k] = sdf(probe k) - sdf(centre); d0 = the centre's own output gradient (G[0] = d0 - sum_k G[k]: the centre row of every probe term)
 template <int O, bool FD>
-__device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (&li)[4], const float (&s4)[4], float (&G)[4], float (&dn)[4][O]) {
+__device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (&li)[4], const float (&ds4)[3], float (&G)[4], float (&dn)[4][O], float& d0) {
+    d0 = 0.f;
     if (O == 1 && FD) {
         const bool active = li[0] < a.n_chunk;
         const size_t i = (size_t)a.i0 + (active ? li[0] : 0);
@@ -437,10 +463,9 @@ __device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (
         if (active) {
             float dnr[3] = {0.f, 0.f, 0.f};
             if (a.d_normal) {
-                const float s = a.sdf[i];
                 float nr[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) nr[k] = (s4[k + 1] - s) / a.c.fd_eps;
+                for (int k = 0; k < 3; ++k) nr[k] = ds4[k] / a.c.fd_eps;
                 const float len = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
                 const float g0 = a.d_normal[3 * i], g1 = a.d_normal[3 * i + 1], g2 = a.d_normal[3 * i + 2];
                 if (len > 1e-12f) {
@@ -453,6 +478,7 @@ __device__ __forceinline__ void tfm_row_grads(const tfm_bwd_args& a, const int (
                 }
             }
             if (a.d_fd_grad) { dnr[0] += a.d_fd_grad[3 * i]; dnr[1] += a.d_fd_grad[3 * i + 1]; dnr[2] += a.d_fd_grad[3 * i + 2]; }
+            d0 = ds;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { dsk[k] = dnr[k] / a.c.fd_eps; ds -= dnr[k] / a.c.fd_eps; }
         }
@@ -529,13 +555,14 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-        tfm_layer1(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
+        tfm_layer1<FD>(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
                 acc[mb][nb] = tfm_mma3(ah, al, bh, bl, acc[mb][nb]);
             }
         });
+        tfm_merge<FD>(acc);
         unsigned long long m1 = 0ull;                                        // bit (mb * 4 + nb) * 4 + r: layer 1's pre-activation > 0
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -544,18 +571,19 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m1 |= (unsigned long long)(acc[mb][nb][r] > 0.f) << ((mb * 4 + nb) * 4 + r);
         half8 vh[2][4], vl[2][4];
-        tfm_relu_frags<4>(acc, c1, vh, vl);
+        tfm_relu_frags<4, FD>(acc, c1, vh, vl);
         tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, vh, vl, acc);
-        // ---- the rows' output gradients (the probes' sdf values feed the normalisation of the finite-difference normal)
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        tfm_merge<FD>(acc);
+        // ---- the rows' output gradients (the probes' sdf differences feed the normalisation of the finite-difference normal)
+        float ds4[3] = {0.f, 0.f, 0.f};
         if (O == 1 && FD) {
             float o[4][1];
-            tfm_layer3<4, 1>(acc, w3s, lg, c2, o);
+            tfm_layer3<4, 1, true>(acc, w3s, lg, c2, o);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + bias4[nb];
+            for (int k = 0; k < 3; ++k) ds4[k] = o[k + 1][0] + (bias4[k + 1] - bias4[0]);
         }
-        float G[4], dn[4][O];
-        tfm_row_grads<O, FD>(a, li, s4, G, dn);
+        float G[4], dn[4][O], d0;
+        tfm_row_grads<O, FD>(a, li, ds4, G, dn, d0);
         // ---- v2 = W3^T dn under layer 2's ReLU mask: the B fragments of the transposed chain
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -573,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
 #pragma unroll
                         for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3v[hb][o][r], v);
                         x[4 * hb + r] = acc[2 * t + hb][nb][r] > 0.f ? v * sV2 : 0.f;
+                        if (FD && nb > 0) x[4 * hb + r] -= acc[2 * t + hb][0][r] > 0.f ? v * sV2 : 0.f;      // (one output: v is the same for the four points)
                     }
                 tfm_split8(x, vh[t][nb], vl[t][nb]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -580,6 +609,7 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
         }
         // ---- u1 = W2^T v2, masked by layer 1's ReLU
         tfm_layer2<4>(img + TFM_OFF_A2TH / 8, img + TFM_OFF_A2TL / 8, lane, vh, vl, acc);
+        tfm_merge<FD>(acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -588,7 +618,10 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[4 * hb + r] = ((m1 >> (((2 * t + hb) * 4 + nb) * 4 + r)) & 1ull) ? acc[2 * t + hb][nb][r] * cU : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        x[4 * hb + r] = ((m1 >> (((2 * t + hb) * 4 + nb) * 4 + r)) & 1ull) ? acc[2 * t + hb][nb][r] * cU : 0.f;
+                        if (FD && nb > 0) x[4 * hb + r] -= ((m1 >> (((2 * t + hb) * 4) * 4 + r)) & 1ull) ? acc[2 * t + hb][0][r] * cU : 0.f;
+                    }
                 tfm_split8(x, vh[t][nb], vl[t][nb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -604,6 +637,7 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) d[nb] = tfm_mma3(ah, al, vh[t][nb], vl[t][nb], d[nb]);
             }
+            if (FD) { d[1] += d[0]; d[2] += d[0]; d[3] += d[0]; }
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 if (li[nb] >= a.n_chunk) continue;
@@ -694,7 +728,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-            tfm_layer1(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
+            tfm_layer1<FD>(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
                 encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = bh;
                 encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = bl;
 #pragma unroll
@@ -706,18 +740,23 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
         }
         // ---- layer 2 (chain orientation): zt <- Z2^T; h1's fragments stay for the swapped product below
         half8 h1h[2][4], h1l[2][4];
-        tfm_relu_frags<4>(zt, c1, h1h, h1l);
+        tfm_merge<FD>(zt);
+        tfm_relu_frags<4, FD>(zt, c1, h1h, h1l);             // FD: [h1_0 | h1_k - h1_0]
         tfm_layer2<4>(img + TFM_OFF_A2H / 8, img + TFM_OFF_A2L / 8, lane, h1h, h1l, zt);
+        tfm_merge<FD>(zt);
         // ---- the rows' output gradients, in the lanes that own the rows, and their exchange to the swapped layout
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        float ds4[3] = {0.f, 0.f, 0.f};
         if (O == 1 && FD) {
             float o[4][1];
-            tfm_layer3<4, 1>(zt, w3s, lg, c2, o);
+            tfm_layer3<4, 1, true>(zt, w3s, lg, c2, o);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s4[nb] = o[nb][0] + bias4[nb];
+            for (int k = 0; k < 3; ++k) ds4[k] = o[k + 1][0] + (bias4[k + 1] - bias4[0]);
         }
-        float G[4], dn[4][O];
-        tfm_row_grads<O, FD>(a, li, s4, G, dn);
+        float G[4], dn[4][O], d0;
+        tfm_row_grads<O, FD>(a, li, ds4, G, dn, d0);
+        // FD: the weight-gradient sums are regrouped around the centre — sum_pt G_pt a_pt (x) b_pt = (d0 a_0 + sum_k G_k (a_k - a_0)) (x) b_0
+        // + sum_k G_k a_k (x) (b_k - b_0) — so the row multipliers are [d0 | G_1 | G_2 | G_3] and every b operand is [b_0 | b_k - b_0]
+        if (FD) G[0] = d0;
         unsigned long long m2t = 0ull;                   // layer 2's ReLU mask in the chain layout (all that is kept of zt)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -728,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
         float gm = fmaxf(fmaxf(fabsf(G[0]), fabsf(G[1])), fmaxf(fabsf(G[2]), fabsf(G[3])));
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
-        gm = tfm_pow2_above(gm);
+        gm = tfm_pow2_above(gm) * (FD ? 8.f : 1.f);      // FD: the centre block's operand sums up to seven terms
         if (gm > S) {                                    // wave-uniform, rare: the accumulators move to the new scale
             const float f = S / gm;                      // 0 for the first tile (the accumulators are zero)
 #pragma unroll
@@ -780,6 +819,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) zn[nb] = tfm_mma3(h1h[t][nb], h1l[t][nb], ah, al, zn[nb]);
             }
+            if (FD) { zn[1] += zn[0]; zn[2] += zn[0]; zn[3] += zn[0]; }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 float x[8], y[8];
@@ -798,8 +838,22 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        x[4 * hb + r] = zn[nb][r] > 0.f ? gq[nb][r] * v[r] * sV2 : 0.f;
-                        y[4 * hb + r] = tfm_relu(zn[nb][r]) * cH2;
+                        if (FD) {
+                            const float v0 = zn[0][r] > 0.f ? v[r] : 0.f;
+                            if (nb == 0) {
+                                float t = gq[0][r] * v0;
+#pragma unroll
+                                for (int k2 = 1; k2 < 4; ++k2) t = fmaf(gq[k2][r], (zn[k2][r] > 0.f ? v[r] : 0.f) - v0, t);
+                                x[4 * hb + r] = t * sV2;
+                                y[4 * hb + r] = tfm_relu(zn[0][r]) * cH2;
+                            } else {
+                                x[4 * hb + r] = zn[nb][r] > 0.f ? gq[nb][r] * v[r] * sV2 : 0.f;
+                                y[4 * hb + r] = (tfm_relu(zn[nb][r]) - tfm_relu(zn[0][r])) * cH2;
+                            }
+                        } else {
+                            x[4 * hb + r] = zn[nb][r] > 0.f ? gq[nb][r] * v[r] * sV2 : 0.f;
+                            y[4 * hb + r] = tfm_relu(zn[nb][r]) * cH2;
+                        }
                     }
                 }
                 tfm_split8(x, gvh[mb][kk], gvl[mb][kk]);
@@ -825,6 +879,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                     zn[nb] = tfm_mma3(bh, bl, ah, al, zn[nb]);
                 }
             }
+            if (FD) { zn[1] += zn[0]; zn[2] += zn[0]; zn[3] += zn[0]; }       // (the probes' lookup fragments are differences)
             half8 hh[2], hl[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -836,6 +891,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                         const float z = zn[2 * kk + hb][r];
                         m1n |= (unsigned long long)(z > 0.f) << ((mi * 4 + 2 * kk + hb) * 4 + r);
                         x[4 * hb + r] = tfm_relu(z) * c1;
+                        if (FD && 2 * kk + hb > 0) x[4 * hb + r] -= tfm_relu(zn[0][r]) * c1;
                     }
                 tfm_split8(x, hh[kk], hl[kk]);
             }
@@ -863,6 +919,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 #pragma unroll
                         for (int o = 0; o < O; ++o) v = fmaf(dn[nb][o], w3v[hb][o][r], v);
                         x[4 * hb + r] = ((m2t >> (((2 * t + hb) * 4 + nb) * 4 + r)) & 1ull) ? v * sV2 : 0.f;
+                        if (FD && nb > 0) x[4 * hb + r] -= ((m2t >> (((2 * t + hb) * 4) * 4 + r)) & 1ull) ? v * sV2 : 0.f;
                     }
                 tfm_split8(x, vh[t][nb], vl[t][nb]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -880,14 +937,25 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) zn[nb] = tfm_mma3(vh[t][nb], vl[t][nb], ah, al, zn[nb]);
             }
+            if (FD) { zn[1] += zn[0]; zn[2] += zn[0]; zn[3] += zn[0]; }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 float x[8];
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        x[4 * hb + r] = ((m1n >> ((mb * 4 + 2 * kk + hb) * 4 + r)) & 1ull) ? gq[2 * kk + hb][r] * zn[2 * kk + hb][r] * cU : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const int nb = 2 * kk + hb;
+                        if (FD && nb == 0) {
+                            const float u0 = ((m1n >> ((mb * 4) * 4 + r)) & 1ull) ? zn[0][r] : 0.f;
+                            float t = gq[0][r] * u0;
+#pragma unroll
+                            for (int k2 = 1; k2 < 4; ++k2) t = fmaf(gq[k2][r], (((m1n >> ((mb * 4 + k2) * 4 + r)) & 1ull) ? zn[k2][r] : 0.f) - u0, t);
+                            x[4 * hb + r] = t * cU;
+                        } else {
+                            x[4 * hb + r] = ((m1n >> ((mb * 4 + nb) * 4 + r)) & 1ull) ? gq[nb][r] * zn[nb][r] * cU : 0.f;
+                        }
+                    }
                 tfm_split8(x, gvh[mb][kk], gvl[mb][kk]);
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -81,6 +81,19 @@ def main():
         torch.cuda.synchronize()
         _, cref, wref = ref64(planes, ws, pts, gs)
         print(f"bwd: planes {l2(dpl, cref):.2e} " + " ".join(f"dW{i} {l2(a, b):.2e}" for i, (a, b) in enumerate(zip(dws, wref))))
+        # without a normal / sdf_grad gradient: one row per sample
+        gs2 = {"sdf": gs["sdf"], "features": gs["features"]}
+        dpl = torch.zeros_like(planes)
+        dws = ops.trifield_bwd(planes, c, w6, pts, sdf, gs2["sdf"].contiguous(), gs2["features"], None, None, dpl)
+        torch.cuda.synchronize()
+        _, cref, wref = ref64(planes, ws, pts, gs2)
+        print(f"bwd (no normal): planes {l2(dpl, cref):.2e} " + " ".join(f"dW{i} {l2(a, b):.2e}" for i, (a, b) in enumerate(zip(dws, wref))))
+        # sdf gradient only
+        dpl = torch.zeros_like(planes)
+        dws = ops.trifield_bwd(planes, c, w6, pts, sdf, gs2["sdf"].contiguous(), None, None, None, dpl)
+        torch.cuda.synchronize()
+        _, cref, wref = ref64(planes, ws, pts, {"sdf": gs["sdf"]})
+        print(f"bwd (sdf only): planes {l2(dpl, cref):.2e} " + " ".join(f"dW{i} {l2(a, b):.2e}" for i, (a, b) in enumerate(zip(dws[:3], wref[:3]))) + f" feature-head grads all zero: {all(float(d.abs().max()) == 0 for d in dws[3:])}")
         dpl = torch.zeros(3, 64, 64, 32, device="cuda")
         sdfb = ops.trifield_fwd(planes, c, w6, big, True, True)[0]
         gb = [torch.randn(big.shape[0], d, device="cuda") for d in (1, 3, 3, 3)]
@@ -93,4 +106,5 @@ def main():
         print(f"backward, 2 M samples: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms")
 
 
-main()
+if __name__ == "__main__":
+    main()
