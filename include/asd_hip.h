@@ -141,7 +141,7 @@ int asd_trifield_fwd_workspace(int64_t* n_floats);   /* scales + split-fp16 frag
 int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights,
                      const float* points, int32_t n, float* sdf, float* features /* or NULL */, float* normal, float* fd_grad,
                      float* workspace, void* stream);
-int asd_trifield_bwd_workspace(int32_t n, int32_t with_normal, int64_t* n_floats);
+int asd_trifield_bwd_workspace(int32_t H, int32_t W, int32_t n, int32_t with_normal, int64_t* n_floats);
 int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights,
                      const float* points, const float* sdf, int32_t n, const float* d_sdf, const float* d_features, const float* d_normal,
                      const float* d_fd_grad, float* d_planes_cl, float* const* d_weights, float* workspace, void* stream);

@@ -539,12 +539,19 @@ int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     return ASD_OK;
 }
 
-int asd_trifield_bwd_workspace(int32_t n, int32_t with_normal, int64_t* n_floats) {
-    ASD_CHECK_ARG(n_floats && n >= 0, "bad argument");
+// ASD_TRI_SORT=0: the run-aggregated atomic scatter (asd_triplane_sample_bwd_rows) instead of the sorted one
+static bool tf_use_sort(int H, int W) {
+    static const bool on = !(getenv("ASD_TRI_SORT") && getenv("ASD_TRI_SORT")[0] == '0');
+    return on && tfs_supported(H, W);
+}
+
+int asd_trifield_bwd_workspace(int32_t H, int32_t W, int32_t n, int32_t with_normal, int64_t* n_floats) {
+    ASD_CHECK_ARG(n_floats && n >= 0 && H > 0 && W > 0, "bad argument");
     const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs = ch * (with_normal ? 4 : 1);
-    // matrix-pipe pass: feature-gradient rows + points for the scatter, scales / weight images; the vector-pipe pass adds the rows of its four
-    // weight-gradient products
-    *n_floats = rs * (TF_NIN + 4) + 1024 + TFM_PREP_FLOATS + (tf_use_mfma() ? 0 : rs * (TF_NIN + 3 * TF_H) + ch * 3 * TF_H);
+    // matrix-pipe pass: feature-gradient rows + points for the scatter, scales / weight images, the sort's bins and row list; the vector-pipe
+    // pass adds the rows of its four weight-gradient products
+    *n_floats = rs * (TF_NIN + 4) + 1024 + TFM_PREP_FLOATS + tfs_work_ints((int)rs, H, W)
+                + (tf_use_mfma() ? 0 : rs * (TF_NIN + 3 * TF_H) + ch * 3 * TF_H);
     return ASD_OK;
 }
 
@@ -564,7 +571,8 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     R.pts = p; p += rs_max * 4;
     p += 1024;
     float* const prep = p; p += TFM_PREP_FLOATS;
-    const bool mfma = tf_use_mfma();
+    int* const sort_work = (int*)p; p += tfs_work_ints((int)rs_max, H, W);
+    const bool mfma = tf_use_mfma(), sorted = tf_use_sort(H, W);
     R.enc = p; p += rs_max * TF_NIN;           // (vector-pipe pass only: not part of the workspace otherwise, and never touched)
     R.h1s = p; p += rs_max * TF_H;
     R.da1s = p; p += rs_max * TF_H;
@@ -599,6 +607,8 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
         if (lds_scatter) {
             const int slices = 20;
             hipLaunchKernelGGL(tf_scatter_kernel, dim3(slices, 3, 4), dim3(512), (size_t)H * W * 8 * 4, s, R.denc, R.pts, rows_s, H, W, slices, d_planes_cl);
+        } else if (sorted) {
+            tfs_scatter(R.denc, R.pts, (int)rows_s, H, W, d_planes_cl, sort_work, s);
         } else {
             static const int run = getenv("ASD_TRI_RUN") ? atoi(getenv("ASD_TRI_RUN")) : 128;     // rows in ray order: C5 step 100.9 ms at 8, 93.6 at 128
             const int rc2 = asd_triplane_sample_bwd_rows(R.denc, H, W, 32, R.pts, (int32_t)rows_s, d_planes_cl, run, stream);

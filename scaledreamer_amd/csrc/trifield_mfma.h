@@ -27,3 +27,7 @@ int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_c
 int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points,
                        const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
                        float* denc, float* pts, float* const* dw6, hipStream_t s);
+// counting sort of the feature-gradient rows by plane cell + segmented reduction (trifield_scatter.hip)
+int64_t tfs_work_ints(int rows, int H, int W);
+bool tfs_supported(int H, int W);
+int tfs_scatter(const float* denc, const float* pts, int R, int H, int W, float* d_planes, int* work, hipStream_t s);

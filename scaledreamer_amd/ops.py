@@ -552,7 +552,7 @@ def trifield_bwd(planes_cl, cfg: FieldCfg, weights6, points, sdf, d_sdf, d_featu
     _, H, W, Cc = planes_cl.shape
     n, dev = points.shape[0], points.device
     nf = C.c_int64(0)
-    check(lib().asd_trifield_bwd_workspace(i32(n), i32(int(d_normal is not None or d_fd_grad is not None)), C.byref(nf)))
+    check(lib().asd_trifield_bwd_workspace(i32(H), i32(W), i32(n), i32(int(d_normal is not None or d_fd_grad is not None)), C.byref(nf)))
     ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
     dws = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))]
     k = _Keep()

@@ -157,7 +157,7 @@ def test_passes_stay_inside_their_buffers():
     for k, (buf, view) in bufs.items():
         assert intact(buf, view.numel()), f"forward wrote outside {k}"
     sdf = bufs["sdf"][1].view(torch.float32).clone()
-    _lib.check(L.asd_trifield_bwd_workspace(_lib.i32(n), _lib.i32(1), C.byref(nf)))
+    _lib.check(L.asd_trifield_bwd_workspace(_lib.i32(64), _lib.i32(64), _lib.i32(n), _lib.i32(1), C.byref(nf)))
     shapes = ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))
     b2 = {"ws": guarded(nf.value * 4), "dpl": guarded(planes.numel() * 4)}
     b2.update({f"dw{i}": guarded(a * b * 4) for i, (a, b) in enumerate(shapes)})
