@@ -100,47 +100,58 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
     const float* w2 = head ? w2_f : w2_s;          // [64][64]
     const float* w3 = head ? w3_f : w3_s;          // [O][64]
     __shared__ float red[256], row1[TF_H], row2[TF_H], bj[TF_H], col2[TF_H], sc[8];
+    // max|W1|, max|W2|: a wave reduction each, then four partials
     float m1 = 0.f, m2 = 0.f;
     for (int q = tid; q < TF_NIN * TF_H; q += 256) m1 = fmaxf(m1, fabsf(w1t[q]));
     for (int q = tid; q < TF_H * TF_H; q += 256) m2 = fmaxf(m2, fabsf(w2[q]));
-    red[tid] = m1;
-    __syncthreads();
-    if (tid == 0) { float m = 0.f; for (int q = 0; q < 256; ++q) m = fmaxf(m, red[q]); sc[1] = m; }
-    __syncthreads();
-    red[tid] = m2;
-    __syncthreads();
-    if (tid == 0) { float m = 0.f; for (int q = 0; q < 256; ++q) m = fmaxf(m, red[q]); sc[2] = m; }
-    if (tid < TF_H) {
-        float a = 0.f;
-        for (int c = 0; c < TF_NIN; ++c) a += fabsf(w1t[c * TF_H + tid]);
-        row1[tid] = a;                                                       // sum_c |W1[j][c]|
-        float a2 = 0.f;
-        for (int i = 0; i < TF_H; ++i) a2 += fabsf(w2[tid * TF_H + i]);
-        row2[tid] = a2;                                                      // sum_i |W2[j][i]|
-        float b = 0.f;
-        for (int o = 0; o < O; ++o) b += fabsf(w3[o * TF_H + tid]);
-        bj[tid] = b;                                                         // |v2[j]| <= sum_o |W3[o][j]|  (output gradient normalised to max 1)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, o, 64)); m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = m1; red[4 + (tid >> 6)] = m2; }
+    // norms: four threads per unit, a quarter of the terms each
+    {
+        const int j = tid >> 2, part = tid & 3;
+        float a = 0.f, a2 = 0.f;
+        for (int c = part; c < TF_NIN; c += 4) a += fabsf(w1t[c * TF_H + j]);
+        for (int i = part; i < TF_H; i += 4) a2 += fabsf(w2[j * TF_H + i]);
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+        a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+        if (part == 0) {
+            row1[j] = a;                                                     // sum_c |W1[j][c]|
+            row2[j] = a2;                                                    // sum_i |W2[j][i]|
+            float b = 0.f;
+            for (int o = 0; o < O; ++o) b += fabsf(w3[o * TF_H + j]);
+            bj[j] = b;                                                       // |v2[j]| <= sum_o |W3[o][j]|  (output gradient normalised to max 1)
+        }
     }
     __syncthreads();
-    if (tid < TF_H) {
+    {
+        const int i = tid >> 2, part = tid & 3;
         float a = 0.f;
-        for (int j = 0; j < TF_H; ++j) a += fabsf(w2[j * TF_H + tid]) * bj[j];
-        col2[tid] = a;                                                       // |u1[i]| <= sum_j |W2[j][i]| |v2[j]|
+        for (int j = part; j < TF_H; j += 4) a += fabsf(w2[j * TF_H + i]) * bj[j];
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+        if (part == 0) col2[i] = a;                                          // |u1[i]| <= sum_j |W2[j][i]| |v2[j]|
     }
     __syncthreads();
-    if (tid == 0) {
-        float r1 = 0.f, r2 = 0.f, b = 0.f, c2 = 0.f;
-        for (int j = 0; j < TF_H; ++j) { r1 = fmaxf(r1, row1[j]); r2 = fmaxf(r2, row2[j]); b = fmaxf(b, bj[j]); c2 = fmaxf(c2, col2[j]); }
-        const float amax_planes = __uint_as_float(((const unsigned*)prep)[0]);
-        float* s = prep + 16 + 16 * head;
-        s[TFM_S_E] = tfm_scale_for(amax_planes);
-        s[TFM_S_W1] = tfm_scale_for(sc[1]);
-        s[TFM_S_W2] = tfm_scale_for(sc[2]);
-        s[TFM_S_H1] = tfm_scale_for(r1 * amax_planes * 1.0001f);
-        s[TFM_S_V2] = tfm_scale_for(b * 1.0001f);
-        s[TFM_S_U1] = tfm_scale_for(c2 * 1.0001f);
-        s[TFM_S_H2] = tfm_scale_for(r2 * r1 * amax_planes * 1.0002f);
-        sc[1] = s[TFM_S_W1]; sc[2] = s[TFM_S_W2];
+    if (tid < 64) {
+        float r1 = row1[tid], r2 = row2[tid], b = bj[tid], c2 = col2[tid];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            r1 = fmaxf(r1, __shfl_xor(r1, o, 64)); r2 = fmaxf(r2, __shfl_xor(r2, o, 64));
+            b = fmaxf(b, __shfl_xor(b, o, 64)); c2 = fmaxf(c2, __shfl_xor(c2, o, 64));
+        }
+        if (tid == 0) {
+            const float aw1 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), aw2 = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+            const float amax_planes = __uint_as_float(((const unsigned*)prep)[0]);
+            float* s = prep + 16 + 16 * head;
+            s[TFM_S_E] = tfm_scale_for(amax_planes);
+            s[TFM_S_W1] = tfm_scale_for(aw1);
+            s[TFM_S_W2] = tfm_scale_for(aw2);
+            s[TFM_S_H1] = tfm_scale_for(r1 * amax_planes * 1.0001f);
+            s[TFM_S_V2] = tfm_scale_for(b * 1.0001f);
+            s[TFM_S_U1] = tfm_scale_for(c2 * 1.0001f);
+            s[TFM_S_H2] = tfm_scale_for(r2 * r1 * amax_planes * 1.0002f);
+            sc[1] = s[TFM_S_W1]; sc[2] = s[TFM_S_W2];
+        }
     }
     __syncthreads();
     const float s1 = sc[1], s2 = sc[2];

@@ -42,25 +42,24 @@ __global__ __launch_bounds__(256) void ts_hist_kernel(const float* __restrict__ 
         if (hist[q]) atomicAdd(&cnt[q], hist[q]);
 }
 
-// pass 2: off[plane][cell] = exclusive prefix of cnt within the plane; cursor = off; len[plane] = total (one block)
+// pass 2: off[plane][cell] = exclusive prefix of cnt within the plane; cursor = off; len[plane] = total (one block per plane)
 __global__ __launch_bounds__(1024) void ts_scan_kernel(const int* __restrict__ cnt, int cells, int* __restrict__ off, int* __restrict__ cursor, int* __restrict__ len) {
     __shared__ int part[1024];
-    for (int pl = 0; pl < 3; ++pl) {
-        const int per = (cells + 1023) / 1024, q0 = threadIdx.x * per, q1 = min(cells, q0 + per);
-        int s = 0;
-        for (int q = q0; q < q1; ++q) s += cnt[pl * cells + q];
-        part[threadIdx.x] = s;
+    const int pl = blockIdx.x, tid = threadIdx.x;
+    const int per = (cells + 1023) / 1024, q0 = tid * per, q1 = min(cells, q0 + per);
+    int s = 0;
+    for (int q = q0; q < q1; ++q) s += cnt[pl * cells + q];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {            // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
-            len[pl] = run;
-        }
-        __syncthreads();
-        int run = part[threadIdx.x];
-        for (int q = q0; q < q1; ++q) { off[pl * cells + q] = run; cursor[pl * cells + q] = run; run += cnt[pl * cells + q]; }
+        part[tid] += v;
         __syncthreads();
     }
+    int run = part[tid] - s;
+    if (tid == 1023) len[pl] = part[1023];
+    for (int q = q0; q < q1; ++q) { off[pl * cells + q] = run; cursor[pl * cells + q] = run; run += cnt[pl * cells + q]; }
 }
 
 // pass 3: sorted[plane][position] = row; a block reserves, per touched cell, a range for its slab's rows, then ranks them in LDS
@@ -130,19 +129,29 @@ __global__ __launch_bounds__(256) void ts_reduce_kernel(const float* __restrict_
             key = ts_cell(pts, row, pl, H, W, x0, y0, fx, fy);
         }
         const int m = min(64, end - b0);
-        for (int j = 0; j < m; ++j) {
-            const int rj = __builtin_amdgcn_readlane(row, j), kj = __builtin_amdgcn_readlane(key, j);
-            const float fxj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fx), j));
-            const float fyj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fy), j));
-            if (kj != cur) {                        // wave-uniform
-                flush();
-                cur = kj;
-                cx = __builtin_amdgcn_readlane(x0, j); cy = __builtin_amdgcn_readlane(y0, j);
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            float g8[8];                                // the gradient loads of eight rows fly together (a row's address comes out of a readlane)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rj = __builtin_amdgcn_readlane(row, (j0 + k) & 63);
+                g8[k] = j0 + k < m ? denc[(size_t)rj * TF_NIN + pl * 32 + c] : 0.f;
             }
-            const float g = denc[(size_t)rj * TF_NIN + pl * 32 + c];
-            const float wy = t ? fyj : 1.f - fyj;
-            a0 = fmaf((1.f - fxj) * wy, g, a0);
-            a1 = fmaf(fxj * wy, g, a1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = j0 + k;
+                if (j >= m) break;                      // wave-uniform
+                const int kj = __builtin_amdgcn_readlane(key, j);
+                const float fxj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fx), j));
+                const float fyj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fy), j));
+                if (kj != cur) {                        // wave-uniform
+                    flush();
+                    cur = kj;
+                    cx = __builtin_amdgcn_readlane(x0, j); cy = __builtin_amdgcn_readlane(y0, j);
+                }
+                const float wy = t ? fyj : 1.f - fyj;
+                a0 = fmaf((1.f - fxj) * wy, g8[k], a0);
+                a1 = fmaf(fxj * wy, g8[k], a1);
+            }
         }
     }
     flush();
@@ -169,7 +178,7 @@ int tfs_scatter(const float* denc, const float* pts, int R, int H, int W, float*
     int blocks = asd_div_up(R, 2048);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(ts_hist_kernel, dim3(blocks), dim3(256), (size_t)3 * cells * sizeof(int), s, pts, R, H, W, cnt);
-    hipLaunchKernelGGL(ts_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, cells, off, cursor, len);
+    hipLaunchKernelGGL(ts_scan_kernel, dim3(3), dim3(1024), 0, s, cnt, cells, off, cursor, len);
     hipLaunchKernelGGL(ts_fill_kernel, dim3(blocks), dim3(256), (size_t)6 * cells * sizeof(int), s, pts, R, H, W, cursor, sorted);
     const int waves = 3 * asd_div_up(R, TS_SEG);
     hipLaunchKernelGGL(ts_reduce_kernel, dim3(asd_div_up(waves, 4)), dim3(256), 0, s, denc, pts, sorted, len, R, H, W, d_planes);
