@@ -207,10 +207,24 @@ __device__ __forceinline__ void tfm_interp(const tfm_raw& r, float (&e)[8]) {
 // through every linear step — enc_k - enc_0 here, formed in fp32 in the lane that holds both — and are made whole (z_k = z_0 + dz_k) only where
 // a ReLU needs them.  A finite difference (s_k - s_0) / eps and the backward pass's (g_k a_k (x) b_k - g_k a_0 (x) b_0) cancel 2-3 digits; on
 // whole values the 22-bit split products would leave that cancellation 4x the noise of fp32 arithmetic, on differences they leave none.
-template <bool FD, typename F>
-__device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __restrict__ planes, const float (&N)[4][3], int lg, float sE, F&& consume) {
+template <bool FD, typename F, typename Z>
+__device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __restrict__ planes, const float (&N)[4][3], int lg, float sE, F&& consume, Z&& zero) {
     // one scheduling region per unit: the matrix products of unit u next to the interpolation / split of unit u + 1 (loads issued one unit ago) and
-    // the tap setup + loads of unit u + 2 — three independent strands for the scheduler to interleave
+    // the tap setup + loads of unit u + 2 — three independent strands for the scheduler to interleave.
+    // FD: the probe + eps e_k has the centre's coordinates in the plane that does not contain axis k (unless the clamp to the box moved them):
+    // its difference fragment is exactly zero there and the unit is skipped — units 3, 6, 9 of 12 when every row of the wave agrees
+    // (zero(plane, nb) instead of consume, for callers that keep the fragments).
+    bool dead[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) dead[u] = false;
+    if (FD) {
+        auto all_same = [&](int k, int a0, int a1) {
+            return __builtin_amdgcn_ballot_w64(__float_as_uint(N[k][a0]) == __float_as_uint(N[0][a0]) && __float_as_uint(N[k][a1]) == __float_as_uint(N[0][a1])) == ~0ull;
+        };
+        dead[3] = all_same(3, 0, 1);                // plane 0 = (x, y), probe + z
+        dead[6] = all_same(2, 0, 2);                // plane 1 = (x, z), probe + y
+        dead[9] = all_same(1, 2, 1);                // plane 2 = (z, y), probe + x
+    }
     tfm_raw r[2];
     half8 bh[2], bl[2];
     float e0[8];
@@ -221,8 +235,9 @@ __device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __rest
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-        consume(u / 4, u % 4, bh[u & 1], bl[u & 1]);
-        if (u + 1 < 12) {
+        if (dead[u]) zero(u / 4, u % 4);
+        else consume(u / 4, u % 4, bh[u & 1], bl[u & 1]);
+        if (u + 1 < 12 && !dead[u + 1 < 12 ? u + 1 : 0]) {
             float e[8];
             tfm_interp(r[(u + 1) & 1], e);
             if (FD) {
@@ -236,7 +251,7 @@ __device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __rest
             }
             tfm_split8(e, bh[(u + 1) & 1], bl[(u + 1) & 1]);
         }
-        if (u + 2 < 12) tfm_issue(g, planes, (u + 2) / 4, N[(u + 2) % 4], 8 * lg, sE, r[u & 1]);
+        if (u + 2 < 12 && !dead[u + 2 < 12 ? u + 2 : 0]) tfm_issue(g, planes, (u + 2) / 4, N[(u + 2) % 4], 8 * lg, sE, r[u & 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void tfm_fwd_kernel(const tf_geom g, const 
                     accf[mb][0] = tfm_mma3(ah, al, bh, bl, accf[mb][0]);
                 }
             }
-        });
+        }, [](int, int) {});
         // ---- layers 2, 3 of the head on all row blocks
         float o[4][OP];
         {
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
                 const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
                 acc[mb][nb] = tfm_mma3(ah, al, bh, bl, acc[mb][nb]);
             }
-        });
+        }, [](int, int) {});
         tfm_merge<FD>(acc);
         unsigned long long m1 = 0ull;                                        // bit (mb * 4 + nb) * 4 + r: layer 1's pre-activation > 0
 #pragma unroll
@@ -747,6 +762,10 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
                     const half8 ah = img[TFM_OFF_A1H / 8 + (mb * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mb * 3 + plane) * 64 + lane];
                     zt[mb][nb] = tfm_mma3(ah, al, bh, bl, zt[mb][nb]);
                 }
+            }, [&](int plane, int nb) __attribute__((always_inline)) {
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = z;
+                encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = z;
             });
         }
         // ---- layer 2 (chain orientation): zt <- Z2^T; h1's fragments stay for the swapped product below
