@@ -493,7 +493,23 @@ __global__ __launch_bounds__(512) void tf_scatter_kernel(const float* __restrict
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
-#define TF_CHUNK (256 * 1024)      // samples per backward chunk (x 4 rows with a normal gradient: 1.5 GB of rows)
+// ASD_TRI_MFMA=0 selects the one-thread-per-sample kernels of this file (the first form of the field, kept as the A/B partner); the default is
+// the matrix-pipe chain of trifield_mfma.hip
+static bool tf_use_mfma() {
+    static const bool on = !(getenv("ASD_TRI_MFMA") && getenv("ASD_TRI_MFMA")[0] == '0');
+    return on;
+}
+
+// samples per backward chunk: the vector-pipe pass keeps 1.5 KB of rows per sample point (x 4 with a normal gradient: 1.5 GB per 256 k samples);
+// the matrix-pipe pass keeps the 400-byte feature-gradient row only and takes 1 M samples at a time (1.7 GB), so that its weight-gradient kernels
+// amortise their prologue (56-80 KB of weight images per block) and epilogue (11 k atomics per wave) over 16-64 tiles per wave
+#define TF_CHUNK_VALU (256 * 1024)
+#define TF_CHUNK_MFMA (1024 * 1024)
+static int64_t tf_chunk() {                    // ASD_TRI_CHUNK (samples, read per call): the tests walk several chunks at small sizes
+    const char* e = getenv("ASD_TRI_CHUNK");
+    if (e && atoll(e) >= 64) return atoll(e);
+    return tf_use_mfma() ? TF_CHUNK_MFMA : TF_CHUNK_VALU;
+}
 
 static int tf_check(const asd_field_cfg* c, int H, int W, int C) {
     ASD_CHECK_ARG(c && H > 0 && W > 0, "bad argument");
@@ -506,13 +522,6 @@ static int tf_check(const asd_field_cfg* c, int H, int W, int C) {
 static tf_weights tf_w(const float* const* w6) { return tf_weights{w6[0], w6[1], w6[2], w6[3], w6[4], w6[5]}; }
 
 extern "C" {
-
-// ASD_TRI_MFMA=0 selects the one-thread-per-sample kernels of this file (the first form of the field, kept as the A/B partner); the default is
-// the matrix-pipe chain of trifield_mfma.hip
-static bool tf_use_mfma() {
-    static const bool on = !(getenv("ASD_TRI_MFMA") && getenv("ASD_TRI_MFMA")[0] == '0');
-    return on;
-}
 
 int asd_trifield_fwd_workspace(int64_t* n_floats) {
     ASD_CHECK_ARG(n_floats, "null argument");
@@ -547,7 +556,7 @@ static bool tf_use_sort(int H, int W) {
 
 int asd_trifield_bwd_workspace(int32_t H, int32_t W, int32_t n, int32_t with_normal, int64_t* n_floats) {
     ASD_CHECK_ARG(n_floats && n >= 0 && H > 0 && W > 0, "bad argument");
-    const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs = ch * (with_normal ? 4 : 1);
+    const int64_t ch = n < tf_chunk() ? n : tf_chunk(), rs = ch * (with_normal ? 4 : 1);
     // matrix-pipe pass: feature-gradient rows + points for the scatter, scales / weight images, the sort's bins and row list; the vector-pipe
     // pass adds the rows of its four weight-gradient products
     *n_floats = rs * (TF_NIN + 4) + 1024 + TFM_PREP_FLOATS + tfs_work_ints((int)rs, H, W)
@@ -564,7 +573,7 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     if (rc != ASD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int with_fd = d_normal != nullptr || d_fd_grad != nullptr, npt = with_fd ? 4 : 1;
-    const int64_t ch = n < TF_CHUNK ? n : TF_CHUNK, rs_max = ch * npt;
+    const int64_t ch = n < tf_chunk() ? n : tf_chunk(), rs_max = ch * npt;
     tf_rows R;
     float* p = workspace;
     R.denc = p; p += rs_max * TF_NIN;

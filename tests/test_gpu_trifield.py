@@ -100,6 +100,23 @@ def test_backward_against_float64(n, tol, mode):
             assert _l2(a, b) < tol, f"dW{i} {_l2(a, b):.1e}"
 
 
+def test_backward_in_chunks(monkeypatch):
+    """the pass walks the samples in chunks (1 M by default): three chunks of 1 100 samples, the last one ragged, against one chunk"""
+    from scaledreamer_amd import ops
+
+    planes, ws, w6, pts, gs = _problem(3001)
+    sdf = ops.trifield_fwd(planes, _cfg(), w6, pts, True, True)[0]
+    res = []
+    for chunk in (None, "1100"):
+        if chunk:
+            monkeypatch.setenv("ASD_TRI_CHUNK", chunk)
+        dpl = torch.zeros_like(planes)
+        dws = ops.trifield_bwd(planes, _cfg(), w6, pts, sdf, gs["sdf"], gs["features"], gs["normal"], gs["sdf_grad"], dpl)
+        res.append([dpl] + list(dws))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5
+
+
 def test_module_default_initialisation_scale():
     """weights of the size torch's Linear init draws (+-0.1): the norm-bound scales of the split must not cost accuracy at that end either"""
     from scaledreamer_amd import ops
