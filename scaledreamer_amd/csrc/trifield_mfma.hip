@@ -893,38 +893,36 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- Z1 in the swapped orientation, one unit block at a time (lookup fragments from LDS) -> h1 with a unit per lane; dW2 += (G v2)^T h1
+        // ---- h1 with a unit per lane: the chain's own fragments [h1_0 | h1_k - h1_0], transposed by identity products in the chain's k order
+        //      (exact: the pieces are fp16 numbers) — a quarter of the products of Z1 = enc W1^T over again and no LDS traffic; dW2 += (G v2)^T h1.
+        //      Layer 1's ReLU mask in this layout is read off the transposed values (hi + lo > 0: equal to z1 > 0 unless 0 < h1 < 2^-40 of its bound)
         unsigned long long m1n = 0ull;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            floatx4 zn[4];
+            half8 idp;                                   // B operand with a one at the k position of unit 16 mi + q16: lane group q16 / 4, element 4 (mi & 1) + q16 % 4
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) zn[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 8; ++e) idp[e] = (half_t)((lg == (q16 >> 2) && e == 4 * (mi & 1) + (q16 & 3)) ? 1.f : 0.f);
+            floatx4 th[4], tl[4];
 #pragma unroll
-            for (int plane = 0; plane < 3; ++plane) {
-                const half8 ah = img[TFM_OFF_A1H / 8 + (mi * 3 + plane) * 64 + lane], al = img[TFM_OFF_A1L / 8 + (mi * 3 + plane) * 64 + lane];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const half8 bh = encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane], bl = encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane];
-                    zn[nb] = tfm_mma3(bh, bl, ah, al, zn[nb]);
-                }
+            for (int nb = 0; nb < 4; ++nb) {
+                const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+                th[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1h[mi >> 1][nb], idp, z, 0, 0, 0);
+                tl[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1l[mi >> 1][nb], idp, z, 0, 0, 0);
             }
-            if (FD) { zn[1] += zn[0]; zn[2] += zn[0]; zn[3] += zn[0]; }       // (the probes' lookup fragments are differences)
             half8 hh[2], hl[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                float x[8];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = zn[2 * kk + hb][r];
-                        m1n |= (unsigned long long)(z > 0.f) << ((mi * 4 + 2 * kk + hb) * 4 + r);
-                        x[4 * hb + r] = tfm_relu(z) * c1;
-                        if (FD && 2 * kk + hb > 0) x[4 * hb + r] -= tfm_relu(zn[0][r]) * c1;
+                        const int nb = 2 * kk + hb;
+                        float whole = th[nb][r] + tl[nb][r];
+                        if (FD && nb > 0) whole += th[0][r] + tl[0][r];
+                        m1n |= (unsigned long long)(whole > 0.f) << ((mi * 4 + nb) * 4 + r);
+                        hh[kk][4 * hb + r] = (half_t)th[nb][r];
+                        hl[kk][4 * hb + r] = (half_t)tl[nb][r];
                     }
-                tfm_split8(x, hh[kk], hl[kk]);
-            }
 #pragma unroll
             for (int mj = 0; mj < 4; ++mj)
 #pragma unroll
