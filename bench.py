@@ -641,7 +641,8 @@ def main():
                                                                        "csrc/conv3d.hip) -> [32,128^3] volume, fused trilinear lookup + MLP heads, VolSDF renderer, SD-2.1 guidance, "
                                                                        "1 prompt+view/GPU",
                                                "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer (fp32 library ops) -> 3x[32,64,64] "
-                                                                  "planes, HIP tri-plane samplers, VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
+                                                                  "planes, fused tri-plane field on the matrix pipe (lookups + both MLP heads + finite-difference normal, "
+                                                                  "csrc/trifield_mfma.hip; sorted plane scatter), VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
             out.pop("kept_samples_last_step", None)
             if args.render:
                 out["config"]["render"] = f"{args.render}x{args.render} (override; the shipped YAML renders 64x64)"
