@@ -542,19 +542,17 @@ __device__ __forceinline__ void tfm_w3_chain(const float* w3s, int mb, int lg, f
 
 template <int O, bool FD>
 __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];             // the head's eight images (80 KB) | W3 [O][64] floats
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // the head's eight images: 80 KB exactly, two blocks per CU (W3 comes from L1)
     constexpr int head = O == 3;
     {
         const uint4* src = (const uint4*)((const half_t*)(a.prep + 64) + (size_t)head * TFM_HEAD_HALVES);
         uint4* dst = (uint4*)smem;
         for (int q = threadIdx.x; q < TFM_HEAD_HALVES * 2 / 16; q += 256) dst[q] = src[q];
-        float* w3d = (float*)(smem + TFM_HEAD_HALVES * 2);
-        for (int q = threadIdx.x; q < O * TF_H; q += 256) w3d[q] = a.w3[q];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15, lg = lane >> 4;
     const half8* img = (const half8*)smem;
-    const float* w3s = (const float*)(smem + TFM_HEAD_HALVES * 2);
+    const float* w3s = a.w3;
     const float* sc = a.prep + 16 + 16 * head;
     const float sE = sc[TFM_S_E], sV2 = sc[TFM_S_V2];
     const float c1 = sc[TFM_S_H1] / (sc[TFM_S_W1] * sE), c2 = 1.f / (sc[TFM_S_W2] * sc[TFM_S_H1]);
@@ -1080,7 +1078,7 @@ int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* p
                        const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
                        float* denc, float* pts, float* const* dw6, hipStream_t s) {
     static bool attr = false;
-    auto ldsd = [](int O) { return (size_t)TFM_HEAD_HALVES * 2 + (size_t)O * TF_H * sizeof(float); };
+    auto ldsd = [](int) { return (size_t)TFM_HEAD_HALVES * 2; };
     auto ldsw = [](int O) { return (size_t)TFM_OFF_A1TH * 2 + 4 * (3 * 4 * 2 * 64 * 16) + 4 * (1 + O) * 64 * sizeof(float) + (size_t)O * TF_H * sizeof(float); };
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)tfm_bwd_weights_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw(1));
