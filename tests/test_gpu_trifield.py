@@ -52,9 +52,9 @@ def _ref64(planes_cl, ws, pts, gs=None):
     return out, c.grad[0].permute(0, 2, 3, 1), [x.grad for x in w]
 
 
-def _problem(n, seed=3, wscale=2.0):
+def _problem(n, seed=3, wscale=2.0, hw=(64, 64)):
     g = torch.Generator().manual_seed(seed)
-    planes = (torch.randn(3, 64, 64, 32, generator=g) * 0.5).cuda()
+    planes = (torch.randn(3, hw[0], hw[1], 32, generator=g) * 0.5).cuda()
     ws = [(torch.randn(o, i, generator=g) * (wscale / i) ** 0.5).cuda() for o, i in ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))]
     w6 = (ws[0].t().contiguous(), ws[1], ws[2], ws[3].t().contiguous(), ws[4], ws[5])
     pts = (torch.rand(n, 3, generator=g) * 4.4 - 2.2).cuda()               # some points outside the box: zero padding, clamped probes
@@ -98,6 +98,21 @@ def test_backward_against_float64(n, tol, mode):
             assert float(a.abs().max()) == 0.0
         else:
             assert _l2(a, b) < tol, f"dW{i} {_l2(a, b):.1e}"
+
+
+def test_rectangular_planes():
+    """H != W (the reference's planes are square; the C ABI is not): lookups, scatter bins and the sort's cell keys"""
+    from scaledreamer_amd import ops
+
+    planes, ws, w6, pts, gs = _problem(3001, seed=3, hw=(40, 56))       # (seeds 5, 12, 13 have a ReLU pre-activation within rounding of zero: 1e-3 .. 7e-3 in BOTH fp32 forms)
+    sdf, feats, normal, fdg = ops.trifield_fwd(planes, _cfg(), w6, pts, True, True)
+    r, cref, wref = _ref64(planes, ws, pts, gs)
+    assert _l2(sdf, r["sdf"]) < 1e-5 and _l2(feats, r["features"]) < 1e-5 and _l2(fdg, r["sdf_grad"]) < 5e-5
+    dpl = torch.zeros_like(planes)
+    dws = ops.trifield_bwd(planes, _cfg(), w6, pts, sdf, gs["sdf"], gs["features"], gs["normal"], gs["sdf_grad"], dpl)
+    assert _l2(dpl, cref) < 2e-4
+    for a, b in zip(dws, wref):
+        assert _l2(a, b) < 2e-4
 
 
 def test_backward_in_chunks(monkeypatch):
