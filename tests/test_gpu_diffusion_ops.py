@@ -403,3 +403,21 @@ def test_layernorm_folded_into_the_consuming_gemm(M, C_, N, tile):
         gg = H.gemm(x, wp2.contiguous(), bias=bp, act=2, tile_cfg=tile + 1, ln=dict(mode=1, sc=scp.view(torch.float32).view(2, N).contiguous()))
         val, gate = ref[:, :N // 2], ref[:, N // 2:]
         _close(gg, val * F.gelu(gate))
+
+
+@pytest.mark.parametrize("ratio,tol", [(16, 6e-4), (40, 8e-4), (100, 3e-3)])
+def test_layernorm_fold_on_rows_with_a_large_mean(ratio, tol):
+    """the folded LayerNorm takes the variance as E[x^2] - mean^2 from one-pass fp32 sums and subtracts mean * rowsum(W) from the product: both
+    cancel when |mean| >> std.  Rows at mean / std = 16, 40, 100 (fp16 inputs) against torch's two-pass LayerNorm + matmul in fp32: the fold
+    stays at the unfolded path's fp16 error (3.5e-4 of the output range) up to 40 and is 1.8e-3 at 100 (measured; bounds with margin)"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+    from scaledreamer_amd.diffusion.weights import _ln_fold
+
+    M = C_ = N = 1280
+    x = (_rand(M, C_, seed=1).float() * 0.5 + 0.5 * ratio).half()
+    gamma, beta = (_rand(C_, seed=3).float() * 0.2 + 1.0), _rand(C_, seed=4).float() * 0.3
+    w, bias = _rand(N, C_, scale=C_ ** -0.5, seed=5), _rand(N, seed=6)
+    ref = F.layer_norm(x.float(), (C_,), gamma.cuda(), beta.cuda(), 1e-5) @ w.float().t() + bias.float()
+    w2, sc = _ln_fold(w, gamma.cuda(), beta.cuda())
+    got = H.gemm(x, w2.contiguous(), bias=bias, split_k=1, ln=dict(mode=1, sc=sc.view(torch.float32).view(2, N).contiguous()))
+    assert float((got.float() - ref).abs().max() / ref.abs().max()) < tol
