@@ -137,7 +137,7 @@ int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int
  * W1^T, W2, W3 [3][64].  Backward: nothing but the points and the sdf is kept from the forward pass; d_planes_cl += (atomics),
  * d_weights [host array of 6 device pointers] += with the FIRST-layer gradients in the NATIVE layout [64][96]; workspace:
  * asd_trifield_bwd_workspace floats (the pass walks the samples in chunks). */
-int asd_trifield_fwd_workspace(int64_t* n_floats);   /* scales + split-fp16 fragment images of the two heads, rebuilt by every call */
+int asd_trifield_fwd_workspace(int32_t H, int32_t W, int64_t* n_floats);   /* scales + split-fp16 fragment images of the two heads + the zero-bordered planes, rebuilt by every call */
 int asd_trifield_fwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, const asd_field_cfg* cfg, const float* const* weights,
                      const float* points, int32_t n, float* sdf, float* features /* or NULL */, float* normal, float* fd_grad,
                      float* workspace, void* stream);

@@ -523,9 +523,9 @@ static tf_weights tf_w(const float* const* w6) { return tf_weights{w6[0], w6[1],
 
 extern "C" {
 
-int asd_trifield_fwd_workspace(int64_t* n_floats) {
-    ASD_CHECK_ARG(n_floats, "null argument");
-    *n_floats = TFM_PREP_FLOATS;
+int asd_trifield_fwd_workspace(int32_t H, int32_t W, int64_t* n_floats) {
+    ASD_CHECK_ARG(n_floats && H > 0 && W > 0, "bad argument");
+    *n_floats = tfm_prep_floats(H, W);
     return ASD_OK;
 }
 
@@ -559,7 +559,7 @@ int asd_trifield_bwd_workspace(int32_t H, int32_t W, int32_t n, int32_t with_nor
     const int64_t ch = n < tf_chunk() ? n : tf_chunk(), rs = ch * (with_normal ? 4 : 1);
     // matrix-pipe pass: feature-gradient rows + points for the scatter, scales / weight images, the sort's bins and row list; the vector-pipe
     // pass adds the rows of its four weight-gradient products
-    *n_floats = rs * (TF_NIN + 4) + 1024 + TFM_PREP_FLOATS + tfs_work_ints((int)rs, H, W)
+    *n_floats = rs * (TF_NIN + 4) + 1024 + tfm_prep_floats(H, W) + tfs_work_ints((int)rs, H, W)
                 + (tf_use_mfma() ? 0 : rs * (TF_NIN + 3 * TF_H) + ch * 3 * TF_H);
     return ASD_OK;
 }
@@ -579,7 +579,7 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     R.denc = p; p += rs_max * TF_NIN;
     R.pts = p; p += rs_max * 4;
     p += 1024;
-    float* const prep = p; p += TFM_PREP_FLOATS;
+    float* const prep = p; p += tfm_prep_floats(H, W);
     int* const sort_work = (int*)p; p += tfs_work_ints((int)rs_max, H, W);
     const bool mfma = tf_use_mfma(), sorted = tf_use_sort(H, W);
     R.enc = p; p += rs_max * TF_NIN;           // (vector-pipe pass only: not part of the workspace otherwise, and never touched)

@@ -17,8 +17,10 @@
 #define TFM_OFF_A1TH (TFM_OFF_A2TL + TFM_A2)
 #define TFM_OFF_A1TL (TFM_OFF_A1TH + TFM_A1T)
 #define TFM_HEAD_HALVES (TFM_OFF_A1TL + TFM_A1T)              // 40960
-// prep buffer (floats): [0] bits of max|planes| | [16 + 16 head + TFM_S_*] scales | [64 ..] two head images
-#define TFM_PREP_FLOATS (64 + 2 * TFM_HEAD_HALVES / 2)
+// prep buffer (floats): [0] bits of max|planes| | [16 + 16 head + TFM_S_*] scales | [64 ..] two head images | [TFM_PREP_FIXED ..] padded planes
+#define TFM_PREP_FIXED (64 + 2 * TFM_HEAD_HALVES / 2)
+// ... followed by the planes with a one-texel ZERO border, [3][H + 2][W + 2][32]: the lookup reads its four taps without range checks
+static inline long long tfm_prep_floats(int H, int W) { return TFM_PREP_FIXED + (long long)3 * (H + 2) * (W + 2) * 32; }
 enum { TFM_S_E = 0, TFM_S_W1, TFM_S_W2, TFM_S_H1, TFM_S_V2, TFM_S_U1, TFM_S_H2 };
 
 int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s);

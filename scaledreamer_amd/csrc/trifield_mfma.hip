@@ -90,6 +90,29 @@ __device__ __forceinline__ float tfm_rows_sum(float v) {
 // k order of a fragment built from two accumulator blocks
 __host__ __device__ __forceinline__ int tfm_perm(int t, int g, int e) { return 32 * t + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4); }
 
+// ---- planes -> planes with a one-texel zero border + max|planes| --------------------------------------------------------------------------------
+// padded [3][H + 2][W + 2][32]; amax: bit pattern, zeroed by the caller (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void tfm_pad_kernel(const float* __restrict__ planes, int H, int W, float* __restrict__ padded, unsigned* __restrict__ amax) {
+    const size_t total = (size_t)3 * (H + 2) * (W + 2) * 8;                  // float4 units
+    float m = 0.f;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(q & 7);
+        size_t v = q >> 3;
+        const int x = (int)(v % (W + 2)) - 1; v /= (W + 2);
+        const int y = (int)(v % (H + 2)) - 1;
+        const int pl = (int)(v / (H + 2));
+        floatx4 t = {0.f, 0.f, 0.f, 0.f};
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            t = *(const floatx4*)(planes + (((size_t)pl * H + y) * W + x) * 32 + 4 * c4);
+            m = fmaxf(fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))), m);
+        }
+        *(floatx4*)(padded + 4 * q) = t;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+
 // ---- weights -> scales + fragment images (one block per head) ----------------------------------------------------------------------------
 // prep (floats): [0] bit pattern of max|planes| (written by asd_absmax_f32 before this kernel) | [16 + 16 head ..] scales | [64 ..] images
 __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__ w1t_s, const float* __restrict__ w2_s, const float* __restrict__ w3_s,
@@ -182,16 +205,23 @@ __global__ __launch_bounds__(256) void tfm_prep_kernel(const float* __restrict__
 // Layer 1 as a software pipeline over its twelve (plane, row block) units: the eight 16-byte loads of unit u + 1 are in flight while unit u is
 // interpolated, split and multiplied (left to the scheduler the loads of a unit are waited for where they are issued: the tile is latency-bound).
 struct tfm_raw { floatx4 v[8]; float w[4]; };
-__device__ __forceinline__ void tfm_issue(const tf_geom& g, const float* __restrict__ planes, int plane, const float (&nrm)[3], int ch, float s, tfm_raw& r) {
-    tf_tap t;
-    tf_setup(g, plane, nrm[0], nrm[1], nrm[2], t);
-#pragma unroll
-    for (int corner = 0; corner < 4; ++corner) {
-        r.w[corner] = t.w[corner] * s;                                       // 0 outside the plane; s a power of two: folding it in here is exact
-        const float* src = planes + (t.off[corner] < 0 ? 0 : t.off[corner]) + ch;
-        r.v[2 * corner] = *(const floatx4*)src;
-        r.v[2 * corner + 1] = *(const floatx4*)(src + 4);
-    }
+__device__ __forceinline__ void tfm_issue(const tf_geom& g, const float* __restrict__ padded, int plane, const float (&nrm)[3], int ch, float s, tfm_raw& r) {
+    // `padded`: the planes with a one-texel zero border ([3][H + 2][W + 2][32], tfm_pad_kernel): grid_sample's zero padding is READ, not tested —
+    // the coordinate is clamped to [-1, size] first, so a point anywhere outside lands on border texels (or on an inside texel with weight 0)
+    float u, v;
+    tf_plane_uv(nrm[0], nrm[1], nrm[2], plane, u, v);
+    const float ix = __builtin_amdgcn_fmed3f(((u + 1.f) * (float)g.W - 1.f) * 0.5f, -1.f, (float)g.W);
+    const float iy = __builtin_amdgcn_fmed3f(((v + 1.f) * (float)g.H - 1.f) * 0.5f, -1.f, (float)g.H);
+    const int x0 = min((int)floorf(ix), g.W - 1), y0 = min((int)floorf(iy), g.H - 1);
+    const float fx = ix - (float)x0, fy = iy - (float)y0;
+    const float* row0 = padded + ((size_t)((plane * (g.H + 2) + y0 + 1) * (g.W + 2) + x0 + 1)) * 32 + ch;
+    const float* row1 = row0 + (size_t)(g.W + 2) * 32;
+    r.w[0] = (1.f - fx) * (1.f - fy) * s; r.w[1] = fx * (1.f - fy) * s;       // s a power of two: folding it in here is exact
+    r.w[2] = (1.f - fx) * fy * s;         r.w[3] = fx * fy * s;
+    r.v[0] = *(const floatx4*)row0;        r.v[1] = *(const floatx4*)(row0 + 4);
+    r.v[2] = *(const floatx4*)(row0 + 32); r.v[3] = *(const floatx4*)(row0 + 36);
+    r.v[4] = *(const floatx4*)row1;        r.v[5] = *(const floatx4*)(row1 + 4);
+    r.v[6] = *(const floatx4*)(row1 + 32); r.v[7] = *(const floatx4*)(row1 + 36);
 }
 __device__ __forceinline__ void tfm_interp(const tfm_raw& r, float (&e)[8]) {
 #pragma unroll
@@ -1043,8 +1073,8 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, float* prep, hipStream_t s) {
     (void)hipMemsetAsync(prep, 0, 64 * sizeof(float), s);
-    const int rc = asd_absmax_f32(planes_cl, (int64_t)3 * H * W * 32, (uint32_t*)prep, (void*)s);
-    if (rc != ASD_OK) return rc;
+    const size_t units = (size_t)3 * (H + 2) * (W + 2) * 8;
+    hipLaunchKernelGGL(tfm_pad_kernel, dim3(asd_grid_for((int64_t)units, 256)), dim3(256), 0, s, planes_cl, H, W, prep + TFM_PREP_FIXED, (unsigned*)prep);
     hipLaunchKernelGGL(tfm_prep_kernel, dim3(2), dim3(256), 0, s, w6[0], w6[1], w6[2], w6[3], w6[4], w6[5], prep);
     return ASD_OK;
 }
@@ -1064,11 +1094,11 @@ int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_c
     int blocks = asd_div_up(tiles, 4);
     if (blocks > 512) blocks = 512;
     if (fd) {
-        hipLaunchKernelGGL(tfm_fwd_kernel<0>, dim3(blocks), dim3(256), lds, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+        hipLaunchKernelGGL(tfm_fwd_kernel<0>, dim3(blocks), dim3(256), lds, s, g, *cfg, prep + TFM_PREP_FIXED, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
     } else {
-        hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+        hipLaunchKernelGGL(tfm_fwd_kernel<1>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, prep + TFM_PREP_FIXED, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
         if (features)
-            hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, planes_cl, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
+            hipLaunchKernelGGL(tfm_fwd_kernel<2>, dim3(blocks), dim3(256), lds / 2, s, g, *cfg, prep + TFM_PREP_FIXED, prep, w6[2], w6[5], points, n, sdf, features, normal, fd_grad);
     }
     return ASD_OK;
 }
@@ -1090,7 +1120,7 @@ int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* p
         attr = true;
     }
     tfm_bwd_args a;
-    a.g = g; a.c = *cfg; a.planes = planes_cl; a.prep = prep; a.points = points; a.sdf = sdf; a.i0 = i0; a.n_chunk = nc; a.npt = npt;
+    a.g = g; a.c = *cfg; a.planes = prep + TFM_PREP_FIXED; a.prep = prep; a.points = points; a.sdf = sdf; a.i0 = i0; a.n_chunk = nc; a.npt = npt;
     a.d_sdf = d_sdf; a.d_features = d_features; a.d_normal = d_normal; a.d_fd_grad = d_fd_grad; a.denc = denc; a.pts = pts;
     auto grid = [&](int per_tile) { int b = asd_div_up(asd_div_up(nc, per_tile), 4); return b > 512 ? 512 : b; };
     auto gridw = [&](int per_tile) { int b = asd_div_up(asd_div_up(nc, per_tile), 4); return b > 256 ? 256 : b; };

@@ -539,7 +539,7 @@ def trifield_fwd(planes_cl: torch.Tensor, cfg: FieldCfg, weights6, points, want_
     normal = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
     fdg = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_normal else None
     nf = C.c_int64(0)
-    check(lib().asd_trifield_fwd_workspace(C.byref(nf)))
+    check(lib().asd_trifield_fwd_workspace(i32(H), i32(W), C.byref(nf)))
     ws = torch.empty(nf.value, device=dev, dtype=torch.float32)
     check(lib().asd_trifield_fwd(ptr(planes_cl), i32(H), i32(W), i32(Cc), C.byref(cfg), _ptr6(weights6), ptr(points), i32(n), ptr(sdf), ptr(feats),
                                  ptr(normal), ptr(fdg), ptr(ws), stream()))

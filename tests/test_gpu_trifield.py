@@ -180,7 +180,7 @@ def test_passes_stay_inside_their_buffers():
     intact = lambda buf, nbytes: bool((buf[:GUARD] == 0xA5).all()) and bool((buf[GUARD + nbytes:] == 0xA5).all())
     ptr6 = lambda ts: (C.c_void_p * 6)(*[t.data_ptr() for t in ts])
     nf = C.c_int64(0)
-    _lib.check(L.asd_trifield_fwd_workspace(C.byref(nf)))
+    _lib.check(L.asd_trifield_fwd_workspace(_lib.i32(64), _lib.i32(64), C.byref(nf)))
     bufs = {k: guarded(sz) for k, sz in (("ws", nf.value * 4), ("sdf", n * 4), ("feat", n * 12), ("normal", n * 12), ("fdg", n * 12))}
     p = lambda k: C.c_void_p(bufs[k][1].data_ptr())
     _lib.check(L.asd_trifield_fwd(_lib.ptr(planes), _lib.i32(64), _lib.i32(64), _lib.i32(32), C.byref(cfg), ptr6(w6), _lib.ptr(pts), _lib.i32(n), p("sdf"),
