@@ -136,7 +136,13 @@ class GenerativeSpaceVolSDFVolumeRenderer(VolumeRenderer):
         def proposal_density(t0, t1):      # [n_rays, S] interval edges -> sigma at the mid-points, no gradient
             mid = ro[:, None, :] + rd[:, None, :] * ((t0 + t1) * 0.5)[..., None]
             with torch.no_grad():
-                sdf = _field_in_chunks(self.geometry, mid.reshape(B, -1, 3), self._chunk(), space_cache=space_cache, output_normal=False)["sdf"]
+                fused_sdf = getattr(self.geometry, "_use_fused", None)
+                if fused_sdf is not None and fused_sdf(mid):
+                    # the reference evaluates the whole field here and keeps `sdf` (generative_space_volsdf_volume_renderer.py:233-252); the fused
+                    # fields have an sdf-only entry (same value: the sdf head does not depend on the feature head)
+                    sdf = self.geometry.forward_sdf(mid.reshape(B, -1, 3), space_cache).reshape(-1, 1)
+                else:
+                    sdf = _field_in_chunks(self.geometry, mid.reshape(B, -1, 3), self._chunk(), space_cache=space_cache, output_normal=False)["sdf"]
                 return volsdf_density(sdf, self.variance(sdf)).reshape(t0.shape)
 
         return self.estimator.sampling(prop_sigma_fns=[proposal_density], prop_samples=[self.cfg.num_samples_per_ray_importance],
