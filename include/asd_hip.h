@@ -189,6 +189,9 @@ int asd_voxel_sample_fwd(const float* voxel_cl, int32_t B, int32_t D, int32_t H,
                          int32_t M, float* out /*[B,M,C]*/, void* stream);
 int asd_voxel_sample_bwd(const float* d_out, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, const float* points,
                          int32_t M, float* d_voxel_cl, void* stream);
+/* the same scatter for rows in ray order with `run` consecutive rows per lane group (the fused voxel field's backward pass) */
+int asd_voxel_sample_bwd_rows(const float* d_out, int32_t D, int32_t H, int32_t W, int32_t C, const float* points, int32_t rows,
+                              float* d_voxel_cl, int32_t run, void* stream);
 int asd_triplane_sample_fwd(const float* planes_cl, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,
                             float coord_scale /* 2 / box_warp */, float* out /*[B,M,3C]*/, void* stream);
 int asd_triplane_sample_bwd(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t C, const float* points, int32_t M,

@@ -139,7 +139,7 @@ SYMBOLS = [
     "asd_grid_meta_init", "asd_hashgrid_fwd", "asd_hashgrid_bwd",
     "asd_field_density", "asd_field_fwd", "asd_field_bwd_workspace", "asd_field_bwd",
     "asd_envmap_fwd", "asd_envmap_bwd",
-    "asd_importance_resample", "asd_transmittance_cdf", "asd_merge_sorted", "asd_voxel_sample_fwd", "asd_voxel_sample_bwd",
+    "asd_importance_resample", "asd_transmittance_cdf", "asd_merge_sorted", "asd_voxel_sample_fwd", "asd_voxel_sample_bwd", "asd_voxel_sample_bwd_rows",
     "asd_triplane_sample_fwd", "asd_triplane_sample_bwd", "asd_triplane_sample_bwd_rows", "asd_relayout_f32",
     "asd_generate_rays", "asd_march_count", "asd_scan_i32", "asd_march_write", "asd_prune_count", "asd_compact",
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",

@@ -999,7 +999,8 @@ int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int
                        dw2_sdf, dw2_feature, (float*)nullptr, 0u, denc, pts)
     if (cfg->n_feature_dims == 3) ASD_VOXFIELD_BWD_LAUNCH(3); else ASD_VOXFIELD_BWD_LAUNCH(0);
 #undef ASD_VOXFIELD_BWD_LAUNCH
-    const int rc = asd_voxel_sample_bwd(denc, 1, D, H, W, C, pts, (int32_t)rows, d_voxel_cl, stream);     // += (atomics), amortized.hip
+    static const int run = getenv("ASD_VOX_RUN") ? atoi(getenv("ASD_VOX_RUN")) : 128;
+    const int rc = asd_voxel_sample_bwd_rows(denc, D, H, W, C, pts, (int32_t)rows, d_voxel_cl, run, stream);     // += (atomics), amortized.hip
     if (rc != ASD_OK) return rc;
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, (const int*)nullptr, n, slabs);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, chunks, 128 * 32, 64 * 32, dw1_sdf, (const int*)nullptr, WG_ROWS);
