@@ -42,11 +42,16 @@ __device__ __forceinline__ void split2(float v, half_t& hi, half_t& lo) {
 __device__ __forceinline__ float abs4max(const floatx4 v, float m) {
     return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
 }
-// one atomicMax per wave of the bit pattern of max|.| (callers zero *out first)
+// the wave's max|.| into *out (bit pattern; callers zero *out first).  Tens of thousands of waves committing to ONE address serialise at its L2
+// channel (~5 ns each: 81 us for any tensor past the grid cap, whatever its size) — and almost none of them raises the maximum: a wave reads
+// the word first (an L2 load: monotone, so a stale value only costs a redundant atomic) and issues the atomic only if it would change it
 __device__ __forceinline__ void wave_amax_commit(float m, unsigned* out) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(m);
+        if (b > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, b);
+    }
 }
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -58,8 +63,19 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
         m = abs4max(a, abs4max(b, abs4max(c, abs4max(d, m))));
     }
     for (; i < n4; i += stride) m = abs4max(*(const floatx4*)(x + 4 * i), m);
-    wave_amax_commit(m, out);
+    // one atomic per BLOCK (and at most 1024 blocks): 7 000 waves finishing together all see the old word and queue their atomics on one L2
+    // channel — 100 us for a 28 MB tensor (tools/absmax_time.py)
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned b = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+        if (b > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, b);
+    }
 }
+static inline int c3_amax_grid(size_t n4) { size_t g = (n4 + 1023) / 1024; return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g)); }
 
 // x fp32 [rows][C] -> hi / lo fp16 [rows][C] (channel-last volume: rows = voxels), 8 channels per thread
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, size_t n8, const unsigned* __restrict__ amax,
@@ -742,10 +758,10 @@ static int c3_run(int D, int H, int W, int cin, int cout, const float* x, const 
     half_t* wl = (half_t*)((char*)wh + al256((size_t)cout * 27 * cin * 2));
     (void)hipMemsetAsync(amax, 0, 8, s);
     if (!amax_x) {
-        hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * cin / 16)), dim3(256), 0, s, x, vox * cin / 4, amax);
+        hipLaunchKernelGGL(absmax_kernel, dim3(c3_amax_grid(vox * cin / 4)), dim3(256), 0, s, x, vox * cin / 4, amax);
         amax_x = amax;
     }
-    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid((size_t)cout * cin * 27 / 16)), dim3(256), 0, s, w, (size_t)cout * cin * 27 / 4, amax + 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(c3_amax_grid((size_t)cout * cin * 27 / 4)), dim3(256), 0, s, w, (size_t)cout * cin * 27 / 4, amax + 1);
     hipLaunchKernelGGL(split_rows_kernel, dim3(c3_grid(vox * cin / 8)), dim3(256), 0, s, x, vox * cin / 8, amax_x, xh, xl);
     hipLaunchKernelGGL(pack_w_kernel, dim3(c3_grid((size_t)cout * cin * 27)), dim3(256), 0, s, w, transpose_w ? cin : cout, transpose_w ? cout : cin,
                        transpose_w, amax + 1, wh, wl);
@@ -830,8 +846,8 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
         (void)hipMemsetAsync(amax, 0, 8, s);
         const unsigned* ax = d->amax_x ? d->amax_x : amax;
         const unsigned* ay = d->amax_dy ? d->amax_dy : amax + 1;
-        if (!d->amax_x) hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cin / 16)), dim3(256), 0, s, x + n * vox * Cin, vox * Cin / 4, amax);
-        if (!d->amax_dy) hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid(vox * Cout / 16)), dim3(256), 0, s, dy + n * vox * Cout, vox * Cout / 4, amax + 1);
+        if (!d->amax_x) hipLaunchKernelGGL(absmax_kernel, dim3(c3_amax_grid(vox * Cin / 4)), dim3(256), 0, s, x + n * vox * Cin, vox * Cin / 4, amax);
+        if (!d->amax_dy) hipLaunchKernelGGL(absmax_kernel, dim3(c3_amax_grid(vox * Cout / 4)), dim3(256), 0, s, dy + n * vox * Cout, vox * Cout / 4, amax + 1);
         // guards and the K tail of every row read zeros: clear the planes' borders (the kernel writes all Vp positions of every row)
         for (int q = 0; q < 4; ++q) {
             half_t* pl = q == 0 ? xh : (q == 1 ? xl : (q == 2 ? yh : yl));
@@ -891,7 +907,7 @@ int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t
 
 int asd_absmax_f32(const float* x, int64_t n, uint32_t* amax_out, void* stream) {
     ASD_CHECK_ARG(x && amax_out && n > 0 && n % 4 == 0, "n must be a positive multiple of 4");
-    hipLaunchKernelGGL(absmax_kernel, dim3(c3_grid((size_t)n / 16)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n / 4, amax_out);
+    hipLaunchKernelGGL(absmax_kernel, dim3(c3_amax_grid((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n / 4, amax_out);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

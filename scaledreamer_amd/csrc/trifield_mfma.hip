@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void tfm_pad_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, __float_as_uint(m));
 }
 
 // ---- weights -> scales + fragment images (one block per head) ----------------------------------------------------------------------------
