@@ -67,7 +67,7 @@ def build_hyper_system(backend: str, seed: int, workload: str = "asd_sd_hyper_in
     with presets.random_weights_allowed():
         cfg = {"asd_sd_hyper_ingp": lambda: presets.asd_sd_hyper_ingp(guidance_backend=backend),
                "asd_sd_3dconv_net": lambda: presets.asd_sd_3dconv_net(guidance_backend=backend),
-               "asd_mv_triplane": presets.asd_mv_triplane_transformer}[workload]()
+               "asd_mv_triplane": lambda: presets.asd_mv_triplane_transformer(n_gpus=int(os.environ.get("WORLD_SIZE", "1")))}[workload]()
     torch.manual_seed(seed)
     random.seed(seed)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -78,7 +78,7 @@ def build_hyper_system(backend: str, seed: int, workload: str = "asd_sd_hyper_in
                                          front_threshold=pp.get("front_threshold", 45.0), back_threshold=pp.get("back_threshold", 45.0),
                                          use_local_text_embeddings=pp.get("use_local_text_embeddings", False),
                                          use_perp_neg=pp.get("use_perp_neg", False))
-    system = find(cfg["system_type"])(cfg["system"], prompt_processor=proc)
+    system = presets.apply_trainer(find(cfg["system_type"])(cfg["system"], prompt_processor=proc), cfg)
     system.train()
     return cfg, system, data
 

@@ -81,7 +81,11 @@ class GradientExchange:
         different collectives;
       * the fixed order is the order in which rank 0 saw the units become ready in its first step (broadcast once), like DDP's
         bucket rebuild: what finishes first is sent first.
-    Usage per step:  ex.prepare()  ->  loss.backward()  ->  ex.finish()  ->  optimizer.step()."""
+    Usage per step:  ex.prepare()  ->  loss.backward()  ->  ex.finish()  ->  optimizer.step().
+    With gradient accumulation over k micro-batches (Lightning's `accumulate_grad_batches`, which wraps the first k - 1 backward passes in
+    DDP's no_sync(); configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:129):
+        ex.prepare(sync=k == 1) -> backward -> [ex.prepare(zero=False, sync=last) -> backward] * (k - 1) -> ex.finish() -> optimizer.step()
+    — the gradients are summed in place in the persistent buckets / large `.grad`s and only the LAST backward launches collectives."""
 
     def __init__(self, params, bucket_bytes: int = None, in_place_bytes: int = None):
         self.params = [p for p in params if p.requires_grad]
@@ -124,7 +128,7 @@ class GradientExchange:
         self._order_learned = False
         self._seen_order: List[int] = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self._armed = False
+        self._armed, self._sync = False, True
         self.exposed_ms_events = None                   # (start, end) CUDA events of the last finish(): un-overlapped exchange time
         self.prepare_called = 0
 
@@ -162,28 +166,32 @@ class GradientExchange:
                                f"({len(self.units)} units, signature {sig[:16]}...): the ranks do not hold the same trainable parameters")
 
     # ---- per step -----------------------------------------------------------------------------------------------------------
-    def prepare(self) -> None:
-        """replaces optimizer.zero_grad(): bucketed gradients are zeroed views of their bucket, large ones start undefined."""
-        for u in self.units:
-            if u["flat"] is None:
-                u["params"][0].grad = None
-            else:
-                u["flat"].zero_()
-                for p, v in zip(u["params"], u["views"]):
-                    if p.grad is not v:
-                        p.grad = v
+    def prepare(self, zero: bool = True, sync: bool = True) -> None:
+        """zero: replaces optimizer.zero_grad() — bucketed gradients are zeroed views of their bucket, large ones start undefined (the
+        first backward of an optimizer step); zero = False keeps what the earlier micro-batches accumulated.  sync: the coming backward
+        is the last one before the optimizer step, its hooks launch the collectives; sync = False is DDP's no_sync() — the hooks only
+        record which parameters received a gradient."""
+        if zero:
+            for u in self.units:
+                if u["flat"] is None:
+                    u["params"][0].grad = None
+                else:
+                    u["flat"].zero_()
+                    for p, v in zip(u["params"], u["views"]):
+                        if p.grad is not v:
+                            p.grad = v
+            self._touched_slot ^= 1
+            if self._touched_events[self._touched_slot] is not None:     # uploaded two steps ago: normally long complete
+                self._touched_events[self._touched_slot].synchronize()
+                self._touched_events[self._touched_slot] = None
+            self._touched_host = self._touched_bufs[self._touched_slot]
+            self._touched_host.zero_()
         self._pending = [len(u["params"]) for u in self.units]
         self._ready = [False] * len(self.units)
         self._launched = 0                              # number of positions of self.order already launched
         self._works = []
         self._seen_order = []
-        self._touched_slot ^= 1
-        if self._touched_events[self._touched_slot] is not None:     # uploaded two steps ago: normally long complete
-            self._touched_events[self._touched_slot].synchronize()
-            self._touched_events[self._touched_slot] = None
-        self._touched_host = self._touched_bufs[self._touched_slot]
-        self._touched_host.zero_()
-        self._armed = True
+        self._armed, self._sync = True, bool(sync)
         self.prepare_called += 1
 
     def _on_grad(self, p) -> None:
@@ -191,6 +199,8 @@ class GradientExchange:
             return
         ui = self._unit_of[id(p)]
         self._touched_host[self._index_of[id(p)]] = 1
+        if not self._sync:                              # an accumulation micro-batch: nothing is exchanged yet
+            return
         self._pending[ui] -= 1
         if self._pending[ui] == 0:
             self._ready[ui] = True

@@ -161,11 +161,13 @@ def asd_sd_3dconv_net(prompts=None, guidance_backend: str = "hip") -> dict:
     return cfg
 
 
-def asd_mv_triplane_transformer(prompts=None) -> dict:
+def asd_mv_triplane_transformer(prompts=None, n_gpus: int = 8) -> dict:
     """configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml: text-conditioned transformer -> three
-    [32, 64, 64] planes per prompt, 4 views per prompt, MVDream guidance, Adan."""
+    [32, 64, 64] planes per prompt, 4 views per prompt, MVDream guidance, Adan; gradients accumulated over 2 batches on the 8-GPU node
+    (:129) and over 8 in the single-GPU variant (_1GPU.yaml:131) — the same 16 prompts x 4 views per optimizer step either way."""
     cfg = asd_sd_hyper_ingp(prompts, "hip-mvdream")
     cfg["name"] = "asd_mv_triplane_100k"
+    cfg["trainer"] = {"max_steps": 100000, "precision": 32, "accumulate_grad_batches": 2 if n_gpus >= 8 else 8}
     lib = cfg["data"]["prompt_library"]
     cfg["data_type"] = "multiprompt-multiview-camera-datamodule"
     cfg["data"] = {"batch_size": 4, "n_view": 4, "width": 64, "height": 64, "camera_distance_range": [0.8, 1.0], "fovy_range": [15, 60],
@@ -199,3 +201,9 @@ def nerf_only_c1() -> dict:
     cfg["system"]["renderer"]["num_samples_per_ray"] = 16
     cfg["system"]["guidance_type"] = ""
     return cfg
+
+
+def apply_trainer(system, cfg: dict):
+    """the `trainer:` keys of a config that change the step itself (Lightning options in the reference): accumulate_grad_batches"""
+    system.accumulate_grad_batches = int(cfg.get("trainer", {}).get("accumulate_grad_batches", 1))
+    return system

@@ -222,7 +222,16 @@ class _RenderFn(torch.autograd.Function):
         ctx.st = st
         ctx.save_for_backward(grid, w1d, w2d, w1f, w2f, bg)
         ctx.set_materialize_grads(False)
-        return st.view("comp_rgb", 3), st.view("rgb_fg", 3), st.view("opacity"), st.view("depth"), st.view("z_var")
+        # asd_render_bwd re-reads opacity / depth / weights from st.ws, which autograd does not version-check: the caller gets COPIES of the
+        # five per-ray outputs (they are the contiguous tail of the layout: one n_rays * ~36 B copy), so an in-place op on a returned tensor
+        # cannot corrupt the gradients and a surviving output does not pin the n_rays * max_steps * ~217 B workspace
+        L, n = st.layout, st.n_rays
+        tail = st.ws[L.opacity:L.total_bytes].clone()
+
+        def out(off, cols):
+            t = tail[off - L.opacity:off - L.opacity + n * max(cols, 1) * 4].view(torch.float32)
+            return t.view(n, cols) if cols else t
+        return out(L.comp_rgb, 3), out(L.rgb_fg, 3), out(L.opacity, 0), out(L.depth, 0), out(L.z_var, 0)
 
     @staticmethod
     def backward(ctx, d_comp, d_fg, d_op, d_dp, d_zv):

@@ -4,8 +4,10 @@
   `Triplane-transformer-sdf` custom/amortized/models/geometry/triplane_transformer.py:20-315 (three [32,64,64] planes from the
                              transformer, 3 bilinear lookups concatenated)
 Both: contract to [-1,1] -> sample features -> VanillaMLP sdf / feature heads -> sdf + sphere bias -> finite-difference
-sdf_grad / normal from 3 offset lookups.  The lookups and their scatter backward are the channel-last HIP kernels of
-samplers.py; the generators (generators.py) and the small MLP heads are library ops.
+sdf_grad / normal from 3 offset lookups.  Shipped configurations run lookup + heads + bias + finite differences as ONE fused HIP kernel each
+way (asd_voxfield_* / asd_trifield_*, `_VoxFieldFn` / `_TriFieldFn` below); the composed form (HIP samplers of samplers.py + torch MLP heads) is
+the fallback for head shapes the fused kernels are not instantiated for and the A/B partner (ASD_VOXFIELD=0 / ASD_TRIFIELD=0).  The generators
+live in generators.py (Generator3D on csrc/conv3d.hip, TriplaneTransformer on csrc/transformer.hip).
 """
 from __future__ import annotations
 
@@ -61,16 +63,19 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             raise ValueError(f"Unknown sdf bias {c.sdf_bias}")
         return sdf + bias
 
-    # Above this many points per call the heads run chunk by chunk under activation checkpointing: the un-fused library MLP heads keep
-    # ~1.2 KB of autograd state per point and SDF evaluation (4 evaluations per point with the finite-difference normal), i.e.
-    # 245 GB for the 50.6 M samples of a 256 x 256 x 4-view step — more than the 288 GB GPU leaves.  Chunks are recomputed in the
-    # backward pass (one extra forward); values and gradients are those of the un-chunked graph.
+    # COMPOSED path only (the fused kernels keep nothing per evaluation but the points, so they never chunk): above this many points per
+    # call the torch MLP heads run chunk by chunk under activation checkpointing — they keep ~1.2 KB of autograd state per point and SDF
+    # evaluation (4 evaluations per point with the finite-difference normal), i.e. 245 GB for the 50.6 M samples of a 256 x 256 x 4-view
+    # step.  Chunks are recomputed in the backward pass (one extra forward); values and gradients are those of the un-chunked graph.
     CHECKPOINT_ABOVE = 8 * 1024 * 1024
     CHECKPOINT_CHUNK = 2 * 1024 * 1024
 
+    def _use_fused(self, points) -> bool:
+        return False
+
     def forward(self, points: torch.Tensor, space_cache: Any, output_normal: bool = False) -> Dict[str, torch.Tensor]:
         batch_size, n_points, _ = points.shape
-        if torch.is_grad_enabled() and batch_size * n_points > self.CHECKPOINT_ABOVE:
+        if torch.is_grad_enabled() and batch_size * n_points > self.CHECKPOINT_ABOVE and not self._use_fused(points):
             from torch.utils.checkpoint import checkpoint
 
             per = max(1, self.CHECKPOINT_CHUNK // batch_size)
@@ -140,31 +145,64 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
             self.finite_difference_normal_eps = self.cfg.finite_difference_normal_eps
 
 
+class _GradSlot:
+    """ONE gradient buffer per feature volume (batch entry) and backward pass.  The VolSDF renderer evaluates the field chunk by chunk and
+    pass by pass (proposal sdf, main samples): every evaluation is its own autograd node, and a node that returned a fresh
+    zeros_like(volume) — 268 MB at 128^3 x 32 — had autograd memset, fill and sum one volume per chunk.  The scatter kernels accumulate, so the
+    first node of a backward pass allocates the buffer and hands it to autograd, the later ones add into it in place and return None.
+    That is sound because the node that consumes the volume's gradient (the generator) cannot run before every node that reads the volume
+    has run (autograd's dependency count), and the buffer of a pass is never reused by another one (keyed by the engine's graph-task id)."""
+
+    __slots__ = ("task", "buf")
+
+    def __init__(self):
+        self.task, self.buf = None, None
+
+    def acquire(self, like: torch.Tensor):
+        """(buffer, first): `first` tells the caller to return the buffer as its gradient"""
+        task = torch._C._current_graph_task_id()
+        if task < 0 or task != self.task or self.buf is None or self.buf.shape != like.shape:
+            self.task, self.buf = task, torch.zeros_like(like)
+            return self.buf, True
+        return self.buf, task < 0
+
+    def release(self):
+        self.buf = None
+
+
+def _grad_slot(owner: torch.Tensor, b: int) -> _GradSlot:
+    """the slot of batch entry b of a space cache: lives on the cache tensor itself (one Python object per step)"""
+    slots = owner.__dict__.setdefault("_asd_grad_slots", {})
+    if b not in slots:
+        slots[b] = _GradSlot()
+    return slots[b]
+
+
 class _VoxFieldFn(torch.autograd.Function):
     """(sdf, features, normal, sdf_grad) of ONE batch entry from its points, its channel-last feature volume and the two MLP heads: trilinear
     lookup, heads, bias and finite differences in one kernel each way (include/asd_hip.h: asd_voxfield_fwd / _bwd)"""
 
     @staticmethod
-    def forward(ctx, points, voxel_cl, w1s, w2s, w1f, w2f, fcfg, want_normal):
+    def forward(ctx, points, voxel_cl, w1s, w2s, w1f, w2f, fcfg, want_normal, slot=None):
         sdf, feats, normal, fdg, enc = ops.voxfield_fwd(voxel_cl, fcfg, w1s, w2s, w1f, w2f, points, want_normal)
         if not want_normal:
             normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
             ctx.mark_non_differentiable(normal, fdg)
         ctx.save_for_backward(points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf)
-        ctx.fcfg, ctx.want_normal = fcfg, want_normal
+        ctx.fcfg, ctx.want_normal, ctx.slot = fcfg, want_normal, slot
         ctx.set_materialize_grads(False)
         return sdf, feats, normal, fdg
 
     @staticmethod
     def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
         points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf = ctx.saved_tensors
-        d_vox = torch.zeros_like(voxel_cl)
         if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
-            return (None, d_vox, *(torch.zeros_like(w) for w in (w1s, w2s, w1f, w2f)), None, None)
+            return (None,) * 9
+        d_vox, first = (ctx.slot or _GradSlot()).acquire(voxel_cl)
         c = lambda t: None if t is None else t.contiguous()
         dw = ops.voxfield_bwd(voxel_cl, ctx.fcfg, w1s, w2s, w1f, w2f, points, enc, sdf, c(d_sdf), c(d_feats),
                               c(d_normal) if ctx.want_normal else None, c(d_fdg) if ctx.want_normal else None, d_vox)
-        return None, d_vox, dw[0], dw[1], dw[2], dw[3], None, None
+        return None, (d_vox if first else None), dw[0], dw[1], dw[2], dw[3], None, None, None
 
 
 @register("3DConv-net")
@@ -264,7 +302,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_VoxFieldFn.apply(pts, vol[b], *w, self._fcfg, bool(output_normal)))
+                outs.append(_VoxFieldFn.apply(pts, vol[b], *w, self._fcfg, bool(output_normal), _grad_slot(space_cache, b)))
             else:
                 with torch.no_grad():
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, pts, bool(output_normal), save_enc=False)[:4])
@@ -287,7 +325,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
             for b in range(B):
                 p = pts[b].contiguous().float()
                 if need_grad:
-                    outs.append(_VoxFieldFn.apply(p, vol[b], *w, self._fcfg, False)[0])
+                    outs.append(_VoxFieldFn.apply(p, vol[b], *w, self._fcfg, False, _grad_slot(space_cache, b))[0])
                 else:
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, p, False, want_features=False, save_enc=False)[0])
         return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)
@@ -298,27 +336,27 @@ class _TriFieldFn(torch.autograd.Function):
     heads (include/asd_hip.h: asd_trifield_fwd / _bwd); nothing but the points and the sdf is kept for the backward pass"""
 
     @staticmethod
-    def forward(ctx, points, planes_cl, s1, s2, s3, f1, f2, f3, fcfg, want_normal):
+    def forward(ctx, points, planes_cl, s1, s2, s3, f1, f2, f3, fcfg, want_normal, slot=None):
         w6 = (s1.t().contiguous(), s2.contiguous(), s3.contiguous(), f1.t().contiguous(), f2.contiguous(), f3.contiguous())
         sdf, feats, normal, fdg = ops.trifield_fwd(planes_cl, fcfg, w6, points, want_normal)
         if not want_normal:
             normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
             ctx.mark_non_differentiable(normal, fdg)
         ctx.save_for_backward(points, planes_cl, sdf, *w6)
-        ctx.fcfg, ctx.want_normal = fcfg, want_normal
+        ctx.fcfg, ctx.want_normal, ctx.slot = fcfg, want_normal, slot
         ctx.set_materialize_grads(False)
         return sdf, feats, normal, fdg
 
     @staticmethod
     def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
         points, planes_cl, sdf, *w6 = ctx.saved_tensors
-        d_pl = torch.zeros_like(planes_cl)
         if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
-            return (None, d_pl, *(torch.zeros(sh, device=sdf.device) for sh in ((64, 96), (64, 64), (1, 64), (64, 96), (64, 64), (3, 64))), None, None)
+            return (None,) * 11
+        d_pl, first = (ctx.slot or _GradSlot()).acquire(planes_cl)
         c = lambda t: None if t is None else t.contiguous()
         dws = ops.trifield_bwd(planes_cl, ctx.fcfg, w6, points, sdf, c(d_sdf), c(d_feats), c(d_normal) if ctx.want_normal else None,
                                c(d_fdg) if ctx.want_normal else None, d_pl)
-        return (None, d_pl, *dws, None, None)
+        return (None, (d_pl if first else None), *dws, None, None, None)
 
 
 @register("Triplane-transformer-sdf")
@@ -391,12 +429,6 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
     def _use_fused(self, points) -> bool:
         return getattr(self, "_fcfg", None) is not None and points.is_cuda and os.environ.get("ASD_TRIFIELD", "1") != "0"
 
-    def forward(self, points, space_cache, output_normal: bool = False):
-        if self._use_fused(points):       # no autograd state per point beyond the points themselves: no chunking / checkpointing at any size
-            batch_size, n_points, _ = points.shape
-            return {k: v.reshape(batch_size * n_points, -1) for k, v in self._forward_points(points, space_cache, output_normal).items()}
-        return super().forward(points, space_cache, output_normal)
-
     def _forward_points(self, points, space_cache, output_normal):
         if not self._use_fused(points):
             return super()._forward_points(points, space_cache, output_normal)
@@ -407,7 +439,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(pts, planes[b], *w, self._fcfg, bool(output_normal)))
+                outs.append(_TriFieldFn.apply(pts, planes[b], *w, self._fcfg, bool(output_normal), _grad_slot(space_cache, b)))
             else:
                 with torch.no_grad():
                     w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
@@ -430,7 +462,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(B):
             p = pts[b].contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(p, planes[b], *w, self._fcfg, False)[0])
+                outs.append(_TriFieldFn.apply(p, planes[b], *w, self._fcfg, False, _grad_slot(space_cache, b))[0])
             else:
                 w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
                 outs.append(ops.trifield_fwd(planes[b], self._fcfg, w6, p, False, want_features=False)[0])

@@ -207,19 +207,31 @@ class StableDreamer(nn.Module, Updateable):
             self._exchange = asd_dist.GradientExchange([p for grp in self.optimizer.param_groups for p in grp["params"]])
         return self._exchange
 
+    # trainer.accumulate_grad_batches of the reference's YAMLs (Lightning; asd_mv_triplane_transformer_10k.yaml:129: 2 on 8 GPUs,
+    # _1GPU.yaml:131: 8): the optimizer steps every k-th batch on the SUM of the k gradients of loss / k, the DDP exchange runs in the k-th
+    # backward only (no_sync before), and global_step — what every C() schedule and update_step sees — counts optimizer steps.
+    accumulate_grad_batches: int = 1
+
     def train_one_step(self, batch) -> torch.Tensor:
-        """on_train_batch_start -> training_step -> backward (gradient all-reduces launched from its hooks) -> optimizer.step."""
+        """on_train_batch_start -> training_step -> backward (gradient all-reduces launched from its hooks) -> optimizer.step; with
+        accumulate_grad_batches = k the exchange and the optimizer run on every k-th call."""
+        k = max(1, int(self.accumulate_grad_batches))
+        micro = getattr(self, "_micro_batch", 0)
+        first, last = micro == 0, micro == k - 1
         self.on_train_batch_start()
         ex = self.gradient_exchange()
-        if ex is None:
-            self.optimizer.zero_grad(set_to_none=True)
-        else:
-            ex.prepare()
-        loss = self.training_step(batch)["loss"]
-        loss.backward()
         if ex is not None:
-            ex.finish()
-        self.optimizer.step()
+            ex.prepare(zero=first, sync=last)
+        elif first:
+            self.optimizer.zero_grad(set_to_none=True)
+        loss = self.training_step(batch)["loss"]
+        (loss if k == 1 else loss / k).backward()
+        if last:
+            if ex is not None:
+                ex.finish()
+            self.optimizer.step()
         self.on_train_batch_end()
-        self.true_global_step += 1
+        if last:
+            self.true_global_step += 1
+        self._micro_batch = 0 if last else micro + 1
         return loss.detach()

@@ -143,6 +143,104 @@ def test_two_rank_real_system_wiring(tmp_path):
         torch.testing.assert_close(a, b)                                      # replicas stay identical
 
 
+def _accumulate_worker(rank, world, port, out_dir):
+    """accumulate_grad_batches = 2 through the REAL train_one_step: two micro-batches per optimizer step on each of two ranks; what the
+    optimizer applies must be the mean over ranks AND micro-batches of the per-batch gradients (Lightning: loss / k per backward, DDP
+    no_sync() on all but the last; configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:129) — i.e. one step on the
+    concatenated batch of a mean-reduced loss."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from scaledreamer_amd import dist as asd_dist
+    from scaledreamer_amd.base import Updateable
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    if world > 1:
+        assert asd_dist.init_from_env("gloo") == world
+    asd_dist.IN_PLACE_BYTES = 1 << 20
+    torch.manual_seed(10 + rank)
+
+    class Renderer(torch.nn.Module, Updateable):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(300_000))
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+            self.second_batch_only = torch.nn.Parameter(torch.randn(3))       # no gradient in the first micro-batch of a step
+            self.updates, self.calls = [], 0
+
+        def update_step(self, epoch, global_step, on_load_weights=False):
+            self.updates.append(global_step)
+
+        def forward(self, rays_d, **kw):
+            rgb = torch.sigmoid(self.mlp(rays_d) + self.table[:3])
+            if self.calls % 2 == 1:
+                rgb = rgb + 0.1 * self.second_batch_only
+            self.calls += 1
+            return {"comp_rgb": rgb, "opacity": rgb.mean(-1, keepdim=True).clamp(0, 1)}
+
+    class Guidance(Updateable):
+        def __call__(self, rgb, prompt_utils, rgb_as_latents=False, **batch):
+            return {"loss_asd": (rgb ** 2).mean()}
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.cfg = ConfigDict(stage="coarse", loss=ConfigDict(lambda_asd=1.0, lambda_orient=0.0, lambda_sparsity=2.0, lambda_opaque=0.0,
+                                                        lambda_z_variance=0.0))
+    s.current_epoch, s.true_global_step, s.logged = 0, 0, {}
+    s.renderer, s.guidance, s.prompt_utils = Renderer(), Guidance(), None
+    s.accumulate_grad_batches = 2
+    asd_dist.broadcast_parameters(s)
+    params = list(s.renderer.parameters())
+    s.optimizer = torch.optim.SGD([{"params": [s.renderer.table]}, {"params": params[1:]}], lr=0.5)
+    steps = []
+    for step in range(2):
+        before = [p.detach().clone() for p in params]
+        local = [torch.zeros_like(p) for p in params]
+        for micro in range(2):
+            batch = {"rays_d": torch.randn(1, 4, 4, 3)}
+            calls = s.renderer.calls
+            gs = torch.autograd.grad(s.training_step(batch)["loss"], params, allow_unused=True)      # this batch's own gradient, on the side
+            s.renderer.calls = calls
+            for acc, g in zip(local, gs):
+                if g is not None:
+                    acc += g
+            s.train_one_step(batch)
+            if micro == 0:
+                assert all(torch.equal(b, p.detach()) for b, p in zip(before, params)), "the optimizer stepped before the k-th batch"
+                assert s.true_global_step == step
+        steps.append((local, [(b - p.detach()) / 0.5 for b, p in zip(before, params)]))
+    ex = s.gradient_exchange()
+    torch.save({"steps": steps, "updates": s.renderer.updates, "global_step": s.true_global_step,
+                "exchanges": None if ex is None else ex.prepare_called, "final": [p.detach().clone() for p in params]},
+               os.path.join(out_dir, f"a{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_accumulate_grad_batches(tmp_path):
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_accumulate_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "a0.pt"), torch.load(tmp_path / "a1.pt")
+    assert r0["updates"] == [0, 0, 1, 1] and r0["global_step"] == 2          # update hooks per batch, global_step per optimizer step
+    assert r0["exchanges"] == 4                                               # prepare() per batch; collectives only in every second one
+    for (g0, a0), (g1, a1) in zip(r0["steps"], r1["steps"]):
+        for x0, x1, y0, y1 in zip(g0, g1, a0, a1):
+            torch.testing.assert_close(y0, (x0 + x1) / 4, rtol=1e-4, atol=1e-6)   # mean over 2 ranks x 2 micro-batches
+            torch.testing.assert_close(y1, y0)
+    for a, b in zip(r0["final"], r1["final"]):
+        torch.testing.assert_close(a, b)
+
+
+def test_single_process_accumulate_grad_batches(tmp_path):
+    _accumulate_worker(0, 1, 0, str(tmp_path))
+    r = torch.load(tmp_path / "a0.pt")
+    assert r["updates"] == [0, 0, 1, 1] and r["global_step"] == 2 and r["exchanges"] is None
+    for g, a in r["steps"]:
+        for x, y in zip(g, a):
+            torch.testing.assert_close(y, x / 2, rtol=1e-4, atol=1e-6)
+
+
 def test_single_process_is_a_noop():
     sys.path.insert(0, ROOT)
     from scaledreamer_amd import dist as asd_dist

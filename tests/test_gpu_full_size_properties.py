@@ -145,9 +145,9 @@ def test_full_size_generator_configs_step(workload, render):
     """BASELINE.json configs[3] / configs[4] at the reference's FULL generator sizes (StyleGAN-3D at 128^3 x 32 channels;
     12-layer / 768-wide triplane transformer, 4 views, MVDream guidance in fp16, Adan) — and configs[4] as BASELINE words it:
     256 x 256 render = 262 144 rays x 193 samples = 50.6 M samples per step (the shipped YAML renders 64 x 64,
-    configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:12-13).  At that size the library MLP heads of the sampled
-    geometry run chunk by chunk under activation checkpointing (sampled_geometry.CHECKPOINT_ABOVE; un-chunked they kept 245 GB of
-    autograd state and the step ran out of the GPU's 288 GB).  The oracle cannot run these sizes in test
+    configs/multi-prompt_benchmark/asd_mv_triplane_transformer_10k.yaml:12-13).  The fused field kernels (asd_voxfield_* / asd_trifield_*) keep
+    nothing per evaluation but the points, so the step runs un-chunked at that size too (the composed torch-head path needed activation
+    checkpointing there: 245 GB of autograd state otherwise).  The oracle cannot run these sizes in test
     time, so the checks are the size-independent ones: finite loss and image, opacity in [0, 1], every generator parameter
     receives a finite gradient and moves, and two systems built from the same seed render the same first image."""
     import bench
