@@ -57,6 +57,20 @@ __device__ __forceinline__ float asd_wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum over each row of 16 lanes, valid in lane 15 of the row (four DPP row shifts, VALU only)
+__device__ __forceinline__ float asd_row_sum15(float v) {
+    int x;
+#define ASD_DPP_ADD(CTRL)                                                                                                \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);                                         \
+    v += __int_as_float(x)
+    ASD_DPP_ADD(0x111);   // row_shr:1
+    ASD_DPP_ADD(0x112);   // row_shr:2
+    ASD_DPP_ADD(0x114);   // row_shr:4
+    ASD_DPP_ADD(0x118);   // row_shr:8
+#undef ASD_DPP_ADD
+    return v;
+}
+
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ float asd_wave_incl_scan(float v) {
     const int lane = asd_lane();
@@ -185,7 +199,7 @@ __device__ __forceinline__ void asd_scatter(const asd_grid_meta& m, float* __res
 #ifndef ASD_PRIV_COPIES
 #define ASD_PRIV_COPIES 8
 #endif
-template <int L, int NAGG, int NPRIV = 0>
+template <int L, int NAGG, int NPRIV = 0, bool FINE = true>
 __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* __restrict__ dparams, float x, float y,
                                                  float z, const float (&denc)[2 * L], bool active, float* __restrict__ priv = nullptr,
                                                  uint32_t priv_stride = 0) {
@@ -250,7 +264,7 @@ __device__ __forceinline__ void asd_scatter_runs(const asd_grid_meta& m, float* 
             if (self_f1 && v[2 * c + 1] != 0.f) atomicAdd(tab + 2u * (size_t)idx + 1, v[2 * c + 1]);
         }
     }
-    if (NAGG >= L) return;
+    if (NAGG >= L || !FINE) return;      // FINE = false: the levels >= NAGG go through the paged scatter (field_paged.hip)
     // ---- fine levels, transposed: lane = (source sample k = lane >> 2 of group q, x corner (lane >> 1) & 1, feature lane & 1)
     const int xb = (lane >> 1) & 1, ft = lane & 1;
 #pragma unroll 1

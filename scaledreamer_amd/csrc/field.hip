@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include "asd_common.h"
+#include "field_paged.h"
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -283,6 +284,12 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #ifndef ASD_FIELD_W2_COPIES
 #define ASD_FIELD_W2_COPIES 16
 #endif
+#ifndef ASD_FIELD_W2_ROWSUM
+#define ASD_FIELD_W2_ROWSUM 1   // 1: second-layer weight-gradient terms are summed over each row of 16 lanes with four DPP adds and the row's
+                                // last lane adds the sum to the row's OWN copy with a plain LDS read-modify-write (16 rows per block = the 16
+                                // copies).  0: every lane issues an LDS float atomic — 256 per sample; LDS float atomics retire ~0.3 lanes per
+                                // clock and CU on gfx950, which made them, not the arithmetic, the bound of this kernel (round 5).
+#endif
 #ifndef ASD_FIELD_NAGG
 #define ASD_FIELD_NAGG 6   // levels scattered with wave-level run aggregation (asd_scatter_runs)
 #endif
@@ -310,14 +317,19 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
     float* __restrict__ enc_fd /*[3n, 2L] or NULL*/, float* __restrict__ dw2d, float* __restrict__ dw2f,
     float* __restrict__ priv /*[ASD_PRIV_COPIES][priv_stride] per-XCD copies of the gradient of levels < ASD_FIELD_NPRIV*/, uint32_t priv_stride,
     float* __restrict__ denc_out = nullptr /* ENC == 1: [rows', 2L] gradient w.r.t. the sampled features, row' = 4 i + pt (i with no normal) */,
-    float* __restrict__ pts_out = nullptr /* ENC == 1: [rows', 3] the sampled positions in grid_sample's [-1, 1] */) {
+    float* __restrict__ pts_out = nullptr /* ENC == 1: [rows', 3] the sampled positions in grid_sample's [-1, 1] */,
+    float* __restrict__ pg_g = nullptr /* paged scatter (field_paged.h): [n_pts * n, 2 (L - NAGG)] gradient w.r.t. the fine levels' features, row = pt * n + i */,
+    float* __restrict__ pg_pos = nullptr /* ... and the rows' unit-cube positions [n_pts * n, 3] */) {
     constexpr int NIN = 2 * L;
     // second-layer weight-gradient sums of the block.  ASD_FIELD_W2_COPIES > 1: no wave-level reduction — every lane adds its own
     // term with an LDS atomic into copy (lane & 15) of the accumulator (row stride W2N + 1: the 16 copies of one h sit in 16 banks, the
     // four lanes of a copy serialise), the copies are summed at the end.  1: six DPP adds + readlane + one LDS atomic per sum.
     constexpr int W2N = (C > 0 ? C : 1) * H + H, W2S = ASD_FIELD_W2_COPIES > 1 ? W2N + 1 : W2N;
     __shared__ float w2_acc[ASD_FIELD_W2_COPIES * W2S];
-    const int w2c = ASD_FIELD_W2_COPIES > 1 ? (threadIdx.x & (ASD_FIELD_W2_COPIES - 1)) * W2S : 0;
+    static_assert(!ASD_FIELD_W2_ROWSUM || ASD_FIELD_W2_COPIES == 16, "row sums: one copy per row of 16 lanes of the 256-thread block");
+    const int w2c = ASD_FIELD_W2_ROWSUM ? (threadIdx.x >> 4) * W2S
+                                        : (ASD_FIELD_W2_COPIES > 1 ? (threadIdx.x & (ASD_FIELD_W2_COPIES - 1)) * W2S : 0);
+    const bool row_last = (threadIdx.x & 15) == 15;
     const int nn = n_dev ? min(*n_dev, n) : n;
     if (n_dev && (int)blockIdx.x * 256 >= nn) return;       // capacity-sized launch (device-side count): nothing lives in this block
     const int tid = threadIdx.x;
@@ -435,7 +447,10 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
-                if (ASD_FIELD_W2_COPIES > 1) {
+                if (ASD_FIELD_W2_ROWSUM) {
+                    const float v = asd_row_sum15(active ? draw * fmaxf(a, 0.f) : 0.f);
+                    if (row_last) w2_acc[w2c + h] += v;
+                } else if (ASD_FIELD_W2_COPIES > 1) {
                     const float v = active ? draw * fmaxf(a, 0.f) : 0.f;
                     if (v != 0.f) atomicAdd(&w2_acc[w2c + h], v);
                 } else {
@@ -471,7 +486,10 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
 #pragma unroll
                         for (int o = 0; o < C; ++o) {
                             dh = fmaf(df[o], w2f[o * H + h], dh);
-                            if (ASD_FIELD_W2_COPIES > 1) {
+                            if (ASD_FIELD_W2_ROWSUM) {
+                                const float v = asd_row_sum15(df[o] * hv);
+                                if (row_last) w2_acc[w2c + H + o * H + h] += v;
+                            } else if (ASD_FIELD_W2_COPIES > 1) {
                                 const float v = df[o] * hv;
                                 if (v != 0.f) atomicAdd(&w2_acc[w2c + H + o * H + h], v);
                             } else {
@@ -501,8 +519,23 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                 pts_out[3 * ro + 2] = 2.f * ((qz - c.bbox_min[2]) / bz) - 1.f;
             }
         } else {
-            asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, (qx - c.bbox_min[0]) / bx, (qy - c.bbox_min[1]) / by,
-                                                                 (qz - c.bbox_min[2]) / bz, denc, active, priv, priv_stride);
+            const float ux = (qx - c.bbox_min[0]) / bx, uy = (qy - c.bbox_min[1]) / by, uz = (qz - c.bbox_min[2]) / bz;
+            if (pg_g) {
+                // coarse levels as before (run-aggregated atomics, per-XCD copies); the fine levels' rows go to the paged scatter
+                asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV, false>(m, d_grid, ux, uy, uz, denc, active, priv, priv_stride);
+                if (active) {
+                    constexpr int NFINE = L - ASD_FIELD_NAGG;
+                    const size_t rr = (size_t)pt * n + i;
+                    float4* dst = reinterpret_cast<float4*>(pg_g + rr * (2 * NFINE));
+#pragma unroll
+                    for (int q = 0; q < NFINE / 2; ++q)
+                        dst[q] = make_float4(denc[2 * ASD_FIELD_NAGG + 4 * q], denc[2 * ASD_FIELD_NAGG + 4 * q + 1],
+                                             denc[2 * ASD_FIELD_NAGG + 4 * q + 2], denc[2 * ASD_FIELD_NAGG + 4 * q + 3]);
+                    pg_pos[3 * rr] = asd_unit(ux); pg_pos[3 * rr + 1] = asd_unit(uy); pg_pos[3 * rr + 2] = asd_unit(uz);
+                }
+            } else {
+                asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV>(m, d_grid, ux, uy, uz, denc, active, priv, priv_stride);
+            }
         }
     }
     __syncthreads();
@@ -872,8 +905,10 @@ int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_no
     const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
     // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs [chunks, 128*32]
     //   + the per-XCD copies of the gradient of the ASD_FIELD_NPRIV coarsest levels (ASD_FIELD_PRIV_CAP floats each)
+    //   + the paged scatter of the fine levels (field_paged.h): their feature gradients [rows, 20], positions [rows, 3], item lists
     *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 +
-                (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0);
+                (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0) +
+                rows * (2 * ASD_PG_NF + 3) + asd_paged_workspace_floats(rows);
     return ASD_OK;
 }
 
@@ -908,17 +943,31 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     } else {
         priv = d_grid_params;
     }
+    // the levels >= ASD_FIELD_NAGG (hashed: neighbouring samples share no entry) through the paged scatter — no global atomics
+    // (ASD_FIELD_PAGED=0: the transposed-lane atomics of asd_scatter_runs, the A/B partner)
+    static_assert(16 - ASD_FIELD_NAGG == ASD_PG_NF, "field_paged.h is sized for the levels >= ASD_FIELD_NAGG of the 16-level grid");
+    static const int paged_on = getenv("ASD_FIELD_PAGED") ? atoi(getenv("ASD_FIELD_PAGED")) : 1;
+    asd_paged_plan plan;
+    const bool paged = paged_on && asd_paged_plan_init(meta, ASD_FIELD_NAGG, &plan);
+    float* pg_g = slabs + (int64_t)chunks * 128 * 32 + 64 + (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0);
+    float* pg_pos = pg_g + rows * (2 * ASD_PG_NF);
+    float* pg_ws = pg_pos + rows * 3;
     const dim3 grid(asd_div_up(n, 256)), block(256);
     ASD_PROBE_START(s);
 #define ASD_FIELD_BWD_LAUNCH(C_)                                                                                                     \
     hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, C_>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density, w2_density,  \
                        w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features, d_normal, d_fd_grad,        \
-                       d_grid_params, da, enc_fd, dw2_density, dw2_feature, priv, priv_stride)
+                       d_grid_params, da, enc_fd, dw2_density, dw2_feature, priv, priv_stride, (float*)nullptr, (float*)nullptr,   \
+                       paged ? pg_g : (float*)nullptr, paged ? pg_pos : (float*)nullptr)
     if (cfg->n_feature_dims == 3) ASD_FIELD_BWD_LAUNCH(3); else ASD_FIELD_BWD_LAUNCH(0);
 #undef ASD_FIELD_BWD_LAUNCH
     if (priv_stride > 0)
         hipLaunchKernelGGL(asd_priv_reduce_kernel, dim3(asd_div_up(priv_stride / 4, 256)), block, 0, s, priv, priv_stride, priv_stride,
                            d_grid_params);
+    if (paged) {
+        const int rc = asd_paged_scatter(meta, &plan, pg_pos, pg_g, n, with_normal ? 4 : 1, n_dev, d_grid_params, pg_ws, s);
+        if (rc != ASD_OK) return rc;
+    }
     ASD_PROBE_STOP(s);
     hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
                        slabs);

@@ -3,6 +3,8 @@
 Tolerances: marcher outputs (integer / lattice work) bit-exact; field values 1e-5 abs (north_star asks 1e-3
 on rendered RGB/sigma); gradients 1e-4 rel (atomic scatter order differs from the oracle's serial order).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -131,6 +133,50 @@ def test_field_backward(oracle, with_normal, n, geom):
         for a, b in zip(got, want[1:]):
             scale = max(1.0, float(np.abs(b).max()))
             np.testing.assert_allclose(a.cpu().numpy() / scale, b / scale, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("paged", ["1", "0"])
+def test_field_backward_crowded_points_and_both_scatter_forms(oracle, paged):
+    """The fine levels of the hash-grid gradient go through the paged scatter (csrc/field_paged.hip: items binned by 64 KB table page,
+    one workgroup per page).  (a) 60 000 points crowded into two cells overflow the fixed-capacity bins of their pages — the overflowing
+    items must arrive through the global-atomic fallback — and hammer a handful of entries (the tag arbitration's retry / LDS-atomic
+    tail); (b) ASD_FIELD_PAGED=0, the transposed-lane atomics the paged form replaced, stays a tested A/B partner.  A subprocess per
+    form: the switch is read once per process."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from oracle import oracle as O
+import test_gpu_renderer_kernels as T
+from scaledreamer_amd import ops
+O.lib()
+om, hm = T._metas(O, T.GEOM)
+oc = O.field_cfg(); hc = T._hip_cfg(oc)
+rng = np.random.default_rng(5)
+grid = rng.uniform(-0.1, 0.1, om.n_params).astype(np.float32)
+w = T._weights(rng)
+n = 60000
+centre = np.where(rng.uniform(size=(n, 1)) < 0.5, 0.2137, -0.3391).astype(np.float32)
+pts = (centre + rng.uniform(-1e-5, 1e-5, (n, 3))).astype(np.float32)
+pts[:500] = rng.uniform(-0.7, 0.7, (500, 3))
+ds = rng.normal(size=n).astype(np.float32); df = rng.normal(size=(n, 3)).astype(np.float32)
+dg, dw = T._dev(grid), [T._dev(a) for a in w]
+sig, feat, nrm, enc = ops.field_fwd(hm, hc, dg, *dw, T._dev(pts), want_normal=False)
+d_grid = torch.zeros(om.n_params, device="cuda")
+ops.field_bwd(hm, hc, dg, *dw, T._dev(pts), enc, sig, T._dev(ds), T._dev(df), None, d_grid)
+want = O.field_bwd(om, oc, grid, *w, pts, ds, df, None)[0]
+got = d_grid.cpu().numpy()
+scale = float(np.abs(want).max())
+err = float(np.abs(got - want).max()) / scale
+print("ERR", err)
+assert err < 2e-4, err          # 30 000 terms per hot entry in fp32, any order
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASD_FIELD_PAGED=paged)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_envmap(oracle):
