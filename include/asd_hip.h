@@ -648,6 +648,31 @@ int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const as
 /* dx = transpose of the upsampling applied to dy; ws: 6 * N * r^3 * C floats */
 int asd_upsample3d_bwd(const float* dy, int32_t N, int32_t r, int32_t C, float* dx, float* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tri-plane transformer generator (custom/amortized/extern/triplane_transformer_modules.py:34-187; the space generator of
+ * `Triplane-transformer-sdf`, custom/amortized/models/geometry/triplane_transformer.py:97-116), trained in fp32 by the reference.
+ * Everything below works on fp32 tensors at fp32-class accuracy: operands are split into two fp16 planes (x * 2^e = hi + lo, one
+ * power-of-two scale per operand row) and a product is hi.hi + hi.lo + lo.hi on the fp16 matrix pipe, accumulated in fp32
+ * (csrc/tritx.hip).  All tensors are row-major fp32 device memory owned by the caller; `ws` are caller-owned workspaces.
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.Linear weight w [N, K] -> operand planes: plane_w [N, 3K] fp16 + inv_w [N] for y = x w^T, and / or plane_wt [K, 3 * round64(N)] fp16 +
+ * inv_wt [K] for the input gradient dx = dy w (either pair may be NULL); ws: >= K floats */
+int asd_tx_pack_weight(const float* w, int32_t N, int32_t K, void* plane_w, float* inv_w, void* plane_wt, float* inv_wt, float* ws, void* stream);
+/* y [M, N] (ldy) = f(x [M, K] (ldx) . W^T + bias) + residual (ldr); W as packed by asd_tx_pack_weight (its plane_wt / inv_wt for an input
+ * gradient: then `K` is the weight's N and must be a multiple of 64).  mode 0: f = identity; 1: f = GELU (erf form, nn.GELU()), the
+ * pre-activation is saved to aux [M, N]; 2: f(v) = v * GELU'(aux) — the gradient through that GELU.  bias / residual may be NULL. */
+int64_t asd_tx_linear_workspace(int32_t M, int32_t N, int32_t K);    /* floats */
+int asd_tx_linear(const float* x, int32_t M, int32_t K, int32_t ldx, const void* plane_w, const float* inv_w, int32_t N, const float* bias, int32_t mode,
+                  float* aux, const float* residual, int32_t ldr, float* y, int32_t ldy, float* ws, void* stream);
+/* weight gradient of that layer: dw [N, K] = dy [M, N]^T . x [M, K], db [N] = column sums of dy (NULL: skipped) */
+int64_t asd_tx_wgrad_workspace(int32_t M, int32_t N, int32_t K);     /* floats */
+int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* dw, float* db, float* ws, void* stream);
+/* nn.LayerNorm(D, eps) over rows (D % 4 == 0, D <= 1024); stats [M, 2] = (mean, rstd).  Backward: dx = input gradient (+ dres if given),
+ * dgamma / dbeta += (the caller zeroes them once per backward pass) */
+int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y, float* stats, void* stream);
+int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
+                         float* dgamma, float* dbeta, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);
