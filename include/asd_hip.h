@@ -673,6 +673,17 @@ int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamm
 int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
                          float* dgamma, float* dbeta, void* stream);
 
+/* diffusers' Attention core as the transformer uses it (head dim 48): o [Lq, ldo] = softmax(q k^T / sqrt(48)) v per head, head h = columns
+ * 48 h .. 48 h + 47 of q / k / v / o (strided views of a fused qkv matrix are fine: ld % 4 == 0).  lse2 [H, Lq] (base-2 log-sum-exp of the
+ * scaled scores) is what asd_tx_attention_bwd needs besides q, k, v, o. */
+int64_t asd_tx_attention_workspace(int32_t Lq, int32_t Lk, int32_t H);   /* floats; serves forward and backward */
+int asd_tx_attention_fwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, int32_t Lq, int32_t Lk, int32_t H,
+                         float* o, int32_t ldo, float* lse2, float* ws, void* stream);
+/* (dq, dk, dv) from d_o (the gradient of o); o / lse2 as the forward left them.  Written, not accumulated. */
+int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* o, int32_t ldo,
+                         const float* d_o, int32_t lddo, const float* lse2, int32_t Lq, int32_t Lk, int32_t H, float* dq, int32_t lddq, float* dk,
+                         int32_t lddk, float* dv, int32_t lddv, float* ws, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -158,6 +158,7 @@ SYMBOLS = [
     "asd_trifield_fwd_workspace", "asd_trifield_fwd", "asd_trifield_bwd_workspace", "asd_trifield_bwd",
     "asd_render_layout_init", "asd_render_fwd", "asd_render_bwd_workspace", "asd_render_bwd",
     "asd_tx_pack_weight", "asd_tx_linear_workspace", "asd_tx_linear", "asd_tx_wgrad_workspace", "asd_tx_linear_wgrad", "asd_tx_layernorm_fwd", "asd_tx_layernorm_bwd",
+    "asd_tx_attention_workspace", "asd_tx_attention_fwd", "asd_tx_attention_bwd",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 
@@ -177,7 +178,7 @@ def lib() -> C.CDLL:
         l.asd_grid_meta_init.restype = C.c_uint32
         l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
         for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_unet_workspace_bytes_shared", "asd_vae_enc_workspace_bytes",
-                   "asd_conv3d_workspace_bytes", "asd_tx_linear_workspace", "asd_tx_wgrad_workspace"):
+                   "asd_conv3d_workspace_bytes", "asd_tx_linear_workspace", "asd_tx_wgrad_workspace", "asd_tx_attention_workspace"):
             getattr(l, fn).restype = C.c_int64
         l.asd_unet_destroy.restype = None
         l.asd_vae_enc_destroy.restype = None

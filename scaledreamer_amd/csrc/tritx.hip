@@ -271,6 +271,400 @@ __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __re
     }
 }
 
+// ---- attention (head dim 48, fp32-class) ------------------------------------------------------------------------------------------------
+// Operand planes (tx_attn_prep_kernel): Q, K row-major fp16 hi / lo [H][L][48] (96-byte rows), V TRANSPOSED [H][48][Lp]; one power-of-two
+// scale per (tensor, head) from tx_attn_absmax_kernel.  Key rows beyond Lk are zero and masked in the kernels.
+//
+// The flash kernels run S^T = K Q^T on v_mfma_f32_32x32x16_f16: a lane then owns ONE query (column l & 31) and 16 of the 32 keys of a block
+// (rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)), so the row maximum / sum of the softmax are 16 in-lane operations plus one exchange with lane
+// l ^ 32, and — after conversion to fp16 hi / lo — those same registers ARE the B operand of O^T = V^T P^T in a permuted key order
+// (k-step u, position p of half h is key 16 u + (p & 3) + 8 (p >> 2) + 4 h), in which the V^T fragments are loaded: P never moves.
+#define TX_HD 48
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ __launch_bounds__(256) void tx_attn_absmax_kernel(const float* __restrict__ x, int L, int ld, int H, unsigned* __restrict__ amax /*[H]*/) {
+    // grid (ceil(L / 64), H): 64 rows x 48 columns per block
+    const int h = blockIdx.y, r0 = blockIdx.x * 64;
+    float m = 0.f;
+    for (int t = threadIdx.x; t < 64 * (TX_HD / 4); t += 256) {
+        const int r = r0 + t / (TX_HD / 4), c = (t % (TX_HD / 4)) * 4;
+        if (r < L) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + h * TX_HD + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+    m = tx_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax + h, __float_as_uint(m));
+}
+
+// row-major planes [H][Lp][48] (rows >= L zero): hi, lo
+__global__ __launch_bounds__(256) void tx_attn_prep_rows_kernel(const float* __restrict__ x, int L, int Lp, int ld, int H, const unsigned* __restrict__ amax,
+                                                                h16* __restrict__ hi, h16* __restrict__ lo) {
+    const int h = blockIdx.y;
+    const float s = tx_scale_for(__uint_as_float(amax[h]));
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;      // one thread per 4 elements
+    const int r = (int)(t / (TX_HD / 4)), c = (int)(t % (TX_HD / 4)) * 4;
+    if (r >= Lp) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + h * TX_HD + c);
+    h16 h0, h1, h2, h3, l0, l1, l2, l3;
+    tx_split(v.x * s, h0, l0); tx_split(v.y * s, h1, l1); tx_split(v.z * s, h2, l2); tx_split(v.w * s, h3, l3);
+    const size_t o = ((size_t)h * Lp + r) * TX_HD + c;
+    *reinterpret_cast<h16x4*>(hi + o) = h16x4{h0, h1, h2, h3};
+    *reinterpret_cast<h16x4*>(lo + o) = h16x4{l0, l1, l2, l3};
+}
+
+// transposed planes [H][48][Lp] (columns >= L zero): 64 rows of x per block through LDS
+__global__ __launch_bounds__(256) void tx_attn_prep_cols_kernel(const float* __restrict__ x, int L, int Lp, int ld, int H, const unsigned* __restrict__ amax,
+                                                                h16* __restrict__ hi, h16* __restrict__ lo) {
+    __shared__ h16 thi[TX_HD][66], tlo[TX_HD][66];
+    const int h = blockIdx.y, r0 = blockIdx.x * 64;
+    const float s = tx_scale_for(__uint_as_float(amax[h]));
+    for (int t = threadIdx.x; t < 64 * TX_HD; t += 256) {
+        const int rl = t / TX_HD, c = t % TX_HD;
+        const float v = r0 + rl < L ? x[(size_t)(r0 + rl) * ld + h * TX_HD + c] : 0.f;
+        h16 a, b;
+        tx_split(v * s, a, b);
+        thi[c][rl] = a; tlo[c][rl] = b;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * TX_HD; t += 256) {
+        const int c = t / 64, rl = t % 64;
+        if (r0 + rl < Lp) {
+            const size_t o = ((size_t)h * TX_HD + c) * Lp + r0 + rl;
+            hi[o] = thi[c][rl]; lo[o] = tlo[c][rl];
+        }
+    }
+}
+
+__device__ __forceinline__ f32x16 tx_mfma(const h16x8 a, const h16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// hi.hi + hi.lo + lo.hi
+__device__ __forceinline__ f32x16 tx_mfma3(const h16x8 ah, const h16x8 al, const h16x8 bh, const h16x8 bl, f32x16 c) {
+    c = tx_mfma(ah, bh, c);
+    c = tx_mfma(ah, bl, c);
+    c = tx_mfma(al, bh, c);
+    return c;
+}
+__device__ __forceinline__ int tx_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }     // C / D row of register r
+
+#define TX_PSCALE 16384.f       // probabilities (<= 1) are split at 2^14
+
+// O [Lq, ldo] (fp32), lse2 [H][Lq] = log2 sum_j 2^(s2_ij), s2 = (q . k) log2(e) / sqrt(48).  grid (ceil(Lq / 128), H), 4 waves x 32 queries
+__global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict__ qh, const h16* __restrict__ ql, const h16* __restrict__ kh,
+                                                          const h16* __restrict__ kl, const h16* __restrict__ vth, const h16* __restrict__ vtl,
+                                                          const unsigned* __restrict__ amax /*[3][H]: q, k, v*/, int Lq, int Lqp, int Lk, int Lkp, int H,
+                                                          float* __restrict__ o, int ldo, float* __restrict__ lse2) {
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= Lq) return;
+    const int j = lane & 31, half = lane >> 5;
+    const float c1 = 1.4426950408889634f * 0.14433756729740643f /* log2(e) / sqrt(48) */ /
+                     (tx_scale_for(__uint_as_float(amax[h])) * tx_scale_for(__uint_as_float(amax[H + h])));
+    const float cv = 1.f / (tx_scale_for(__uint_as_float(amax[2 * H + h])) * TX_PSCALE);
+    // Q fragments: B operand of S^T = K Q^T — lane (query j, half): d = 16 t + 8 half .. + 7
+    h16x8 bqh[3], bql[3];
+    {
+        const size_t qrow = ((size_t)h * Lqp + q0 + j) * TX_HD + 8 * half;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bqh[t] = *reinterpret_cast<const h16x8*>(qh + qrow + 16 * t);
+            bql[t] = *reinterpret_cast<const h16x8*>(ql + qrow + 16 * t);
+        }
+    }
+    f32x16 ot[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const h16* kbase_h = kh + (size_t)h * Lkp * TX_HD, * kbase_l = kl + (size_t)h * Lkp * TX_HD;
+    const h16* vbase_h = vth + (size_t)h * TX_HD * Lkp, * vbase_l = vtl + (size_t)h * TX_HD * Lkp;
+    for (int k0 = 0; k0 < Lk; k0 += 32) {               // (the planes are zero-padded to Lkp rows: the last block may run past Lk)
+        // S^T block: A = K rows (key j of the block, d range as above)
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        {
+            const size_t krow = (size_t)(k0 + j) * TX_HD + 8 * half;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(kbase_h + krow + 16 * t);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(kbase_l + krow + 16 * t);
+                st = tx_mfma3(ah, al, bqh[t], bql[t], st);
+            }
+        }
+        float mb = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s2 = st[r] * c1;
+            if (k0 + 32 > Lk && k0 + tx_row_of(r, half) >= Lk) s2 = -INFINITY;
+            st[r] = s2;
+            mb = fmaxf(mb, s2);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m, mb);
+        const float alpha = exp2f(m - m_new);           // m = -inf on the first block: 0
+        float lb = 0.f;
+        h16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(st[r] - m_new);
+            lb += p;
+            h16 a, b;
+            tx_split(p * TX_PSCALE, a, b);
+            ph[r >> 3][r & 7] = a; pl[r >> 3][r & 7] = b;
+        }
+        lb += __shfl_xor(lb, 32, 64);
+        l = l * alpha + lb;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+        // O^T += V^T P^T: A = V^T rows d = 32 mt + j, keys k0 + 16 u + 4 half + {0..3} and + 8
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int d = 32 * mt + j;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                h16x8 ah, al;
+                if (d < TX_HD) {
+                    const size_t vo = (size_t)d * Lkp + k0 + 16 * u + 4 * half;
+                    const h16x4 a0 = *reinterpret_cast<const h16x4*>(vbase_h + vo), a1 = *reinterpret_cast<const h16x4*>(vbase_h + vo + 8);
+                    const h16x4 b0 = *reinterpret_cast<const h16x4*>(vbase_l + vo), b1 = *reinterpret_cast<const h16x4*>(vbase_l + vo + 8);
+                    ah = h16x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    al = h16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                } else {
+                    ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    al = ah;
+                }
+                ot[mt] = tx_mfma3(ah, al, ph[u], pl[u], ot[mt]);
+            }
+        }
+    }
+    // O[q][h * 48 + d] = O^T[d][q] * cv / l
+    if (q0 + j < Lq) {
+        const float f = cv / l;
+        float* orow = o + (size_t)(q0 + j) * ldo + h * TX_HD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = 32 * mt + tx_row_of(r, half);
+                if (d < TX_HD) orow[d] = ot[mt][r] * f;
+            }
+        if (half == 0) lse2[(size_t)h * Lq + q0 + j] = m + log2f(l);
+    }
+}
+
+// D[h][q] = sum_d dO[q][h 48 + d] O[q][h 48 + d]: one thread per (query, head)
+__global__ __launch_bounds__(256) void tx_attn_rowdot_kernel(const float* __restrict__ d_o, int ldd, const float* __restrict__ o, int ldo, int Lq, int H,
+                                                             float* __restrict__ dsum /*[H][Lq]*/) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Lq * H) return;
+    const int q = t / H, h = t % H;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < TX_HD; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(d_o + (size_t)q * ldd + h * TX_HD + c), y = *reinterpret_cast<const float4*>(o + (size_t)q * ldo + h * TX_HD + c);
+        a += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    dsum[(size_t)h * Lq + q] = a;
+}
+
+// 8 halves of a transposed plane row at the permuted positions of k-step u: columns c0 + 16 u + 4 half + {0..3} and + 8
+__device__ __forceinline__ h16x8 tx_load_perm(const h16* __restrict__ rowp, int c0, int u, int half) {
+    const h16x4 a = *reinterpret_cast<const h16x4*>(rowp + c0 + 16 * u + 4 * half), b = *reinterpret_cast<const h16x4*>(rowp + c0 + 16 * u + 4 * half + 8);
+    return h16x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
+struct tx_attn_bwd_args {
+    const h16 *qh, *ql, *kh, *kl, *vh, *vl, *doh, *dol;     // row-major planes [H][Lp][48]
+    const h16 *qth, *qtl, *doth, *dotl, *kth, *ktl;         // transposed planes [H][48][Lp]
+    const unsigned* amax;                                   // [4][H]: q, k, v, dO
+    const float *lse2, *dsum;                               // [H][Lq]
+    int Lq, Lqp, Lk, Lkp, H;
+    float *dq, *dk, *dv;
+    int lddq, lddk, lddv;
+};
+// static bound of |P (dP - D)| per head: |dP_ij| <= 48 max|dO| max|V|, |D_i| <= 48 max|dO| max|O| and |O| <= max|V| (convex combination)
+__device__ __forceinline__ float tx_ds_scale(const unsigned* amax, int H, int h) {
+    return tx_scale_for(96.f * __uint_as_float(amax[3 * H + h]) * __uint_as_float(amax[2 * H + h]));
+}
+
+// dK, dV: a wave owns 32 keys and walks the query blocks.  S = Q K^T (rows = queries, column = the lane's key), P = 2^(S2 - lse2),
+// dV^T += dO^T P, dP = dO V^T, dS = P (dP - D), dK^T += Q^T dS.  grid (ceil(Lk / 128), H)
+__global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_args a) {
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    if (k0 >= a.Lk) return;
+    const int j = lane & 31, half = lane >> 5, H = a.H;
+    const float sq = tx_scale_for(__uint_as_float(a.amax[h])), sk = tx_scale_for(__uint_as_float(a.amax[H + h]));
+    const float sv = tx_scale_for(__uint_as_float(a.amax[2 * H + h])), sdo = tx_scale_for(__uint_as_float(a.amax[3 * H + h]));
+    const float sds = tx_ds_scale(a.amax, H, h);
+    const float c1 = 1.4426950408889634f * 0.14433756729740643f / (sq * sk), cdp = 1.f / (sdo * sv);
+    // resident B operands: K^T and V^T columns = this lane's key, d range 16 t + 8 half .. + 7
+    h16x8 bkh[3], bkl[3], bvh[3], bvl[3];
+    {
+        const size_t krow = ((size_t)h * a.Lkp + k0 + j) * TX_HD + 8 * half;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bkh[t] = *reinterpret_cast<const h16x8*>(a.kh + krow + 16 * t); bkl[t] = *reinterpret_cast<const h16x8*>(a.kl + krow + 16 * t);
+            bvh[t] = *reinterpret_cast<const h16x8*>(a.vh + krow + 16 * t); bvl[t] = *reinterpret_cast<const h16x8*>(a.vl + krow + 16 * t);
+        }
+    }
+    f32x16 dvt[2], dkt[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvt[0][r] = dvt[1][r] = dkt[0][r] = dkt[1][r] = 0.f; }
+    const h16 *qbh = a.qh + (size_t)h * a.Lqp * TX_HD, *qbl = a.ql + (size_t)h * a.Lqp * TX_HD;
+    const h16 *dbh = a.doh + (size_t)h * a.Lqp * TX_HD, *dbl = a.dol + (size_t)h * a.Lqp * TX_HD;
+    const h16 *qtbh = a.qth + (size_t)h * TX_HD * a.Lqp, *qtbl = a.qtl + (size_t)h * TX_HD * a.Lqp;
+    const h16 *dtbh = a.doth + (size_t)h * TX_HD * a.Lqp, *dtbl = a.dotl + (size_t)h * TX_HD * a.Lqp;
+    const float *lse = a.lse2 + (size_t)h * a.Lq, *dsm = a.dsum + (size_t)h * a.Lq;
+    const bool key_ok = k0 + j < a.Lk;
+    for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        {
+            const size_t qrow = (size_t)(q0 + j) * TX_HD + 8 * half;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(qbh + qrow + 16 * t), al = *reinterpret_cast<const h16x8*>(qbl + qrow + 16 * t);
+                s = tx_mfma3(ah, al, bkh[t], bkl[t], s);
+                const h16x8 dh = *reinterpret_cast<const h16x8*>(dbh + qrow + 16 * t), dl = *reinterpret_cast<const h16x8*>(dbl + qrow + 16 * t);
+                dp = tx_mfma3(dh, dl, bvh[t], bvl[t], dp);
+            }
+        }
+        h16x8 ph[2], pl[2], gh[2], gl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = q0 + tx_row_of(r, half);
+            float p = 0.f, g = 0.f;
+            if (qi < a.Lq && key_ok) {
+                p = exp2f(s[r] * c1 - lse[qi]);
+                g = p * (dp[r] * cdp - dsm[qi]);
+            }
+            h16 x, y;
+            tx_split(p * TX_PSCALE, x, y);
+            ph[r >> 3][r & 7] = x; pl[r >> 3][r & 7] = y;
+            tx_split(g * sds, x, y);
+            gh[r >> 3][r & 7] = x; gl[r >> 3][r & 7] = y;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int d = 32 * mt + j;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                h16x8 ah, al, ch, cl;
+                if (d < TX_HD) {
+                    ah = tx_load_perm(dtbh + (size_t)d * a.Lqp, q0, u, half); al = tx_load_perm(dtbl + (size_t)d * a.Lqp, q0, u, half);
+                    ch = tx_load_perm(qtbh + (size_t)d * a.Lqp, q0, u, half); cl = tx_load_perm(qtbl + (size_t)d * a.Lqp, q0, u, half);
+                } else {
+                    ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    al = ah; ch = ah; cl = ah;
+                }
+                dvt[mt] = tx_mfma3(ah, al, ph[u], pl[u], dvt[mt]);
+                dkt[mt] = tx_mfma3(ch, cl, gh[u], gl[u], dkt[mt]);
+            }
+        }
+    }
+    if (key_ok) {
+        const float fv = 1.f / (sdo * TX_PSCALE), fk = 0.14433756729740643f / (sq * sds);
+        float* dvrow = a.dv + (size_t)(k0 + j) * a.lddv + h * TX_HD;
+        float* dkrow = a.dk + (size_t)(k0 + j) * a.lddk + h * TX_HD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = 32 * mt + tx_row_of(r, half);
+                if (d < TX_HD) { dvrow[d] = dvt[mt][r] * fv; dkrow[d] = dkt[mt][r] * fk; }
+            }
+    }
+}
+
+// dQ: a wave owns 32 queries and walks the key blocks in the forward's orientation: S^T = K Q^T, dP^T = V dO^T (column = the lane's query),
+// dS^T = P^T (dP^T - D), dQ^T += K^T dS^T.  grid (ceil(Lq / 128), H)
+__global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_args a) {
+    const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= a.Lq) return;
+    const int j = lane & 31, half = lane >> 5, H = a.H;
+    const float sq = tx_scale_for(__uint_as_float(a.amax[h])), sk = tx_scale_for(__uint_as_float(a.amax[H + h]));
+    const float sv = tx_scale_for(__uint_as_float(a.amax[2 * H + h])), sdo = tx_scale_for(__uint_as_float(a.amax[3 * H + h]));
+    const float sds = tx_ds_scale(a.amax, H, h);
+    const float c1 = 1.4426950408889634f * 0.14433756729740643f / (sq * sk), cdp = 1.f / (sdo * sv);
+    h16x8 bqh[3], bql[3], bdh[3], bdl[3];
+    {
+        const size_t qrow = ((size_t)h * a.Lqp + q0 + j) * TX_HD + 8 * half;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bqh[t] = *reinterpret_cast<const h16x8*>(a.qh + qrow + 16 * t); bql[t] = *reinterpret_cast<const h16x8*>(a.ql + qrow + 16 * t);
+            bdh[t] = *reinterpret_cast<const h16x8*>(a.doh + qrow + 16 * t); bdl[t] = *reinterpret_cast<const h16x8*>(a.dol + qrow + 16 * t);
+        }
+    }
+    const bool q_ok = q0 + j < a.Lq;
+    const float lse = q_ok ? a.lse2[(size_t)h * a.Lq + q0 + j] : 0.f, dsm = q_ok ? a.dsum[(size_t)h * a.Lq + q0 + j] : 0.f;
+    f32x16 dqt[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dqt[0][r] = dqt[1][r] = 0.f; }
+    const h16 *kbh = a.kh + (size_t)h * a.Lkp * TX_HD, *kbl = a.kl + (size_t)h * a.Lkp * TX_HD;
+    const h16 *vbh = a.vh + (size_t)h * a.Lkp * TX_HD, *vbl = a.vl + (size_t)h * a.Lkp * TX_HD;
+    const h16 *ktbh = a.kth + (size_t)h * TX_HD * a.Lkp, *ktbl = a.ktl + (size_t)h * TX_HD * a.Lkp;
+    for (int k0 = 0; k0 < a.Lk; k0 += 32) {
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+        {
+            const size_t krow = (size_t)(k0 + j) * TX_HD + 8 * half;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(kbh + krow + 16 * t), al = *reinterpret_cast<const h16x8*>(kbl + krow + 16 * t);
+                st = tx_mfma3(ah, al, bqh[t], bql[t], st);
+                const h16x8 vh_ = *reinterpret_cast<const h16x8*>(vbh + krow + 16 * t), vl_ = *reinterpret_cast<const h16x8*>(vbl + krow + 16 * t);
+                dpt = tx_mfma3(vh_, vl_, bdh[t], bdl[t], dpt);
+            }
+        }
+        h16x8 gh[2], gl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float g = 0.f;
+            if (q_ok && k0 + tx_row_of(r, half) < a.Lk) {
+                const float p = exp2f(st[r] * c1 - lse);
+                g = p * (dpt[r] * cdp - dsm);
+            }
+            h16 x, y;
+            tx_split(g * sds, x, y);
+            gh[r >> 3][r & 7] = x; gl[r >> 3][r & 7] = y;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int d = 32 * mt + j;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                h16x8 ah, al;
+                if (d < TX_HD) {
+                    ah = tx_load_perm(ktbh + (size_t)d * a.Lkp, k0, u, half); al = tx_load_perm(ktbl + (size_t)d * a.Lkp, k0, u, half);
+                } else {
+                    ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    al = ah;
+                }
+                dqt[mt] = tx_mfma3(ah, al, gh[u], gl[u], dqt[mt]);
+            }
+        }
+    }
+    if (q_ok) {
+        const float fq = 0.14433756729740643f / (sk * sds);
+        float* row = a.dq + (size_t)(q0 + j) * a.lddq + h * TX_HD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = 32 * mt + tx_row_of(r, half);
+                if (d < TX_HD) row[d] = dqt[mt][r] * fq;
+            }
+    }
+}
+
 // a page of zeros per device for asd_gemm_f16's out-of-range rows
 const void* tx_zero_page() {
     static std::mutex mu;
@@ -395,6 +789,85 @@ int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, co
     int grid = asd_div_up(M, 4 * 6);
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(tx_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+
+// ---- attention ---------------------------------------------------------------------------------------------------------------------------
+static inline int tx_lp(int L) { return (L + 127) & ~127; }      // plane rows: whole 128-row blocks (32 per wave) so no load leaves the plane
+int64_t asd_tx_attention_workspace(int32_t Lq, int32_t Lk, int32_t H) {
+    // six planes of halfs (Q, K row-major hi / lo; V^T hi / lo), the backward's extra planes (Q^T, dO, dO^T) and 5 * H scale words
+    const int64_t Lqp = tx_lp(Lq), Lkp = tx_lp(Lk);
+    return tx_al((int64_t)H * TX_HD * (8 * Lqp + 6 * Lkp) / 2 + 256) + tx_al(8 * H) + tx_al((int64_t)H * Lq);
+}
+
+// o [Lq, ldo] = softmax(q k^T / sqrt(48)) v per head (head h = columns 48 h .. 48 h + 47 of q / k / v / o), lse2 [H, Lq] for the backward
+int asd_tx_attention_fwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, int32_t Lq, int32_t Lk, int32_t H,
+                         float* o, int32_t ldo, float* lse2, float* ws, void* stream) {
+    ASD_CHECK_ARG(q && k && v && o && lse2 && ws && Lq > 0 && Lk > 0 && H > 0 && H <= 64, "null argument");
+    ASD_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "leading dimensions must be multiples of 4 floats");
+    hipStream_t s = (hipStream_t)stream;
+    const int Lqp = tx_lp(Lq), Lkp = tx_lp(Lk);
+    h16* p = reinterpret_cast<h16*>(ws);
+    h16* qh = p; p += (size_t)H * Lqp * TX_HD;
+    h16* ql = p; p += (size_t)H * Lqp * TX_HD;
+    h16* kh = p; p += (size_t)H * Lkp * TX_HD;
+    h16* kl = p; p += (size_t)H * Lkp * TX_HD;
+    h16* vth = p; p += (size_t)H * Lkp * TX_HD;
+    h16* vtl = p; p += (size_t)H * Lkp * TX_HD;
+    unsigned* amax = reinterpret_cast<unsigned*>(ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256));
+    (void)hipMemsetAsync(amax, 0, (size_t)8 * H * 4, s);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, q, Lq, ldq, H, amax);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, k, Lk, ldk, H, amax + H);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, v, Lk, ldv, H, amax + 2 * H);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lqp * (TX_HD / 4), 256), H), dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qh, ql);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lkp * (TX_HD / 4), 256), H), dim3(256), 0, s, k, Lk, Lkp, ldk, H, amax + H, kh, kl);
+    hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lkp / 64, H), dim3(256), 0, s, v, Lk, Lkp, ldv, H, amax + 2 * H, vth, vtl);
+    hipLaunchKernelGGL(tx_attn_fwd_kernel, dim3(asd_div_up(Lq, 128), H), dim3(256), 0, s, qh, ql, kh, kl, vth, vtl, amax, Lq, Lqp, Lk, Lkp, H, o, ldo, lse2);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+
+// (dq, dk, dv) of asd_tx_attention_fwd from the gradient d_o of its output; o and lse2 are the forward's outputs
+int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* o, int32_t ldo,
+                         const float* d_o, int32_t lddo, const float* lse2, int32_t Lq, int32_t Lk, int32_t H, float* dq, int32_t lddq, float* dk,
+                         int32_t lddk, float* dv, int32_t lddv, float* ws, void* stream) {
+    ASD_CHECK_ARG(q && k && v && o && d_o && lse2 && dq && dk && dv && ws && Lq > 0 && Lk > 0 && H > 0 && H <= 64, "null argument");
+    ASD_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0, "leading dimensions must be multiples of 4 floats");
+    hipStream_t s = (hipStream_t)stream;
+    const int Lqp = tx_lp(Lq), Lkp = tx_lp(Lk);
+    const size_t nq = (size_t)H * Lqp * TX_HD, nk = (size_t)H * Lkp * TX_HD;
+    h16* p = reinterpret_cast<h16*>(ws);
+    tx_attn_bwd_args a;
+    h16 *qh = p, *ql = p + nq, *doh = p + 2 * nq, *dol = p + 3 * nq, *qth = p + 4 * nq, *qtl = p + 5 * nq, *doth = p + 6 * nq, *dotl = p + 7 * nq;
+    p += 8 * nq;
+    h16 *kh = p, *kl = p + nk, *vh = p + 2 * nk, *vl = p + 3 * nk, *kth = p + 4 * nk, *ktl = p + 5 * nk;
+    float* tail = ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256);
+    unsigned* amax = reinterpret_cast<unsigned*>(tail);
+    float* dsum = tail + tx_al(8 * H);
+    (void)hipMemsetAsync(amax, 0, (size_t)8 * H * 4, s);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, q, Lq, ldq, H, amax);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, k, Lk, ldk, H, amax + H);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, v, Lk, ldv, H, amax + 2 * H);
+    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, d_o, Lq, lddo, H, amax + 3 * H);
+    const dim3 gq(asd_div_up((int64_t)Lqp * (TX_HD / 4), 256), H), gk(asd_div_up((int64_t)Lkp * (TX_HD / 4), 256), H);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gq, dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qh, ql);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gq, dim3(256), 0, s, d_o, Lq, Lqp, lddo, H, amax + 3 * H, doh, dol);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gk, dim3(256), 0, s, k, Lk, Lkp, ldk, H, amax + H, kh, kl);
+    hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gk, dim3(256), 0, s, v, Lk, Lkp, ldv, H, amax + 2 * H, vh, vl);
+    hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lqp / 64, H), dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qth, qtl);
+    hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lqp / 64, H), dim3(256), 0, s, d_o, Lq, Lqp, lddo, H, amax + 3 * H, doth, dotl);
+    hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lkp / 64, H), dim3(256), 0, s, k, Lk, Lkp, ldk, H, amax + H, kth, ktl);
+    hipLaunchKernelGGL(tx_attn_rowdot_kernel, dim3(asd_div_up((int64_t)Lq * H, 256)), dim3(256), 0, s, d_o, lddo, o, ldo, Lq, H, dsum);
+    a.qh = qh; a.ql = ql; a.kh = kh; a.kl = kl; a.vh = vh; a.vl = vl; a.doh = doh; a.dol = dol;
+    a.qth = qth; a.qtl = qtl; a.doth = doth; a.dotl = dotl; a.kth = kth; a.ktl = ktl;
+    a.amax = amax; a.lse2 = lse2; a.dsum = dsum;
+    a.Lq = Lq; a.Lqp = Lqp; a.Lk = Lk; a.Lkp = Lkp; a.H = H;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    hipLaunchKernelGGL(tx_attn_bwd_kv_kernel, dim3(asd_div_up(Lk, 128), H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tx_attn_bwd_q_kernel, dim3(asd_div_up(Lq, 128), H), dim3(256), 0, s, a);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -113,3 +113,82 @@ def test_layernorm_forward_backward():
     L.check(L.lib().asd_tx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(gamma), L.i32(M), L.i32(D), L.ptr(dres), L.ptr(dx), L.ptr(dg), L.ptr(db), L.stream()))
     assert rel(dx, xd.grad + dres.double()) < 2e-6
     assert rel(dg, gd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
+
+
+def attention_fwd(q, k, v, H):
+    L = _lib()
+    Lq, Lk = q.shape[0], k.shape[0]
+    o = torch.empty(Lq, H * 48, device="cuda")
+    lse = torch.empty(H, Lq, device="cuda")
+    ws = _ws(L.lib().asd_tx_attention_workspace(L.i32(Lq), L.i32(Lk), L.i32(H)))
+    L.check(L.lib().asd_tx_attention_fwd(C.c_void_p(q.data_ptr()), L.i32(q.stride(0)), C.c_void_p(k.data_ptr()), L.i32(k.stride(0)), C.c_void_p(v.data_ptr()),
+                                         L.i32(v.stride(0)), L.i32(Lq), L.i32(Lk), L.i32(H), L.ptr(o), L.i32(H * 48), L.ptr(lse), L.ptr(ws), L.stream()))
+    return o, lse, ws
+
+
+def _attn_ref(q, k, v, H):
+    """float64: softmax(q k^T / sqrt(d)) v per head, and the base-2 log-sum-exp of the scaled scores"""
+    Lq, Lk = q.shape[0], k.shape[0]
+    qd, kd, vd = (t.double().view(t.shape[0], H, 48).transpose(0, 1) for t in (q, k, v))
+    s = qd @ kd.transpose(1, 2) / 48 ** 0.5
+    o = torch.softmax(s, -1) @ vd
+    return o.transpose(0, 1).reshape(Lq, H * 48), torch.logsumexp(s, -1) / np.log(2.0)
+
+
+@pytest.mark.parametrize("Lq,Lk,H,fused", [(3072, 3072, 16, True), (3072, 77, 16, False), (100, 50, 2, False), (257, 33, 3, True)])
+def test_attention_forward(Lq, Lk, H, fused):
+    g = torch.Generator(device="cuda").manual_seed(Lq + Lk)
+    D = H * 48
+    if fused and Lq == Lk:            # strided views of one qkv matrix, as the self-attention uses them
+        qkv = torch.randn(Lq, 3 * D, device="cuda", generator=g)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q = torch.randn(Lq, D, device="cuda", generator=g)
+        kv = torch.randn(Lk, 2 * D, device="cuda", generator=g) * 1.7
+        k, v = kv[:, :D], kv[:, D:]
+    q = q * 2.0                       # scores of a few units: a peaked softmax
+    o, lse, _ = attention_fwd(q, k, v, H)
+    ref_o, ref_lse = _attn_ref(q, k, v, H)
+    qh, kh, vh = (t.reshape(t.shape[0], H, 48).transpose(0, 1) for t in (q, k, v))
+    o32 = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None])[0].transpose(0, 1).reshape(Lq, D)
+    e, e32 = rel(o, ref_o), rel(o32, ref_o)
+    assert e < 3e-6, (e, e32)
+    assert float((lse.double() - ref_lse).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("Lq,Lk,H,fused", [(3072, 3072, 16, True), (3072, 77, 16, False), (100, 50, 2, False), (257, 33, 3, True)])
+def test_attention_backward(Lq, Lk, H, fused):
+    L = _lib()
+    g = torch.Generator(device="cuda").manual_seed(Lq + 3 * Lk)
+    D = H * 48
+    if fused and Lq == Lk:
+        qkv = torch.randn(Lq, 3 * D, device="cuda", generator=g)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q = torch.randn(Lq, D, device="cuda", generator=g)
+        kv = torch.randn(Lk, 2 * D, device="cuda", generator=g) * 1.7
+        k, v = kv[:, :D], kv[:, D:]
+    q = q * 2.0
+    d_o = torch.randn(Lq, D, device="cuda", generator=g) * 1e-3          # gradients are small numbers in training
+    o, lse, ws = attention_fwd(q, k, v, H)
+    dqkv = torch.empty(Lq, 3 * D, device="cuda") if fused and Lq == Lk else None
+    if dqkv is not None:
+        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+    else:
+        dq, dkv = torch.empty(Lq, D, device="cuda"), torch.empty(Lk, 2 * D, device="cuda")
+        dk, dv = dkv[:, :D], dkv[:, D:]
+    P = lambda t: C.c_void_p(t.data_ptr())
+    L.check(L.lib().asd_tx_attention_bwd(P(q), L.i32(q.stride(0)), P(k), L.i32(k.stride(0)), P(v), L.i32(v.stride(0)), P(o), L.i32(D), P(d_o), L.i32(D), P(lse),
+                                         L.i32(Lq), L.i32(Lk), L.i32(H), P(dq), L.i32(dq.stride(0)), P(dk), L.i32(dk.stride(0)), P(dv), L.i32(dv.stride(0)),
+                                         L.ptr(ws), L.stream()))
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    split = lambda t: t.view(t.shape[0], H, 48).transpose(0, 1)
+    ref = (torch.softmax(split(qd) @ split(kd).transpose(1, 2) / 48 ** 0.5, -1) @ split(vd)).transpose(0, 1).reshape(Lq, D)
+    ref.backward(d_o.double())
+    # fp32 library path on the same problem, for scale
+    q32, k32, v32 = (t.clone().requires_grad_(True) for t in (q, k, v))
+    s32 = lambda t: t.view(t.shape[0], H, 48).transpose(0, 1)[None]
+    torch.nn.functional.scaled_dot_product_attention(s32(q32), s32(k32), s32(v32))[0].transpose(0, 1).reshape(Lq, D).backward(d_o)
+    for name, got, want, lib32 in (("dq", dq, qd.grad, q32.grad), ("dk", dk, kd.grad, k32.grad), ("dv", dv, vd.grad, v32.grad)):
+        e, e32 = rel(got, want), rel(lib32, want)
+        assert e < 5e-6, (name, e, e32)
