@@ -684,6 +684,32 @@ int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ld
                          const float* d_o, int32_t lddo, const float* lse2, int32_t Lq, int32_t Lk, int32_t H, float* dq, int32_t lddq, float* dk,
                          int32_t lddk, float* dv, int32_t lddv, float* ws, void* stream);
 
+/* The generator as ONE call each way.  Parameter table `params` (device pointers, fp32), per layer l at 20 l + i:
+ *   0 norm1.weight 1 norm1.bias 2 cross_attn.to_q.weight [D,D] 3 cross_attn.to_k.weight [D,Dc] 4 cross_attn.to_v.weight [D,Dc]
+ *   5 cross_attn.to_out.0.weight [D,D] 6 cross_attn.to_out.0.bias 7 norm2.weight 8 norm2.bias 9 self_attn.to_q.weight 10 self_attn.to_k.weight
+ *   11 self_attn.to_v.weight 12 self_attn.to_out.0.weight 13 self_attn.to_out.0.bias 14 norm3.weight 15 norm3.bias 16 mlp.0.weight [F,D]
+ *   17 mlp.0.bias 18 mlp.3.weight [D,F] 19 mlp.3.bias;   then 20 L + {0 pos_embed [3 R R, D], 1 norm.weight, 2 norm.bias, 3 deconv.weight [D, C, 2, 2]}
+ * (state-dict names of triplane_transformer_modules.py:115-187).  Gradient table `grads`, per layer at 17 l + i:
+ *   0 norm1.w 1 norm1.b 2 cross to_q 3 cross to_k|to_v STACKED [2D,Dc] 4 cross to_out.w 5 cross to_out.b 6 norm2.w 7 norm2.b
+ *   8 self to_q|to_k|to_v STACKED [3D,D] 9 self to_out.w 10 self to_out.b 11 norm3.w 12 norm3.b 13 mlp.0.w 14 mlp.0.b 15 mlp.3.w 16 mlp.3.b;
+ *   then 17 L + {pos_embed, norm.w, norm.b, deconv.w} — every entry is WRITTEN (sum over the batch).
+ * asd_tritx_pack splits every weight into its operand planes (call it when the weights have changed); asd_tritx_fwd maps
+ * text_embed [batch, Tc, Dc] to channel-last planes [batch, 3, 2R, 2R, C] (the reference's [batch, 3, C, 2R, 2R] permuted) and keeps the
+ * activations the backward needs in `save`; asd_tritx_bwd takes the gradient of those planes. */
+typedef struct asd_tritx_desc {
+    int32_t n_layers, dim /* D = heads * 48 */, heads, cond_dim /* Dc */, cond_tokens /* Tc */, hidden /* F */, low_res /* R: 3 R R tokens */,
+            out_channels /* C */;
+    float eps;
+} asd_tritx_desc;
+int64_t asd_tritx_packed_floats(const asd_tritx_desc* desc);
+int64_t asd_tritx_save_floats(const asd_tritx_desc* desc, int32_t batch);
+int64_t asd_tritx_workspace_floats(const asd_tritx_desc* desc);
+int asd_tritx_pack(const asd_tritx_desc* desc, const float* const* params, float* packed, void* stream);
+int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const float* packed, const float* text_embed, int32_t batch, float* planes_cl,
+                  float* save, float* ws, void* stream);
+int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const float* packed, const float* text_embed, int32_t batch,
+                  const float* d_planes_cl, const float* save, float* const* grads, float* ws, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -117,6 +117,11 @@ class OptTensor(C.Structure):
                 ("bias_correction2", C.c_float), ("bias_correction2_sqrt", C.c_float)]
 
 
+class TritxDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32), ("cond_dim", C.c_int32), ("cond_tokens", C.c_int32),
+                ("hidden", C.c_int32), ("low_res", C.c_int32), ("out_channels", C.c_int32), ("eps", C.c_float)]
+
+
 class WeightInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
@@ -159,6 +164,7 @@ SYMBOLS = [
     "asd_render_layout_init", "asd_render_fwd", "asd_render_bwd_workspace", "asd_render_bwd",
     "asd_tx_pack_weight", "asd_tx_linear_workspace", "asd_tx_linear", "asd_tx_wgrad_workspace", "asd_tx_linear_wgrad", "asd_tx_layernorm_fwd", "asd_tx_layernorm_bwd",
     "asd_tx_attention_workspace", "asd_tx_attention_fwd", "asd_tx_attention_bwd",
+    "asd_tritx_packed_floats", "asd_tritx_save_floats", "asd_tritx_workspace_floats", "asd_tritx_pack", "asd_tritx_fwd", "asd_tritx_bwd",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 
@@ -178,7 +184,8 @@ def lib() -> C.CDLL:
         l.asd_grid_meta_init.restype = C.c_uint32
         l.asd_grid_meta_init.argtypes = [C.POINTER(GridMeta), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
         for fn in ("asd_gemm_workspace_bytes", "asd_unet_workspace_bytes", "asd_unet_workspace_bytes_shared", "asd_vae_enc_workspace_bytes",
-                   "asd_conv3d_workspace_bytes", "asd_tx_linear_workspace", "asd_tx_wgrad_workspace", "asd_tx_attention_workspace"):
+                   "asd_conv3d_workspace_bytes", "asd_tx_linear_workspace", "asd_tx_wgrad_workspace", "asd_tx_attention_workspace",
+                   "asd_tritx_packed_floats", "asd_tritx_save_floats", "asd_tritx_workspace_floats"):
             getattr(l, fn).restype = C.c_int64
         l.asd_unet_destroy.restype = None
         l.asd_vae_enc_destroy.restype = None

@@ -872,4 +872,325 @@ int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ld
     return ASD_OK;
 }
 
+
+// ---- the whole generator: forward / backward schedules -------------------------------------------------------------------------------------
+// y [T, 4 C] (token t = (plane p, h, w) of the low-res grid R x R; column co * 4 + i * 2 + j) <-> channel-last planes [3][2R][2R][C]
+__global__ __launch_bounds__(256) void tx_shuffle_kernel(const float* __restrict__ y, int R, int Cc, float* __restrict__ out, int inverse) {
+    const size_t n = (size_t)3 * R * R * 4 * Cc;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        // t indexes the channel-last side: [p][Y][X][co]
+        const int co = (int)(t % Cc);
+        size_t r = t / Cc;
+        const int X = (int)(r % (2 * R)); r /= 2 * R;
+        const int Y = (int)(r % (2 * R));
+        const int p = (int)(r / (2 * R));
+        const size_t tok = ((size_t)p * R + (Y >> 1)) * R + (X >> 1);
+        const size_t yi = tok * 4 * Cc + co * 4 + (Y & 1) * 2 + (X & 1);
+        if (inverse) const_cast<float*>(y)[yi] = out[t]; else out[t] = y[yi];
+    }
+}
+__global__ __launch_bounds__(256) void tx_add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n4, int accumulate) {
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(src)[t];
+        if (accumulate) { const float4 b = reinterpret_cast<float4*>(dst)[t]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        reinterpret_cast<float4*>(dst)[t] = a;
+    }
+}
+
+namespace {
+struct TxDims {
+    int layers, D, H, Dc, T, Tc, F, Cc, R, O;     // O = 4 * Cc: the deconvolution as a Linear
+    explicit TxDims(const asd_tritx_desc& d) : layers(d.n_layers), D(d.dim), H(d.heads), Dc(d.cond_dim), T(3 * d.low_res * d.low_res), Tc(d.cond_tokens),
+                                               F(d.hidden), Cc(d.out_channels), R(d.low_res), O(4 * d.out_channels) {}
+};
+inline int64_t plane_floats(int64_t rows, int64_t k) { return tx_al(rows * 3 * k / 2 + 64); }
+
+// packed weights of one layer / of the head, as offsets (floats) into the packed buffer
+struct TxPackLayer { int64_t caq_w, caq_iw, caq_t, caq_it, cakv_w, cakv_iw, cao_w, cao_iw, cao_t, cao_it, qkv_w, qkv_iw, qkv_t, qkv_it, sao_w, sao_iw, sao_t, sao_it,
+                             fc1_w, fc1_iw, fc1_t, fc1_it, fc2_w, fc2_iw, fc2_t, fc2_it, end; };
+TxPackLayer tx_pack_layout(const TxDims& d, int64_t base) {
+    TxPackLayer L;
+    int64_t o = base;
+    auto take = [&](int64_t n) { const int64_t at = o; o += tx_al(n); return at; };
+    auto planes = [&](int N, int K, int64_t& w, int64_t& iw, int64_t* t, int64_t* it) {
+        w = o; o += plane_floats(N, K); iw = take(N);
+        if (t) { *t = o; o += plane_floats(K, tx_rp(N)); *it = take(K); }
+    };
+    planes(d.D, d.D, L.caq_w, L.caq_iw, &L.caq_t, &L.caq_it);
+    planes(2 * d.D, d.Dc, L.cakv_w, L.cakv_iw, nullptr, nullptr);
+    planes(d.D, d.D, L.cao_w, L.cao_iw, &L.cao_t, &L.cao_it);
+    planes(3 * d.D, d.D, L.qkv_w, L.qkv_iw, &L.qkv_t, &L.qkv_it);
+    planes(d.D, d.D, L.sao_w, L.sao_iw, &L.sao_t, &L.sao_it);
+    planes(d.F, d.D, L.fc1_w, L.fc1_iw, &L.fc1_t, &L.fc1_it);
+    planes(d.D, d.F, L.fc2_w, L.fc2_iw, &L.fc2_t, &L.fc2_it);
+    L.end = o;
+    return L;
+}
+struct TxPackHead { int64_t dc_w, dc_iw, dc_t, dc_it, end; };
+TxPackHead tx_pack_head(const TxDims& d, int64_t base) {
+    TxPackHead h;
+    int64_t o = base;
+    h.dc_w = o; o += plane_floats(d.O, d.D); h.dc_iw = o; o += tx_al(d.O);
+    h.dc_t = o; o += plane_floats(d.D, tx_rp(d.O)); h.dc_it = o; o += tx_al(d.D);
+    h.end = o;
+    return h;
+}
+
+// saved activations of one layer (offsets in floats from the layer's base)
+struct TxSave { int64_t x_in, st1, n1, q_ca, kv_ca, o_ca, lse_ca, x1, st2, n2, qkv, o_sa, lse_sa, x2, st3, n3, u, hmid, end; };
+TxSave tx_save_layout(const TxDims& d) {
+    TxSave s;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += tx_al(n); return at; };
+    const int64_t TD = (int64_t)d.T * d.D;
+    s.x_in = take(TD); s.st1 = take(2 * d.T); s.n1 = take(TD); s.q_ca = take(TD); s.kv_ca = take((int64_t)d.Tc * 2 * d.D); s.o_ca = take(TD);
+    s.lse_ca = take((int64_t)d.H * d.T); s.x1 = take(TD); s.st2 = take(2 * d.T); s.n2 = take(TD); s.qkv = take(3 * TD); s.o_sa = take(TD);
+    s.lse_sa = take((int64_t)d.H * d.T); s.x2 = take(TD); s.st3 = take(2 * d.T); s.n3 = take(TD); s.u = take((int64_t)d.T * d.F); s.hmid = take((int64_t)d.T * d.F);
+    s.end = o;
+    return s;
+}
+// per batch element: layers x TxSave, then x_final, stF, nF, y
+inline int64_t tx_save_per_sample(const TxDims& d) {
+    return (int64_t)d.layers * tx_save_layout(d).end + tx_al((int64_t)d.T * d.D) * 2 + tx_al(2 * d.T) + tx_al((int64_t)d.T * d.O);
+}
+inline int64_t tx_max64(int64_t a, int64_t b) { return a > b ? a : b; }
+inline int64_t tx_op_ws(const TxDims& d) {
+    int64_t w = 0;
+    w = tx_max64(w, asd_tx_linear_workspace(d.T, d.F, d.D));
+    w = tx_max64(w, asd_tx_linear_workspace(d.T, d.D, d.F));
+    w = tx_max64(w, asd_tx_linear_workspace(d.T, 3 * d.D, d.D));
+    w = tx_max64(w, asd_tx_linear_workspace(d.T, d.D, 3 * d.D));
+    w = tx_max64(w, asd_tx_linear_workspace(d.Tc, 2 * d.D, d.Dc));
+    w = tx_max64(w, asd_tx_wgrad_workspace(d.T, d.F, d.D));
+    w = tx_max64(w, asd_tx_wgrad_workspace(d.T, d.D, d.F));
+    w = tx_max64(w, asd_tx_wgrad_workspace(d.T, 3 * d.D, d.D));
+    w = tx_max64(w, asd_tx_wgrad_workspace(d.Tc, 2 * d.D, d.Dc));
+    w = tx_max64(w, asd_tx_wgrad_workspace(d.T, d.D, d.O));
+    w = tx_max64(w, asd_tx_attention_workspace(d.T, d.T, d.H));
+    w = tx_max64(w, asd_tx_attention_workspace(d.T, d.Tc, d.H));
+    return tx_al(w);
+}
+inline int64_t tx_stage_floats(const TxDims& d) {
+    int64_t w = (int64_t)d.F * d.D;
+    w = tx_max64(w, (int64_t)3 * d.D * d.D);
+    w = tx_max64(w, (int64_t)2 * d.D * d.Dc);
+    w = tx_max64(w, (int64_t)d.D * d.O);
+    return tx_al(w) + tx_al(tx_max64(d.F, 3 * d.D));
+}
+int tx_check_desc(const asd_tritx_desc* d) {
+    ASD_CHECK_ARG(d && d->n_layers > 0 && d->heads > 0 && d->dim == d->heads * TX_HD, "tritx: dim must be heads * 48");
+    ASD_CHECK_ARG(d->dim % 64 == 0 && d->dim <= 1024 && d->cond_dim % 64 == 0 && d->hidden % 64 == 0 && (4 * d->out_channels) % 64 == 0 && d->low_res > 0 &&
+                  d->cond_tokens > 0, "tritx: dim / cond_dim / hidden / 4 * out_channels must be multiples of 64, dim <= 1024");
+    return ASD_OK;
+}
+#define TXS(call) do { const int rc__ = (call); if (rc__ != ASD_OK) return rc__; } while (0)
+}  // namespace
+
+int64_t asd_tritx_packed_floats(const asd_tritx_desc* desc) {
+    if (tx_check_desc(desc) != ASD_OK) return -1;
+    const TxDims d(*desc);
+    const int64_t per_layer = tx_pack_layout(d, 0).end;
+    // + staging for the stacked q|k|v and k|v weights
+    return tx_pack_head(d, per_layer * d.layers).end + tx_al((int64_t)3 * d.D * d.D) + tx_al((int64_t)2 * d.D * d.Dc) + tx_al(d.F + d.D + d.Dc + 64);
+}
+int64_t asd_tritx_save_floats(const asd_tritx_desc* desc, int32_t batch) {
+    if (tx_check_desc(desc) != ASD_OK) return -1;
+    return tx_save_per_sample(TxDims(*desc)) * batch;
+}
+int64_t asd_tritx_workspace_floats(const asd_tritx_desc* desc) {
+    if (tx_check_desc(desc) != ASD_OK) return -1;
+    const TxDims d(*desc);
+    // transient gradients of the backward pass: dx ping-pong (2), dn, do, dqkv (3), dkv, du, dy, the weight-gradient staging of batch
+    // elements > 0, + the op workspace
+    return tx_op_ws(d) + tx_al((int64_t)d.T * d.D) * 7 + tx_al((int64_t)d.Tc * 2 * d.D) + tx_al((int64_t)d.T * d.F) + tx_al((int64_t)d.T * d.O) +
+           tx_stage_floats(d) + 256;
+}
+
+// params: 20 * n_layers + 4 device pointers (order: include/asd_hip.h) -> packed operand planes of every weight
+int asd_tritx_pack(const asd_tritx_desc* desc, const float* const* params, float* packed, void* stream) {
+    TXS(tx_check_desc(desc));
+    ASD_CHECK_ARG(params && packed, "null argument");
+    const TxDims d(*desc);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t per_layer = tx_pack_layout(d, 0).end;
+    const TxPackHead hd = tx_pack_head(d, per_layer * d.layers);
+    float* stage_qkv = packed + hd.end;
+    float* stage_kv = stage_qkv + tx_al((int64_t)3 * d.D * d.D);
+    float* cws = stage_kv + tx_al((int64_t)2 * d.D * d.Dc);
+#define PK(w, N, K, WP, IW, TP, IT) TXS(asd_tx_pack_weight(w, N, K, packed + (WP), packed + (IW), (TP) >= 0 ? (void*)(packed + (TP)) : nullptr, (TP) >= 0 ? packed + (IT) : nullptr, cws, stream))
+    for (int l = 0; l < d.layers; ++l) {
+        const float* const* P = params + 20 * l;
+        const TxPackLayer L = tx_pack_layout(d, per_layer * l);
+        PK(P[2], d.D, d.D, L.caq_w, L.caq_iw, L.caq_t, L.caq_it);
+        (void)hipMemcpyAsync(stage_kv, P[3], (size_t)d.D * d.Dc * 4, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(stage_kv + (size_t)d.D * d.Dc, P[4], (size_t)d.D * d.Dc * 4, hipMemcpyDeviceToDevice, s);
+        PK(stage_kv, 2 * d.D, d.Dc, L.cakv_w, L.cakv_iw, (int64_t)-1, (int64_t)-1);
+        PK(P[5], d.D, d.D, L.cao_w, L.cao_iw, L.cao_t, L.cao_it);
+        for (int q = 0; q < 3; ++q) (void)hipMemcpyAsync(stage_qkv + (size_t)q * d.D * d.D, P[9 + q], (size_t)d.D * d.D * 4, hipMemcpyDeviceToDevice, s);
+        PK(stage_qkv, 3 * d.D, d.D, L.qkv_w, L.qkv_iw, L.qkv_t, L.qkv_it);
+        PK(P[12], d.D, d.D, L.sao_w, L.sao_iw, L.sao_t, L.sao_it);
+        PK(P[16], d.F, d.D, L.fc1_w, L.fc1_iw, L.fc1_t, L.fc1_it);
+        PK(P[18], d.D, d.F, L.fc2_w, L.fc2_iw, L.fc2_t, L.fc2_it);
+    }
+#undef PK
+    // ConvTranspose2d(D -> C, 2, 2) weight V [D, 4 C] is the TRANSPOSE of the equivalent Linear's weight [4 C, D]: its plane for y = x W^T is
+    // the column split of V, its plane for dx = dy W the row split of V
+    const float* V = params[20 * d.layers + 3];
+    unsigned* colmax = reinterpret_cast<unsigned*>(cws);
+    (void)hipMemsetAsync(colmax, 0, (size_t)d.O * 4, s);
+    hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(d.O, 64), asd_div_up(d.D, 256)), dim3(256), 0, s, V, d.D, d.O, d.O, 256, colmax, (float*)nullptr);
+    hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(d.O, 64), tx_rp(d.D) / 64), dim3(256), 0, s, V, d.D, d.O, d.O, tx_rp(d.D), colmax,
+                       reinterpret_cast<h16*>(packed + hd.dc_w), packed + hd.dc_iw);
+    hipLaunchKernelGGL((tx_split_rows_kernel<1>), dim3(asd_div_up(d.D, 4)), dim3(256), 0, s, V, d.D, d.O, d.O, reinterpret_cast<h16*>(packed + hd.dc_t), packed + hd.dc_it);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+// text_embed [batch, Tc, Dc] -> planes_cl [batch, 3, 2R, 2R, C] (channel-last); `save` keeps what asd_tritx_bwd needs
+int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const float* packed, const float* text_embed, int32_t batch, float* planes_cl,
+                  float* save, float* ws, void* stream) {
+    TXS(tx_check_desc(desc));
+    ASD_CHECK_ARG(params && packed && text_embed && planes_cl && save && ws && batch > 0, "null argument");
+    const TxDims d(*desc);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t per_layer = tx_pack_layout(d, 0).end;
+    const TxPackHead hd = tx_pack_head(d, per_layer * d.layers);
+    const TxSave S = tx_save_layout(d);
+    const int64_t TD = (int64_t)d.T * d.D;
+    const float eps = desc->eps;
+    for (int n = 0; n < batch; ++n) {
+        float* sv = save + (int64_t)n * tx_save_per_sample(d);
+        const float* cond = text_embed + (int64_t)n * d.Tc * d.Dc;
+        const float* x = params[20 * d.layers];        // pos_embed
+        for (int l = 0; l < d.layers; ++l) {
+            const float* const* P = params + 20 * l;
+            const TxPackLayer L = tx_pack_layout(d, per_layer * l);
+            float* B = sv + (int64_t)l * S.end;
+            if (x != B + S.x_in)     // layer 0: the position embedding; later layers found their input written in place by the layer before
+                hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(TD / 4, 256)), dim3(256), 0, s, B + S.x_in, x, (size_t)(TD / 4), 0);
+            x = B + S.x_in;
+            // cross-attention
+            TXS(asd_tx_layernorm_fwd(x, d.T, d.D, P[0], P[1], eps, B + S.n1, B + S.st1, stream));
+            TXS(asd_tx_linear(B + S.n1, d.T, d.D, d.D, packed + L.caq_w, packed + L.caq_iw, d.D, nullptr, 0, nullptr, nullptr, 0, B + S.q_ca, d.D, ws, stream));
+            TXS(asd_tx_linear(cond, d.Tc, d.Dc, d.Dc, packed + L.cakv_w, packed + L.cakv_iw, 2 * d.D, nullptr, 0, nullptr, nullptr, 0, B + S.kv_ca, 2 * d.D, ws, stream));
+            TXS(asd_tx_attention_fwd(B + S.q_ca, d.D, B + S.kv_ca, 2 * d.D, B + S.kv_ca + d.D, 2 * d.D, d.T, d.Tc, d.H, B + S.o_ca, d.D, B + S.lse_ca, ws, stream));
+            TXS(asd_tx_linear(B + S.o_ca, d.T, d.D, d.D, packed + L.cao_w, packed + L.cao_iw, d.D, P[6], 0, nullptr, x, d.D, B + S.x1, d.D, ws, stream));
+            // self-attention
+            TXS(asd_tx_layernorm_fwd(B + S.x1, d.T, d.D, P[7], P[8], eps, B + S.n2, B + S.st2, stream));
+            TXS(asd_tx_linear(B + S.n2, d.T, d.D, d.D, packed + L.qkv_w, packed + L.qkv_iw, 3 * d.D, nullptr, 0, nullptr, nullptr, 0, B + S.qkv, 3 * d.D, ws, stream));
+            TXS(asd_tx_attention_fwd(B + S.qkv, 3 * d.D, B + S.qkv + d.D, 3 * d.D, B + S.qkv + 2 * d.D, 3 * d.D, d.T, d.T, d.H, B + S.o_sa, d.D, B + S.lse_sa, ws, stream));
+            TXS(asd_tx_linear(B + S.o_sa, d.T, d.D, d.D, packed + L.sao_w, packed + L.sao_iw, d.D, P[13], 0, nullptr, B + S.x1, d.D, B + S.x2, d.D, ws, stream));
+            // MLP
+            TXS(asd_tx_layernorm_fwd(B + S.x2, d.T, d.D, P[14], P[15], eps, B + S.n3, B + S.st3, stream));
+            TXS(asd_tx_linear(B + S.n3, d.T, d.D, d.D, packed + L.fc1_w, packed + L.fc1_iw, d.F, P[17], 1, B + S.u, nullptr, 0, B + S.hmid, d.F, ws, stream));
+            float* xo = l + 1 < d.layers ? sv + (int64_t)(l + 1) * S.end + S.x_in : sv + (int64_t)d.layers * S.end;     // next layer's input slot / x_final
+            TXS(asd_tx_linear(B + S.hmid, d.T, d.F, d.F, packed + L.fc2_w, packed + L.fc2_iw, d.D, P[19], 0, nullptr, B + S.x2, d.D, xo, d.D, ws, stream));
+            x = xo;
+        }
+        float* xf = sv + (int64_t)d.layers * S.end;
+        float* stF = xf + tx_al(TD);
+        float* nF = stF + tx_al(2 * d.T);
+        float* y = nF + tx_al(TD);
+        TXS(asd_tx_layernorm_fwd(xf, d.T, d.D, params[20 * d.layers + 1], params[20 * d.layers + 2], eps, nF, stF, stream));
+        TXS(asd_tx_linear(nF, d.T, d.D, d.D, packed + hd.dc_w, packed + hd.dc_iw, d.O, nullptr, 0, nullptr, nullptr, 0, y, d.O, ws, stream));
+        hipLaunchKernelGGL(tx_shuffle_kernel, dim3(asd_grid_for((int64_t)d.T * d.O, 256)), dim3(256), 0, s, y, d.R, d.Cc, planes_cl + (int64_t)n * d.T * d.O, 0);
+    }
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+// grads: 17 * n_layers + 4 device pointers (order: include/asd_hip.h; q|k|v and k|v gradients stacked), WRITTEN (summed over the batch)
+int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const float* packed, const float* text_embed, int32_t batch,
+                  const float* d_planes_cl, const float* save, float* const* grads, float* ws, void* stream) {
+    TXS(tx_check_desc(desc));
+    ASD_CHECK_ARG(params && packed && text_embed && d_planes_cl && save && grads && ws && batch > 0, "null argument");
+    const TxDims d(*desc);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t per_layer = tx_pack_layout(d, 0).end;
+    const TxPackHead hd = tx_pack_head(d, per_layer * d.layers);
+    const TxSave S = tx_save_layout(d);
+    const int64_t TD = (int64_t)d.T * d.D;
+    float* p = ws + tx_op_ws(d);
+    float* dxa = p; p += tx_al(TD);
+    float* dxb = p; p += tx_al(TD);
+    float* dn = p; p += tx_al(TD);
+    float* dob = p; p += tx_al(TD);
+    float* dqkv = p; p += 3 * tx_al(TD);
+    float* dkv = p; p += tx_al((int64_t)d.Tc * 2 * d.D);
+    float* du = p; p += tx_al((int64_t)d.T * d.F);
+    float* dy = p; p += tx_al((int64_t)d.T * d.O);
+    float* stage = p;
+    float* stage_b = stage + (tx_stage_floats(d) - tx_al(tx_max64(d.F, 3 * d.D)));
+    // LayerNorm gradients accumulate over layers' rows and the batch: zero them once
+    for (int l = 0; l < d.layers; ++l) {
+        float* const* G = grads + 17 * l;
+        for (int q : {0, 1, 6, 7, 11, 12}) (void)hipMemsetAsync(G[q], 0, (size_t)d.D * 4, s);
+    }
+    float* const* GH = grads + 17 * d.layers;       // pos_embed, norm.w, norm.b, deconv.w
+    (void)hipMemsetAsync(GH[1], 0, (size_t)d.D * 4, s);
+    (void)hipMemsetAsync(GH[2], 0, (size_t)d.D * 4, s);
+    // weight gradients of batch element n > 0 are added to those of the elements before it: staged through `stage`
+    auto wgrad = [&](const float* dyp, int ldy, const float* xp, int ldx, int M, int N, int K, float* dw, float* db, bool acc) -> int {
+        if (!acc) return asd_tx_linear_wgrad(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, stream);
+        float* tmp = stage;
+        float* tb = stage_b;
+        TXS(asd_tx_linear_wgrad(dyp, ldy, xp, ldx, M, N, K, tmp, db ? tb : nullptr, ws, stream));
+        hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, dw, tmp, (size_t)((int64_t)N * K / 4), 1);
+        if (db) hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(N / 4, 256)), dim3(256), 0, s, db, tb, (size_t)(N / 4), 1);
+        return ASD_OK;
+    };
+    for (int n = 0; n < batch; ++n) {
+        const bool acc = n > 0;
+        const float* sv = save + (int64_t)n * tx_save_per_sample(d);
+        const float* cond = text_embed + (int64_t)n * d.Tc * d.Dc;
+        const float* xf = sv + (int64_t)d.layers * S.end;
+        const float* stF = xf + tx_al(TD);
+        const float* nF = stF + tx_al(2 * d.T);
+        // head: planes -> y -> nF -> x_final
+        hipLaunchKernelGGL(tx_shuffle_kernel, dim3(asd_grid_for((int64_t)d.T * d.O, 256)), dim3(256), 0, s, dy, d.R, d.Cc,
+                           const_cast<float*>(d_planes_cl) + (int64_t)n * d.T * d.O, 1);
+        // dV [D, 4C] = nF^T dy: the "Linear" with the roles of x and dy swapped
+        TXS(wgrad(nF, d.D, dy, d.O, d.T, d.D, d.O, GH[3], nullptr, acc));
+        TXS(asd_tx_linear(dy, d.T, d.O, d.O, packed + hd.dc_t, packed + hd.dc_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
+        float* dx = dxa;
+        float* dx_other = dxb;
+        TXS(asd_tx_layernorm_bwd(dn, xf, stF, params[20 * d.layers + 1], d.T, d.D, nullptr, dx, GH[1], GH[2], stream));
+        for (int l = d.layers - 1; l >= 0; --l) {
+            const float* const* P = params + 20 * l;
+            float* const* G = grads + 17 * l;
+            const TxPackLayer L = tx_pack_layout(d, per_layer * l);
+            const float* B = sv + (int64_t)l * S.end;
+            // ---- MLP: x3 = x2 + fc2(gelu(fc1(n3)))
+            TXS(wgrad(dx, d.D, B + S.hmid, d.F, d.T, d.D, d.F, G[15], G[16], acc));
+            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.fc2_t, packed + L.fc2_it, d.F, nullptr, 2, const_cast<float*>(B + S.u), nullptr, 0, du, d.F, ws, stream));
+            TXS(asd_tx_linear(du, d.T, d.F, d.F, packed + L.fc1_t, packed + L.fc1_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
+            TXS(wgrad(du, d.F, B + S.n3, d.D, d.T, d.F, d.D, G[13], G[14], acc));
+            TXS(asd_tx_layernorm_bwd(dn, B + S.x2, B + S.st3, P[14], d.T, d.D, dx, dx_other, G[11], G[12], stream));
+            { float* t = dx; dx = dx_other; dx_other = t; }
+            // ---- self-attention: x2 = x1 + o_sa Wo^T + bo
+            TXS(wgrad(dx, d.D, B + S.o_sa, d.D, d.T, d.D, d.D, G[9], G[10], acc));
+            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.sao_t, packed + L.sao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, stream));
+            TXS(asd_tx_attention_bwd(B + S.qkv, 3 * d.D, B + S.qkv + d.D, 3 * d.D, B + S.qkv + 2 * d.D, 3 * d.D, B + S.o_sa, d.D, dob, d.D, B + S.lse_sa, d.T, d.T, d.H,
+                                     dqkv, 3 * d.D, dqkv + d.D, 3 * d.D, dqkv + 2 * d.D, 3 * d.D, ws, stream));
+            TXS(wgrad(dqkv, 3 * d.D, B + S.n2, d.D, d.T, 3 * d.D, d.D, G[8], nullptr, acc));
+            TXS(asd_tx_linear(dqkv, d.T, 3 * d.D, 3 * d.D, packed + L.qkv_t, packed + L.qkv_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
+            TXS(asd_tx_layernorm_bwd(dn, B + S.x1, B + S.st2, P[7], d.T, d.D, dx, dx_other, G[6], G[7], stream));
+            { float* t = dx; dx = dx_other; dx_other = t; }
+            // ---- cross-attention: x1 = x0 + o_ca Wo^T + bo
+            TXS(wgrad(dx, d.D, B + S.o_ca, d.D, d.T, d.D, d.D, G[4], G[5], acc));
+            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.cao_t, packed + L.cao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, stream));
+            TXS(asd_tx_attention_bwd(B + S.q_ca, d.D, B + S.kv_ca, 2 * d.D, B + S.kv_ca + d.D, 2 * d.D, B + S.o_ca, d.D, dob, d.D, B + S.lse_ca, d.T, d.Tc, d.H,
+                                     dqkv, d.D, dkv, 2 * d.D, dkv + d.D, 2 * d.D, ws, stream));
+            TXS(wgrad(dqkv, d.D, B + S.n1, d.D, d.T, d.D, d.D, G[2], nullptr, acc));
+            TXS(wgrad(dkv, 2 * d.D, cond, d.Dc, d.Tc, 2 * d.D, d.Dc, G[3], nullptr, acc));
+            TXS(asd_tx_linear(dqkv, d.T, d.D, d.D, packed + L.caq_t, packed + L.caq_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
+            TXS(asd_tx_layernorm_bwd(dn, B + S.x_in, B + S.st1, P[0], d.T, d.D, dx, dx_other, G[0], G[1], stream));
+            { float* t = dx; dx = dx_other; dx_other = t; }
+        }
+        hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(TD / 4, 256)), dim3(256), 0, s, GH[0], dx, (size_t)(TD / 4), acc ? 1 : 0);
+    }
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
 }  // extern "C"

@@ -16,12 +16,16 @@ Parameter names and shapes are the reference's, so its checkpoints load with loa
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
 
 
 # ---- StyleGAN-3D --------------------------------------------------------------------------------------------------------
@@ -450,10 +454,64 @@ class ConditionModulationBlockwoCrossAttn(nn.Module):
         return x[:, 1:, :]
 
 
+class _TritxFn(torch.autograd.Function):
+    """the whole generator as ONE autograd node on the HIP path (include/asd_hip.h: asd_tritx_pack / _fwd / _bwd, csrc/tritx.hip): every
+    Linear / attention product on the fp16 matrix pipe at fp32-class accuracy (operands split into two fp16 planes), LayerNorm / GELU /
+    residuals in fp32; nothing in between is a Python-issued launch"""
+
+    @staticmethod
+    def forward(ctx, module, text_embed, *params):
+        desc, table, packed = module._tritx_state(params)
+        n = text_embed.shape[0]
+        dev = text_embed.device
+        L = _lib.lib()
+        planes = torch.empty((n, 3, 2 * desc.low_res, 2 * desc.low_res, desc.out_channels), device=dev, dtype=torch.float32)
+        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        save = torch.empty(L.asd_tritx_save_floats(C.byref(desc), _lib.i32(n)), device=dev, dtype=torch.float32)
+        ws = module._tritx_workspace(desc, dev)
+        te = text_embed.contiguous().float()
+        _lib.check(L.asd_tritx_fwd(C.byref(desc), table, _lib.ptr(packed), _lib.ptr(te), _lib.i32(n), _lib.ptr(planes), _lib.ptr(save), _lib.ptr(ws), _lib.stream()))
+        ctx.module, ctx.desc, ctx.table, ctx.packed, ctx.save, ctx.te = module, desc, table, packed, save, te
+        ctx.params = params                     # (held for their pointers: the table refers to them)
+        ctx.set_materialize_grads(False)
+        return planes.permute(0, 1, 4, 2, 3)     # the reference's [N, 3, C, H, W] as a view of the channel-last planes
+
+    @staticmethod
+    def backward(ctx, d_planes):
+        params, desc, module = ctx.params, ctx.desc, ctx.module
+        if d_planes is None:
+            return (None, None) + (None,) * len(params)
+        dev = d_planes.device
+        d_cl = d_planes.permute(0, 1, 3, 4, 2).contiguous().float()
+        nl, D, Dc = desc.n_layers, desc.dim, desc.cond_dim
+        grads, ptrs = [None] * len(params), []
+        for l in range(nl):
+            P = params[20 * l:20 * l + 20]
+            kv = torch.empty((2 * D, Dc), device=dev)
+            qkv = torch.empty((3 * D, D), device=dev)
+            g = {i: torch.empty_like(P[i]) for i in (0, 1, 2, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19)}
+            g[3], g[4] = kv[:D], kv[D:]
+            g[9], g[10], g[11] = qkv[:D], qkv[D:2 * D], qkv[2 * D:]
+            for i in range(20):
+                grads[20 * l + i] = g[i]
+            ptrs += [g[0], g[1], g[2], kv, g[5], g[6], g[7], g[8], qkv, g[12], g[13], g[14], g[15], g[16], g[17], g[18], g[19]]
+        for i in range(4):
+            grads[20 * nl + i] = torch.empty_like(params[20 * nl + i])
+            ptrs.append(grads[20 * nl + i])
+        gtable = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
+        ws = module._tritx_workspace(desc, dev)
+        n = ctx.te.shape[0]
+        _lib.check(_lib.lib().asd_tritx_bwd(C.byref(desc), ctx.table, _lib.ptr(ctx.packed), _lib.ptr(ctx.te), _lib.i32(n), _lib.ptr(d_cl), _lib.ptr(ctx.save),
+                                            gtable, _lib.ptr(ws), _lib.stream()))
+        ctx.save = None
+        return (None, None) + tuple(g if p.requires_grad else None for g, p in zip(grads, params))
+
+
 class TriplaneTransformer(nn.Module):
     def __init__(self, inner_dim, condition_dim, triplane_low_res, triplane_high_res, triplane_dim, num_layers, num_heads, local_text,
-                 mlp_ratio=4.0, eps=1e-6, **unused):
+                 mlp_ratio=4.0, eps=1e-6, backend="hip", **unused):
         super().__init__()
+        self.backend, self.eps, self.num_heads = backend, eps, num_heads
         self.triplane_low_res, self.triplane_high_res, self.triplane_dim = triplane_low_res, triplane_high_res, triplane_dim
         self.pos_embed = nn.Parameter(torch.randn(1, 3 * triplane_low_res ** 2, inner_dim) * (1.0 / inner_dim) ** 0.5)
         self.needs_local_text = local_text
@@ -465,7 +523,60 @@ class TriplaneTransformer(nn.Module):
         if not local_text:
             self.proj = nn.Linear(condition_dim, inner_dim)
 
+    # ---- HIP path (the shipped configuration: local_text = True, head dim 48) ----------------------------------------------------------------
+    _LAYER_KEYS = ("norm1.weight", "norm1.bias", "cross_attn.to_q.weight", "cross_attn.to_k.weight", "cross_attn.to_v.weight", "cross_attn.to_out.0.weight",
+                   "cross_attn.to_out.0.bias", "norm2.weight", "norm2.bias", "self_attn.to_q.weight", "self_attn.to_k.weight", "self_attn.to_v.weight",
+                   "self_attn.to_out.0.weight", "self_attn.to_out.0.bias", "norm3.weight", "norm3.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias")
+
+    def _hip_ok(self, text_embed) -> bool:
+        d = self.pos_embed.shape[-1]
+        return (self.backend == "hip" and self.needs_local_text and text_embed.is_cuda and text_embed.dim() == 3 and d == self.num_heads * 48
+                and d % 64 == 0 and d <= 1024 and self.triplane_high_res == 2 * self.triplane_low_res and (4 * self.triplane_dim) % 64 == 0
+                and os.environ.get("ASD_TRITX", "1") != "0")
+
+    def _hip_params(self):
+        ps = []
+        for layer in self.layers:
+            named = dict(layer.named_parameters())
+            ps += [named[k] for k in self._LAYER_KEYS]
+        return ps + [self.pos_embed, self.norm.weight, self.norm.bias, self.deconv.weight]
+
+    def _tritx_state(self, params):
+        """(descriptor, pointer table, packed operand planes); the planes are rebuilt when a weight has changed (optimizer step, checkpoint load)"""
+        key = (self._cond_tokens,) + tuple((p.data_ptr(), p._version) for p in params)
+        st = getattr(self, "_tritx_cache", None)
+        if st is not None and st[0] == key:
+            return st[1], st[2], st[3]
+        layer0 = self.layers[0]
+        desc = _lib.TritxDesc(n_layers=len(self.layers), dim=self.pos_embed.shape[-1], heads=self.num_heads, cond_dim=layer0.cross_attn.to_k.weight.shape[1],
+                              cond_tokens=self._cond_tokens, hidden=layer0.mlp[0].weight.shape[0], low_res=self.triplane_low_res,
+                              out_channels=self.triplane_dim, eps=float(self.eps))
+        for p in params:
+            if not (p.is_contiguous() and p.dtype == torch.float32):
+                raise _lib.AsdError("TriplaneTransformer (HIP): parameters must be contiguous fp32")
+        table = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        n = _lib.lib().asd_tritx_packed_floats(C.byref(desc))
+        if n < 0:
+            raise _lib.AsdError(_lib.lib().asd_last_error().decode())
+        packed = st[3] if st is not None and st[3].numel() == n else torch.empty(n, device=params[0].device, dtype=torch.float32)
+        _lib.check(_lib.lib().asd_tritx_pack(C.byref(desc), table, _lib.ptr(packed), _lib.stream()))
+        self._tritx_cache = (key, desc, table, packed)
+        return desc, table, packed
+
+    def _tritx_workspace(self, desc, dev):
+        n = _lib.lib().asd_tritx_workspace_floats(C.byref(desc))
+        ws = getattr(self, "_tritx_ws", None)
+        if ws is None or ws.numel() < n or ws.device != dev:
+            ws = self._tritx_ws = torch.empty(n, device=dev, dtype=torch.float32)
+        return ws
+
     def forward(self, text_embed):
+        if self._hip_ok(text_embed):
+            self._cond_tokens = text_embed.shape[1]
+            return _TritxFn.apply(self, text_embed, *self._hip_params())
+        if self.backend == "hip" and text_embed.is_cuda and self.needs_local_text and os.environ.get("ASD_TRITX", "1") != "0":
+            raise NotImplementedError("TriplaneTransformer (HIP): built for head dim 48, width % 64 == 0 and <= 1024, 2x deconvolution "
+                                      "(the shipped asd_mv_triplane_transformer configs); pass backend='library' for other shapes")
         N, Hh = text_embed.shape[0], self.triplane_low_res
         if not self.needs_local_text:
             text_embed = self.proj(text_embed).unsqueeze(1)

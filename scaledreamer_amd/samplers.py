@@ -65,7 +65,12 @@ def channels_last(x: torch.Tensor) -> torch.Tensor:
 
 
 def planes_channels_last(planes: torch.Tensor) -> torch.Tensor:
-    """[N, 3, C, H, W] -> [N, 3, H, W, C], cached per tensor version."""
+    """[N, 3, C, H, W] -> [N, 3, H, W, C], cached per tensor version.  Planes that already are channel-last in memory (the HIP transformer's
+    output: a permuted view) are handed on as that view — no kernel, no copy."""
+    cl = planes.permute(0, 1, 3, 4, 2)
+    if cl.is_contiguous():
+        return cl
+
     def make(p):
         N, _, Cc, H, W = p.shape
         return _ChannelsLast.apply(p.reshape(N * 3, Cc, H, W)).view(N, 3, H, W, Cc)

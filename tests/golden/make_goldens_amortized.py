@@ -214,6 +214,37 @@ def make_generator_goldens(seed=12):
     print("generator goldens written")
 
 
+TRI_HD48 = dict(inner_dim=192, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4, local_text=True,
+                mlp_ratio=4)
+
+
+def make_tritx_hd48_golden(seed=21):
+    """the reference TriplaneTransformer at the shipped configuration's HEAD DIMENSION (48 = 768 / 16; asd_mv_triplane_transformer_10k.yaml:44-50)
+    on a reduced width — the shape family the HIP generator (csrc/tritx.hip) is built for: planes and the gradient of EVERY parameter,
+    batch of two prompts with 77 text tokens each."""
+    from scaledreamer_amd import generators as G
+    H._mod("diffusers")
+    H._mod("diffusers.models")
+    H._mod("diffusers.models.attention_processor", Attention=G.Attention)
+    from custom.amortized.extern.triplane_transformer_modules import TriplaneTransformer
+
+    tt = TriplaneTransformer(**TRI_HD48).double()
+    with torch.no_grad():
+        for k, p in tt.named_parameters():
+            scale = 1.0 if k.endswith(("norm1.weight", "norm2.weight", "norm3.weight")) or k == "norm.weight" else 0.2
+            p.copy_(seeded(f"tri48.{k}", tuple(p.shape), seed, scale).double())
+    te = seeded("tri48.text", (2, 77, 128), seed).double()
+    planes = tt(te)
+    gp = seeded("tri48.g", tuple(planes.shape), seed).double()
+    (planes * gp).sum().backward()
+    save = {"seed": seed, "keys": np.array(list(tt.state_dict().keys())), "planes": planes.detach().float().numpy()}
+    for k, p in tt.named_parameters():
+        save["g." + k] = p.grad.float().numpy()
+    path = os.path.join(HERE, "amortized_triplane_transformer_hd48.npz")
+    np.savez_compressed(path, **save)
+    print(f"tritx hd48 golden: planes {tuple(planes.shape)} |planes| max {planes.abs().max().item():.3f} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 GEN3D_SMALL = dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16, img_channels=32, channel_multiplier=1)
 TRI_SMALL = dict(inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
                  local_text=True, mlp_ratio=4)
@@ -276,6 +307,9 @@ def make_adan_golden(seed=5):
 
 
 if __name__ == "__main__":
+    if "--tritx" in sys.argv:
+        make_tritx_hd48_golden()
+        sys.exit(0)
     if "--generators" in sys.argv:
         make_generator_goldens()
         make_sampled_geometry_goldens()

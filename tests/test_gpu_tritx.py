@@ -192,3 +192,54 @@ def test_attention_backward(Lq, Lk, H, fused):
     for name, got, want, lib32 in (("dq", dq, qd.grad, q32.grad), ("dk", dk, kd.grad, k32.grad), ("dv", dv, vd.grad, v32.grad)):
         e, e32 = rel(got, want), rel(lib32, want)
         assert e < 5e-6, (name, e, e32)
+
+
+def _seeded(name, shape, seed, scale=1.0):
+    import zlib
+    g = torch.Generator().manual_seed((seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g) * scale
+
+
+TRI_HD48 = dict(inner_dim=192, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4, local_text=True,
+                mlp_ratio=4)
+
+
+def test_whole_generator_matches_the_reference_module():
+    """scaledreamer_amd.generators.TriplaneTransformer on its HIP path (one autograd node over asd_tritx_fwd / _bwd) against the REFERENCE's
+    own TriplaneTransformer (custom/amortized/extern/triplane_transformer_modules.py:115-187) evaluated in float64 in the build container
+    (tests/golden/make_goldens_amortized.py --tritx -> amortized_triplane_transformer_hd48.npz): the planes and the gradient of every one
+    of the 44 parameters, two prompts x 77 text tokens, head dimension 48 as in the shipped configuration."""
+    import os
+
+    from scaledreamer_amd.generators import TriplaneTransformer
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "amortized_triplane_transformer_hd48.npz"))
+    seed = int(g["seed"])
+    tt = TriplaneTransformer(**TRI_HD48)
+    assert list(tt.state_dict().keys()) == g["keys"].tolist()
+    with torch.no_grad():
+        for k, p in tt.named_parameters():
+            scale = 1.0 if k.endswith(("norm1.weight", "norm2.weight", "norm3.weight")) or k == "norm.weight" else 0.2
+            p.copy_(_seeded(f"tri48.{k}", tuple(p.shape), seed, scale))
+    tt = tt.cuda()
+    te = _seeded("tri48.text", (2, 77, 128), seed).cuda()
+    planes = tt(te)
+    assert planes.shape == (2, 3, 32, 16, 16) and planes.permute(0, 1, 3, 4, 2).is_contiguous()      # channel-last in memory: the field kernels' layout
+    want = torch.from_numpy(g["planes"]).double().cuda()
+    gp = _seeded("tri48.g", tuple(planes.shape), seed).cuda()
+    (planes * gp).sum().backward()
+    # the same module on library fp32 ops (what the HIP path replaces) sets the scale: this seeded network amplifies rounding ~30x
+    tl = TriplaneTransformer(**TRI_HD48, backend="library").cuda()
+    tl.load_state_dict(tt.state_dict())
+    pl = tl(te)
+    (pl * gp).sum().backward()
+    e_hip, e_lib = rel(planes.detach(), want), rel(pl.detach(), want)
+    worst, worst_lib = ("", 0.0), ("", 0.0)
+    lib_grads = dict(tl.named_parameters())
+    for k, p in tt.named_parameters():
+        ref = torch.from_numpy(g["g." + k]).double().cuda()
+        worst = max(worst, (k, rel(p.grad, ref)), key=lambda t: t[1])
+        worst_lib = max(worst_lib, (k, rel(lib_grads[k].grad, ref)), key=lambda t: t[1])
+    print("planes: hip", e_hip, "library fp32", e_lib, "| worst parameter gradient: hip", worst, "library fp32", worst_lib)
+    assert e_hip < max(2e-5, 3 * e_lib), (e_hip, e_lib)
+    assert worst[1] < max(5e-5, 3 * worst_lib[1]), (worst, worst_lib)
