@@ -700,6 +700,7 @@ typedef struct asd_tritx_desc {
     int32_t n_layers, dim /* D = heads * 48 */, heads, cond_dim /* Dc */, cond_tokens /* Tc */, hidden /* F */, low_res /* R: 3 R R tokens */,
             out_channels /* C */;
     float eps;
+    int32_t grads_prezeroed;   /* asd_tritx_bwd: the caller has zeroed every LayerNorm / bias gradient buffer (they are accumulated into) */
 } asd_tritx_desc;
 int64_t asd_tritx_packed_floats(const asd_tritx_desc* desc);
 int64_t asd_tritx_save_floats(const asd_tritx_desc* desc, int32_t batch);

@@ -119,7 +119,7 @@ class OptTensor(C.Structure):
 
 class TritxDesc(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32), ("cond_dim", C.c_int32), ("cond_tokens", C.c_int32),
-                ("hidden", C.c_int32), ("low_res", C.c_int32), ("out_channels", C.c_int32), ("eps", C.c_float)]
+                ("hidden", C.c_int32), ("low_res", C.c_int32), ("out_channels", C.c_int32), ("eps", C.c_float), ("grads_prezeroed", C.c_int32)]
 
 
 class WeightInfo(C.Structure):

@@ -79,26 +79,37 @@ __global__ __launch_bounds__(256) void tx_split_rows_kernel(const float* __restr
     }
 }
 
-// column max |x| (as uint bits: monotone for non-negative floats) and column sums of X [R, C]: blocks of 64 columns x `rows_per_block` rows
+// column max |x| (as uint bits: monotone for non-negative floats) and column sums of X [R, C] (C % 4 == 0): a block covers 64 columns (16
+// float4 lanes) x `rows_per_block` rows (16 row lanes); one atomic per column and block
 __global__ __launch_bounds__(256) void tx_colstat_kernel(const float* __restrict__ x, int R, int C, int ld, int rows_per_block,
                                                          unsigned* __restrict__ colmax, float* __restrict__ colsum) {
-    __shared__ float smax[4][64], ssum[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ float4 smax[16][16], ssum[16][16];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float m = 0.f, s = 0.f;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = m;
     if (c < C)
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const float v = x[(size_t)r * ld + c];
-            m = fmaxf(m, fabsf(v));
-            s += v;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + c);
+            m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-    smax[rl][threadIdx.x & 63] = m; ssum[rl][threadIdx.x & 63] = s;
+    smax[rl][cg] = m; ssum[rl][cg] = s;
     __syncthreads();
-    if (rl == 0 && c < C) {
-        m = fmaxf(fmaxf(smax[0][threadIdx.x], smax[1][threadIdx.x]), fmaxf(smax[2][threadIdx.x], smax[3][threadIdx.x]));
-        s = (ssum[0][threadIdx.x] + ssum[1][threadIdx.x]) + (ssum[2][threadIdx.x] + ssum[3][threadIdx.x]);
-        if (colmax) atomicMax(colmax + c, __float_as_uint(m));
-        if (colsum) atomicAdd(colsum + c, s);
+    if (threadIdx.x < 64) {
+        const int col = threadIdx.x, g = col >> 2, e = col & 3;
+        float mm = 0.f, sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 a = smax[q][g], b = ssum[q][g];
+            mm = fmaxf(mm, e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w);
+            sm += e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
+        }
+        const int cc = blockIdx.x * 64 + col;
+        if (cc < C) {
+            if (colmax) atomicMax(colmax + cc, __float_as_uint(mm));
+            if (colsum) atomicAdd(colsum + cc, sm);
+        }
     }
 }
 
@@ -261,12 +272,24 @@ __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __re
             }
         }
     }
+    // the block's four waves meet in LDS: one atomic per column and block
+    __shared__ float4 sg[4][256], sb[4][256];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane * 4 + 256 * i;
+    for (int i = 0; i < 4; ++i) { sg[w][lane + 64 * i] = ag[i]; sb[w][lane + 64 * i] = ab[i]; }
+    __syncthreads();
+    {
+        const int t = threadIdx.x;          // float4 slot t <-> columns (t & 63) * 4 + 256 * (t >> 6)
+        const int c = (t & 63) * 4 + 256 * (t >> 6);
         if (c < D) {
-            atomicAdd(dgamma + c, ag[i].x); atomicAdd(dgamma + c + 1, ag[i].y); atomicAdd(dgamma + c + 2, ag[i].z); atomicAdd(dgamma + c + 3, ag[i].w);
-            atomicAdd(dbeta + c, ab[i].x); atomicAdd(dbeta + c + 1, ab[i].y); atomicAdd(dbeta + c + 2, ab[i].z); atomicAdd(dbeta + c + 3, ab[i].w);
+            float4 a = sg[0][t], b = sb[0][t];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                a.x += sg[q][t].x; a.y += sg[q][t].y; a.z += sg[q][t].z; a.w += sg[q][t].w;
+                b.x += sb[q][t].x; b.y += sb[q][t].y; b.z += sb[q][t].z; b.w += sb[q][t].w;
+            }
+            atomicAdd(dgamma + c, a.x); atomicAdd(dgamma + c + 1, a.y); atomicAdd(dgamma + c + 2, a.z); atomicAdd(dgamma + c + 3, a.w);
+            atomicAdd(dbeta + c, b.x); atomicAdd(dbeta + c + 1, b.y); atomicAdd(dbeta + c + 2, b.z); atomicAdd(dbeta + c + 3, b.w);
         }
     }
 }
@@ -283,11 +306,16 @@ __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __re
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__global__ __launch_bounds__(256) void tx_attn_absmax_kernel(const float* __restrict__ x, int L, int ld, int H, unsigned* __restrict__ amax /*[H]*/) {
-    // grid (ceil(L / 64), H): 64 rows x 48 columns per block
-    const int h = blockIdx.y, r0 = blockIdx.x * 64;
+struct tx_absmax_args { const float* x[4]; int L[4], ld[4]; };
+// max |x| per (tensor, head): grid (blocks of 256 rows, H, tensors); 12 float4 lanes per row, one atomic per block
+__global__ __launch_bounds__(256) void tx_attn_absmax_kernel(const tx_absmax_args a, int H, unsigned* __restrict__ amax /*[tensors][H]*/) {
+    __shared__ float part[4];
+    const int h = blockIdx.y, z = blockIdx.z, L = a.L[z], ld = a.ld[z];
+    const float* x = a.x[z];
+    const int r0 = blockIdx.x * 256;
+    if (r0 >= L) return;
     float m = 0.f;
-    for (int t = threadIdx.x; t < 64 * (TX_HD / 4); t += 256) {
+    for (int t = threadIdx.x; t < 256 * (TX_HD / 4); t += 256) {
         const int r = r0 + t / (TX_HD / 4), c = (t % (TX_HD / 4)) * 4;
         if (r < L) {
             const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + h * TX_HD + c);
@@ -295,7 +323,9 @@ __global__ __launch_bounds__(256) void tx_attn_absmax_kernel(const float* __rest
         }
     }
     m = tx_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(amax + h, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax + z * H + h, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 // row-major planes [H][Lp][48] (rows >= L zero): hi, lo
@@ -350,6 +380,48 @@ __device__ __forceinline__ f32x16 tx_mfma3(const h16x8 ah, const h16x8 al, const
 }
 __device__ __forceinline__ int tx_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }     // C / D row of register r
 
+// ---- streamed tiles through LDS: the four waves of a block walk the same sequence of 32-token tiles -----------------------------------
+// A row-major plane tile is 32 rows x 48 halfs (contiguous in the plane), kept at a 112-byte row pitch: ds_read_b128 of 32 rows at one
+// offset is conflict-free (28 banks per row: rows i and i + 16 would collide, and they never sit in the same 16-lane group).  A transposed
+// plane tile is 48 rows (d) x 32 tokens at a 72-byte pitch (18 banks: 32 distinct even banks for the 8-byte reads of 32 rows).
+#define TX_RP 56            // halfs per row of a row-major tile in LDS
+#define TX_TP 36            // halfs per row of a transposed tile in LDS
+#define TX_RT (32 * TX_RP)  // halfs per row-major tile
+#define TX_TT (TX_HD * TX_TP)
+// plane k of a stage is loaded by threads 0..191, one 16-byte chunk each (192 chunks per tile of either kind)
+template <int NR, int NT>
+struct TxStage {
+    uint4 r[NR + NT];
+    // rsrc[k]: first half of the tile in row-major plane k;  tsrc[k]: element (d = 0, first token) of the tile in transposed plane k (row pitch Lp)
+    __device__ __forceinline__ void load(const h16* const (&rsrc)[NR], const h16* const (&tsrc)[NT == 0 ? 1 : NT], int Lp, int tid) {
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) r[k] = *reinterpret_cast<const uint4*>(rsrc[k] + tid * 8);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) r[NR + k] = *reinterpret_cast<const uint4*>(tsrc[k] + (size_t)(tid >> 2) * Lp + (tid & 3) * 8);
+        }
+    }
+    __device__ __forceinline__ void store(h16* lds, int tid) const {
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) *reinterpret_cast<uint4*>(lds + k * TX_RT + (tid / 6) * TX_RP + (tid % 6) * 8) = r[k];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                h16* d = lds + NR * TX_RT + k * TX_TT + (tid >> 2) * TX_TP + (tid & 3) * 8;
+                *reinterpret_cast<uint2*>(d) = make_uint2(r[NR + k].x, r[NR + k].y);
+                *reinterpret_cast<uint2*>(d + 4) = make_uint2(r[NR + k].z, r[NR + k].w);
+            }
+        }
+    }
+};
+__device__ __forceinline__ h16x8 tx_lds_row(const h16* tile, int row, int t, int half) {       // A / B fragment of k-step t from a row-major tile
+    return *reinterpret_cast<const h16x8*>(tile + row * TX_RP + 16 * t + 8 * half);
+}
+__device__ __forceinline__ h16x8 tx_lds_perm(const h16* tile, int d, int u, int half) {        // permuted-order fragment from a transposed tile
+    const h16x4 a = *reinterpret_cast<const h16x4*>(tile + d * TX_TP + 16 * u + 4 * half), b = *reinterpret_cast<const h16x4*>(tile + d * TX_TP + 16 * u + 4 * half + 8);
+    return h16x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
 #define TX_PSCALE 16384.f       // probabilities (<= 1) are split at 2^14
 
 // O [Lq, ldo] (fp32), lse2 [H][Lq] = log2 sum_j 2^(s2_ij), s2 = (q . k) log2(e) / sqrt(48).  grid (ceil(Lq / 128), H), 4 waves x 32 queries
@@ -358,8 +430,7 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
                                                           const unsigned* __restrict__ amax /*[3][H]: q, k, v*/, int Lq, int Lqp, int Lk, int Lkp, int H,
                                                           float* __restrict__ o, int ldo, float* __restrict__ lse2) {
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    if (q0 >= Lq) return;
+    const int q0 = blockIdx.x * 128 + wave * 32;       // (waves past Lq work on zero rows of the padded planes and store nothing: every wave meets the barriers)
     const int j = lane & 31, half = lane >> 5;
     const float c1 = 1.4426950408889634f * 0.14433756729740643f /* log2(e) / sqrt(48) */ /
                      (tx_scale_for(__uint_as_float(amax[h])) * tx_scale_for(__uint_as_float(amax[H + h])));
@@ -380,20 +451,31 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
     float m = -INFINITY, l = 0.f;
     const h16* kbase_h = kh + (size_t)h * Lkp * TX_HD, * kbase_l = kl + (size_t)h * Lkp * TX_HD;
     const h16* vbase_h = vth + (size_t)h * TX_HD * Lkp, * vbase_l = vtl + (size_t)h * TX_HD * Lkp;
-    for (int k0 = 0; k0 < Lk; k0 += 32) {               // (the planes are zero-padded to Lkp rows: the last block may run past Lk)
-        // S^T block: A = K rows (key j of the block, d range as above)
+    // streamed per key block: K rows (hi, lo) and V^T (hi, lo), double-buffered in LDS
+    constexpr int STAGE = 2 * TX_RT + 2 * TX_TT;
+    __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+    TxStage<2, 2> st_regs;
+    {
+        const h16* const rs[2] = {kbase_h, kbase_l};
+        const h16* const ts[2] = {vbase_h, vbase_l};
+        st_regs.load(rs, ts, Lkp, threadIdx.x);
+        st_regs.store(lds, threadIdx.x);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < Lk; k0 += 32, buf ^= 1) {
+        const bool more = k0 + 32 < Lk;
+        if (more) {
+            const h16* const rs[2] = {kbase_h + (size_t)(k0 + 32) * TX_HD, kbase_l + (size_t)(k0 + 32) * TX_HD};
+            const h16* const ts[2] = {vbase_h + k0 + 32, vbase_l + k0 + 32};
+            st_regs.load(rs, ts, Lkp, threadIdx.x);
+        }
+        const h16* tile = lds + buf * STAGE;
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        {
-            const size_t krow = (size_t)(k0 + j) * TX_HD + 8 * half;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const h16x8 ah = *reinterpret_cast<const h16x8*>(kbase_h + krow + 16 * t);
-                const h16x8 al = *reinterpret_cast<const h16x8*>(kbase_l + krow + 16 * t);
-                st = tx_mfma3(ah, al, bqh[t], bql[t], st);
-            }
-        }
+        for (int t = 0; t < 3; ++t) st = tx_mfma3(tx_lds_row(tile, j, t, half), tx_lds_row(tile + TX_RT, j, t, half), bqh[t], bql[t], st);
         float mb = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -420,7 +502,7 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
         m = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
-        // O^T += V^T P^T: A = V^T rows d = 32 mt + j, keys k0 + 16 u + 4 half + {0..3} and + 8
+        // O^T += V^T P^T: A = V^T rows d = 32 mt + j in the permuted key order of P's registers
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int d = 32 * mt + j;
@@ -428,11 +510,8 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
             for (int u = 0; u < 2; ++u) {
                 h16x8 ah, al;
                 if (d < TX_HD) {
-                    const size_t vo = (size_t)d * Lkp + k0 + 16 * u + 4 * half;
-                    const h16x4 a0 = *reinterpret_cast<const h16x4*>(vbase_h + vo), a1 = *reinterpret_cast<const h16x4*>(vbase_h + vo + 8);
-                    const h16x4 b0 = *reinterpret_cast<const h16x4*>(vbase_l + vo), b1 = *reinterpret_cast<const h16x4*>(vbase_l + vo + 8);
-                    ah = h16x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    al = h16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    ah = tx_lds_perm(tile + 2 * TX_RT, d, u, half);
+                    al = tx_lds_perm(tile + 2 * TX_RT + TX_TT, d, u, half);
                 } else {
                     ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     al = ah;
@@ -440,6 +519,8 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
                 ot[mt] = tx_mfma3(ah, al, ph[u], pl[u], ot[mt]);
             }
         }
+        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        __syncthreads();
     }
     // O[q][h * 48 + d] = O^T[d][q] * cv / l
     if (q0 + j < Lq) {
@@ -493,10 +574,9 @@ __device__ __forceinline__ float tx_ds_scale(const unsigned* amax, int H, int h)
 
 // dK, dV: a wave owns 32 keys and walks the query blocks.  S = Q K^T (rows = queries, column = the lane's key), P = 2^(S2 - lse2),
 // dV^T += dO^T P, dP = dO V^T, dS = P (dP - D), dK^T += Q^T dS.  grid (ceil(Lk / 128), H)
-__global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_args a) {
+__global__ __launch_bounds__(256, 2) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_args a) {
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * 128 + wave * 32;
-    if (k0 >= a.Lk) return;
+    const int k0 = blockIdx.x * 128 + wave * 32;        // (waves past Lk work on zero rows of the padded planes and store nothing)
     const int j = lane & 31, half = lane >> 5, H = a.H;
     const float sq = tx_scale_for(__uint_as_float(a.amax[h])), sk = tx_scale_for(__uint_as_float(a.amax[H + h]));
     const float sv = tx_scale_for(__uint_as_float(a.amax[2 * H + h])), sdo = tx_scale_for(__uint_as_float(a.amax[3 * H + h]));
@@ -521,19 +601,37 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
     const h16 *dtbh = a.doth + (size_t)h * TX_HD * a.Lqp, *dtbl = a.dotl + (size_t)h * TX_HD * a.Lqp;
     const float *lse = a.lse2 + (size_t)h * a.Lq, *dsm = a.dsum + (size_t)h * a.Lq;
     const bool key_ok = k0 + j < a.Lk;
-    for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+    // few keys (the cross-attention's 77): the query range is cut over blockIdx.z and the partial sums meet in dk / dv through atomics
+    const int q_per = ((a.Lq + (int)gridDim.z - 1) / (int)gridDim.z + 31) & ~31;
+    const int q_begin = (int)blockIdx.z * q_per, q_end = min(a.Lq, q_begin + q_per);
+    // streamed per query block: Q and dO rows (row-major) and Q^T, dO^T (transposed), hi / lo each, double-buffered in LDS
+    constexpr int STAGE = 4 * TX_RT + 4 * TX_TT;
+    __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+    TxStage<4, 4> st_regs;
+    if (q_begin < q_end) {
+        const h16* const rs[4] = {qbh + (size_t)q_begin * TX_HD, qbl + (size_t)q_begin * TX_HD, dbh + (size_t)q_begin * TX_HD, dbl + (size_t)q_begin * TX_HD};
+        const h16* const ts[4] = {qtbh + q_begin, qtbl + q_begin, dtbh + q_begin, dtbl + q_begin};
+        st_regs.load(rs, ts, a.Lqp, threadIdx.x);
+        st_regs.store(lds, threadIdx.x);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int q0 = q_begin; q0 < q_end; q0 += 32, buf ^= 1) {
+        const bool more = q0 + 32 < q_end;
+        if (more) {
+            const size_t ro = (size_t)(q0 + 32) * TX_HD;
+            const h16* const rs[4] = {qbh + ro, qbl + ro, dbh + ro, dbl + ro};
+            const h16* const ts[4] = {qtbh + q0 + 32, qtbl + q0 + 32, dtbh + q0 + 32, dtbl + q0 + 32};
+            st_regs.load(rs, ts, a.Lqp, threadIdx.x);
+        }
+        const h16* tile = lds + buf * STAGE;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        {
-            const size_t qrow = (size_t)(q0 + j) * TX_HD + 8 * half;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const h16x8 ah = *reinterpret_cast<const h16x8*>(qbh + qrow + 16 * t), al = *reinterpret_cast<const h16x8*>(qbl + qrow + 16 * t);
-                s = tx_mfma3(ah, al, bkh[t], bkl[t], s);
-                const h16x8 dh = *reinterpret_cast<const h16x8*>(dbh + qrow + 16 * t), dl = *reinterpret_cast<const h16x8*>(dbl + qrow + 16 * t);
-                dp = tx_mfma3(dh, dl, bvh[t], bvl[t], dp);
-            }
+        for (int t = 0; t < 3; ++t) {
+            s = tx_mfma3(tx_lds_row(tile, j, t, half), tx_lds_row(tile + TX_RT, j, t, half), bkh[t], bkl[t], s);
+            dp = tx_mfma3(tx_lds_row(tile + 2 * TX_RT, j, t, half), tx_lds_row(tile + 3 * TX_RT, j, t, half), bvh[t], bvl[t], dp);
         }
         h16x8 ph[2], pl[2], gh[2], gl[2];
 #pragma unroll
@@ -550,6 +648,7 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
             tx_split(g * sds, x, y);
             gh[r >> 3][r & 7] = x; gl[r >> 3][r & 7] = y;
         }
+        const h16* tt = tile + 4 * TX_RT;        // Q^T hi, lo, dO^T hi, lo
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int d = 32 * mt + j;
@@ -557,8 +656,8 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
             for (int u = 0; u < 2; ++u) {
                 h16x8 ah, al, ch, cl;
                 if (d < TX_HD) {
-                    ah = tx_load_perm(dtbh + (size_t)d * a.Lqp, q0, u, half); al = tx_load_perm(dtbl + (size_t)d * a.Lqp, q0, u, half);
-                    ch = tx_load_perm(qtbh + (size_t)d * a.Lqp, q0, u, half); cl = tx_load_perm(qtbl + (size_t)d * a.Lqp, q0, u, half);
+                    ch = tx_lds_perm(tt, d, u, half); cl = tx_lds_perm(tt + TX_TT, d, u, half);
+                    ah = tx_lds_perm(tt + 2 * TX_TT, d, u, half); al = tx_lds_perm(tt + 3 * TX_TT, d, u, half);
                 } else {
                     ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     al = ah; ch = ah; cl = ah;
@@ -567,6 +666,8 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
                 dkt[mt] = tx_mfma3(ch, cl, gh[u], gl[u], dkt[mt]);
             }
         }
+        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        __syncthreads();
     }
     if (key_ok) {
         const float fv = 1.f / (sdo * TX_PSCALE), fk = 0.14433756729740643f / (sq * sds);
@@ -577,7 +678,10 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * mt + tx_row_of(r, half);
-                if (d < TX_HD) { dvrow[d] = dvt[mt][r] * fv; dkrow[d] = dkt[mt][r] * fk; }
+                if (d < TX_HD) {
+                    if (gridDim.z > 1) { atomicAdd(dvrow + d, dvt[mt][r] * fv); atomicAdd(dkrow + d, dkt[mt][r] * fk); }
+                    else { dvrow[d] = dvt[mt][r] * fv; dkrow[d] = dkt[mt][r] * fk; }
+                }
             }
     }
 }
@@ -586,8 +690,7 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_kv_kernel(const tx_attn_bwd_a
 // dS^T = P^T (dP^T - D), dQ^T += K^T dS^T.  grid (ceil(Lq / 128), H)
 __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_args a) {
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    if (q0 >= a.Lq) return;
+    const int q0 = blockIdx.x * 128 + wave * 32;        // (waves past Lq: zero rows, nothing stored)
     const int j = lane & 31, half = lane >> 5, H = a.H;
     const float sq = tx_scale_for(__uint_as_float(a.amax[h])), sk = tx_scale_for(__uint_as_float(a.amax[H + h]));
     const float sv = tx_scale_for(__uint_as_float(a.amax[2 * H + h])), sdo = tx_scale_for(__uint_as_float(a.amax[3 * H + h]));
@@ -610,19 +713,34 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
     const h16 *kbh = a.kh + (size_t)h * a.Lkp * TX_HD, *kbl = a.kl + (size_t)h * a.Lkp * TX_HD;
     const h16 *vbh = a.vh + (size_t)h * a.Lkp * TX_HD, *vbl = a.vl + (size_t)h * a.Lkp * TX_HD;
     const h16 *ktbh = a.kth + (size_t)h * TX_HD * a.Lkp, *ktbl = a.ktl + (size_t)h * TX_HD * a.Lkp;
-    for (int k0 = 0; k0 < a.Lk; k0 += 32) {
+    // streamed per key block: K and V rows (row-major) and K^T (transposed), hi / lo each
+    constexpr int STAGE = 4 * TX_RT + 2 * TX_TT;
+    __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+    TxStage<4, 2> st_regs;
+    {
+        const h16* const rs[4] = {kbh, kbl, vbh, vbl};
+        const h16* const ts[2] = {ktbh, ktbl};
+        st_regs.load(rs, ts, a.Lkp, threadIdx.x);
+        st_regs.store(lds, threadIdx.x);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < a.Lk; k0 += 32, buf ^= 1) {
+        const bool more = k0 + 32 < a.Lk;
+        if (more) {
+            const size_t ro = (size_t)(k0 + 32) * TX_HD;
+            const h16* const rs[4] = {kbh + ro, kbl + ro, vbh + ro, vbl + ro};
+            const h16* const ts[2] = {ktbh + k0 + 32, ktbl + k0 + 32};
+            st_regs.load(rs, ts, a.Lkp, threadIdx.x);
+        }
+        const h16* tile = lds + buf * STAGE;
         f32x16 st, dpt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
-        {
-            const size_t krow = (size_t)(k0 + j) * TX_HD + 8 * half;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const h16x8 ah = *reinterpret_cast<const h16x8*>(kbh + krow + 16 * t), al = *reinterpret_cast<const h16x8*>(kbl + krow + 16 * t);
-                st = tx_mfma3(ah, al, bqh[t], bql[t], st);
-                const h16x8 vh_ = *reinterpret_cast<const h16x8*>(vbh + krow + 16 * t), vl_ = *reinterpret_cast<const h16x8*>(vbl + krow + 16 * t);
-                dpt = tx_mfma3(vh_, vl_, bdh[t], bdl[t], dpt);
-            }
+        for (int t = 0; t < 3; ++t) {
+            st = tx_mfma3(tx_lds_row(tile, j, t, half), tx_lds_row(tile + TX_RT, j, t, half), bqh[t], bql[t], st);
+            dpt = tx_mfma3(tx_lds_row(tile + 2 * TX_RT, j, t, half), tx_lds_row(tile + 3 * TX_RT, j, t, half), bdh[t], bdl[t], dpt);
         }
         h16x8 gh[2], gl[2];
 #pragma unroll
@@ -636,6 +754,7 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
             tx_split(g * sds, x, y);
             gh[r >> 3][r & 7] = x; gl[r >> 3][r & 7] = y;
         }
+        const h16* tt = tile + 4 * TX_RT;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int d = 32 * mt + j;
@@ -643,7 +762,7 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
             for (int u = 0; u < 2; ++u) {
                 h16x8 ah, al;
                 if (d < TX_HD) {
-                    ah = tx_load_perm(ktbh + (size_t)d * a.Lkp, k0, u, half); al = tx_load_perm(ktbl + (size_t)d * a.Lkp, k0, u, half);
+                    ah = tx_lds_perm(tt, d, u, half); al = tx_lds_perm(tt + TX_TT, d, u, half);
                 } else {
                     ah = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     al = ah;
@@ -651,6 +770,8 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
                 dqt[mt] = tx_mfma3(ah, al, gh[u], gl[u], dqt[mt]);
             }
         }
+        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        __syncthreads();
     }
     if (q_ok) {
         const float fq = 0.14433756729740643f / (sk * sds);
@@ -679,18 +800,55 @@ const void* tx_zero_page() {
     return pages[dev];
 }
 
+// Zeroed counter words (absmax / column-max cells, the cells atomics add into).  Stand-alone entry points clear their own cells with a
+// memset; inside asd_tritx_fwd / _bwd ONE memset at the start of the pass clears a pool the ~25 entries per layer then carve up
+// (281 memset launches per step otherwise: 1.3 ms of GPU time and as many launch boundaries).
+struct TxPool { unsigned* p; size_t left; bool outputs_zeroed; };
+thread_local TxPool tx_pool = {nullptr, 0, false};
+unsigned* tx_zeroed(unsigned* own, size_t words, hipStream_t s) {
+    const size_t w = (words + 63) & ~(size_t)63;
+    if (tx_pool.p && tx_pool.left >= w) {
+        unsigned* r = tx_pool.p;
+        tx_pool.p += w; tx_pool.left -= w;
+        return r;
+    }
+    (void)hipMemsetAsync(own, 0, words * 4, s);
+    return own;
+}
+
 inline int64_t tx_al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }
 inline int tx_rp(int r) { return (r + 63) & ~63; }      // rows of a transposed operand padded to the GEMM's k-step
 
-// C32 [M, N] = planeA [M, 3K] . planeW [N, 3K]^T  (fp32 result of the three fp16 products)
-int tx_gemm(const h16* pa, const h16* pw, int M, int N, int K3, float* c32, hipStream_t s) {
+// tile configuration (1-based index into csrc/gemm.hip's table) and split-K per product shape, from tools/tritx_gemm_sweep.py on the shipped
+// model's shapes (12 layers x 768 wide x 3072 tokens; profiles/r05_tritx_gemm_sweep.txt); other shapes: cost model, no split
+struct TxPlan { int M, N, K3, cfg, sk; };
+const TxPlan tx_plans[] = {
+    {3072, 768, 2304, 1, 1}, {3072, 2304, 2304, 4, 1}, {3072, 3072, 2304, 8, 1}, {3072, 768, 9216, 4, 3}, {3072, 768, 6912, 2, 3}, {77, 1536, 3072, 1, 6},
+    {3072, 128, 2304, 1, 4}, {3072, 768, 384, 1, 1}, {768, 768, 9216, 1, 6}, {2304, 768, 9216, 2, 4}, {768, 3072, 9216, 4, 3}, {1536, 1024, 384, 1, 1},
+    {768, 128, 9216, 1, 8},
+};
+void tx_plan(int M, int N, int K3, int* cfg, int* sk) {
+    *cfg = 0; *sk = 1;
+    for (const TxPlan& p : tx_plans)
+        if (p.M == M && p.N == N && p.K3 == K3) { *cfg = p.cfg; *sk = p.sk; return; }
+}
+inline int64_t tx_gemm_ws_floats(int M, int N, int K3) {
+    int cfg, sk;
+    tx_plan(M, N, K3, &cfg, &sk);
+    return sk > 1 ? tx_al((int64_t)sk * M * N) : 0;
+}
+
+// C32 [M, N] = planeA [M, 3K] . planeW [N, 3K]^T  (fp32 result of the three fp16 products); slabs: tx_gemm_ws_floats(M, N, K3) floats
+int tx_gemm(const h16* pa, const h16* pw, int M, int N, int K3, float* c32, float* slabs, hipStream_t s) {
     asd_gemm_args a;
     memset(&a, 0, sizeof(a));
     a.A = pa; a.W = pw; a.C = c32;
     a.M = M; a.N = N; a.K = K3;
     a.lda = K3; a.ldw = K3; a.ldc = N;
     a.out_f32 = 1;
-    a.split_k = 1;
+    int cfg, sk;
+    tx_plan(M, N, K3, &cfg, &sk);
+    a.split_k = sk; a.tile_cfg = cfg; a.workspace = slabs;
     a.zero_page = tx_zero_page();
     if (!a.zero_page) { asd_set_error("tritx: could not allocate the zero page"); return ASD_ERR_LAUNCH; }
     return asd_gemm_f16(&a, s);
@@ -710,8 +868,7 @@ int asd_tx_pack_weight(const float* w, int32_t N, int32_t K, void* plane_w, floa
     }
     if (plane_wt) {      // rows of W^T = columns of W [N, K]: K rows of 3 * Np halfs
         ASD_CHECK_ARG(inv_wt && ws, "inv_wt / ws missing");
-        unsigned* colmax = reinterpret_cast<unsigned*>(ws);
-        (void)hipMemsetAsync(colmax, 0, (size_t)K * 4, s);
+        unsigned* colmax = tx_zeroed(reinterpret_cast<unsigned*>(ws), (size_t)K, s);
         hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(K, 64), asd_div_up(N, 256)), dim3(256), 0, s, w, N, K, K, 256, colmax, (float*)nullptr);
         hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(K, 64), tx_rp(N) / 64), dim3(256), 0, s, w, N, K, K, tx_rp(N), colmax, (h16*)plane_wt, inv_wt);
     }
@@ -721,7 +878,7 @@ int asd_tx_pack_weight(const float* w, int32_t N, int32_t K, void* plane_w, floa
 
 int64_t asd_tx_linear_workspace(int32_t M, int32_t N, int32_t K) {
     // A plane [M, 3K] halfs + row scales + fp32 product [M, N]
-    return tx_al((int64_t)M * 3 * K / 2 + 64) + tx_al(M) + tx_al((int64_t)M * N);
+    return tx_al((int64_t)M * 3 * K / 2 + 64) + tx_al(M) + tx_al((int64_t)M * N) + tx_gemm_ws_floats(M, N, 3 * K);
 }
 
 // y [M, N] (ldy) = f(x [M, K] (ldx) . W^T + bias) + residual, W given as packed plane [N, 3K] + inv_w [N] (asd_tx_pack_weight; pass the
@@ -735,7 +892,7 @@ int asd_tx_linear(const float* x, int32_t M, int32_t K, int32_t ldx, const void*
     float* ia = ws + tx_al((int64_t)M * 3 * K / 2 + 64);
     float* c32 = ia + tx_al(M);
     hipLaunchKernelGGL((tx_split_rows_kernel<0>), dim3(asd_div_up(M, 4)), dim3(256), 0, s, x, M, K, ldx, pa, ia);
-    const int rc = tx_gemm(pa, (const h16*)plane_w, M, N, 3 * K, c32, s);
+    const int rc = tx_gemm(pa, (const h16*)plane_w, M, N, 3 * K, c32, c32 + tx_al((int64_t)M * N), s);
     if (rc != ASD_OK) return rc;
     hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)M * N / 4, 256)), dim3(256), 0, s, c32, M, N, ia, inv_w, bias, mode, aux, N, residual, ldr, y, ldy);
     ASD_LAUNCH_CHECK();
@@ -744,7 +901,8 @@ int asd_tx_linear(const float* x, int32_t M, int32_t K, int32_t ldx, const void*
 
 int64_t asd_tx_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
     const int64_t Mp = tx_rp(M);
-    return tx_al((int64_t)N * 3 * Mp / 2 + 64) + tx_al((int64_t)K * 3 * Mp / 2 + 64) + tx_al(N) + tx_al(K) + tx_al(N) + tx_al(K) + tx_al((int64_t)N * K);
+    return tx_al((int64_t)N * 3 * Mp / 2 + 64) + tx_al((int64_t)K * 3 * Mp / 2 + 64) + tx_al(N) + tx_al(K) + tx_al(N) + tx_al(K) + tx_al((int64_t)N * K) +
+           tx_gemm_ws_floats(N, K, 3 * (int)Mp);
 }
 
 // dw [N, K] = dy [M, N]^T . x [M, K]  (contraction over the M rows), db [N] = column sums of dy (optional)
@@ -759,15 +917,16 @@ int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ld
     float* ia = p; p += tx_al(N);
     float* iw = p; p += tx_al(K);
     unsigned* cmax_a = reinterpret_cast<unsigned*>(p); p += tx_al(N);
-    unsigned* cmax_w = reinterpret_cast<unsigned*>(p); p += tx_al(K);
+    p += tx_al(K);
     float* c32 = p;
-    (void)hipMemsetAsync(cmax_a, 0, (size_t)(tx_al(N) + tx_al(K)) * 4, s);
-    if (db) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
+    cmax_a = tx_zeroed(cmax_a, (size_t)(tx_al(N) + tx_al(K)), s);
+    unsigned* cmax_w = cmax_a + tx_al(N);
+    if (db && !tx_pool.outputs_zeroed) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(N, 64), asd_div_up(M, 256)), dim3(256), 0, s, dy, M, N, ldy, 256, cmax_a, db);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(K, 64), asd_div_up(M, 256)), dim3(256), 0, s, x, M, K, ldx, 256, cmax_w, (float*)nullptr);
     hipLaunchKernelGGL((tx_split_cols_kernel<0>), dim3(asd_div_up(N, 64), Mp / 64), dim3(256), 0, s, dy, M, N, ldy, Mp, cmax_a, pa, ia);
     hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(K, 64), Mp / 64), dim3(256), 0, s, x, M, K, ldx, Mp, cmax_w, pw, iw);
-    const int rc = tx_gemm(pa, pw, N, K, 3 * Mp, c32, s);
+    const int rc = tx_gemm(pa, pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), s);
     if (rc != ASD_OK) return rc;
     hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, c32, N, K, ia, iw, (const float*)nullptr, 0, (float*)nullptr, 0,
                        (const float*)nullptr, 0, dw, K);
@@ -786,8 +945,8 @@ int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamm
 int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
                          float* dgamma, float* dbeta, void* stream) {
     ASD_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "LayerNorm: D % 4 == 0, D <= 1024");
-    int grid = asd_div_up(M, 4 * 6);
-    if (grid > 512) grid = 512;
+    int grid = asd_div_up(M, 4 * 2);          // two rows per wave
+    if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(tx_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
@@ -816,11 +975,12 @@ int asd_tx_attention_fwd(const float* q, int32_t ldq, const float* k, int32_t ld
     h16* kl = p; p += (size_t)H * Lkp * TX_HD;
     h16* vth = p; p += (size_t)H * Lkp * TX_HD;
     h16* vtl = p; p += (size_t)H * Lkp * TX_HD;
-    unsigned* amax = reinterpret_cast<unsigned*>(ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256));
-    (void)hipMemsetAsync(amax, 0, (size_t)8 * H * 4, s);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, q, Lq, ldq, H, amax);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, k, Lk, ldk, H, amax + H);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, v, Lk, ldv, H, amax + 2 * H);
+    unsigned* amax = tx_zeroed(reinterpret_cast<unsigned*>(ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256)), (size_t)8 * H, s);
+    {
+        tx_absmax_args m;
+        m.x[0] = q; m.L[0] = Lq; m.ld[0] = ldq; m.x[1] = k; m.L[1] = Lk; m.ld[1] = ldk; m.x[2] = v; m.L[2] = Lk; m.ld[2] = ldv; m.x[3] = nullptr; m.L[3] = 0; m.ld[3] = 0;
+        hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq > Lk ? Lq : Lk, 256), H, 3), dim3(256), 0, s, m, H, amax);
+    }
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lqp * (TX_HD / 4), 256), H), dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qh, ql);
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lkp * (TX_HD / 4), 256), H), dim3(256), 0, s, k, Lk, Lkp, ldk, H, amax + H, kh, kl);
     hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lkp / 64, H), dim3(256), 0, s, v, Lk, Lkp, ldv, H, amax + 2 * H, vth, vtl);
@@ -845,13 +1005,13 @@ int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ld
     p += 8 * nq;
     h16 *kh = p, *kl = p + nk, *vh = p + 2 * nk, *vl = p + 3 * nk, *kth = p + 4 * nk, *ktl = p + 5 * nk;
     float* tail = ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256);
-    unsigned* amax = reinterpret_cast<unsigned*>(tail);
+    unsigned* amax = tx_zeroed(reinterpret_cast<unsigned*>(tail), (size_t)8 * H, s);
     float* dsum = tail + tx_al(8 * H);
-    (void)hipMemsetAsync(amax, 0, (size_t)8 * H * 4, s);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, q, Lq, ldq, H, amax);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, k, Lk, ldk, H, amax + H);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lk, 64), H), dim3(256), 0, s, v, Lk, ldv, H, amax + 2 * H);
-    hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq, 64), H), dim3(256), 0, s, d_o, Lq, lddo, H, amax + 3 * H);
+    {
+        tx_absmax_args m;
+        m.x[0] = q; m.L[0] = Lq; m.ld[0] = ldq; m.x[1] = k; m.L[1] = Lk; m.ld[1] = ldk; m.x[2] = v; m.L[2] = Lk; m.ld[2] = ldv; m.x[3] = d_o; m.L[3] = Lq; m.ld[3] = lddo;
+        hipLaunchKernelGGL(tx_attn_absmax_kernel, dim3(asd_div_up(Lq > Lk ? Lq : Lk, 256), H, 4), dim3(256), 0, s, m, H, amax);
+    }
     const dim3 gq(asd_div_up((int64_t)Lqp * (TX_HD / 4), 256), H), gk(asd_div_up((int64_t)Lkp * (TX_HD / 4), 256), H);
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gq, dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qh, ql);
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, gq, dim3(256), 0, s, d_o, Lq, Lqp, lddo, H, amax + 3 * H, doh, dol);
@@ -866,7 +1026,17 @@ int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ld
     a.amax = amax; a.lse2 = lse2; a.dsum = dsum;
     a.Lq = Lq; a.Lqp = Lqp; a.Lk = Lk; a.Lkp = Lkp; a.H = H;
     a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    hipLaunchKernelGGL(tx_attn_bwd_kv_kernel, dim3(asd_div_up(Lk, 128), H), dim3(256), 0, s, a);
+    int qsplit = 1;
+    if (asd_div_up(Lk, 128) * H < 256) {       // fewer key blocks than CUs
+        qsplit = 128 / (asd_div_up(Lk, 128) * H);
+        if (qsplit > asd_div_up(Lq, 128)) qsplit = asd_div_up(Lq, 128);
+        if (qsplit < 1) qsplit = 1;
+    }
+    if (qsplit > 1) {       // (row by row: dk / dv may be column slices of a wider matrix)
+        (void)hipMemset2DAsync(dk, (size_t)lddk * 4, 0, (size_t)H * TX_HD * 4, Lk, s);
+        (void)hipMemset2DAsync(dv, (size_t)lddv * 4, 0, (size_t)H * TX_HD * 4, Lk, s);
+    }
+    hipLaunchKernelGGL(tx_attn_bwd_kv_kernel, dim3(asd_div_up(Lk, 128), H, qsplit), dim3(256), 0, s, a);
     hipLaunchKernelGGL(tx_attn_bwd_q_kernel, dim3(asd_div_up(Lq, 128), H), dim3(256), 0, s, a);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
@@ -997,13 +1167,19 @@ int64_t asd_tritx_save_floats(const asd_tritx_desc* desc, int32_t batch) {
     if (tx_check_desc(desc) != ASD_OK) return -1;
     return tx_save_per_sample(TxDims(*desc)) * batch;
 }
+static int64_t tx_pool_words(const TxDims& d) {
+    // per layer: two attention calls (forward or backward) + seven weight gradients (column-max cells of both operands)
+    const int64_t wg = tx_al(d.D) * 8 + tx_al(d.F) * 2 + tx_al(3 * d.D) + tx_al(2 * d.D) + tx_al(d.Dc) + 7 * 64;
+    return (int64_t)d.layers * (2 * tx_al(8 * d.H) + wg) + tx_al(d.D) + tx_al(d.O) + 4096;
+}
+
 int64_t asd_tritx_workspace_floats(const asd_tritx_desc* desc) {
     if (tx_check_desc(desc) != ASD_OK) return -1;
     const TxDims d(*desc);
     // transient gradients of the backward pass: dx ping-pong (2), dn, do, dqkv (3), dkv, du, dy, the weight-gradient staging of batch
     // elements > 0, + the op workspace
     return tx_op_ws(d) + tx_al((int64_t)d.T * d.D) * 7 + tx_al((int64_t)d.Tc * 2 * d.D) + tx_al((int64_t)d.T * d.F) + tx_al((int64_t)d.T * d.O) +
-           tx_stage_floats(d) + 256;
+           tx_stage_floats(d) + tx_pool_words(d) + 256;
 }
 
 // params: 20 * n_layers + 4 device pointers (order: include/asd_hip.h) -> packed operand planes of every weight
@@ -1058,7 +1234,11 @@ int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const 
     const TxSave S = tx_save_layout(d);
     const int64_t TD = (int64_t)d.T * d.D;
     const float eps = desc->eps;
+    struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
+    unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
     for (int n = 0; n < batch; ++n) {
+        (void)hipMemsetAsync(pool, 0, (size_t)tx_pool_words(d) * 4, s);
+        tx_pool = {pool, (size_t)tx_pool_words(d), false};
         float* sv = save + (int64_t)n * tx_save_per_sample(d);
         const float* cond = text_embed + (int64_t)n * d.Tc * d.Dc;
         const float* x = params[20 * d.layers];        // pos_embed
@@ -1121,14 +1301,19 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     float* dy = p; p += tx_al((int64_t)d.T * d.O);
     float* stage = p;
     float* stage_b = stage + (tx_stage_floats(d) - tx_al(tx_max64(d.F, 3 * d.D)));
-    // LayerNorm gradients accumulate over layers' rows and the batch: zero them once
-    for (int l = 0; l < d.layers; ++l) {
-        float* const* G = grads + 17 * l;
-        for (int q : {0, 1, 6, 7, 11, 12}) (void)hipMemsetAsync(G[q], 0, (size_t)d.D * 4, s);
-    }
+    // LayerNorm gradients accumulate over layers' rows and the batch, bias gradients are atomic column sums: zero them once — or take the
+    // caller's word that it did (desc->grads_prezeroed: the Python side carves all of them out of one zeroed buffer)
     float* const* GH = grads + 17 * d.layers;       // pos_embed, norm.w, norm.b, deconv.w
-    (void)hipMemsetAsync(GH[1], 0, (size_t)d.D * 4, s);
-    (void)hipMemsetAsync(GH[2], 0, (size_t)d.D * 4, s);
+    if (!desc->grads_prezeroed) {
+        for (int l = 0; l < d.layers; ++l) {
+            float* const* G = grads + 17 * l;
+            for (int q : {0, 1, 6, 7, 11, 12}) (void)hipMemsetAsync(G[q], 0, (size_t)d.D * 4, s);
+        }
+        (void)hipMemsetAsync(GH[1], 0, (size_t)d.D * 4, s);
+        (void)hipMemsetAsync(GH[2], 0, (size_t)d.D * 4, s);
+    }
+    struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
+    unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
     // weight gradients of batch element n > 0 are added to those of the elements before it: staged through `stage`
     auto wgrad = [&](const float* dyp, int ldy, const float* xp, int ldx, int M, int N, int K, float* dw, float* db, bool acc) -> int {
         if (!acc) return asd_tx_linear_wgrad(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, stream);
@@ -1141,6 +1326,9 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     };
     for (int n = 0; n < batch; ++n) {
         const bool acc = n > 0;
+        (void)hipMemsetAsync(pool, 0, (size_t)tx_pool_words(d) * 4, s);
+        // bias gradients of the first batch element land in caller-zeroed cells; later elements go through the staging buffer (own memset)
+        tx_pool = {pool, (size_t)tx_pool_words(d), desc->grads_prezeroed != 0 && !acc};
         const float* sv = save + (int64_t)n * tx_save_per_sample(d);
         const float* cond = text_embed + (int64_t)n * d.Tc * d.Dc;
         const float* xf = sv + (int64_t)d.layers * S.end;

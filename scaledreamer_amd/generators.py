@@ -483,25 +483,36 @@ class _TritxFn(torch.autograd.Function):
             return (None, None) + (None,) * len(params)
         dev = d_planes.device
         d_cl = d_planes.permute(0, 1, 3, 4, 2).contiguous().float()
-        nl, D, Dc = desc.n_layers, desc.dim, desc.cond_dim
+        nl, D, Dc, Fh = desc.n_layers, desc.dim, desc.cond_dim, desc.hidden
         grads, ptrs = [None] * len(params), []
+        # every vector-shaped gradient (LayerNorm weights / biases, Linear biases: the kernels ACCUMULATE into them) from one zeroed buffer
+        small = torch.zeros(nl * (9 * D + Fh) + 2 * D, device=dev)
+        cut = [0]
+
+        def vec(n):
+            cut[0] += n
+            return small[cut[0] - n:cut[0]]
         for l in range(nl):
             P = params[20 * l:20 * l + 20]
             kv = torch.empty((2 * D, Dc), device=dev)
             qkv = torch.empty((3 * D, D), device=dev)
-            g = {i: torch.empty_like(P[i]) for i in (0, 1, 2, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19)}
+            g = {i: torch.empty_like(P[i]) for i in (2, 5, 12, 16, 18)}
+            for i in (0, 1, 6, 7, 8, 13, 14, 15, 17, 19):
+                g[i] = vec(P[i].numel())
             g[3], g[4] = kv[:D], kv[D:]
             g[9], g[10], g[11] = qkv[:D], qkv[D:2 * D], qkv[2 * D:]
             for i in range(20):
                 grads[20 * l + i] = g[i]
             ptrs += [g[0], g[1], g[2], kv, g[5], g[6], g[7], g[8], qkv, g[12], g[13], g[14], g[15], g[16], g[17], g[18], g[19]]
         for i in range(4):
-            grads[20 * nl + i] = torch.empty_like(params[20 * nl + i])
+            grads[20 * nl + i] = vec(D) if i in (1, 2) else torch.empty_like(params[20 * nl + i])
             ptrs.append(grads[20 * nl + i])
+        bdesc = _lib.TritxDesc.from_buffer_copy(desc)
+        bdesc.grads_prezeroed = 1
         gtable = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
         ws = module._tritx_workspace(desc, dev)
         n = ctx.te.shape[0]
-        _lib.check(_lib.lib().asd_tritx_bwd(C.byref(desc), ctx.table, _lib.ptr(ctx.packed), _lib.ptr(ctx.te), _lib.i32(n), _lib.ptr(d_cl), _lib.ptr(ctx.save),
+        _lib.check(_lib.lib().asd_tritx_bwd(C.byref(bdesc), ctx.table, _lib.ptr(ctx.packed), _lib.ptr(ctx.te), _lib.i32(n), _lib.ptr(d_cl), _lib.ptr(ctx.save),
                                             gtable, _lib.ptr(ws), _lib.stream()))
         ctx.save = None
         return (None, None) + tuple(g if p.requires_grad else None for g, p in zip(grads, params))
