@@ -585,9 +585,14 @@ class TriplaneTransformer(nn.Module):
         if self._hip_ok(text_embed):
             self._cond_tokens = text_embed.shape[1]
             return _TritxFn.apply(self, text_embed, *self._hip_params())
-        if self.backend == "hip" and text_embed.is_cuda and self.needs_local_text and os.environ.get("ASD_TRITX", "1") != "0":
-            raise NotImplementedError("TriplaneTransformer (HIP): built for head dim 48, width % 64 == 0 and <= 1024, 2x deconvolution "
-                                      "(the shipped asd_mv_triplane_transformer configs); pass backend='library' for other shapes")
+        if self.backend == "hip" and text_embed.is_cuda and not getattr(self, "_warned_library", False):
+            # the HIP generator is instantiated for the shipped shape family (local text tokens, head dim 48, width % 64 == 0 and <= 1024,
+            # 2x deconvolution): anything else — reduced test models, the global-text variant — runs the torch-op restatement below
+            import warnings
+
+            warnings.warn("TriplaneTransformer: this configuration is outside the HIP generator's shape family (local_text, head dim 48, width % 64 == 0, "
+                          "<= 1024); running the library-op restatement")
+            self._warned_library = True
         N, Hh = text_embed.shape[0], self.triplane_low_res
         if not self.needs_local_text:
             text_embed = self.proj(text_embed).unsqueeze(1)
