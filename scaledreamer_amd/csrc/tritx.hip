@@ -392,28 +392,24 @@ __device__ __forceinline__ int tx_row_of(int r, int half) { return (r & 3) + 8 *
 template <int NR, int NT>
 struct TxStage {
     uint4 r[NR + NT];
-    // rsrc[k]: first half of the tile in row-major plane k;  tsrc[k]: element (d = 0, first token) of the tile in transposed plane k (row pitch Lp)
-    __device__ __forceinline__ void load(const h16* const (&rsrc)[NR], const h16* const (&tsrc)[NT == 0 ? 1 : NT], int Lp, int tid) {
-        if (tid < 192) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) r[k] = *reinterpret_cast<const uint4*>(rsrc[k] + tid * 8);
-#pragma unroll
-            for (int k = 0; k < NT; ++k) r[NR + k] = *reinterpret_cast<const uint4*>(tsrc[k] + (size_t)(tid >> 2) * Lp + (tid & 3) * 8);
-        }
-    }
-    __device__ __forceinline__ void store(h16* lds, int tid) const {
-        if (tid < 192) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) *reinterpret_cast<uint4*>(lds + k * TX_RT + (tid / 6) * TX_RP + (tid % 6) * 8) = r[k];
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                h16* d = lds + NR * TX_RT + k * TX_TT + (tid >> 2) * TX_TP + (tid & 3) * 8;
-                *reinterpret_cast<uint2*>(d) = make_uint2(r[NR + k].x, r[NR + k].y);
-                *reinterpret_cast<uint2*>(d + 4) = make_uint2(r[NR + k].z, r[NR + k].w);
-            }
-        }
-    }
 };
+// rsrc[k]: first half of the tile in row-major plane k;  tsrc[k]: element (d = 0, first token) of the tile in transposed plane k (row pitch Lp)
+#define TX_STAGE_LOAD(ST, NR_, NT_, RSRC, TSRC, LP)                                                                                   \
+    if (threadIdx.x < 192) {                                                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NR_); ++k_) (ST).r[k_] = *reinterpret_cast<const uint4*>((RSRC)[k_] + threadIdx.x * 8); \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NT_); ++k_)                                                                          \
+            (ST).r[(NR_) + k_] = *reinterpret_cast<const uint4*>((TSRC)[k_] + (size_t)(threadIdx.x >> 2) * (LP) + (threadIdx.x & 3) * 8); \
+    }
+#define TX_STAGE_STORE(ST, NR_, NT_, LDS)                                                                                             \
+    if (threadIdx.x < 192) {                                                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NR_); ++k_)                                                                          \
+            *reinterpret_cast<uint4*>((LDS) + k_ * TX_RT + (threadIdx.x / 6) * TX_RP + (threadIdx.x % 6) * 8) = (ST).r[k_];         \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NT_); ++k_) {                                                                        \
+            h16* d_ = (LDS) + (NR_) * TX_RT + k_ * TX_TT + (threadIdx.x >> 2) * TX_TP + (threadIdx.x & 3) * 8;                       \
+            *reinterpret_cast<uint2*>(d_) = make_uint2((ST).r[(NR_) + k_].x, (ST).r[(NR_) + k_].y);                                   \
+            *reinterpret_cast<uint2*>(d_ + 4) = make_uint2((ST).r[(NR_) + k_].z, (ST).r[(NR_) + k_].w);                             \
+        }                                                                                                                             \
+    }
 __device__ __forceinline__ h16x8 tx_lds_row(const h16* tile, int row, int t, int half) {       // A / B fragment of k-step t from a row-major tile
     return *reinterpret_cast<const h16x8*>(tile + row * TX_RP + 16 * t + 8 * half);
 }
@@ -422,13 +418,21 @@ __device__ __forceinline__ h16x8 tx_lds_perm(const h16* tile, int d, int u, int 
     return h16x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 }
 
+// 2^x on v_exp_f32 alone (arguments here are <= 0 or -inf: no range reduction / denormal fix-up needed)
+__device__ __forceinline__ float tx_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// the value of lane l ^ 32 (v_permlane32_swap: VALU, no LDS round trip)
+__device__ __forceinline__ float tx_other_half(float v) {
+    auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(((threadIdx.x >> 5) & 1) ? t[0] : t[1]);
+}
 #define TX_PSCALE 16384.f       // probabilities (<= 1) are split at 2^14
 
 // O [Lq, ldo] (fp32), lse2 [H][Lq] = log2 sum_j 2^(s2_ij), s2 = (q . k) log2(e) / sqrt(48).  grid (ceil(Lq / 128), H), 4 waves x 32 queries
-__global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict__ qh, const h16* __restrict__ ql, const h16* __restrict__ kh,
+__global__ __launch_bounds__(256, 3) void tx_attn_fwd_kernel(const h16* __restrict__ qh, const h16* __restrict__ ql, const h16* __restrict__ kh,
                                                           const h16* __restrict__ kl, const h16* __restrict__ vth, const h16* __restrict__ vtl,
                                                           const unsigned* __restrict__ amax /*[3][H]: q, k, v*/, int Lq, int Lqp, int Lk, int Lkp, int H,
-                                                          float* __restrict__ o, int ldo, float* __restrict__ lse2) {
+                                                          float* __restrict__ o, int ldo, float* __restrict__ lse2,
+                                                          float* __restrict__ part /* gridDim.z > 1: [z][Lq][H 48] unnormalised O, then [z][H][Lq] m, [z][H][Lq] l */) {
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = blockIdx.x * 128 + wave * 32;       // (waves past Lq work on zero rows of the padded planes and store nothing: every wave meets the barriers)
     const int j = lane & 31, half = lane >> 5;
@@ -455,20 +459,23 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
     constexpr int STAGE = 2 * TX_RT + 2 * TX_TT;
     __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
     TxStage<2, 2> st_regs;
-    {
-        const h16* const rs[2] = {kbase_h, kbase_l};
-        const h16* const ts[2] = {vbase_h, vbase_l};
-        st_regs.load(rs, ts, Lkp, threadIdx.x);
-        st_regs.store(lds, threadIdx.x);
+    // the key range is cut over blockIdx.z (more, shorter blocks: 1.5 waves per SIMD otherwise); the pieces meet in tx_attn_fwd_combine_kernel
+    const int k_per = ((Lk + (int)gridDim.z - 1) / (int)gridDim.z + 31) & ~31;
+    const int k_begin = (int)blockIdx.z * k_per, k_end = min(Lk, k_begin + k_per);
+    if (k_begin < k_end) {
+        const h16* const rs[2] = {kbase_h + (size_t)k_begin * TX_HD, kbase_l + (size_t)k_begin * TX_HD};
+        const h16* const ts[2] = {vbase_h + k_begin, vbase_l + k_begin};
+        TX_STAGE_LOAD(st_regs, 2, 2, rs, ts, Lkp);
+        TX_STAGE_STORE(st_regs, 2, 2, lds);
     }
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < Lk; k0 += 32, buf ^= 1) {
-        const bool more = k0 + 32 < Lk;
+    for (int k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
+        const bool more = k0 + 32 < k_end;
         if (more) {
             const h16* const rs[2] = {kbase_h + (size_t)(k0 + 32) * TX_HD, kbase_l + (size_t)(k0 + 32) * TX_HD};
             const h16* const ts[2] = {vbase_h + k0 + 32, vbase_l + k0 + 32};
-            st_regs.load(rs, ts, Lkp, threadIdx.x);
+            TX_STAGE_LOAD(st_regs, 2, 2, rs, ts, Lkp);
         }
         const h16* tile = lds + buf * STAGE;
         f32x16 st;
@@ -484,20 +491,20 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
             st[r] = s2;
             mb = fmaxf(mb, s2);
         }
-        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        mb = fmaxf(mb, tx_other_half(mb));
         const float m_new = fmaxf(m, mb);
-        const float alpha = exp2f(m - m_new);           // m = -inf on the first block: 0
+        const float alpha = tx_exp2(m - m_new);           // m = -inf on the first block: 0
         float lb = 0.f;
         h16x8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(st[r] - m_new);
+            const float p = tx_exp2(st[r] - m_new);
             lb += p;
             h16 a, b;
             tx_split(p * TX_PSCALE, a, b);
             ph[r >> 3][r & 7] = a; pl[r >> 3][r & 7] = b;
         }
-        lb += __shfl_xor(lb, 32, 64);
+        lb += tx_other_half(lb);
         l = l * alpha + lb;
         m = m_new;
 #pragma unroll
@@ -519,13 +526,14 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
                 ot[mt] = tx_mfma3(ah, al, ph[u], pl[u], ot[mt]);
             }
         }
-        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        if (more) { TX_STAGE_STORE(st_regs, 2, 2, lds + (buf ^ 1) * STAGE); }
         __syncthreads();
     }
     // O[q][h * 48 + d] = O^T[d][q] * cv / l
     if (q0 + j < Lq) {
-        const float f = cv / l;
-        float* orow = o + (size_t)(q0 + j) * ldo + h * TX_HD;
+        const bool whole = gridDim.z == 1;
+        const float f = whole ? cv / l : cv;
+        float* orow = whole ? o + (size_t)(q0 + j) * ldo + h * TX_HD : part + ((size_t)blockIdx.z * Lq + q0 + j) * (H * TX_HD) + h * TX_HD;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -533,8 +541,52 @@ __global__ __launch_bounds__(256) void tx_attn_fwd_kernel(const h16* __restrict_
                 const int d = 32 * mt + tx_row_of(r, half);
                 if (d < TX_HD) orow[d] = ot[mt][r] * f;
             }
-        if (half == 0) lse2[(size_t)h * Lq + q0 + j] = m + log2f(l);
+        if (half == 0) {
+            if (whole) lse2[(size_t)h * Lq + q0 + j] = m + log2f(l);
+            else {
+                float* ml = part + (size_t)gridDim.z * Lq * H * TX_HD;
+                ml[((size_t)blockIdx.z * H + h) * Lq + q0 + j] = m;
+                ml[((size_t)(gridDim.z + blockIdx.z) * H + h) * Lq + q0 + j] = l;
+            }
+        }
     }
+}
+
+// pieces of a key-split forward: O = sum_z O_z 2^(m_z - M) / sum_z l_z 2^(m_z - M); one thread per (query, head, 4 channels)
+__global__ __launch_bounds__(256) void tx_attn_fwd_combine_kernel(const float* __restrict__ part, int Z, int Lq, int H, float* __restrict__ o, int ldo,
+                                                                  float* __restrict__ lse2) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t % (TX_HD / 4)) * 4;
+    const size_t qh = t / (TX_HD / 4);
+    const int h = (int)(qh % H), q = (int)(qh / H);
+    if (q >= Lq) return;
+    const float* ml = part + (size_t)Z * Lq * H * TX_HD;
+    float M = -INFINITY;
+    for (int z = 0; z < Z; ++z) M = fmaxf(M, ml[((size_t)z * H + h) * Lq + q]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < Z; ++z) {
+        const float w = tx_exp2(ml[((size_t)z * H + h) * Lq + q] - M);
+        L += ml[((size_t)(Z + z) * H + h) * Lq + q] * w;
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)z * Lq + q) * (H * TX_HD) + h * TX_HD + c);
+        acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<float4*>(o + (size_t)q * ldo + h * TX_HD + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (c == 0) lse2[(size_t)h * Lq + q] = M + log2f(L);
+}
+// out[r][h 48 + c] (ld) = sum_z part[z][r][H 48]
+__global__ __launch_bounds__(256) void tx_attn_sum_parts_kernel(const float* __restrict__ part, int Z, int L, int HD_all, float* __restrict__ out, int ld) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t % (HD_all / 4)) * 4;
+    const size_t r = t / (HD_all / 4);
+    if (r >= (size_t)L) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < Z; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)z * L + r) * HD_all + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + r * ld + c) = acc;
 }
 
 // D[h][q] = sum_d dO[q][h 48 + d] O[q][h 48 + d]: one thread per (query, head)
@@ -566,6 +618,7 @@ struct tx_attn_bwd_args {
     int Lq, Lqp, Lk, Lkp, H;
     float *dq, *dk, *dv;
     int lddq, lddk, lddv;
+    float* part;        // gridDim.z > 1: partial sums of the split range
 };
 // static bound of |P (dP - D)| per head: |dP_ij| <= 48 max|dO| max|V|, |D_i| <= 48 max|dO| max|O| and |O| <= max|V| (convex combination)
 __device__ __forceinline__ float tx_ds_scale(const unsigned* amax, int H, int h) {
@@ -601,18 +654,30 @@ __global__ __launch_bounds__(256, 2) void tx_attn_bwd_kv_kernel(const tx_attn_bw
     const h16 *dtbh = a.doth + (size_t)h * TX_HD * a.Lqp, *dtbl = a.dotl + (size_t)h * TX_HD * a.Lqp;
     const float *lse = a.lse2 + (size_t)h * a.Lq, *dsm = a.dsum + (size_t)h * a.Lq;
     const bool key_ok = k0 + j < a.Lk;
-    // few keys (the cross-attention's 77): the query range is cut over blockIdx.z and the partial sums meet in dk / dv through atomics
+    // the query range is cut over blockIdx.z (balance: four short blocks per slot instead of 384 long ones on 512 slots; the
+    // cross-attention's 77 keys: 16 blocks otherwise); the partial sums land in a_.part and are added up by tx_attn_sum_parts_kernel
     const int q_per = ((a.Lq + (int)gridDim.z - 1) / (int)gridDim.z + 31) & ~31;
     const int q_begin = (int)blockIdx.z * q_per, q_end = min(a.Lq, q_begin + q_per);
     // streamed per query block: Q and dO rows (row-major) and Q^T, dO^T (transposed), hi / lo each, double-buffered in LDS
     constexpr int STAGE = 4 * TX_RT + 4 * TX_TT;
     __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+    __shared__ float row_stats[2][64];            // [stage][lse2 of the tile's 32 queries | D of the same]
     TxStage<4, 4> st_regs;
+    float stat_reg = 0.f;
+    const int stat_i = (int)threadIdx.x - 192;   // 0..31: lse2, 32..63: D
+    auto stat_load = [&](int q0_) {
+        if (stat_i >= 0) {
+            const int qi = q0_ + (stat_i & 31);
+            stat_reg = qi < a.Lq ? (stat_i < 32 ? lse[qi] : dsm[qi]) : 0.f;
+        }
+    };
     if (q_begin < q_end) {
+        stat_load(q_begin);
+        if (stat_i >= 0) row_stats[0][stat_i] = stat_reg;
         const h16* const rs[4] = {qbh + (size_t)q_begin * TX_HD, qbl + (size_t)q_begin * TX_HD, dbh + (size_t)q_begin * TX_HD, dbl + (size_t)q_begin * TX_HD};
         const h16* const ts[4] = {qtbh + q_begin, qtbl + q_begin, dtbh + q_begin, dtbl + q_begin};
-        st_regs.load(rs, ts, a.Lqp, threadIdx.x);
-        st_regs.store(lds, threadIdx.x);
+        TX_STAGE_LOAD(st_regs, 4, 4, rs, ts, a.Lqp);
+        TX_STAGE_STORE(st_regs, 4, 4, lds);
     }
     __syncthreads();
     int buf = 0;
@@ -622,7 +687,8 @@ __global__ __launch_bounds__(256, 2) void tx_attn_bwd_kv_kernel(const tx_attn_bw
             const size_t ro = (size_t)(q0 + 32) * TX_HD;
             const h16* const rs[4] = {qbh + ro, qbl + ro, dbh + ro, dbl + ro};
             const h16* const ts[4] = {qtbh + q0 + 32, qtbl + q0 + 32, dtbh + q0 + 32, dtbl + q0 + 32};
-            st_regs.load(rs, ts, a.Lqp, threadIdx.x);
+            TX_STAGE_LOAD(st_regs, 4, 4, rs, ts, a.Lqp);
+            stat_load(q0 + 32);
         }
         const h16* tile = lds + buf * STAGE;
         f32x16 s, dp;
@@ -636,11 +702,11 @@ __global__ __launch_bounds__(256, 2) void tx_attn_bwd_kv_kernel(const tx_attn_bw
         h16x8 ph[2], pl[2], gh[2], gl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qi = q0 + tx_row_of(r, half);
+            const int ql = tx_row_of(r, half), qi = q0 + ql;
             float p = 0.f, g = 0.f;
             if (qi < a.Lq && key_ok) {
-                p = exp2f(s[r] * c1 - lse[qi]);
-                g = p * (dp[r] * cdp - dsm[qi]);
+                p = tx_exp2(s[r] * c1 - row_stats[buf][ql]);
+                g = p * (dp[r] * cdp - row_stats[buf][32 + ql]);
             }
             h16 x, y;
             tx_split(p * TX_PSCALE, x, y);
@@ -666,29 +732,31 @@ __global__ __launch_bounds__(256, 2) void tx_attn_bwd_kv_kernel(const tx_attn_bw
                 dkt[mt] = tx_mfma3(ch, cl, gh[u], gl[u], dkt[mt]);
             }
         }
-        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        if (more) {
+            TX_STAGE_STORE(st_regs, 4, 4, lds + (buf ^ 1) * STAGE);
+            if (stat_i >= 0) row_stats[buf ^ 1][stat_i] = stat_reg;
+        }
         __syncthreads();
     }
     if (key_ok) {
         const float fv = 1.f / (sdo * TX_PSCALE), fk = 0.14433756729740643f / (sq * sds);
-        float* dvrow = a.dv + (size_t)(k0 + j) * a.lddv + h * TX_HD;
-        float* dkrow = a.dk + (size_t)(k0 + j) * a.lddk + h * TX_HD;
+        const bool whole = gridDim.z == 1;
+        const size_t pstride = (size_t)a.Lk * H * TX_HD;       // one [Lk][H 48] partial
+        float* dvrow = whole ? a.dv + (size_t)(k0 + j) * a.lddv + h * TX_HD : a.part + (size_t)(gridDim.z + blockIdx.z) * pstride + (size_t)(k0 + j) * (H * TX_HD) + h * TX_HD;
+        float* dkrow = whole ? a.dk + (size_t)(k0 + j) * a.lddk + h * TX_HD : a.part + (size_t)blockIdx.z * pstride + (size_t)(k0 + j) * (H * TX_HD) + h * TX_HD;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * mt + tx_row_of(r, half);
-                if (d < TX_HD) {
-                    if (gridDim.z > 1) { atomicAdd(dvrow + d, dvt[mt][r] * fv); atomicAdd(dkrow + d, dkt[mt][r] * fk); }
-                    else { dvrow[d] = dvt[mt][r] * fv; dkrow[d] = dkt[mt][r] * fk; }
-                }
+                if (d < TX_HD) { dvrow[d] = dvt[mt][r] * fv; dkrow[d] = dkt[mt][r] * fk; }
             }
     }
 }
 
 // dQ: a wave owns 32 queries and walks the key blocks in the forward's orientation: S^T = K Q^T, dP^T = V dO^T (column = the lane's query),
 // dS^T = P^T (dP^T - D), dQ^T += K^T dS^T.  grid (ceil(Lq / 128), H)
-__global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_args a) {
+__global__ __launch_bounds__(256, 2) void tx_attn_bwd_q_kernel(const tx_attn_bwd_args a) {
     const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = blockIdx.x * 128 + wave * 32;        // (waves past Lq: zero rows, nothing stored)
     const int j = lane & 31, half = lane >> 5, H = a.H;
@@ -717,21 +785,24 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
     constexpr int STAGE = 4 * TX_RT + 2 * TX_TT;
     __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
     TxStage<4, 2> st_regs;
-    {
-        const h16* const rs[4] = {kbh, kbl, vbh, vbl};
-        const h16* const ts[2] = {ktbh, ktbl};
-        st_regs.load(rs, ts, a.Lkp, threadIdx.x);
-        st_regs.store(lds, threadIdx.x);
+    const int k_per = ((a.Lk + (int)gridDim.z - 1) / (int)gridDim.z + 31) & ~31;
+    const int k_begin = (int)blockIdx.z * k_per, k_end = min(a.Lk, k_begin + k_per);
+    if (k_begin < k_end) {
+        const size_t ro = (size_t)k_begin * TX_HD;
+        const h16* const rs[4] = {kbh + ro, kbl + ro, vbh + ro, vbl + ro};
+        const h16* const ts[2] = {ktbh + k_begin, ktbl + k_begin};
+        TX_STAGE_LOAD(st_regs, 4, 2, rs, ts, a.Lkp);
+        TX_STAGE_STORE(st_regs, 4, 2, lds);
     }
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < a.Lk; k0 += 32, buf ^= 1) {
-        const bool more = k0 + 32 < a.Lk;
+    for (int k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
+        const bool more = k0 + 32 < k_end;
         if (more) {
             const size_t ro = (size_t)(k0 + 32) * TX_HD;
             const h16* const rs[4] = {kbh + ro, kbl + ro, vbh + ro, vbl + ro};
             const h16* const ts[2] = {ktbh + k0 + 32, ktbl + k0 + 32};
-            st_regs.load(rs, ts, a.Lkp, threadIdx.x);
+            TX_STAGE_LOAD(st_regs, 4, 2, rs, ts, a.Lkp);
         }
         const h16* tile = lds + buf * STAGE;
         f32x16 st, dpt;
@@ -747,7 +818,7 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
         for (int r = 0; r < 16; ++r) {
             float g = 0.f;
             if (q_ok && k0 + tx_row_of(r, half) < a.Lk) {
-                const float p = exp2f(st[r] * c1 - lse);
+                const float p = tx_exp2(st[r] * c1 - lse);
                 g = p * (dpt[r] * cdp - dsm);
             }
             h16 x, y;
@@ -770,12 +841,13 @@ __global__ __launch_bounds__(256) void tx_attn_bwd_q_kernel(const tx_attn_bwd_ar
                 dqt[mt] = tx_mfma3(ah, al, gh[u], gl[u], dqt[mt]);
             }
         }
-        if (more) st_regs.store(lds + (buf ^ 1) * STAGE, threadIdx.x);
+        if (more) { TX_STAGE_STORE(st_regs, 4, 2, lds + (buf ^ 1) * STAGE); }
         __syncthreads();
     }
     if (q_ok) {
         const float fq = 0.14433756729740643f / (sk * sds);
-        float* row = a.dq + (size_t)(q0 + j) * a.lddq + h * TX_HD;
+        float* row = gridDim.z == 1 ? a.dq + (size_t)(q0 + j) * a.lddq + h * TX_HD
+                                    : a.part + ((size_t)blockIdx.z * a.Lq + q0 + j) * (H * TX_HD) + h * TX_HD;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -954,11 +1026,25 @@ int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, co
 
 
 // ---- attention ---------------------------------------------------------------------------------------------------------------------------
-static inline int tx_lp(int L) { return (L + 127) & ~127; }      // plane rows: whole 128-row blocks (32 per wave) so no load leaves the plane
+static inline int tx_lp(int L) { return (L + 127) & ~127; }
+// range splits: enough blocks for ~3 per CU (forward / dQ: keys; dK, dV: queries), pieces of whole 32-token tiles
+static inline int tx_split_for(int blocks, int target, int tiles) {
+    int z = blocks > 0 ? target / blocks : 1;
+    if (z > tiles / 4) z = tiles / 4;          // at least four tiles per piece
+    if (z > 16) z = 16;
+    return z < 1 ? 1 : z;
+}
+static inline int64_t tx_attn_part_floats(int64_t Lq, int64_t Lk, int64_t H) {
+    const int64_t a = 16 * (Lq * H * TX_HD + 2 * H * Lq), b = 16 * 2 * Lk * H * TX_HD;     // at most 16 pieces
+    const int64_t zq = tx_split_for((int)((Lq + 127) / 128 * H), 768, (int)((Lk + 31) / 32)), zk = tx_split_for((int)((Lk + 127) / 128 * H), 1536, (int)((Lq + 31) / 32));
+    const int64_t nq = zq > 1 ? zq * (Lq * H * TX_HD + 2 * H * Lq) : 0, nk = zk > 1 ? zk * 2 * Lk * H * TX_HD : 0;
+    (void)a; (void)b;
+    return tx_al((nq > nk ? nq : nk) + 64);
+}      // plane rows: whole 128-row blocks (32 per wave) so no load leaves the plane
 int64_t asd_tx_attention_workspace(int32_t Lq, int32_t Lk, int32_t H) {
     // six planes of halfs (Q, K row-major hi / lo; V^T hi / lo), the backward's extra planes (Q^T, dO, dO^T) and 5 * H scale words
     const int64_t Lqp = tx_lp(Lq), Lkp = tx_lp(Lk);
-    return tx_al((int64_t)H * TX_HD * (8 * Lqp + 6 * Lkp) / 2 + 256) + tx_al(8 * H) + tx_al((int64_t)H * Lq);
+    return tx_al((int64_t)H * TX_HD * (8 * Lqp + 6 * Lkp) / 2 + 256) + tx_al(8 * H) + tx_al((int64_t)H * Lq) + tx_attn_part_floats(Lq, Lk, H);
 }
 
 // o [Lq, ldo] = softmax(q k^T / sqrt(48)) v per head (head h = columns 48 h .. 48 h + 47 of q / k / v / o), lse2 [H, Lq] for the backward
@@ -984,7 +1070,11 @@ int asd_tx_attention_fwd(const float* q, int32_t ldq, const float* k, int32_t ld
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lqp * (TX_HD / 4), 256), H), dim3(256), 0, s, q, Lq, Lqp, ldq, H, amax, qh, ql);
     hipLaunchKernelGGL(tx_attn_prep_rows_kernel, dim3(asd_div_up((int64_t)Lkp * (TX_HD / 4), 256), H), dim3(256), 0, s, k, Lk, Lkp, ldk, H, amax + H, kh, kl);
     hipLaunchKernelGGL(tx_attn_prep_cols_kernel, dim3(Lkp / 64, H), dim3(256), 0, s, v, Lk, Lkp, ldv, H, amax + 2 * H, vth, vtl);
-    hipLaunchKernelGGL(tx_attn_fwd_kernel, dim3(asd_div_up(Lq, 128), H), dim3(256), 0, s, qh, ql, kh, kl, vth, vtl, amax, Lq, Lqp, Lk, Lkp, H, o, ldo, lse2);
+    float* part = ws + tx_al((int64_t)H * TX_HD * (8 * (int64_t)Lqp + 6 * (int64_t)Lkp) / 2 + 256) + tx_al(8 * H) + tx_al((int64_t)H * Lq);
+    const int zk = tx_split_for(asd_div_up(Lq, 128) * H, 768, asd_div_up(Lk, 32));
+    hipLaunchKernelGGL(tx_attn_fwd_kernel, dim3(asd_div_up(Lq, 128), H, zk), dim3(256), 0, s, qh, ql, kh, kl, vth, vtl, amax, Lq, Lqp, Lk, Lkp, H, o, ldo, lse2, part);
+    if (zk > 1)
+        hipLaunchKernelGGL(tx_attn_fwd_combine_kernel, dim3(asd_div_up((int64_t)Lq * H * (TX_HD / 4), 256)), dim3(256), 0, s, part, zk, Lq, H, o, ldo, lse2);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -1026,18 +1116,19 @@ int asd_tx_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ld
     a.amax = amax; a.lse2 = lse2; a.dsum = dsum;
     a.Lq = Lq; a.Lqp = Lqp; a.Lk = Lk; a.Lkp = Lkp; a.H = H;
     a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    int qsplit = 1;
-    if (asd_div_up(Lk, 128) * H < 256) {       // fewer key blocks than CUs
-        qsplit = 128 / (asd_div_up(Lk, 128) * H);
-        if (qsplit > asd_div_up(Lq, 128)) qsplit = asd_div_up(Lq, 128);
-        if (qsplit < 1) qsplit = 1;
-    }
-    if (qsplit > 1) {       // (row by row: dk / dv may be column slices of a wider matrix)
-        (void)hipMemset2DAsync(dk, (size_t)lddk * 4, 0, (size_t)H * TX_HD * 4, Lk, s);
-        (void)hipMemset2DAsync(dv, (size_t)lddv * 4, 0, (size_t)H * TX_HD * 4, Lk, s);
-    }
+    a.part = dsum + tx_al((int64_t)H * Lq);
+    const int qsplit = tx_split_for(asd_div_up(Lk, 128) * H, 1536, asd_div_up(Lq, 32));
     hipLaunchKernelGGL(tx_attn_bwd_kv_kernel, dim3(asd_div_up(Lk, 128), H, qsplit), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(tx_attn_bwd_q_kernel, dim3(asd_div_up(Lq, 128), H), dim3(256), 0, s, a);
+    if (qsplit > 1) {
+        const int HDa = H * TX_HD;
+        const dim3 g(asd_div_up((int64_t)Lk * (HDa / 4), 256));
+        hipLaunchKernelGGL(tx_attn_sum_parts_kernel, g, dim3(256), 0, s, a.part, qsplit, Lk, HDa, dk, lddk);
+        hipLaunchKernelGGL(tx_attn_sum_parts_kernel, g, dim3(256), 0, s, a.part + (size_t)qsplit * Lk * HDa, qsplit, Lk, HDa, dv, lddv);
+    }
+    const int ksplit = tx_split_for(asd_div_up(Lq, 128) * H, 768, asd_div_up(Lk, 32));
+    hipLaunchKernelGGL(tx_attn_bwd_q_kernel, dim3(asd_div_up(Lq, 128), H, ksplit), dim3(256), 0, s, a);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(tx_attn_sum_parts_kernel, dim3(asd_div_up((int64_t)Lq * (H * TX_HD / 4), 256)), dim3(256), 0, s, a.part, ksplit, Lq, H * TX_HD, dq, lddq);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
