@@ -154,7 +154,9 @@ __device__ __forceinline__ float tx_gelu_grad(float u) {
 }
 // y[i][j] = f(acc[i][j] * ia[i] * iw[j] + bias[j]) + residual[i][j]
 //   mode 0: f = identity;  1: f = GELU, the pre-activation goes to `aux`;  2: f(v) = v * GELU'(aux[i][j])  (gradient through a GELU)
-__global__ __launch_bounds__(256) void tx_epilogue_kernel(const float* __restrict__ acc, int M, int N, const float* __restrict__ ia,
+// nslab > 1: `acc` holds the split-K slabs [nslab][M][N] of the product (asd_gemm_f16 with partials_only): they are summed here instead of
+// by a reduction launch of their own
+__global__ __launch_bounds__(256) void tx_epilogue_kernel(const float* __restrict__ acc, int nslab, int M, int N, const float* __restrict__ ia,
                                                           const float* __restrict__ iw, const float* __restrict__ bias, int mode,
                                                           float* __restrict__ aux, int ld_aux, const float* __restrict__ residual, int ldr,
                                                           float* __restrict__ y, int ldy) {
@@ -162,6 +164,10 @@ __global__ __launch_bounds__(256) void tx_epilogue_kernel(const float* __restric
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < (size_t)M * n4; t += (size_t)gridDim.x * 256) {
         const int i = (int)(t / n4), j = (int)(t % n4) * 4;
         float4 v = *reinterpret_cast<const float4*>(acc + (size_t)i * N + j);
+        for (int z = 1; z < nslab; ++z) {
+            const float4 u = *reinterpret_cast<const float4*>(acc + ((size_t)z * M + i) * N + j);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
         const float a = ia[i];
         const float4 w = *reinterpret_cast<const float4*>(iw + j);
         v.x *= a * w.x; v.y *= a * w.y; v.z *= a * w.z; v.w *= a * w.w;
@@ -910,8 +916,9 @@ inline int64_t tx_gemm_ws_floats(int M, int N, int K3) {
     return sk > 1 ? tx_al((int64_t)sk * M * N) : 0;
 }
 
-// C32 [M, N] = planeA [M, 3K] . planeW [N, 3K]^T  (fp32 result of the three fp16 products); slabs: tx_gemm_ws_floats(M, N, K3) floats
-int tx_gemm(const h16* pa, const h16* pw, int M, int N, int K3, float* c32, float* slabs, hipStream_t s) {
+// planeA [M, 3K] . planeW [N, 3K]^T (fp32 result of the three fp16 products): *res / *nslab tell the epilogue where the result is — c32
+// [M, N] (nslab 1) or the unreduced split-K slabs [nslab][M][N] in `slabs` (tx_gemm_ws_floats(M, N, K3) floats)
+int tx_gemm(const h16* pa, const h16* pw, int M, int N, int K3, float* c32, float* slabs, const float** res, int* nslab, hipStream_t s) {
     asd_gemm_args a;
     memset(&a, 0, sizeof(a));
     a.A = pa; a.W = pw; a.C = c32;
@@ -921,6 +928,9 @@ int tx_gemm(const h16* pa, const h16* pw, int M, int N, int K3, float* c32, floa
     int cfg, sk;
     tx_plan(M, N, K3, &cfg, &sk);
     a.split_k = sk; a.tile_cfg = cfg; a.workspace = slabs;
+    a.partials_only = sk > 1;
+    *res = sk > 1 ? slabs : c32;
+    *nslab = sk;
     a.zero_page = tx_zero_page();
     if (!a.zero_page) { asd_set_error("tritx: could not allocate the zero page"); return ASD_ERR_LAUNCH; }
     return asd_gemm_f16(&a, s);
@@ -964,9 +974,11 @@ int asd_tx_linear(const float* x, int32_t M, int32_t K, int32_t ldx, const void*
     float* ia = ws + tx_al((int64_t)M * 3 * K / 2 + 64);
     float* c32 = ia + tx_al(M);
     hipLaunchKernelGGL((tx_split_rows_kernel<0>), dim3(asd_div_up(M, 4)), dim3(256), 0, s, x, M, K, ldx, pa, ia);
-    const int rc = tx_gemm(pa, (const h16*)plane_w, M, N, 3 * K, c32, c32 + tx_al((int64_t)M * N), s);
+    const float* res;
+    int nslab;
+    const int rc = tx_gemm(pa, (const h16*)plane_w, M, N, 3 * K, c32, c32 + tx_al((int64_t)M * N), &res, &nslab, s);
     if (rc != ASD_OK) return rc;
-    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)M * N / 4, 256)), dim3(256), 0, s, c32, M, N, ia, inv_w, bias, mode, aux, N, residual, ldr, y, ldy);
+    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)M * N / 4, 256)), dim3(256), 0, s, res, nslab, M, N, ia, inv_w, bias, mode, aux, N, residual, ldr, y, ldy);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -998,9 +1010,11 @@ int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ld
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(K, 64), asd_div_up(M, 256)), dim3(256), 0, s, x, M, K, ldx, 256, cmax_w, (float*)nullptr);
     hipLaunchKernelGGL((tx_split_cols_kernel<0>), dim3(asd_div_up(N, 64), Mp / 64), dim3(256), 0, s, dy, M, N, ldy, Mp, cmax_a, pa, ia);
     hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(K, 64), Mp / 64), dim3(256), 0, s, x, M, K, ldx, Mp, cmax_w, pw, iw);
-    const int rc = tx_gemm(pa, pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), s);
+    const float* res;
+    int nslab;
+    const int rc = tx_gemm(pa, pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), &res, &nslab, s);
     if (rc != ASD_OK) return rc;
-    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, c32, N, K, ia, iw, (const float*)nullptr, 0, (float*)nullptr, 0,
+    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, res, nslab, N, K, ia, iw, (const float*)nullptr, 0, (float*)nullptr, 0,
                        (const float*)nullptr, 0, dw, K);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
