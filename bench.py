@@ -125,22 +125,13 @@ def to_device(batch, dev):
     return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-# HBM-side bytes per launch from dedicated rocprofv3 PMC passes (tools/roofline_kernel_only.py under `--pmc FETCH_SIZE` and
-# `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; summaries in
-# profiles/r02_g_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.csv for the current plans, r01_final* for the earlier ones), keyed by (op, autotuned plan).
-# Round 3 (profiles/r03_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.csv, tools/roofline_pmc.sh): conv3x3_pp_kernel<4,4> on the 512^2 layer 72.4 MB
-# read + 79.6 MB written for 134.5 MB algorithmic; the other two entries re-measured unchanged.
-PMC_TRAFFIC = {("vae512", (24, 1)): 152.0e6, ("vae512", (12, 1)): 140.3e6, ("vae512", (10, 1)): 145.5e6, ("unet64", (11, 1)): 50.1e6, ("unet64", (14, 1)): 50.1e6,
-               ("gemm320", (3, 1)): 37.2e6, ("unet64", (3, 1)): 45.3e6, ("unet64", (7, 3)): 195.3e6}
-
-
-# the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of the CSV) and inside
-# the timed steps (profiles/r03_step_breakdown.txt: 1.67 ms of every 15.1 ms step)
+# the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of
+# profiles/r05_kernel_stats.csv) and inside the timed steps (profiles/r05_step_breakdown.txt)
 DOMINANT = "pp_conv"
-DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row conv3x3_pp_kernel<4,4>; inside the timed steps "
-                   "(profiles/r03_step_breakdown.txt) it is first too with 1.67 ms per step (24 launches on seven shapes, all in the VAE encoder's forward and "
-                   "input-gradient pass), then gemm_f16_kernel<256,64> 1.35 ms, attention 1.2 ms, field_bwd_sample_kernel 1.13 ms (round 2's `roofline` kernel, now "
-                   "`roofline_field_bwd`: 0.047 of HBM, bound by the L2's atomic request rate)")
+DOMINANT_SOURCE = ("profiles/r05_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row conv3x3_pp_kernel<4,4>; inside the timed "
+                   "steps (profiles/r05_step_breakdown.txt) it is first too (24 launches on seven shapes, all in the VAE encoder's forward and input-gradient "
+                   "pass), then gemm_f16_kernel<256,64>, attention, and the hash-grid gradient (`roofline_field_bwd`: field_bwd_sample_kernel + the paged "
+                   "scatter of csrc/field_paged.hip)")
 
 # every launch of conv3x3_pp_kernel<4,4> in one step (tools/gemm_shapes.py trace of the step, gpurun_out/gemm_shapes.txt): (H = W, Cin, Cout,
 # residual, GroupNorm records in the epilogue: 0 none (the input-gradient launches) / 1 forward statistics / 2 the backward reductions of the
@@ -148,34 +139,30 @@ DOMINANT_SOURCE = ("profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --st
 PP44_LAUNCHES = [(512, 128, 128, 0, 0, 4), (512, 128, 128, 1, 1, 2), (512, 128, 128, 0, 1, 2), (128, 512, 512, 0, 0, 3), (128, 512, 512, 1, 1, 2),
                  (128, 512, 512, 0, 1, 1), (256, 256, 256, 0, 0, 3), (256, 256, 256, 1, 1, 2), (256, 256, 256, 0, 1, 1), (128, 256, 512, 0, 1, 1),
                  (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 0, 1), (512, 32, 128, 0, 1, 1)]
-# HBM bytes per launch of that kernel, averaged over the launches of `python bench.py` (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-# profiles/r03_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)
-PP44_PMC_BYTES = 70.21e6 + 49.47e6      # (round 3's figure: used only when the committed CSVs below are missing)
+PROFILE_ROUND = "r05"
 
 
-def pmc_traffic_of(kernel_substr: str):
-    """HBM bytes per launch of a kernel from the COMMITTED per-kernel PMC summaries (profiles/r04_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv, falling back to
-    round 3's; separate rocprofv3 --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950) — read at run
-    time, so the figure follows the profile that is committed next to the code instead of a constant pasted into this file"""
+def pmc_traffic_of(*kernel_substrs: str):
+    """HBM bytes per launch of a kernel (or the sum over several kernels that form one span) from the COMMITTED per-kernel PMC summaries of this
+    round (profiles/r05_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate rocprofv3 --pmc passes of `python bench.py`, tools/r5_pmc.sh; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950) — read at run time, so the figure follows the profile committed next to
+    the code; None when a kernel is missing from either file (no fall-back to an older round)."""
     import csv
 
     tot = 0.0
-    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
-        val = None
-        for rnd in ("r04", "r03"):
-            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cnt}_per_kernel.csv")
-            if not os.path.exists(path):
-                continue
-            with open(path) as fh:
-                for row in csv.reader(fh):          # kernel, dispatches, sum KB, avg KB, avg MB per dispatch (FETCH_SIZE already doubled there)
-                    if len(row) >= 5 and kernel_substr in row[0]:
-                        val = float(row[4]) * 1e6
-                        break
-            if val is not None:
-                break
-        if val is None:
-            return None
-        tot += val
+    for name in kernel_substrs:
+        for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+            path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{cnt}_per_kernel.csv")
+            val = None
+            if os.path.exists(path):
+                with open(path) as fh:
+                    for row in csv.reader(fh):          # kernel, dispatches, sum KB, avg KB, avg MB per dispatch (FETCH_SIZE already doubled there)
+                        if len(row) >= 5 and name in row[0]:
+                            val = float(row[4]) * 1e6
+                            break
+            if val is None:
+                return None
+            tot += val
     return tot
 
 
@@ -232,8 +219,8 @@ def roofline_pp_kernel(reps: int = 3):
                       "staggered by a barrier, counted vmcnt, 32-channel k-steps); all its launches of one step (VAE encoder forward + input gradient), each with its "
                       "step epilogue", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": pmc_traffic_of("conv3x3_pp_kernel<4, 4>") or PP44_PMC_BYTES,
-            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r0N_pmc_*_per_kernel.csv at run time)",
+            "traffic": pmc_traffic_of("conv3x3_pp_kernel<4, 4>"),
+            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r05_pmc_*_per_kernel.csv at run time)",
             "operands": "HBM-cold: >= 600 MB of distinct operand sets rotated per shape (as inside the step)",
             "launches_per_step": int(launches), "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
             "avg_launch_ms": round(secs / launches * 1e3, 4), "ms_per_step": round(secs * 1e3, 3),
@@ -310,7 +297,7 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     shape = "3x3 conv 128->128 @512x512 (VAE encoder)" if which == "vae512" else "3x3 conv 320->320 @64x64, UNet batch 5"
     return {"kernel": f"{kern} split_k={plan[1]} on {shape}; autotuned plan", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": PMC_TRAFFIC.get((which, plan)), "traffic_unit": "bytes/launch (PMC, profiles/)", "flops_per_launch": flops,
+            "traffic": None, "traffic_unit": "bytes/launch (no per-shape PMC pass in round 5: null rather than an older round's figure)", "flops_per_launch": flops,
             "avg_launch_ms": round(ms, 4)}
 
 
@@ -338,7 +325,7 @@ def roofline_gemm_kernel(reps: int = 50):
     return {"kernel": f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}> split_k={plan[1]} on linear 320->320, M=20480 (UNet 64x64 tokens x batch 5)"
                       if plan[0] else "gemm_f16_kernel<model tile> on linear 320->320, M=20480",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC.get(("gemm320", plan)), "traffic_unit": "bytes/launch (PMC, profiles/)", "bytes_per_launch": nbytes,
+            "traffic": None, "traffic_unit": "bytes/launch (no per-shape PMC pass in round 5: null rather than an older round's figure)", "bytes_per_launch": nbytes,
             "avg_launch_ms": round(ms, 4)}
 
 
@@ -421,19 +408,20 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     ms_call = t0_.elapsed_time(t1_) / reps
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
-    # PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default `python bench.py`, tools/final_profiles.sh; the LAST 10 launches
-    # of the kernel = this leg, 433 k samples each: profiles/r03_pmc_roofline_kernel.txt: 1089.6 + 69.2 MB; r02_h): WRITE_SIZE 1059.4 MB + FETCH_SIZE 69.0 MB
-    # (gfx950 correction applied) per launch = 2605 B per sample, 2.2x the algorithmic bytes — every fp32 atomic dirties a 32-64 B
-    # sector.  (Round 2's earlier 616 + 36 MB came from a 5-step run whose launches had fewer samples and were scaled as if they had
-    # 433 k: per sample the figure was about the same as now.)  Scaled to this launch's sample count:
-    traffic = n * (1089.63e6 + 69.21e6) / 433172.0
-    return {"kernel": "field_bwd_sample_kernel<16,64,3> (hash-grid gradient scatter, request-coalesced fp32 atomics, per-XCD copies of the three coarsest levels + asd_priv_reduce_kernel; one launch per step)", "bound": "hbm",
+    # PMC: the span is field_bwd_sample_kernel (MLP backward + the coarse levels' run-aggregated atomics) + pg_fill_kernel + pg_accum_kernel (the
+    # paged scatter of the ten hashed levels); bytes per launch from this round's per-kernel passes, where every launch of these kernels has
+    # the step's sample count
+    traffic = pmc_traffic_of("field_bwd_sample_kernel", "pg_fill_kernel", "pg_accum_kernel")
+    return {"kernel": "asd_field_bwd's gradient span: field_bwd_sample_kernel<16,64,3> (MLP backward, coarse levels 0-5 as run-aggregated fp32 atomics with per-XCD "
+                      "copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the ten hashed levels binned by 64 KB table page, one workgroup "
+                      "per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(traffic), "traffic_unit": "bytes/launch (PMC WRITE_SIZE + FETCH_SIZE of the last 10 launches, profiles/r03_pmc_roofline_kernel.txt, scaled by samples)",
+            "traffic": None if traffic is None else round(traffic),
+            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/r05_pmc_*_per_kernel.csv)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
-            "atomic_dwords_per_sample": 256, "atomic_dword_rate_G_per_s": round(n * 256 / (ms * 1e-3) / 1e9, 1),
-            "binding_limit": "atomic request rate of the L2 (tools/atomic_probe2.hip: ~21 G requests/s; 4 dwords per request after coalescing), not bytes"}
+            "binding_limit": "inside the span: the sample kernel (arithmetic + ~3.5 M coarse-level atomic requests), then the item stream of the paged scatter "
+                             "(128 B per sample and hashed level written + read) and its 640 pages on 512 workgroup slots (DESIGN.md 4.7)"}
 
 
 def cpu_baseline(system, batch, seed: int):
@@ -640,8 +628,8 @@ def main():
             out["config"].update({"workload": {"asd_sd_3dconv_net": "asd_sd_3dconv_net: StyleGAN-3D generator on the HIP path (split-fp16 3x3x3 convolutions fwd / dgrad / wgrad, "
                                                                        "csrc/conv3d.hip) -> [32,128^3] volume, fused trilinear lookup + MLP heads, VolSDF renderer, SD-2.1 guidance, "
                                                                        "1 prompt+view/GPU",
-                                               "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer (fp32 library ops) -> 3x[32,64,64] "
-                                                                  "planes, fused tri-plane field on the matrix pipe (lookups + both MLP heads + finite-difference normal, "
+                                               "asd_mv_triplane": "asd_mv_triplane_transformer: 12-layer triplane transformer on the HIP path (csrc/tritx.hip: split-fp16 linears + "
+                                                                  "flash attention at fp32-class accuracy) -> 3x[32,64,64] planes, fused tri-plane field on the matrix pipe (lookups + both MLP heads + finite-difference normal, "
                                                                   "csrc/trifield_mfma.hip; sorted plane scatter), VolSDF renderer, MVDream guidance, 4 views/GPU, Adan"}[args.workload]})
             out.pop("kept_samples_last_step", None)
             if args.render:
@@ -667,7 +655,7 @@ def main():
         dom = DOMINANT if DOMINANT in lines and lines[DOMINANT] is not None else ("conv3d" if "conv3d" in lines else "gemm")
         out["roofline"] = lines.pop(dom)
         out["roofline"]["rank_source"] = (DOMINANT_SOURCE if dom == DOMINANT else
-                                          "profiles/r04_c4_3dconv_step_breakdown.txt: the generator's convolution kernels lead this workload's step" if dom == "conv3d"
+                                          "profiles/r04_c4_3dconv_step_breakdown.txt (generator unchanged in round 5): its convolution kernels lead this workload's step" if dom == "conv3d"
                                           else "secondary workload: most frequent GEMM of the diffusion prior")
         for k, v in lines.items():
             out["roofline_" + k] = v
