@@ -19,6 +19,6 @@ for f in files:
             cnt[k].add(row.get("Dispatch_Id", row.get("Correlation_Id")))
 scale = 2.0 if counter == "FETCH_SIZE" else 1.0
 print(f"kernel,dispatches,sum_{counter}_KB,avg_KB_per_dispatch,avg_MB_per_dispatch_corrected")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:40]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 400]:
     n = max(1, len(cnt[k]))
     print(f"\"{k[:90]}\",{n},{v:.1f},{v / n:.1f},{v / n * scale / 1024:.2f}")
