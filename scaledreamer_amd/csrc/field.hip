@@ -448,8 +448,10 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) a = fmaf(w1d[h * NIN + k], e[k], a);
                 if (ASD_FIELD_W2_ROWSUM) {
+#ifndef ASD_FIELD_ABL_NOW2
                     const float v = asd_row_sum15(active ? draw * fmaxf(a, 0.f) : 0.f);
                     if (row_last) w2_acc[w2c + h] += v;
+#endif
                 } else if (ASD_FIELD_W2_COPIES > 1) {
                     const float v = active ? draw * fmaxf(a, 0.f) : 0.f;
                     if (v != 0.f) atomicAdd(&w2_acc[w2c + h], v);
@@ -487,8 +489,10 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                         for (int o = 0; o < C; ++o) {
                             dh = fmaf(df[o], w2f[o * H + h], dh);
                             if (ASD_FIELD_W2_ROWSUM) {
+#ifndef ASD_FIELD_ABL_NOW2
                                 const float v = asd_row_sum15(df[o] * hv);
                                 if (row_last) w2_acc[w2c + H + o * H + h] += v;
+#endif
                             } else if (ASD_FIELD_W2_COPIES > 1) {
                                 const float v = df[o] * hv;
                                 if (v != 0.f) atomicAdd(&w2_acc[w2c + H + o * H + h], v);
@@ -522,7 +526,9 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
             const float ux = (qx - c.bbox_min[0]) / bx, uy = (qy - c.bbox_min[1]) / by, uz = (qz - c.bbox_min[2]) / bz;
             if (pg_g) {
                 // coarse levels as before (run-aggregated atomics, per-XCD copies); the fine levels' rows go to the paged scatter
+#ifndef ASD_FIELD_ABL_NOCOARSE      // (timing-only ablation, tools/r5_field_abl.sh: what the coarse levels' atomics cost inside this kernel)
                 asd_scatter_runs<L, ASD_FIELD_NAGG, ASD_FIELD_NPRIV, false>(m, d_grid, ux, uy, uz, denc, active, priv, priv_stride);
+#endif
                 if (active) {
                     constexpr int NFINE = L - ASD_FIELD_NAGG;
                     const size_t rr = (size_t)pt * n + i;

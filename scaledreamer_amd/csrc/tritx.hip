@@ -16,6 +16,7 @@
 // passes (4-10 B per element).
 #include <math.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include <hip/hip_fp16.h>
@@ -1031,7 +1032,8 @@ int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamm
 int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
                          float* dgamma, float* dbeta, void* stream) {
     ASD_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "LayerNorm: D % 4 == 0, D <= 1024");
-    int grid = asd_div_up(M, 4 * 2);          // two rows per wave
+    static const int rows_per_wave = getenv("ASD_TX_LN_ROWS") ? atoi(getenv("ASD_TX_LN_ROWS")) : 8;      // tools/tritx_time.py: 81 / 44 / 29 / 28 / 40 us at 1 / 2 / 4 / 8 / 16 rows per wave (the per-block atomics of dgamma / dbeta dominate)
+    int grid = asd_div_up(M, 4 * (rows_per_wave > 0 ? rows_per_wave : 8));
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(tx_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta);
     ASD_LAUNCH_CHECK();

@@ -53,3 +53,12 @@ for M, K, N in ((3072, 768, 768), (3072, 768, 2304), (3072, 768, 3072), (3072, 3
     t1, t2, t3 = timed(lin), timed(wg), timed(lambda: x @ w.t())
     fl = 2.0 * M * N * K
     print(f"linear {M}x{K}->{N}: fwd {t1:7.1f} us ({fl / t1 / 1e6:6.1f} TF/s fp32-eq)  wgrad {t2:7.1f} us ({fl / t2 / 1e6:6.1f})  torch fp32 matmul {t3:7.1f} us ({fl / t3 / 1e6:6.1f})")
+
+M, Dm = 3072, 768
+x, dy, dres = (torch.randn(M, Dm, device="cuda", generator=g) for _ in range(3))
+gamma, beta = torch.randn(Dm, device="cuda", generator=g), torch.randn(Dm, device="cuda", generator=g)
+y, stats, dx = torch.empty_like(x), torch.empty(M, 2, device="cuda"), torch.empty_like(x)
+dg, db = torch.zeros(Dm, device="cuda"), torch.zeros(Dm, device="cuda")
+lnf = lambda: L.check(L.lib().asd_tx_layernorm_fwd(L.ptr(x), L.i32(M), L.i32(Dm), L.ptr(gamma), L.ptr(beta), L.f32(1e-6), L.ptr(y), L.ptr(stats), L.stream()))
+lnb = lambda: L.check(L.lib().asd_tx_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(gamma), L.i32(M), L.i32(Dm), L.ptr(dres), L.ptr(dx), L.ptr(dg), L.ptr(db), L.stream()))
+print(f"layernorm {M}x{Dm}: fwd {timed(lnf):6.1f} us  bwd {timed(lnb):6.1f} us  (ASD_TX_LN_ROWS={os.environ.get('ASD_TX_LN_ROWS', '2')})")
