@@ -28,6 +28,18 @@ void asd_set_error(const char* fmt, ...);
 
 static inline int asd_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be issued once per kernel AND device (a process may drive several GPUs): one bit
+// per device in a per-call-site mask; the call is idempotent, so two threads racing here both set it and nothing is lost
+#include <atomic>
+static inline bool asd_attr_needed(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+
 // Memory-bound grid sizing (guide G11): cap at 256 CUs x 8 blocks and grid-stride the rest.
 static inline int asd_grid_for(int64_t n, int block) {
     int g = asd_div_up(n, block);

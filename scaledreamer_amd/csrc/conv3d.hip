@@ -782,13 +782,13 @@ static int c3_run(int D, int H, int W, int cin, int cout, const float* x, const 
     const int blocks = 8 * asd_div_up(tiles_m * tiles_n, 8);
     const size_t lds = (size_t)4 * 18 * 24 * 64 + (size_t)6 * bn * 64;
     if (tn == 4) {
-        static bool attr = false;
+        static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         ASD_PROBE_START(s);
         hipLaunchKernelGGL((conv3d_pp_kernel<4>), dim3(blocks), dim3(512), lds, s, k);
         ASD_PROBE_STOP(s);
     } else {
-        static bool attr = false;
+        static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         ASD_PROBE_START(s);
         hipLaunchKernelGGL((conv3d_pp_kernel<2>), dim3(blocks), dim3(512), lds, s, k);

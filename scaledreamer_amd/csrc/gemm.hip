@@ -1211,7 +1211,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
             const size_t lds2 = (size_t)41 * 1024 + (size_t)2 * bn * 128;
 #define WIN2_LAUNCH(BN_, NW_)                                                                                                          \
     do {                                                                                                                               \
-        static bool attr_set = false;                                                                                                  \
+        static std::atomic<unsigned long long> attr_set_devmask{0}; bool attr_set = !asd_attr_needed(attr_set_devmask);                                                                                                  \
         if (!attr_set) {                                                                                                               \
             (void)hipFuncSetAttribute((const void*)conv3x3_win2_kernel<BN_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
             attr_set = true;                                                                                                           \
@@ -1231,7 +1231,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
             ASD_LAUNCH_CHECK();
             return ASD_OK;
         }
-        static bool attr64 = false, attr128 = false;
+        static std::atomic<unsigned long long> attr64_devmask{0}; bool attr64 = !asd_attr_needed(attr64_devmask);static std::atomic<unsigned long long> attr128_devmask{0}; bool attr128 = !asd_attr_needed(attr128_devmask);
         if (bn == 64) {
             if (!attr64) { (void)hipFuncSetAttribute((const void*)conv3x3_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); attr64 = true; }
             hipLaunchKernelGGL((conv3x3_win_kernel<64>), dim3(tiles_w), dim3(512), lds_w, sw, *a);
@@ -1254,7 +1254,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define GEMM_LAUNCH(BM_, BN_, WM_, WN_, CONV_, NST_, KG_, LN_)                                                           \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
+        static std::atomic<unsigned long long> attr_set_devmask{0}; bool attr_set = !asd_attr_needed(attr_set_devmask);                                                                                    \
         if (!attr_set) {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<BM_, BN_, WM_, WN_, CONV_, NST_, KG_, LN_>,           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, NST_ * KG_ * (BM_ + BN_) * 128);       \

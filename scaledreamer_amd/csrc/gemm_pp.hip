@@ -318,7 +318,7 @@ int asd_conv_pp_launch(int variant, const asd_gemm_args* a, int blocks, hipStrea
     const size_t lds = asd_conv_pp_lds_bytes(variant);
 #define PP_LAUNCH(TM_, TN_)                                                                                                       \
     do {                                                                                                                          \
-        static bool attr_set = false;                                                                                             \
+        static std::atomic<unsigned long long> attr_set_devmask{0}; bool attr_set = !asd_attr_needed(attr_set_devmask);                                                                                             \
         if (!attr_set) {                                                                                                          \
             (void)hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                                      \

@@ -599,7 +599,7 @@ int asd_trifield_bwd(const float* planes_cl, int32_t H, int32_t W, int32_t C, co
     static const bool want_lds = getenv("ASD_TRI_LDS_SCATTER") && getenv("ASD_TRI_LDS_SCATTER")[0] == '1';
     const bool lds_scatter = want_lds && (size_t)H * W * 8 * 4 <= 150 * 1024;
     if (lds_scatter) {
-        static bool attr = false;
+        static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
         if (!attr) { (void)hipFuncSetAttribute((const void*)tf_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
     }
     for (int64_t i0 = 0; i0 < n; i0 += ch) {

@@ -1081,7 +1081,7 @@ int tfm_prepare(const float* planes_cl, int H, int W, const float* const* w6, fl
 
 int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points, int n, float* sdf,
                 float* features, float* normal, float* fd_grad, hipStream_t s) {
-    static bool attr = false;
+    static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
     const size_t lds = (size_t)2 * TFM_FWD_HALVES * 2;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)tfm_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1107,7 +1107,7 @@ int tfm_forward(const tf_geom g, const asd_field_cfg* cfg, const float* planes_c
 int tfm_backward_chunk(const tf_geom g, const asd_field_cfg* cfg, const float* planes_cl, const float* const* w6, const float* prep, const float* points,
                        const float* sdf, int i0, int nc, int npt, const float* d_sdf, const float* d_features, const float* d_normal, const float* d_fd_grad,
                        float* denc, float* pts, float* const* dw6, hipStream_t s) {
-    static bool attr = false;
+    static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
     auto ldsd = [](int) { return (size_t)TFM_HEAD_HALVES * 2; };
     auto ldsw = [](int O) { return (size_t)TFM_OFF_A1TH * 2 + 4 * (3 * 4 * 2 * 64 * 16) + 4 * (1 + O) * 64 * sizeof(float) + (size_t)O * TF_H * sizeof(float); };
     if (!attr) {

@@ -168,7 +168,7 @@ int tfs_scatter(const float* denc, const float* pts, int R, int H, int W, float*
     int* cursor = off + 3 * cells;
     int* len = cursor + 3 * cells;                  // [3] (+ pad)
     int* sorted = len + 64;                         // [3][R]
-    static bool attr = false;
+    static std::atomic<unsigned long long> attr_devmask{0}; bool attr = !asd_attr_needed(attr_devmask);
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)ts_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute((const void*)ts_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -330,18 +330,29 @@ def triplane_sample_bwd(d_out: torch.Tensor, points: torch.Tensor, shape, coord_
 
 
 # ---- generator backbone: split-fp16 3x3x3 convolution + layer tail on channel-last fp32 volumes (csrc/conv3d.hip) ----------------------
-_conv3d_ws = {}     # device -> grow-only workspace (uint8); one conv runs at a time on a stream, so the passes share it
+_conv3d_ws = {}     # (device, stream) -> grow-only workspace (uint8): the passes of one convolution share it, one conv runs at a time on a stream
 _zero_pages = {}
 
 
 def _ws(device, nbytes: int) -> torch.Tensor:
-    cur = _conv3d_ws.get(device)
+    """the convolution workspace of the CURRENT stream.  When it has to grow, the old buffer may still be read by kernels queued on that
+    stream: record_stream keeps the caching allocator from handing it out before they have run."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    cur = _conv3d_ws.get(key)
     if cur is None or cur.numel() < nbytes:
-        cur = None
-        _conv3d_ws.pop(device, None)
+        if cur is not None:
+            cur.record_stream(torch.cuda.current_stream(device))
         cur = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
-        _conv3d_ws[device] = cur
+        _conv3d_ws[key] = cur
     return cur
+
+
+def free_workspaces() -> None:
+    """release the grow-only convolution workspaces (e.g. before evaluation or torch.cuda.empty_cache()): the 128^3 weight-gradient planes and
+    slabs otherwise stay resident for the life of the process"""
+    for key, buf in list(_conv3d_ws.items()):
+        buf.record_stream(torch.cuda.current_stream(key[0]))
+    _conv3d_ws.clear()
 
 
 def _zero_page(device) -> torch.Tensor:
