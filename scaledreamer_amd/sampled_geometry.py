@@ -150,8 +150,11 @@ class _GradSlot:
     pass by pass (proposal sdf, main samples): every evaluation is its own autograd node, and a node that returned a fresh
     zeros_like(volume) — 268 MB at 128^3 x 32 — had autograd memset, fill and sum one volume per chunk.  The scatter kernels accumulate, so the
     first node of a backward pass allocates the buffer and hands it to autograd, the later ones add into it in place and return None.
-    That is sound because the node that consumes the volume's gradient (the generator) cannot run before every node that reads the volume
-    has run (autograd's dependency count), and the buffer of a pass is never reused by another one (keyed by the engine's graph-task id)."""
+    That is sound because (a) the buffer is the gradient of the WHOLE channel-last cache, which reaches the cache's producer only through
+    view nodes (permute) or through the one shared relayout node — no node in between copies it early (a per-entry `cache[b]` select would:
+    its backward copies as soon as its own consumer has run, which is why the field functions take the whole cache and an index), (b) the
+    producer cannot run before every node that reads the cache has run (autograd's dependency count), and (c) the buffer of a pass is
+    never reused by another one (keyed by the engine's graph-task id)."""
 
     __slots__ = ("task", "buf")
 
@@ -170,12 +173,12 @@ class _GradSlot:
         self.buf = None
 
 
-def _grad_slot(owner: torch.Tensor, b: int) -> _GradSlot:
-    """the slot of batch entry b of a space cache: lives on the cache tensor itself (one Python object per step)"""
-    slots = owner.__dict__.setdefault("_asd_grad_slots", {})
-    if b not in slots:
-        slots[b] = _GradSlot()
-    return slots[b]
+def _grad_slot(owner: torch.Tensor) -> _GradSlot:
+    """the slot of a space cache: lives on the cache tensor itself (one Python object per step)"""
+    slot = owner.__dict__.get("_asd_grad_slot")
+    if slot is None:
+        slot = owner.__dict__["_asd_grad_slot"] = _GradSlot()
+    return slot
 
 
 class _VoxFieldFn(torch.autograd.Function):
@@ -183,26 +186,27 @@ class _VoxFieldFn(torch.autograd.Function):
     lookup, heads, bias and finite differences in one kernel each way (include/asd_hip.h: asd_voxfield_fwd / _bwd)"""
 
     @staticmethod
-    def forward(ctx, points, voxel_cl, w1s, w2s, w1f, w2f, fcfg, want_normal, slot=None):
-        sdf, feats, normal, fdg, enc = ops.voxfield_fwd(voxel_cl, fcfg, w1s, w2s, w1f, w2f, points, want_normal)
+    def forward(ctx, points, vol_cl, b, w1s, w2s, w1f, w2f, fcfg, want_normal, slot=None):
+        """vol_cl: the WHOLE channel-last cache [B, D, H, W, C] (contiguous), b: the entry these points sample"""
+        sdf, feats, normal, fdg, enc = ops.voxfield_fwd(vol_cl[b], fcfg, w1s, w2s, w1f, w2f, points, want_normal)
         if not want_normal:
             normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
             ctx.mark_non_differentiable(normal, fdg)
-        ctx.save_for_backward(points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf)
-        ctx.fcfg, ctx.want_normal, ctx.slot = fcfg, want_normal, slot
+        ctx.save_for_backward(points, vol_cl, w1s, w2s, w1f, w2f, enc, sdf)
+        ctx.fcfg, ctx.want_normal, ctx.slot, ctx.b = fcfg, want_normal, slot, b
         ctx.set_materialize_grads(False)
         return sdf, feats, normal, fdg
 
     @staticmethod
     def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
-        points, voxel_cl, w1s, w2s, w1f, w2f, enc, sdf = ctx.saved_tensors
+        points, vol_cl, w1s, w2s, w1f, w2f, enc, sdf = ctx.saved_tensors
         if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
-            return (None,) * 9
-        d_vox, first = (ctx.slot or _GradSlot()).acquire(voxel_cl)
+            return (None,) * 10
+        d_vol, first = (ctx.slot or _GradSlot()).acquire(vol_cl)
         c = lambda t: None if t is None else t.contiguous()
-        dw = ops.voxfield_bwd(voxel_cl, ctx.fcfg, w1s, w2s, w1f, w2f, points, enc, sdf, c(d_sdf), c(d_feats),
-                              c(d_normal) if ctx.want_normal else None, c(d_fdg) if ctx.want_normal else None, d_vox)
-        return None, (d_vox if first else None), dw[0], dw[1], dw[2], dw[3], None, None, None
+        dw = ops.voxfield_bwd(vol_cl[ctx.b], ctx.fcfg, w1s, w2s, w1f, w2f, points, enc, sdf, c(d_sdf), c(d_feats),
+                              c(d_normal) if ctx.want_normal else None, c(d_fdg) if ctx.want_normal else None, d_vol[ctx.b])
+        return None, (d_vol if first else None), None, dw[0], dw[1], dw[2], dw[3], None, None, None
 
 
 @register("3DConv-net")
@@ -302,7 +306,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_VoxFieldFn.apply(pts, vol[b], *w, self._fcfg, bool(output_normal), _grad_slot(space_cache, b)))
+                outs.append(_VoxFieldFn.apply(pts, vol, b, *w, self._fcfg, bool(output_normal), _grad_slot(space_cache)))
             else:
                 with torch.no_grad():
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, pts, bool(output_normal), save_enc=False)[:4])
@@ -325,7 +329,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
             for b in range(B):
                 p = pts[b].contiguous().float()
                 if need_grad:
-                    outs.append(_VoxFieldFn.apply(p, vol[b], *w, self._fcfg, False, _grad_slot(space_cache, b))[0])
+                    outs.append(_VoxFieldFn.apply(p, vol, b, *w, self._fcfg, False, _grad_slot(space_cache))[0])
                 else:
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, p, False, want_features=False, save_enc=False)[0])
         return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)
@@ -336,14 +340,15 @@ class _TriFieldFn(torch.autograd.Function):
     heads (include/asd_hip.h: asd_trifield_fwd / _bwd); nothing but the points and the sdf is kept for the backward pass"""
 
     @staticmethod
-    def forward(ctx, points, planes_cl, s1, s2, s3, f1, f2, f3, fcfg, want_normal, slot=None):
+    def forward(ctx, points, planes_cl, b, s1, s2, s3, f1, f2, f3, fcfg, want_normal, slot=None):
+        """planes_cl: the WHOLE channel-last cache [B, 3, H, W, 32] (contiguous), b: the entry these points sample"""
         w6 = (s1.t().contiguous(), s2.contiguous(), s3.contiguous(), f1.t().contiguous(), f2.contiguous(), f3.contiguous())
-        sdf, feats, normal, fdg = ops.trifield_fwd(planes_cl, fcfg, w6, points, want_normal)
+        sdf, feats, normal, fdg = ops.trifield_fwd(planes_cl[b], fcfg, w6, points, want_normal)
         if not want_normal:
             normal, fdg = sdf.new_zeros(0), sdf.new_zeros(0)
             ctx.mark_non_differentiable(normal, fdg)
         ctx.save_for_backward(points, planes_cl, sdf, *w6)
-        ctx.fcfg, ctx.want_normal, ctx.slot = fcfg, want_normal, slot
+        ctx.fcfg, ctx.want_normal, ctx.slot, ctx.b = fcfg, want_normal, slot, b
         ctx.set_materialize_grads(False)
         return sdf, feats, normal, fdg
 
@@ -351,12 +356,12 @@ class _TriFieldFn(torch.autograd.Function):
     def backward(ctx, d_sdf, d_feats, d_normal, d_fdg):
         points, planes_cl, sdf, *w6 = ctx.saved_tensors
         if d_sdf is None and d_feats is None and d_normal is None and d_fdg is None:
-            return (None,) * 11
+            return (None,) * 12
         d_pl, first = (ctx.slot or _GradSlot()).acquire(planes_cl)
         c = lambda t: None if t is None else t.contiguous()
-        dws = ops.trifield_bwd(planes_cl, ctx.fcfg, w6, points, sdf, c(d_sdf), c(d_feats), c(d_normal) if ctx.want_normal else None,
-                               c(d_fdg) if ctx.want_normal else None, d_pl)
-        return (None, (d_pl if first else None), *dws, None, None, None)
+        dws = ops.trifield_bwd(planes_cl[ctx.b], ctx.fcfg, w6, points, sdf, c(d_sdf), c(d_feats), c(d_normal) if ctx.want_normal else None,
+                               c(d_fdg) if ctx.want_normal else None, d_pl[ctx.b])
+        return (None, (d_pl if first else None), None, *dws, None, None, None)
 
 
 @register("Triplane-transformer-sdf")
@@ -439,7 +444,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(pts, planes[b], *w, self._fcfg, bool(output_normal), _grad_slot(space_cache, b)))
+                outs.append(_TriFieldFn.apply(pts, planes, b, *w, self._fcfg, bool(output_normal), _grad_slot(space_cache)))
             else:
                 with torch.no_grad():
                     w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
@@ -462,7 +467,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(B):
             p = pts[b].contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(p, planes[b], *w, self._fcfg, False, _grad_slot(space_cache, b))[0])
+                outs.append(_TriFieldFn.apply(p, planes, b, *w, self._fcfg, False, _grad_slot(space_cache))[0])
             else:
                 w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
                 outs.append(ops.trifield_fwd(planes[b], self._fcfg, w6, p, False, want_features=False)[0])

@@ -413,3 +413,55 @@ def test_fused_triplane_field_across_backward_chunks_against_float64(monkeypatch
     assert e1 < max(4 * e0, 5e-3)
     for a, b, r in zip(h1, h0, href):
         assert l2(a, r) < max(4 * l2(b, r), 5e-3)
+
+
+@pytest.mark.parametrize("kind", ["voxel", "triplane"])
+def test_fused_field_several_evaluations_of_one_cache_share_one_gradient_buffer(kind, monkeypatch):
+    """The VolSDF renderer evaluates the field several times per step (proposal sdf, shading samples, optionally chunk by chunk): every fused
+    evaluation is its own autograd node, all of them accumulate into ONE gradient buffer per cache and backward pass (sampled_geometry._GradSlot).
+    Three forward() chunks + one forward_sdf() of the same two-entry cache in one graph must give the cache gradient of ONE evaluation of all the
+    points (the kernels are linear in the upstream gradients), and a second backward pass must not see the first one's buffer."""
+    import scaledreamer_amd.plugins  # noqa: F401
+    from scaledreamer_amd.registry import find
+
+    g = torch.Generator().manual_seed(9)
+    torch.manual_seed(9)
+    if kind == "voxel":
+        geo = find("3DConv-net")(dict(_SAMPLED_COMMON, space_generator_config=dict(z_dim=64, w_dim=256, c_dim=1024, num_layers=2, img_resolution=16,
+                                                                                  img_channels=32, channel_multiplier=1)))
+        cache0 = torch.randn(2, 32, 16, 16, 16, generator=g) * 0.5
+    else:
+        geo = find("Triplane-transformer-sdf")(dict(_SAMPLED_COMMON, space_generator_config=dict(_TRI_GEN)))
+        cache0 = torch.randn(2, 3, 32, 64, 64, generator=g) * 0.5
+    geo = geo.cuda()
+    geo.do_update_step(0, 0)
+    n = 900
+    pts = (torch.rand(2, n, 3, generator=g) * 3.6 - 1.8).cuda()
+    pts_sdf = (torch.rand(2, 300, 3, generator=g) * 3.6 - 1.8).cuda()
+    gs = {k: torch.randn(2 * n, d, generator=g).cuda() for k, d in (("sdf", 1), ("features", 3), ("normal", 3), ("sdf_grad", 3))}
+    g_sdf = torch.randn(2, 300, 1, generator=g).cuda()
+
+    def loss_of(c, chunks):
+        total = 0.0
+        bounds = [0, n] if chunks == 1 else [0, 250, 600, n]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            out = geo(pts[:, a:b].contiguous(), c, output_normal=True)
+            for k in gs:
+                gk = gs[k].view(2, n, -1)[:, a:b].reshape(2 * (b - a), -1)
+                total = total + (out[k] * gk).sum()
+        return total + (geo.forward_sdf(pts_sdf, c) * g_sdf).sum()
+
+    def grads(chunks):
+        for p in geo.parameters():
+            p.grad = None
+        c = cache0.clone().cuda().requires_grad_(True)
+        loss_of(c, chunks).backward()
+        return c.grad.clone(), {k: p.grad.clone() for k, p in geo.named_parameters() if p.grad is not None}
+
+    c1, h1 = grads(1)
+    c3, h3 = grads(3)
+    c3b, _ = grads(3)           # a fresh graph and backward pass: nothing of the previous pass's buffer may leak in
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    assert rel(c3, c1) < 1e-5 and rel(c3b, c1) < 1e-5, (rel(c3, c1), rel(c3b, c1))
+    for k in h1:
+        assert rel(h3[k], h1[k]) < 1e-4, k
