@@ -629,3 +629,60 @@ def test_presets_do_not_allow_a_random_prior_unless_asked():
         assert presets.asd_sd_nerf()["system"]["guidance"]["allow_random_weights"] is True
     finally:
         presets.ALLOW_RANDOM_WEIGHTS = saved
+
+
+def test_grad_slot_shares_one_buffer_per_backward_pass_cpu():
+    """sampled_geometry._GradSlot on CPU tensors with a stand-in for the fused field nodes: several autograd nodes read one cache through
+    their own view of it and ACCUMULATE into one gradient buffer (first node of a backward pass hands it to autograd, the others add in place
+    and return None).  The cache gradient must equal the plain sum, for two backward passes in a row, and a consumer of another kind on the
+    same cache (its gradient arrives through the normal accumulation) must still be added."""
+    import torch
+
+    from scaledreamer_amd.sampled_geometry import _GradSlot
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, cache_view, b, weight, slot):
+            ctx.save_for_backward(cache_view, weight)
+            ctx.b, ctx.slot = b, slot
+            return (cache_view[b] * weight).sum(0)
+
+        @staticmethod
+        def backward(ctx, g):
+            cache_view, weight = ctx.saved_tensors
+            buf, first = ctx.slot.acquire(cache_view)
+            buf[ctx.b] += weight * g                  # "the scatter kernel accumulates"
+            return (buf if first else None), None, None, None
+
+    torch.manual_seed(0)
+    base = torch.randn(2, 3, 4, 5)
+    ws = [torch.randn(4, 5) for _ in range(5)]
+    for _ in range(2):                                   # second round: a new graph task must not see the first one's buffer
+        cache = base.clone().requires_grad_(True)
+        slot = _GradSlot()
+        total = (cache * 0.5).sum()                      # another consumer of the cache
+        for i, w in enumerate(ws):
+            total = total + Node.apply(cache.permute(0, 2, 3, 1), i % 2, w.unsqueeze(-1).expand(4, 5, 3), slot).sum()
+        total.backward()
+        ref = base.clone().requires_grad_(True)
+        t2 = (ref * 0.5).sum()
+        for i, w in enumerate(ws):
+            t2 = t2 + (ref.permute(0, 2, 3, 1)[i % 2] * w.unsqueeze(-1)).sum()
+        t2.backward()
+        torch.testing.assert_close(cache.grad, ref.grad)
+
+
+def test_trainer_keys_of_the_presets_reach_the_system():
+    """accumulate_grad_batches of the reference's YAMLs (asd_mv_triplane_transformer_10k.yaml:129: 2 on the 8-GPU node, _1GPU.yaml:131: 8)"""
+    from scaledreamer_amd import presets
+
+    with presets.random_weights_allowed():
+        assert presets.asd_mv_triplane_transformer(n_gpus=8)["trainer"]["accumulate_grad_batches"] == 2
+        assert presets.asd_mv_triplane_transformer(n_gpus=1)["trainer"]["accumulate_grad_batches"] == 8
+        assert "accumulate_grad_batches" not in presets.asd_sd_nerf()["trainer"]
+
+    class S:
+        pass
+
+    s = presets.apply_trainer(S(), {"trainer": {"accumulate_grad_batches": 4}})
+    assert s.accumulate_grad_batches == 4 and presets.apply_trainer(S(), {}).accumulate_grad_batches == 1
