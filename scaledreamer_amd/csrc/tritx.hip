@@ -191,10 +191,31 @@ __global__ __launch_bounds__(256) void tx_epilogue_kernel(const float* __restric
     }
 }
 
+// the A-operand planes of a row that a wave holds in registers (float4 v[i] = columns 4 lane + 256 i): what tx_split_rows_kernel<0> would
+// write, without the row going through memory again
+__device__ __forceinline__ void tx_row_planes(const float4 (&v)[4], int D, int lane, float amax_lane, h16* __restrict__ dst, float* __restrict__ inv) {
+    const float s = tx_scale_for(tx_wave_max(amax_lane));
+    if (lane == 0) *inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            h16 h0, h1, h2, h3, l0, l1, l2, l3;
+            tx_split(v[i].x * s, h0, l0); tx_split(v[i].y * s, h1, l1); tx_split(v[i].z * s, h2, l2); tx_split(v[i].w * s, h3, l3);
+            const h16x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+            *reinterpret_cast<h16x4*>(dst + c) = hi;
+            *reinterpret_cast<h16x4*>(dst + D + c) = hi;
+            *reinterpret_cast<h16x4*>(dst + 2 * D + c) = lo;
+        }
+    }
+}
+
 // ---- LayerNorm (fp32, one wave per row, D % 4 == 0, D <= 1024) -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tx_layernorm_fwd_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float* __restrict__ y,
-                                                               float* __restrict__ stats /*[M,2] mean, rstd*/) {
+                                                               float* __restrict__ stats /*[M,2] mean, rstd*/,
+                                                               h16* __restrict__ plane /* optional: the row's A-operand planes [M, 3D] (hi | hi | lo) */,
+                                                               float* __restrict__ inv /* ... and 1 / its scale */) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= M) return;
     const float* row = x + (size_t)r * D;
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(256) void tx_layernorm_fwd_kernel(const float* __re
     }
     const float rstd = rsqrtf(tx_wave_sum(q) / (float)D + eps);
     if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -227,8 +249,11 @@ __global__ __launch_bounds__(256) void tx_layernorm_fwd_kernel(const float* __re
             o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
             *reinterpret_cast<float4*>(y + (size_t)r * D + c) = o;
+            v[i] = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+    if (plane) tx_row_planes(v, D, lane, amax, plane + (size_t)r * 3 * D, inv + r);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g xhat)), g = dy * gamma, (+ residual gradient `dres`); dgamma += sum dy xhat, dbeta += sum dy.
@@ -236,7 +261,9 @@ __global__ __launch_bounds__(256) void tx_layernorm_fwd_kernel(const float* __re
 // and wave at the end.
 __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                                                const float* __restrict__ gamma, int M, int D, const float* __restrict__ dres,
-                                                               float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               h16* __restrict__ plane /* optional: A-operand planes of the dx rows [M, 3D] */,
+                                                               float* __restrict__ inv) {
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     float4 g4[4], ag[4], ab[4];
 #pragma unroll
@@ -265,6 +292,7 @@ __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __re
             }
         }
         const float c1 = tx_wave_sum(s1) / (float)D, c2 = tx_wave_sum(s2) / (float)D;
+        float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane * 4 + 256 * i;
@@ -276,8 +304,11 @@ __global__ __launch_bounds__(256) void tx_layernorm_bwd_kernel(const float* __re
                     o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
                 }
                 *reinterpret_cast<float4*>(dx + (size_t)r * D + c) = o;
+                gg[i] = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
         }
+        if (plane) tx_row_planes(gg, D, lane, amax, plane + (size_t)r * 3 * D, inv + r);
     }
     // the block's four waves meet in LDS: one atomic per column and block
     __shared__ float4 sg[4][256], sb[4][256];
@@ -865,6 +896,30 @@ __global__ __launch_bounds__(256, 2) void tx_attn_bwd_q_kernel(const tx_attn_bwd
     }
 }
 
+// per-column bounds (as float bits) of the activations whose size follows from the weights alone:
+//   LayerNorm output: |xhat| <= sqrt(D - 1), so |n_c| <= sqrt(D - 1) |gamma_c| + |beta_c|;   GELU(fc1(n3)): |h_j| <= |u_j| <= sum_c |W1[j][c]| B3_c + |b1_j|
+// They stand in for the column maxima when those activations are split into fp16 planes (a loose power-of-two scale costs nothing: fp16 is
+// a floating format, the second plane still carries the next 11 bits).  grid: 3 blocks for the LayerNorms + F / 4 blocks (one wave per hidden unit)
+__global__ __launch_bounds__(256) void tx_bounds_kernel(const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2, const float* __restrict__ b2,
+                                                        const float* __restrict__ g3, const float* __restrict__ b3, const float* __restrict__ w1, const float* __restrict__ fb1,
+                                                        int D, int F, unsigned* __restrict__ bn1, unsigned* __restrict__ bn2, unsigned* __restrict__ bn3,
+                                                        unsigned* __restrict__ bh) {
+    const float rt = 1.01f * sqrtf((float)(D - 1));
+    if (blockIdx.x < 3) {
+        const float* g = blockIdx.x == 0 ? g1 : blockIdx.x == 1 ? g2 : g3;
+        const float* b = blockIdx.x == 0 ? b1 : blockIdx.x == 1 ? b2 : b3;
+        unsigned* o = blockIdx.x == 0 ? bn1 : blockIdx.x == 1 ? bn2 : bn3;
+        for (int c = threadIdx.x; c < D; c += 256) o[c] = __float_as_uint(rt * fabsf(g[c]) + fabsf(b[c]));
+        return;
+    }
+    const int j = (blockIdx.x - 3) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= F) return;
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += fabsf(w1[(size_t)j * D + c]) * (rt * fabsf(g3[c]) + fabsf(b3[c]));
+    a = tx_wave_sum(a);
+    if (lane == 0) bh[j] = __float_as_uint(1.01f * a + fabsf(fb1[j]));
+}
+
 // a page of zeros per device for asd_gemm_f16's out-of-range rows
 const void* tx_zero_page() {
     static std::mutex mu;
@@ -966,15 +1021,25 @@ int64_t asd_tx_linear_workspace(int32_t M, int32_t N, int32_t K) {
 
 // y [M, N] (ldy) = f(x [M, K] (ldx) . W^T + bias) + residual, W given as packed plane [N, 3K] + inv_w [N] (asd_tx_pack_weight; pass the
 // W^T plane for an input gradient).  mode 0 identity, 1 GELU (pre-activation saved to aux), 2 multiply by GELU'(aux) (aux [M, N], ld N)
+// planes_ready: the A-operand planes and row scales of x already sit in ws where this function would put them (written by the LayerNorm
+// kernel that produced x: tx_linear_planes_of)
+static int tx_linear_core(const float* x, int32_t M, int32_t K, int32_t ldx, const void* plane_w, const float* inv_w, int32_t N, const float* bias, int32_t mode,
+                          float* aux, const float* residual, int32_t ldr, float* y, int32_t ldy, float* ws, bool planes_ready, void* stream);
+static inline h16* tx_linear_planes_of(float* ws) { return reinterpret_cast<h16*>(ws); }
+static inline float* tx_linear_inv_of(float* ws, int M, int K) { return ws + tx_al((int64_t)M * 3 * K / 2 + 64); }
 int asd_tx_linear(const float* x, int32_t M, int32_t K, int32_t ldx, const void* plane_w, const float* inv_w, int32_t N, const float* bias, int32_t mode,
                   float* aux, const float* residual, int32_t ldr, float* y, int32_t ldy, float* ws, void* stream) {
+    return tx_linear_core(x, M, K, ldx, plane_w, inv_w, N, bias, mode, aux, residual, ldr, y, ldy, ws, false, stream);
+}
+static int tx_linear_core(const float* x, int32_t M, int32_t K, int32_t ldx, const void* plane_w, const float* inv_w, int32_t N, const float* bias, int32_t mode,
+                          float* aux, const float* residual, int32_t ldr, float* y, int32_t ldy, float* ws, bool planes_ready, void* stream) {
     ASD_CHECK_ARG(x && plane_w && inv_w && y && ws && M > 0 && N > 0 && K > 0, "null argument");
     ASD_CHECK_ARG(K % 64 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (mode == 0 || aux), "K % 64, N % 4, leading dimensions % 4; aux for GELU modes");
     hipStream_t s = (hipStream_t)stream;
     h16* pa = reinterpret_cast<h16*>(ws);
     float* ia = ws + tx_al((int64_t)M * 3 * K / 2 + 64);
     float* c32 = ia + tx_al(M);
-    hipLaunchKernelGGL((tx_split_rows_kernel<0>), dim3(asd_div_up(M, 4)), dim3(256), 0, s, x, M, K, ldx, pa, ia);
+    if (!planes_ready) hipLaunchKernelGGL((tx_split_rows_kernel<0>), dim3(asd_div_up(M, 4)), dim3(256), 0, s, x, M, K, ldx, pa, ia);
     const float* res;
     int nslab;
     const int rc = tx_gemm(pa, (const h16*)plane_w, M, N, 3 * K, c32, c32 + tx_al((int64_t)M * N), &res, &nslab, s);
@@ -991,8 +1056,11 @@ int64_t asd_tx_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
 }
 
 // dw [N, K] = dy [M, N]^T . x [M, K]  (contraction over the M rows), db [N] = column sums of dy (optional)
-int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* dw, float* db, float* ws, void* stream) {
-    ASD_CHECK_ARG(dy && x && dw && ws && M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0, "bad argument");
+// x_planes / x_inv: the transposed planes of x made earlier (the text tokens serve all twelve layers); x_bound: per-column bounds of |x|
+// known without looking at x (LayerNorm outputs: sqrt(D - 1) |gamma_c| + |beta_c|; ...) — either spares the statistics pass over x
+static int tx_wgrad_core(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* dw, float* db, float* ws,
+                         const h16* x_planes, const float* x_inv, const unsigned* x_bound, void* stream) {
+    ASD_CHECK_ARG(dy && (x || x_planes) && dw && ws && M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int Mp = tx_rp(M);
     h16* pa = reinterpret_cast<h16*>(ws);                                   // dy^T [N, 3 Mp]
@@ -1008,34 +1076,49 @@ int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ld
     unsigned* cmax_w = cmax_a + tx_al(N);
     if (db && !tx_pool.outputs_zeroed) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(N, 64), asd_div_up(M, 256)), dim3(256), 0, s, dy, M, N, ldy, 256, cmax_a, db);
-    hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(K, 64), asd_div_up(M, 256)), dim3(256), 0, s, x, M, K, ldx, 256, cmax_w, (float*)nullptr);
     hipLaunchKernelGGL((tx_split_cols_kernel<0>), dim3(asd_div_up(N, 64), Mp / 64), dim3(256), 0, s, dy, M, N, ldy, Mp, cmax_a, pa, ia);
-    hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(K, 64), Mp / 64), dim3(256), 0, s, x, M, K, ldx, Mp, cmax_w, pw, iw);
+    if (!x_planes) {
+        if (!x_bound) hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(K, 64), asd_div_up(M, 256)), dim3(256), 0, s, x, M, K, ldx, 256, cmax_w, (float*)nullptr);
+        hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(K, 64), Mp / 64), dim3(256), 0, s, x, M, K, ldx, Mp, x_bound ? x_bound : cmax_w, pw, iw);
+    }
     const float* res;
     int nslab;
-    const int rc = tx_gemm(pa, pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), &res, &nslab, s);
+    const int rc = tx_gemm(pa, x_planes ? x_planes : pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), &res, &nslab, s);
     if (rc != ASD_OK) return rc;
-    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, res, nslab, N, K, ia, iw, (const float*)nullptr, 0, (float*)nullptr, 0,
-                       (const float*)nullptr, 0, dw, K);
+    hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, res, nslab, N, K, ia, x_planes ? x_inv : iw, (const float*)nullptr, 0,
+                       (float*)nullptr, 0, (const float*)nullptr, 0, dw, K);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
+int asd_tx_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* dw, float* db, float* ws, void* stream) {
+    return tx_wgrad_core(dy, ldy, x, ldx, M, N, K, dw, db, ws, nullptr, nullptr, nullptr, stream);
+}
 
-int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y, float* stats, void* stream) {
+static int tx_layernorm_fwd_core(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y, float* stats, h16* plane, float* inv,
+                                 void* stream) {
     ASD_CHECK_ARG(x && gamma && beta && y && stats && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "LayerNorm: D % 4 == 0, D <= 1024");
-    hipLaunchKernelGGL(tx_layernorm_fwd_kernel, dim3(asd_div_up(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, D, gamma, beta, eps, y, stats);
+    hipLaunchKernelGGL(tx_layernorm_fwd_kernel, dim3(asd_div_up(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, D, gamma, beta, eps, y, stats, plane, inv);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
+}
+int asd_tx_layernorm_fwd(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y, float* stats, void* stream) {
+    return tx_layernorm_fwd_core(x, M, D, gamma, beta, eps, y, stats, nullptr, nullptr, stream);
 }
 
 // dx = LayerNorm input gradient (+ dres); dgamma / dbeta are ACCUMULATED (+=: the caller zeroes them once per backward pass)
+static int tx_layernorm_bwd_core(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
+                                 float* dgamma, float* dbeta, h16* plane, float* inv, void* stream);
 int asd_tx_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
                          float* dgamma, float* dbeta, void* stream) {
+    return tx_layernorm_bwd_core(dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta, nullptr, nullptr, stream);
+}
+static int tx_layernorm_bwd_core(const float* dy, const float* x, const float* stats, const float* gamma, int32_t M, int32_t D, const float* dres, float* dx,
+                                 float* dgamma, float* dbeta, h16* plane, float* inv, void* stream) {
     ASD_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "LayerNorm: D % 4 == 0, D <= 1024");
     static const int rows_per_wave = getenv("ASD_TX_LN_ROWS") ? atoi(getenv("ASD_TX_LN_ROWS")) : 8;      // tools/tritx_time.py: 81 / 44 / 29 / 28 / 40 us at 1 / 2 / 4 / 8 / 16 rows per wave (the per-block atomics of dgamma / dbeta dominate)
     int grid = asd_div_up(M, 4 * (rows_per_wave > 0 ? rows_per_wave : 8));
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(tx_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta);
+    hipLaunchKernelGGL(tx_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, M, D, dres, dx, dgamma, dbeta, plane, inv);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -1184,7 +1267,7 @@ inline int64_t plane_floats(int64_t rows, int64_t k) { return tx_al(rows * 3 * k
 
 // packed weights of one layer / of the head, as offsets (floats) into the packed buffer
 struct TxPackLayer { int64_t caq_w, caq_iw, caq_t, caq_it, cakv_w, cakv_iw, cao_w, cao_iw, cao_t, cao_it, qkv_w, qkv_iw, qkv_t, qkv_it, sao_w, sao_iw, sao_t, sao_it,
-                             fc1_w, fc1_iw, fc1_t, fc1_it, fc2_w, fc2_iw, fc2_t, fc2_it, end; };
+                             fc1_w, fc1_iw, fc1_t, fc1_it, fc2_w, fc2_iw, fc2_t, fc2_it, bn1, bn2, bn3, bh, end; };
 TxPackLayer tx_pack_layout(const TxDims& d, int64_t base) {
     TxPackLayer L;
     int64_t o = base;
@@ -1200,6 +1283,7 @@ TxPackLayer tx_pack_layout(const TxDims& d, int64_t base) {
     planes(d.D, d.D, L.sao_w, L.sao_iw, &L.sao_t, &L.sao_it);
     planes(d.F, d.D, L.fc1_w, L.fc1_iw, &L.fc1_t, &L.fc1_it);
     planes(d.D, d.F, L.fc2_w, L.fc2_iw, &L.fc2_t, &L.fc2_it);
+    L.bn1 = take(d.D); L.bn2 = take(d.D); L.bn3 = take(d.D); L.bh = take(d.F);        // column bounds of n1, n2, n3, gelu(fc1): tx_bounds_kernel
     L.end = o;
     return L;
 }
@@ -1286,7 +1370,7 @@ int64_t asd_tritx_workspace_floats(const asd_tritx_desc* desc) {
     // transient gradients of the backward pass: dx ping-pong (2), dn, do, dqkv (3), dkv, du, dy, the weight-gradient staging of batch
     // elements > 0, + the op workspace
     return tx_op_ws(d) + tx_al((int64_t)d.T * d.D) * 7 + tx_al((int64_t)d.Tc * 2 * d.D) + tx_al((int64_t)d.T * d.F) + tx_al((int64_t)d.T * d.O) +
-           tx_stage_floats(d) + tx_pool_words(d) + 256;
+           tx_stage_floats(d) + tx_pool_words(d) + tx_al((int64_t)d.Dc * 3 * tx_rp(d.Tc) / 2 + 64) + 2 * tx_al(d.Dc) + 256;
 }
 
 // params: 20 * n_layers + 4 device pointers (order: include/asd_hip.h) -> packed operand planes of every weight
@@ -1314,6 +1398,9 @@ int asd_tritx_pack(const asd_tritx_desc* desc, const float* const* params, float
         PK(P[12], d.D, d.D, L.sao_w, L.sao_iw, L.sao_t, L.sao_it);
         PK(P[16], d.F, d.D, L.fc1_w, L.fc1_iw, L.fc1_t, L.fc1_it);
         PK(P[18], d.D, d.F, L.fc2_w, L.fc2_iw, L.fc2_t, L.fc2_it);
+        hipLaunchKernelGGL(tx_bounds_kernel, dim3(3 + asd_div_up(d.F, 4)), dim3(256), 0, s, P[0], P[1], P[7], P[8], P[14], P[15], P[16], P[17], d.D, d.F,
+                           reinterpret_cast<unsigned*>(packed + L.bn1), reinterpret_cast<unsigned*>(packed + L.bn2), reinterpret_cast<unsigned*>(packed + L.bn3),
+                           reinterpret_cast<unsigned*>(packed + L.bh));
     }
 #undef PK
     // ConvTranspose2d(D -> C, 2, 2) weight V [D, 4 C] is the TRANSPOSE of the equivalent Linear's weight [4 C, D]: its plane for y = x W^T is
@@ -1357,19 +1444,20 @@ int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const 
                 hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(TD / 4, 256)), dim3(256), 0, s, B + S.x_in, x, (size_t)(TD / 4), 0);
             x = B + S.x_in;
             // cross-attention
-            TXS(asd_tx_layernorm_fwd(x, d.T, d.D, P[0], P[1], eps, B + S.n1, B + S.st1, stream));
-            TXS(asd_tx_linear(B + S.n1, d.T, d.D, d.D, packed + L.caq_w, packed + L.caq_iw, d.D, nullptr, 0, nullptr, nullptr, 0, B + S.q_ca, d.D, ws, stream));
+            // (every LayerNorm leaves the operand planes of its output where the Linear that consumes it looks for them)
+            TXS(tx_layernorm_fwd_core(x, d.T, d.D, P[0], P[1], eps, B + S.n1, B + S.st1, tx_linear_planes_of(ws), tx_linear_inv_of(ws, d.T, d.D), stream));
+            TXS(tx_linear_core(B + S.n1, d.T, d.D, d.D, packed + L.caq_w, packed + L.caq_iw, d.D, nullptr, 0, nullptr, nullptr, 0, B + S.q_ca, d.D, ws, true, stream));
             TXS(asd_tx_linear(cond, d.Tc, d.Dc, d.Dc, packed + L.cakv_w, packed + L.cakv_iw, 2 * d.D, nullptr, 0, nullptr, nullptr, 0, B + S.kv_ca, 2 * d.D, ws, stream));
             TXS(asd_tx_attention_fwd(B + S.q_ca, d.D, B + S.kv_ca, 2 * d.D, B + S.kv_ca + d.D, 2 * d.D, d.T, d.Tc, d.H, B + S.o_ca, d.D, B + S.lse_ca, ws, stream));
             TXS(asd_tx_linear(B + S.o_ca, d.T, d.D, d.D, packed + L.cao_w, packed + L.cao_iw, d.D, P[6], 0, nullptr, x, d.D, B + S.x1, d.D, ws, stream));
             // self-attention
-            TXS(asd_tx_layernorm_fwd(B + S.x1, d.T, d.D, P[7], P[8], eps, B + S.n2, B + S.st2, stream));
-            TXS(asd_tx_linear(B + S.n2, d.T, d.D, d.D, packed + L.qkv_w, packed + L.qkv_iw, 3 * d.D, nullptr, 0, nullptr, nullptr, 0, B + S.qkv, 3 * d.D, ws, stream));
+            TXS(tx_layernorm_fwd_core(B + S.x1, d.T, d.D, P[7], P[8], eps, B + S.n2, B + S.st2, tx_linear_planes_of(ws), tx_linear_inv_of(ws, d.T, d.D), stream));
+            TXS(tx_linear_core(B + S.n2, d.T, d.D, d.D, packed + L.qkv_w, packed + L.qkv_iw, 3 * d.D, nullptr, 0, nullptr, nullptr, 0, B + S.qkv, 3 * d.D, ws, true, stream));
             TXS(asd_tx_attention_fwd(B + S.qkv, 3 * d.D, B + S.qkv + d.D, 3 * d.D, B + S.qkv + 2 * d.D, 3 * d.D, d.T, d.T, d.H, B + S.o_sa, d.D, B + S.lse_sa, ws, stream));
             TXS(asd_tx_linear(B + S.o_sa, d.T, d.D, d.D, packed + L.sao_w, packed + L.sao_iw, d.D, P[13], 0, nullptr, B + S.x1, d.D, B + S.x2, d.D, ws, stream));
             // MLP
-            TXS(asd_tx_layernorm_fwd(B + S.x2, d.T, d.D, P[14], P[15], eps, B + S.n3, B + S.st3, stream));
-            TXS(asd_tx_linear(B + S.n3, d.T, d.D, d.D, packed + L.fc1_w, packed + L.fc1_iw, d.F, P[17], 1, B + S.u, nullptr, 0, B + S.hmid, d.F, ws, stream));
+            TXS(tx_layernorm_fwd_core(B + S.x2, d.T, d.D, P[14], P[15], eps, B + S.n3, B + S.st3, tx_linear_planes_of(ws), tx_linear_inv_of(ws, d.T, d.D), stream));
+            TXS(tx_linear_core(B + S.n3, d.T, d.D, d.D, packed + L.fc1_w, packed + L.fc1_iw, d.F, P[17], 1, B + S.u, nullptr, 0, B + S.hmid, d.F, ws, true, stream));
             float* xo = l + 1 < d.layers ? sv + (int64_t)(l + 1) * S.end + S.x_in : sv + (int64_t)d.layers * S.end;     // next layer's input slot / x_final
             TXS(asd_tx_linear(B + S.hmid, d.T, d.F, d.F, packed + L.fc2_w, packed + L.fc2_iw, d.D, P[19], 0, nullptr, B + S.x2, d.D, xo, d.D, ws, stream));
             x = xo;
@@ -1406,6 +1494,9 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     float* dkv = p; p += tx_al((int64_t)d.Tc * 2 * d.D);
     float* du = p; p += tx_al((int64_t)d.T * d.F);
     float* dy = p; p += tx_al((int64_t)d.T * d.O);
+    h16* cond_planes = reinterpret_cast<h16*>(p); p += tx_al((int64_t)d.Dc * 3 * tx_rp(d.Tc) / 2 + 64);      // text tokens^T [Dc, 3 Tcp]: one split for all layers
+    float* cond_inv = p; p += tx_al(d.Dc);
+    unsigned* cond_max = reinterpret_cast<unsigned*>(p); p += tx_al(d.Dc);
     float* stage = p;
     float* stage_b = stage + (tx_stage_floats(d) - tx_al(tx_max64(d.F, 3 * d.D)));
     // LayerNorm gradients accumulate over layers' rows and the batch, bias gradients are atomic column sums: zero them once — or take the
@@ -1422,11 +1513,16 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
     unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
     // weight gradients of batch element n > 0 are added to those of the elements before it: staged through `stage`
+    const h16* xpl = nullptr;          // precomputed transposed planes of x (+ scales) / column bounds of x for the NEXT wgrad call
+    const float* xinv = nullptr;
+    const unsigned* xbound = nullptr;
     auto wgrad = [&](const float* dyp, int ldy, const float* xp, int ldx, int M, int N, int K, float* dw, float* db, bool acc) -> int {
-        if (!acc) return asd_tx_linear_wgrad(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, stream);
+        const h16* pl = xpl; const float* pi = xinv; const unsigned* pb = xbound;
+        xpl = nullptr; xinv = nullptr; xbound = nullptr;
+        if (!acc) return tx_wgrad_core(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, pl, pi, pb, stream);
         float* tmp = stage;
         float* tb = stage_b;
-        TXS(asd_tx_linear_wgrad(dyp, ldy, xp, ldx, M, N, K, tmp, db ? tb : nullptr, ws, stream));
+        TXS(tx_wgrad_core(dyp, ldy, xp, ldx, M, N, K, tmp, db ? tb : nullptr, ws, pl, pi, pb, stream));
         hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, dw, tmp, (size_t)((int64_t)N * K / 4), 1);
         if (db) hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(N / 4, 256)), dim3(256), 0, s, db, tb, (size_t)(N / 4), 1);
         return ASD_OK;
@@ -1441,6 +1537,12 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
         const float* xf = sv + (int64_t)d.layers * S.end;
         const float* stF = xf + tx_al(TD);
         const float* nF = stF + tx_al(2 * d.T);
+        {   // the text tokens' transposed planes, once per batch element
+            (void)hipMemsetAsync(cond_max, 0, (size_t)d.Dc * 4, s);
+            hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(d.Dc, 64), asd_div_up(d.Tc, 256)), dim3(256), 0, s, cond, d.Tc, d.Dc, d.Dc, 256, cond_max, (float*)nullptr);
+            hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(d.Dc, 64), tx_rp(d.Tc) / 64), dim3(256), 0, s, cond, d.Tc, d.Dc, d.Dc, tx_rp(d.Tc), cond_max, cond_planes,
+                               cond_inv);
+        }
         // head: planes -> y -> nF -> x_final
         hipLaunchKernelGGL(tx_shuffle_kernel, dim3(asd_grid_for((int64_t)d.T * d.O, 256)), dim3(256), 0, s, dy, d.R, d.Cc,
                            const_cast<float*>(d_planes_cl) + (int64_t)n * d.T * d.O, 1);
@@ -1449,37 +1551,46 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
         TXS(asd_tx_linear(dy, d.T, d.O, d.O, packed + hd.dc_t, packed + hd.dc_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
         float* dx = dxa;
         float* dx_other = dxb;
-        TXS(asd_tx_layernorm_bwd(dn, xf, stF, params[20 * d.layers + 1], d.T, d.D, nullptr, dx, GH[1], GH[2], stream));
+        // (every LayerNorm backward leaves the operand planes of its dx where the next input-gradient Linear looks for them: that Linear runs
+        // BEFORE the weight gradient that shares dx with it, whose workspace would overwrite the planes)
+        h16* const lp = tx_linear_planes_of(ws);
+        float* const li = tx_linear_inv_of(ws, d.T, d.D);
+        TXS(tx_layernorm_bwd_core(dn, xf, stF, params[20 * d.layers + 1], d.T, d.D, nullptr, dx, GH[1], GH[2], lp, li, stream));
         for (int l = d.layers - 1; l >= 0; --l) {
             const float* const* P = params + 20 * l;
             float* const* G = grads + 17 * l;
             const TxPackLayer L = tx_pack_layout(d, per_layer * l);
             const float* B = sv + (int64_t)l * S.end;
             // ---- MLP: x3 = x2 + fc2(gelu(fc1(n3)))
+            TXS(tx_linear_core(dx, d.T, d.D, d.D, packed + L.fc2_t, packed + L.fc2_it, d.F, nullptr, 2, const_cast<float*>(B + S.u), nullptr, 0, du, d.F, ws, true, stream));
+            xbound = reinterpret_cast<const unsigned*>(packed + L.bh);
             TXS(wgrad(dx, d.D, B + S.hmid, d.F, d.T, d.D, d.F, G[15], G[16], acc));
-            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.fc2_t, packed + L.fc2_it, d.F, nullptr, 2, const_cast<float*>(B + S.u), nullptr, 0, du, d.F, ws, stream));
             TXS(asd_tx_linear(du, d.T, d.F, d.F, packed + L.fc1_t, packed + L.fc1_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
+            xbound = reinterpret_cast<const unsigned*>(packed + L.bn3);
             TXS(wgrad(du, d.F, B + S.n3, d.D, d.T, d.F, d.D, G[13], G[14], acc));
-            TXS(asd_tx_layernorm_bwd(dn, B + S.x2, B + S.st3, P[14], d.T, d.D, dx, dx_other, G[11], G[12], stream));
+            TXS(tx_layernorm_bwd_core(dn, B + S.x2, B + S.st3, P[14], d.T, d.D, dx, dx_other, G[11], G[12], lp, li, stream));
             { float* t = dx; dx = dx_other; dx_other = t; }
             // ---- self-attention: x2 = x1 + o_sa Wo^T + bo
+            TXS(tx_linear_core(dx, d.T, d.D, d.D, packed + L.sao_t, packed + L.sao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, true, stream));
             TXS(wgrad(dx, d.D, B + S.o_sa, d.D, d.T, d.D, d.D, G[9], G[10], acc));
-            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.sao_t, packed + L.sao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, stream));
             TXS(asd_tx_attention_bwd(B + S.qkv, 3 * d.D, B + S.qkv + d.D, 3 * d.D, B + S.qkv + 2 * d.D, 3 * d.D, B + S.o_sa, d.D, dob, d.D, B + S.lse_sa, d.T, d.T, d.H,
                                      dqkv, 3 * d.D, dqkv + d.D, 3 * d.D, dqkv + 2 * d.D, 3 * d.D, ws, stream));
+            xbound = reinterpret_cast<const unsigned*>(packed + L.bn2);
             TXS(wgrad(dqkv, 3 * d.D, B + S.n2, d.D, d.T, 3 * d.D, d.D, G[8], nullptr, acc));
             TXS(asd_tx_linear(dqkv, d.T, 3 * d.D, 3 * d.D, packed + L.qkv_t, packed + L.qkv_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
-            TXS(asd_tx_layernorm_bwd(dn, B + S.x1, B + S.st2, P[7], d.T, d.D, dx, dx_other, G[6], G[7], stream));
+            TXS(tx_layernorm_bwd_core(dn, B + S.x1, B + S.st2, P[7], d.T, d.D, dx, dx_other, G[6], G[7], lp, li, stream));
             { float* t = dx; dx = dx_other; dx_other = t; }
             // ---- cross-attention: x1 = x0 + o_ca Wo^T + bo
+            TXS(tx_linear_core(dx, d.T, d.D, d.D, packed + L.cao_t, packed + L.cao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, true, stream));
             TXS(wgrad(dx, d.D, B + S.o_ca, d.D, d.T, d.D, d.D, G[4], G[5], acc));
-            TXS(asd_tx_linear(dx, d.T, d.D, d.D, packed + L.cao_t, packed + L.cao_it, d.D, nullptr, 0, nullptr, nullptr, 0, dob, d.D, ws, stream));
             TXS(asd_tx_attention_bwd(B + S.q_ca, d.D, B + S.kv_ca, 2 * d.D, B + S.kv_ca + d.D, 2 * d.D, B + S.o_ca, d.D, dob, d.D, B + S.lse_ca, d.T, d.Tc, d.H,
                                      dqkv, d.D, dkv, 2 * d.D, dkv + d.D, 2 * d.D, ws, stream));
+            xbound = reinterpret_cast<const unsigned*>(packed + L.bn1);
             TXS(wgrad(dqkv, d.D, B + S.n1, d.D, d.T, d.D, d.D, G[2], nullptr, acc));
+            xpl = cond_planes; xinv = cond_inv;
             TXS(wgrad(dkv, 2 * d.D, cond, d.Dc, d.Tc, 2 * d.D, d.Dc, G[3], nullptr, acc));
             TXS(asd_tx_linear(dqkv, d.T, d.D, d.D, packed + L.caq_t, packed + L.caq_it, d.D, nullptr, 0, nullptr, nullptr, 0, dn, d.D, ws, stream));
-            TXS(asd_tx_layernorm_bwd(dn, B + S.x_in, B + S.st1, P[0], d.T, d.D, dx, dx_other, G[0], G[1], stream));
+            TXS(tx_layernorm_bwd_core(dn, B + S.x_in, B + S.st1, P[0], d.T, d.D, dx, dx_other, G[0], G[1], lp, li, stream));
             { float* t = dx; dx = dx_other; dx_other = t; }
         }
         hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(TD / 4, 256)), dim3(256), 0, s, GH[0], dx, (size_t)(TD / 4), acc ? 1 : 0);
