@@ -711,6 +711,19 @@ int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const 
 int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const float* packed, const float* text_embed, int32_t batch,
                   const float* d_planes_cl, const float* save, float* const* grads, float* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel exchange: what Lightning's DDP does for the reference (launch.py:233-240: the mean of every trainable gradient once per
+ * optimizer step, one process per GPU).  A communicator per process over RCCL (xGMI inside a node), resolved at run time from the process
+ * image (PyTorch's librccl.so) or dlopen("librccl.so"); rank 0 calls asd_comm_unique_id and hands the 128 bytes to the other ranks by
+ * whatever channel the host has (torch.distributed store, MPI, a file), every rank then calls asd_comm_create on ITS device.
+ * asd_allreduce_mean_f32 is in place, enqueued on the caller's stream, never synchronises the host.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct asd_comm asd_comm;
+int asd_comm_unique_id(void* id128 /* [host] 128 bytes out */);
+int asd_comm_create(const void* id128, int32_t rank, int32_t world, asd_comm** comm);
+int asd_comm_destroy(asd_comm* comm);
+int asd_allreduce_mean_f32(asd_comm* comm, float* buf, int64_t n, void* stream);
+
 /* library info */
 const char* asd_version(void);
 const char* asd_last_error(void);

@@ -165,6 +165,7 @@ SYMBOLS = [
     "asd_tx_pack_weight", "asd_tx_linear_workspace", "asd_tx_linear", "asd_tx_wgrad_workspace", "asd_tx_linear_wgrad", "asd_tx_layernorm_fwd", "asd_tx_layernorm_bwd",
     "asd_tx_attention_workspace", "asd_tx_attention_fwd", "asd_tx_attention_bwd",
     "asd_tritx_packed_floats", "asd_tritx_save_floats", "asd_tritx_workspace_floats", "asd_tritx_pack", "asd_tritx_fwd", "asd_tritx_bwd",
+    "asd_comm_unique_id", "asd_comm_create", "asd_comm_destroy", "asd_allreduce_mean_f32",
     "asd_version", "asd_last_error", "asd_probe_events",
 ]
 

@@ -66,6 +66,54 @@ def shutdown() -> None:
             dist.destroy_process_group()
 
 
+class OwnCollective:
+    """the exchange on the library's own communicator (include/asd_hip.h: asd_comm_* / asd_allreduce_mean_f32, RCCL resolved at run time)
+    instead of torch.distributed's process group: opt-in (ASD_OWN_ALLREDUCE=1), GPU tensors only.  torch.distributed is still what carries
+    the 128-byte unique id from rank 0 to the others at start-up.  All-reduces run on a side stream of their own: `launch` orders them
+    behind the work already enqueued on the current stream (the kernel that produced the gradient), `wait` puts the current stream behind
+    them — the same hand-offs torch's ProcessGroupNCCL makes."""
+
+    def __init__(self, device: torch.device):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C, self._lib = C, _lib
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(_lib.lib().asd_comm_unique_id(buf))
+            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        dev_uid = uid.to(device) if dist.get_backend() == "nccl" else uid
+        dist.broadcast(dev_uid, src=0)
+        raw = bytes(dev_uid.cpu().tolist())
+        self.comm = C.c_void_p()
+        with torch.cuda.device(device), stdout_to_stderr():
+            _lib.check(_lib.lib().asd_comm_create(C.c_char_p(raw), _lib.i32(rank), _lib.i32(world), C.byref(self.comm)))
+        self.stream = torch.cuda.Stream(device=device)
+        self._pending = False
+
+    def launch(self, flat: torch.Tensor) -> None:
+        """mean all-reduce of a contiguous fp32 tensor, in place, asynchronous"""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        self.stream.wait_stream(torch.cuda.current_stream(flat.device))
+        flat.record_stream(self.stream)
+        self._lib.check(self._lib.lib().asd_allreduce_mean_f32(self.comm, self._C.c_void_p(flat.data_ptr()), self._C.c_int64(flat.numel()),
+                                                              self._C.c_void_p(self.stream.cuda_stream)))
+        self._pending = True
+
+    def wait(self) -> None:
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self._pending = False
+
+    def close(self) -> None:
+        if self.comm:
+            self._lib.lib().asd_comm_destroy(self.comm)
+            self.comm = None
+
+
 class GradientExchange:
     """The one exchange step of the data-parallel path (launch.py:233-240: Lightning DDP): mean of every trainable gradient.
 
@@ -127,6 +175,11 @@ class GradientExchange:
         self.order = list(range(len(self.units)))      # launch order (positions into self.units)
         self._order_learned = False
         self._seen_order: List[int] = []
+        # opt-in: the library's own communicator instead of torch.distributed's (GPU, fp32 gradients only)
+        self._own = None
+        if (os.environ.get("ASD_OWN_ALLREDUCE", "0") == "1" and is_distributed() and dist.get_backend() == "nccl" and self.params
+                and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)):
+            self._own = OwnCollective(self.params[0].device)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._armed, self._sync = False, True
         self.exposed_ms_events = None                   # (start, end) CUDA events of the last finish(): un-overlapped exchange time
@@ -223,7 +276,12 @@ class GradientExchange:
                 if buf is None:
                     p.grad = p.grad.contiguous()
                     buf = p.grad
-                self._works.append(dist.all_reduce(buf.view(-1), op=avg, async_op=True))
+                if self._own is not None:
+                    self._own.launch(buf.view(-1))
+                else:
+                    self._works.append(dist.all_reduce(buf.view(-1), op=avg, async_op=True))
+            elif self._own is not None:
+                self._own.launch(u["flat"])
             else:
                 self._works.append(dist.all_reduce(u["flat"], op=avg, async_op=True))
             self._launched += 1
@@ -245,6 +303,8 @@ class GradientExchange:
         self._works.append(dist.all_reduce(self._touched_dev, op=dist.ReduceOp.MAX, async_op=True))
         for w in self._works:
             w.wait()
+        if self._own is not None:
+            self._own.wait()
         if dist.get_backend() != "nccl":
             world = dist.get_world_size()
             for u in self.units:
@@ -277,6 +337,9 @@ class GradientExchange:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._own is not None:
+            self._own.close()
+            self._own = None
 
 
 def allreduce_mean_grads(optimizer: torch.optim.Optimizer) -> None:

@@ -99,3 +99,65 @@ def test_hooked_gradient_exchange_runs_inside_a_real_training_step_on_rccl(monke
         spread = max(float((b - b2).abs().max()), float((b - b3).abs().max()), float((b2 - b3).abs().max()))
         # (a wrong reduction — a sum taken for a mean, a bucket exchanged twice, a stale view — moves entries by ~max|b|, far outside this)
         assert float((a - b).abs().max()) <= 4.0 * spread + 2e-2 * float(b.abs().max()) + 1e-12
+
+
+def test_library_communicator_mean_allreduce_single_rank_through_the_c_abi():
+    """include/asd_hip.h asd_comm_* / asd_allreduce_mean_f32 with bare ctypes: a one-rank communicator on this device, the in-place
+    mean of a large buffer on a side stream (identity for one rank, bit for bit), error codes for bad arguments."""
+    import ctypes as C
+
+    from scaledreamer_amd import _lib
+
+    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    lib = _lib.lib()
+    uid = (C.c_char * 128)()
+    assert lib.asd_comm_unique_id(uid) == 0, lib.asd_last_error()
+    comm = C.c_void_p()
+    assert lib.asd_comm_create(uid, C.c_int32(0), C.c_int32(1), C.byref(comm)) == 0, lib.asd_last_error()
+    try:
+        x = torch.randn(12_599_920, device="cuda")                   # the hash table gradient of the headline configuration: 50 MB
+        want = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        assert lib.asd_allreduce_mean_f32(comm, C.c_void_p(x.data_ptr()), C.c_int64(x.numel()), C.c_void_p(side.cuda_stream)) == 0
+        assert lib.asd_allreduce_mean_f32(comm, C.c_void_p(x.data_ptr()), C.c_int64(0), C.c_void_p(side.cuda_stream)) == 0
+        side.synchronize()
+        assert torch.equal(x, want)
+        assert lib.asd_allreduce_mean_f32(None, C.c_void_p(x.data_ptr()), C.c_int64(4), None) != 0
+        assert lib.asd_comm_create(uid, C.c_int32(1), C.c_int32(1), C.byref(C.c_void_p())) != 0       # rank outside the world
+    finally:
+        assert lib.asd_comm_destroy(comm) == 0
+
+
+def test_gradient_exchange_on_the_library_communicator(monkeypatch):
+    """ASD_OWN_ALLREDUCE=1: GradientExchange launches its units through asd_allreduce_mean_f32 (side stream, stream hand-offs) instead
+    of torch.distributed; one rank, so the gradients come back unchanged and the optimizer sees them."""
+    import torch.distributed as dist
+
+    from scaledreamer_amd import dist as asd_dist
+
+    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("ASD_OWN_ALLREDUCE", "1")
+    with tempfile.TemporaryDirectory() as d:
+        dist.init_process_group(backend="nccl", init_method=f"file://{d}/rdv", rank=0, world_size=1)
+        try:
+            monkeypatch.setattr(asd_dist, "is_distributed", lambda: True)
+            big = torch.nn.Parameter(torch.randn(2 << 20, device="cuda"))
+            small = [torch.nn.Parameter(torch.randn(64, 32, device="cuda")), torch.nn.Parameter(torch.randn(7, device="cuda"))]
+            opt = torch.optim.SGD([{"params": [big]}, {"params": small}], lr=1.0)
+            ex = asd_dist.GradientExchange([big] + small)
+            assert ex._own is not None
+            for step in range(3):
+                ex.prepare()
+                loss = (big * big).sum() * 0.5 + sum((p * p).sum() * 0.5 for p in small)        # d/dp = p
+                want = [p.detach().clone() for p in [big] + small]
+                loss.backward()
+                ex.finish()
+                torch.cuda.synchronize()
+                for p, w in zip([big] + small, want):
+                    assert torch.equal(p.grad.view_as(w), w)
+            ex.close()
+        finally:
+            dist.destroy_process_group()

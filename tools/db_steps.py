@@ -15,6 +15,19 @@ starts = [i for i, r in enumerate(rows) if marker in r[2]]
 starts = [s for k, s in enumerate(starts) if k == 0 or s - starts[k - 1] > 50]
 # bench.py: the steps are followed by roofline micro-benchmarks that also march; use --skip-last S to stay inside the timed region
 skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0
+if "--skip-last" not in sys.argv and len(starts) > nlast + 1:
+    # no explicit skip: a training step is an interval between two marker launches with the typical launch count (the micro-benchmarks
+    # after the timed region march with a handful of launches in between) — take the last run of nlast such intervals
+    counts = [starts[i + 1] - starts[i] for i in range(len(starts) - 1)]
+    med = sorted(counts)[len(counts) // 2]
+    good = [abs(cn - med) <= 0.03 * med for cn in counts]
+    end = None
+    for i in range(len(counts), nlast - 1, -1):
+        if all(good[i - nlast:i]):
+            end = i
+            break
+    if end is not None:
+        skip = len(starts) - 1 - end
 a, b = starts[-nlast - 1 - skip], starts[-1 - skip]
 n = nlast
 seg = rows[a:b]
