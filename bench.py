@@ -166,6 +166,15 @@ def pmc_traffic_of(*kernel_substrs: str):
     return tot
 
 
+def trace_mark():
+    """an empty launch named asd_trace_mark_kernel on the current stream: the per-step tables of profiles/ are cut between two of them"""
+    import ctypes as C
+
+    from scaledreamer_amd._lib import lib
+
+    lib().asd_probe_mark(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
 def roofline_pp_kernel(reps: int = 3):
     """conv3x3_pp_kernel<4,4> (csrc/gemm_pp.hip) over ALL its launches of one step, each with the epilogue it has in the step (residual,
     GroupNorm statistics / backward reductions), back to back on the launch stream between HIP events.  achieved = algorithmic flops of
@@ -543,6 +552,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    trace_mark()                                      # outside the timed region: opens it in a kernel trace (tools/db_steps.py)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -558,6 +568,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trace_mark()                                      # ... and closes it
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -573,6 +573,18 @@ int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_d
 /* d loss / d moments (fp32 [B,hl,wl,2C]) given grad: d z = upstream * grad / B (upstream: device scalar or NULL = 1) */
 int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C,
                     int32_t hl, int32_t wl, float scaling, float* d_moments_nhwc, void* stream);
+/* loss assembly of training_step (scaledreamer.py:62-126) in one launch each way:
+ *   total = sum_j weights[j] * terms[j][0] + lambda_sparsity * mean(sqrt(opacity^2 + 0.01))
+ *         + lambda_opaque * mean(-(x log x + (1 - x) log(1 - x))), x = clamp(opacity, 1e-3, 1 - 1e-3)   (threestudio/utils/ops.py:365-369)
+ *         + lambda_z_variance * mean(z_variance[opacity > 0.5])
+ * terms: HOST array of n_terms (<= 8) device scalars, weights: HOST floats; opacity, z_variance: fp32 [n_rays]; a term whose lambda is
+ * <= 0 is skipped (z_variance may then be NULL).  out5 (device) = {total, sparsity, opaque, z_variance, #rays above 0.5}.
+ * bwd: upstream = d total (device scalar, NULL = 1); d_terms [n_terms], d_opacity [n_rays], d_z_variance [n_rays] or NULL. */
+int asd_loss_tail_fwd(const float* const* terms, const float* weights, int32_t n_terms, const float* opacity, const float* z_variance,
+                      int64_t n_rays, float lambda_sparsity, float lambda_opaque, float lambda_z_variance, float* out5, void* stream);
+int asd_loss_tail_bwd(const float* upstream, const float* weights, int32_t n_terms, const float* opacity, int64_t n_rays, float lambda_sparsity,
+                      float lambda_opaque, float lambda_z_variance, const float* out5, float* d_terms, float* d_opacity, float* d_z_variance,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step (csrc/optim.hip): multi-tensor fused fp32 kernels for the reference's two optimizers — torch.optim.AdamW / Adam as
@@ -732,6 +744,8 @@ const char* asd_last_error(void);
  * (asd_field_bwd: field_bwd_sample_kernel, the gradient scatter), so its duration can be read with hipEventElapsedTime without a
  * profiler.  Pass NULL, NULL to clear.  Process-wide; not meant for concurrent callers. */
 int asd_probe_events(void* start_event, void* stop_event);
+/* one empty launch named asd_trace_mark_kernel on `stream`: brackets a region of a kernel trace */
+int asd_probe_mark(void* stream);
 
 #ifdef __cplusplus
 }

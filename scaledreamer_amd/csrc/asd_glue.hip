@@ -220,6 +220,64 @@ __global__ __launch_bounds__(256) void latents_bwd_kernel(const float* __restric
 }
 
 
+// ---- loss assembly: weighted scalar terms + the per-ray regularisers, one launch forward and one backward --------------------------
+// scaledreamer.py:62-126 (training_step): loss = sum_j lambda_j loss_j + lambda_sparsity mean(sqrt(opacity^2 + 0.01))
+//   + lambda_opaque BCE(clamp(opacity, 1e-3, 1 - 1e-3)) (threestudio/utils/ops.py:365-369, the clamped opacity as input AND target, both
+//   differentiated) + lambda_z_variance mean(z_variance[opacity > 0.5]).  As tensor ops this is ~25 launches of a few hundred bytes between
+//   the score and the VAE backward, issued while the host has nothing queued ahead (the autograd pass starts here): the device waits.
+#define ASD_LOSS_MAX_TERMS 8
+struct LossTerms {
+    const float* value[ASD_LOSS_MAX_TERMS];
+    float weight[ASD_LOSS_MAX_TERMS];
+    int n;
+};
+
+// out[5] = {total, sparsity, opaque, z_variance, number of rays with opacity > 0.5}; a term with lambda <= 0 is not evaluated (0)
+__global__ __launch_bounds__(1024) void loss_tail_fwd_kernel(LossTerms terms, const float* __restrict__ opacity, const float* __restrict__ z_var,
+                                                              long long n, float lam_s, float lam_o, float lam_z, float* __restrict__ out) {
+    __shared__ float red[16];
+    float ss = 0.f, so = 0.f, sz = 0.f, cnt = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float o = opacity[i];
+        if (lam_s > 0.f) ss += sqrtf(o * o + 0.01f);
+        if (lam_o > 0.f) {
+            const float x = fminf(fmaxf(o, 1.0e-3f), 1.0f - 1.0e-3f);
+            so -= x * logf(x) + (1.f - x) * logf(1.f - x);
+        }
+        if (lam_z > 0.f && o > 0.5f) { sz += z_var[i]; cnt += 1.f; }
+    }
+    ss = block_sum_1024(ss, red);
+    so = block_sum_1024(so, red);
+    sz = block_sum_1024(sz, red);
+    cnt = block_sum_1024(cnt, red);
+    if (threadIdx.x == 0) {
+        const float inv_n = 1.f / (float)n;
+        const float sparsity = lam_s > 0.f ? ss * inv_n : 0.f, opaque = lam_o > 0.f ? so * inv_n : 0.f;
+        const float zv = lam_z > 0.f ? sz / cnt : 0.f;          // no ray above 0.5: 0 / 0 = NaN, the mean of an empty selection
+        float total = 0.f;
+        for (int j = 0; j < terms.n; ++j) total += terms.weight[j] * terms.value[j][0];
+        if (lam_s > 0.f) total += sparsity * lam_s;
+        if (lam_o > 0.f) total += opaque * lam_o;
+        if (lam_z > 0.f) total += zv * lam_z;
+        out[0] = total; out[1] = sparsity; out[2] = opaque; out[3] = zv; out[4] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTerms terms, const float* __restrict__ upstream, const float* __restrict__ opacity,
+                                                             long long n, float lam_s, float lam_o, float lam_z, const float* __restrict__ fwd_out,
+                                                             float* __restrict__ d_terms, float* __restrict__ d_opacity, float* __restrict__ d_zvar) {
+    const float up = upstream ? upstream[0] : 1.f;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < terms.n) d_terms[i] = up * terms.weight[i];
+    if (i >= n) return;
+    const float o = opacity[i], inv_n = 1.f / (float)n;
+    float g = 0.f;
+    if (lam_s > 0.f) g += lam_s * inv_n * o / sqrtf(o * o + 0.01f);
+    if (lam_o > 0.f && o >= 1.0e-3f && o <= 1.0f - 1.0e-3f) g += lam_o * inv_n * (logf(1.f - o) - logf(o));
+    d_opacity[i] = up * g;
+    if (d_zvar) d_zvar[i] = (lam_z > 0.f && o > 0.5f) ? up * lam_z / fwd_out[4] : 0.f;
+}
+
 // ---- view-dependent prompt selection, written straight into the UNet's context buffer ---------------------------------------------
 // prompt_processors/base.py:82-167 (get_text_embeddings_perp_neg) and :262-294 (direction by thresholds: side < front < back <
 // overhead), as one launch: a block owns one output token row.  Row blends keep the reference's fp32 arithmetic
@@ -360,6 +418,35 @@ int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_d
     const int slots = (layout == 0 ? 3 : 5) * batch;
     hipLaunchKernelGGL(prompt_context_kernel, dim3(slots * n_tok), dim3(128), 0, (hipStream_t)stream, text_vd, uncond_vd, n_dir, n_tok, dim, elevation,
                        azimuth, batch, layout, pp, neg_scale, (half_t*)context_f16, ctx_stride, neg_w);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_loss_tail_fwd(const float* const* terms, const float* weights, int32_t n_terms, const float* opacity, const float* z_variance,
+                      int64_t n_rays, float lambda_sparsity, float lambda_opaque, float lambda_z_variance, float* out5, void* stream) {
+    ASD_CHECK_ARG(opacity && out5 && n_rays > 0 && n_terms >= 0 && n_terms <= ASD_LOSS_MAX_TERMS, "bad argument");
+    ASD_CHECK_ARG(n_terms == 0 || (terms && weights), "null term table");
+    ASD_CHECK_ARG(!(lambda_z_variance > 0.f) || z_variance, "lambda_z_variance > 0 needs z_variance");
+    LossTerms t;
+    t.n = n_terms;
+    for (int j = 0; j < ASD_LOSS_MAX_TERMS; ++j) { t.value[j] = j < n_terms ? terms[j] : nullptr; t.weight[j] = j < n_terms ? weights[j] : 0.f; }
+    for (int j = 0; j < n_terms; ++j) ASD_CHECK_ARG(terms[j], "null term");
+    hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, opacity, z_variance, (long long)n_rays, lambda_sparsity,
+                       lambda_opaque, lambda_z_variance, out5);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_loss_tail_bwd(const float* upstream, const float* weights, int32_t n_terms, const float* opacity, int64_t n_rays, float lambda_sparsity,
+                      float lambda_opaque, float lambda_z_variance, const float* out5, float* d_terms, float* d_opacity, float* d_z_variance,
+                      void* stream) {
+    ASD_CHECK_ARG(opacity && out5 && d_opacity && n_rays > 0 && n_terms >= 0 && n_terms <= ASD_LOSS_MAX_TERMS, "bad argument");
+    ASD_CHECK_ARG(n_terms == 0 || (weights && d_terms), "null term table");
+    LossTerms t;
+    t.n = n_terms;
+    for (int j = 0; j < ASD_LOSS_MAX_TERMS; ++j) { t.value[j] = nullptr; t.weight[j] = j < n_terms ? weights[j] : 0.f; }
+    hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(asd_div_up((int)n_rays, 256)), dim3(256), 0, (hipStream_t)stream, t, upstream, opacity,
+                       (long long)n_rays, lambda_sparsity, lambda_opaque, lambda_z_variance, out5, d_terms, d_opacity, d_z_variance);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

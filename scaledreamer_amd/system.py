@@ -8,6 +8,7 @@ all-reduced once per optimizer step over RCCL (what Lightning's DDP does in the 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, Optional
 
@@ -26,6 +27,53 @@ def dot(x, y):
 
 def binary_cross_entropy(inp, target):
     return -(target * torch.log(inp) + (1 - target) * torch.log(1 - inp)).mean()
+
+
+class _LossTailFn(torch.autograd.Function):
+    """sum_j w_j term_j + the per-ray regularisers (sparsity, opaque, z_variance) as one launch forward, one backward (include/asd_hip.h
+    asd_loss_tail_fwd / _bwd) instead of ~25 tensor ops issued at the moment the autograd pass starts and the host has nothing queued."""
+
+    @staticmethod
+    def forward(ctx, opacity, z_variance, lams, weights, *terms):
+        import ctypes as C
+
+        from . import _lib
+
+        op = opacity.detach().contiguous()
+        zv = None if z_variance is None else z_variance.detach().contiguous()
+        ts = [t.detach().reshape(1).float() for t in terms]
+        out = torch.empty(5, device=op.device, dtype=torch.float32)
+        n = len(ts)
+        tab = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts])
+        w = (C.c_float * max(n, 1))(*[float(x) for x in weights])
+        _lib.check(_lib.lib().asd_loss_tail_fwd(tab, w, _lib.i32(n), _lib.ptr(op), _lib.ptr(zv), C.c_int64(op.numel()), _lib.f32(lams[0]),
+                                                _lib.f32(lams[1]), _lib.f32(lams[2]), _lib.ptr(out), _lib.stream()))
+        ctx.save_for_backward(op, out)
+        ctx.meta = (lams, list(weights), opacity.shape, None if z_variance is None else z_variance.shape,
+                    [t.shape for t in terms], [t.dtype for t in terms])
+        total, values = out[0], out[1:4]
+        ctx.mark_non_differentiable(values)
+        return total, values
+
+    @staticmethod
+    def backward(ctx, d_total, _d_values):
+        import ctypes as C
+
+        from . import _lib
+
+        op, out = ctx.saved_tensors
+        lams, weights, op_shape, zv_shape, t_shapes, t_dtypes = ctx.meta
+        n = len(weights)
+        up = d_total.detach().reshape(1).float().contiguous()
+        d_op = torch.empty_like(op)
+        d_zv = torch.empty_like(op) if zv_shape is not None and ctx.needs_input_grad[1] else None
+        d_terms = torch.empty(max(n, 1), device=op.device, dtype=torch.float32)
+        w = (C.c_float * max(n, 1))(*[float(x) for x in weights])
+        _lib.check(_lib.lib().asd_loss_tail_bwd(_lib.ptr(up), w, _lib.i32(n), _lib.ptr(op), C.c_int64(op.numel()), _lib.f32(lams[0]),
+                                                _lib.f32(lams[1]), _lib.f32(lams[2]), _lib.ptr(out), _lib.ptr(d_terms), _lib.ptr(d_op),
+                                                _lib.ptr(d_zv), _lib.stream()))
+        g_terms = [d_terms[j].reshape(t_shapes[j]).to(t_dtypes[j]) if ctx.needs_input_grad[4 + j] else None for j in range(n)]
+        return (d_op.view(op_shape), None if d_zv is None else d_zv.view(zv_shape), None, None, *g_terms)
 
 
 def getattr_recursive(m, attr):
@@ -157,16 +205,20 @@ class StableDreamer(nn.Module, Updateable):
     }
     OPTIONAL_LAMBDAS = ("eikonal",)
 
+    FUSED_REGULARISERS = ("sparsity", "opaque", "z_variance")     # the per-ray terms of _LossTailFn, in its lambda order
+
     def _guidance_terms(self, image, batch, prefix: str, weight: float, rgb_as_latents: bool = False):
-        total = 0.0
+        """[(value, weight * lambda)] of the guidance's loss_* entries"""
+        terms = []
         for name, value in self.guidance(image, self.prompt_utils, **batch, rgb_as_latents=rgb_as_latents).items():
             self.log(f"train/{prefix}{name}", value)
             if name.startswith("loss_"):
-                total = total + weight * value * self.C(self.cfg.loss["lambda_" + name[len("loss_"):]])
-        return total
+                terms.append((value, weight * self.C(self.cfg.loss["lambda_" + name[len("loss_"):]])))
+        return terms
 
-    def _regulariser_terms(self, out):
-        total = 0.0
+    def _regulariser_terms(self, out, fused: bool):
+        """[(value, lambda)] of the regularisers evaluated as tensor ops, and the lambdas of the ones left to _LossTailFn (fused)"""
+        terms, lams = [], {}
         for name, (needs, message, fn) in self.REGULARISERS.items():
             key = "lambda_" + name
             if name in self.OPTIONAL_LAMBDAS and key not in self.cfg.loss:
@@ -176,11 +228,31 @@ class StableDreamer(nn.Module, Updateable):
                 continue
             if needs not in out:
                 raise ValueError(message)
+            if fused and name in self.FUSED_REGULARISERS:
+                lams[name] = lam
+                continue
             value = fn(out)
             self.log(f"train/loss_{name}", value)
-            total = total + value * lam
+            terms.append((value, lam))
             if name == "eikonal":
                 self.log("train/inv_std", out["inv_std"])
+        return terms, lams
+
+    def _assemble_loss(self, terms, out, lams):
+        """sum of weight * value over `terms` plus the fused per-ray regularisers `lams`; in the reference's order of additions when
+        nothing is fused (CPU tensors: the host-logic tests)"""
+        if not lams and not (terms and terms[0][0].is_cuda):
+            total = 0.0
+            for value, w in terms:
+                total = total + value * w
+            return total
+        opacity = out["opacity"]
+        z_var = out["z_variance"] if "z_variance" in lams else None
+        lam3 = tuple(float(lams.get(k, 0.0)) for k in self.FUSED_REGULARISERS)
+        total, values = _LossTailFn.apply(opacity, z_var, lam3, tuple(float(w) for _, w in terms), *[v for v, _ in terms])
+        for i, k in enumerate(self.FUSED_REGULARISERS):
+            if k in lams:
+                self.log(f"train/loss_{k}", values[i])
         return total
 
     def _rgb_as_latents(self) -> bool:
@@ -192,12 +264,15 @@ class StableDreamer(nn.Module, Updateable):
             # 'geometry' / 'texture' (mesh stages: normal consistency, laplacian) are not on the ASD hot path
             raise ValueError(f"stage {stage!r}: only the NeRF stages 'coarse' and 'coarse+geometry' are implemented")
         out = self(batch)
-        loss = self._guidance_terms(out["comp_rgb"], batch, "", 1.0, self._rgb_as_latents())
-        loss = loss + self._regulariser_terms(out)
+        terms = self._guidance_terms(out["comp_rgb"], batch, "", 1.0, self._rgb_as_latents())
+        fused = ("opacity" in out and torch.is_tensor(out["opacity"]) and out["opacity"].is_cuda and out["opacity"].dtype == torch.float32
+                 and os.environ.get("ASD_LOSS_TAIL", "1") != "0")        # =0: the tensor-op form (A/B, tools/r5_ab_env.sh)
+        reg_terms, lams = self._regulariser_terms(out, fused)
+        terms = terms + reg_terms
         if stage == "coarse+geometry":   # second guidance pass on the normal image
             normal_img = torch.nan_to_num(out["comp_normal"], nan=0.0, posinf=0.0, neginf=0.0)
-            loss = loss + self._guidance_terms(normal_img, batch, "shape_", self.GEOMETRY_PASS_WEIGHT)
-        return {"loss": loss}
+            terms = terms + self._guidance_terms(normal_img, batch, "shape_", self.GEOMETRY_PASS_WEIGHT)
+        return {"loss": self._assemble_loss(terms, out, lams)}
 
     def gradient_exchange(self):
         """the DP exchange object of this system (None on a single process): created on first use, after the process group."""

@@ -228,3 +228,57 @@ def test_prompt_context_kernel_matches_the_prompt_processor(perp_neg):
                                    (C.c_float * 15)(*params), f32(0.0), ptr(ctx), i32(stride), None, stream()))
     emb = pu.get_text_embeddings(el, az, torch.ones(B), False)
     assert torch.equal(ctx[:3 * B * stride].view(3 * B, stride, dim)[:, :n_tok].cpu(), torch.cat([emb, emb[:B]], 0).half())
+
+
+@pytest.mark.parametrize("case", ["asd_sd_nerf_step0", "asd_sd_nerf_step10001", "all_terms", "coarse_geometry"])
+def test_training_step_loss_assembly_on_the_device_matches_the_reference(case):
+    """StableDreamer.training_step with CUDA tensors — the weighted terms and the per-ray regularisers go through asd_loss_tail_fwd / _bwd
+    (one launch each way) — against the values the reference's training_step (scaledreamer.py:48-170) produced on the same tensors
+    (tests/golden/system_training_step.npz): loss, every logged value, the gradient w.r.t. every renderer output."""
+    import os
+
+    import numpy as np
+    from golden_util import GOLDEN_DIR
+    from test_host_logic_cpu import A10_CASES, _a10_out
+
+    from scaledreamer_amd.config import ConfigDict
+    from scaledreamer_amd.system import StableDreamer
+
+    g = dict(np.load(os.path.join(GOLDEN_DIR, "system_training_step.npz")))
+    stage, loss_cfg = A10_CASES[case]
+    out = {k: (v.detach().cuda().requires_grad_(v.requires_grad) if torch.is_tensor(v) else v) for k, v in _a10_out(int(g["seed"])).items()}
+
+    def guidance(rgb, prompt_utils, rgb_as_latents=False, **batch):
+        probe = torch.linspace(-1.0, 2.0, rgb.numel(), dtype=rgb.dtype).view_as(rgb).to(rgb.device)
+        return {"loss_asd": (rgb * probe).sum() + 0.5 * (rgb ** 2).sum(), "grad_norm": rgb.detach().norm(), "min_step": 20, "max_step": 980}
+
+    s = object.__new__(StableDreamer)
+    torch.nn.Module.__init__(s)
+    s.cfg = ConfigDict(stage=stage, loss=ConfigDict(loss_cfg))
+    s.current_epoch, s.true_global_step = 0, int(g[case + ".step"])
+    s.logged = {}
+    s.renderer = lambda **batch: dict(out)
+    s.guidance, s.prompt_utils = guidance, None
+    loss = s.training_step({"elevation": torch.zeros(1)})["loss"]
+    assert type(loss.grad_fn).__name__ == "_LossTailFnBackward"
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[case + ".loss"]), rel=2e-6)
+    want_logged = {k[len(case) + 5:]: float(v) for k, v in g.items() if k.startswith(case + ".log.")}
+    assert sorted(s.logged) == sorted(want_logged)
+    for k, v in want_logged.items():
+        assert float(s.logged[k]) == pytest.approx(v, rel=2e-6), k
+    for k, t in out.items():
+        if torch.is_tensor(t) and t.requires_grad:
+            want = torch.from_numpy(g[f"{case}.grad.{k}"])
+            got = t.grad.cpu() if t.grad is not None else torch.zeros_like(want)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-7, msg=k)
+
+
+def test_loss_tail_z_variance_without_a_ray_above_one_half_is_nan_like_the_empty_mean():
+    from scaledreamer_amd.system import _LossTailFn
+
+    op = torch.full((1, 8, 8, 1), 0.25, device="cuda", requires_grad=True)
+    zv = torch.rand(1, 8, 8, 1, device="cuda", requires_grad=True)
+    total, values = _LossTailFn.apply(op, zv, (0.0, 0.0, 2.0), ())
+    assert torch.isnan(total) and torch.isnan(values[2])
+    assert torch.isnan(zv[op > 0.5].mean())                            # what the tensor-op form gives

@@ -15,7 +15,13 @@ starts = [i for i, r in enumerate(rows) if marker in r[2]]
 starts = [s for k, s in enumerate(starts) if k == 0 or s - starts[k - 1] > 50]
 # bench.py: the steps are followed by roofline micro-benchmarks that also march; use --skip-last S to stay inside the timed region
 skip = int(sys.argv[sys.argv.index("--skip-last") + 1]) if "--skip-last" in sys.argv else 0
-if "--skip-last" not in sys.argv and len(starts) > nlast + 1:
+bracket = [i for i, r in enumerate(rows) if "asd_trace_mark_kernel" in r[2]]
+if len(bracket) >= 2 and "--skip-last" not in sys.argv:
+    # bench.py brackets its timed region with two empty launches: the steps are the marker launches in between, plus the closing mark
+    inside = [s_ for s_ in starts if bracket[0] < s_ < bracket[1]]
+    starts = inside + [bracket[1]]
+    nlast = min(nlast, len(starts) - 1)
+elif "--skip-last" not in sys.argv and len(starts) > nlast + 1:
     # no explicit skip: a training step is an interval between two marker launches with the typical launch count (the micro-benchmarks
     # after the timed region march with a handful of launches in between) — take the last run of nlast such intervals
     counts = [starts[i + 1] - starts[i] for i in range(len(starts) - 1)]
@@ -79,3 +85,9 @@ if "--list" in sys.argv:     # durations (us) of the launches of one kernel name
     m = min(len(p_) for p_ in per)
     print(f"{pat}: {m} launches per step; mean us per position over {nlast} steps:")
     print(" ".join(f"{sum(p_[i] for p_ in per) / nlast:.1f}" for i in range(m)))
+
+if "--dump" in sys.argv:     # every launch of the last analysed step in program order: offset from the step start (us), duration (us), name
+    step = rows[starts[-2 - skip]:starts[-1 - skip]]
+    with open(sys.argv[sys.argv.index("--dump") + 1], "w") as fh:
+        for s_, e_, nm in step:
+            fh.write(f"{(s_ - step[0][0]) / 1e3:10.1f} {(e_ - s_) / 1e3:8.1f}  {short(nm)[:110]}\n")
