@@ -645,6 +645,15 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* desc, const float* x, const float* d
  * term); amax_out (optional, zeroed by the caller): max|dz| for asd_conv3d_desc.amax_dy */
 int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t rows, int32_t C, float gain, float clamp, float* dz,
                       float* d_bias, float* d_rowsum, uint32_t* amax_out, void* stream);
+/* the per-sample weights of a modulated convolution (custom/amortized/extern/stylegan_3dconv_modules.py:64-82 modulated_conv3d):
+ *   wm[n][co][ci][k] = weight[co][ci][k] * styles[n][ci] * gain * dcoef[n][co],
+ *   dcoef = rsqrt(sum_{ci,k} (weight styles gain)^2 + 1e-8) when demodulate, 1 otherwise (toRGB: gain = its weight_gain).  1 <= N <= 8.
+ * bwd: d_weight [Cout][Cin][K] and d_styles [N][Cin] from d_wm; K = 1 or 27. */
+int asd_modulated_weights_fwd(const float* weight, const float* styles, int32_t N, int32_t Cout, int32_t Cin, int32_t K, float gain,
+                              int32_t demodulate, float* wm, float* dcoef, void* stream);
+int asd_modulated_weights_bwd(const float* d_wm, const float* wm, const float* weight, const float* styles, const float* dcoef, int32_t N,
+                              int32_t Cout, int32_t Cin, int32_t K, float gain, int32_t demodulate, float* d_weight, float* d_styles,
+                              void* stream);
 /* *amax_out = max(*amax_out, bit pattern of max|x|) over n floats (n % 4 == 0): for tensors whose producer left no such word */
 int asd_absmax_f32(const float* x, int64_t n, uint32_t* amax_out, void* stream);
 /* toRGB (ToRGBLayer, :283-296: 1x1x1 modulated convolution onto the 32-channel skip volume) on channel-last rows, exact fp32:

@@ -699,6 +699,103 @@ __global__ __launch_bounds__(256) void torgb_wgrad_kernel(const float* __restric
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
+// ---- the per-sample weights of a modulated convolution (stylegan_3dconv_modules.py:64-82 modulated_conv3d) ------------------------------
+// wm[n][co][ci][k] = W[co][ci][k] s[n][ci] g d[n][co],  d = rsqrt(sum_{ci,k} (W s g)^2 + 1e-8) with demodulation, 1 without (toRGB: g is its
+// weight_gain).  As tensor ops that is six passes over N Cout Cin K floats forward and a dozen backward (28 MB each at 512 -> 512 channels);
+// here one launch forward, two backward.  A block owns one output channel; a thread owns whole (ci) rows of K taps, so the style gradient of
+// a row is a register sum.
+__device__ __forceinline__ float c3_block_sum(float v, float* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void modw_fwd_kernel(const float* __restrict__ W, const float* __restrict__ s, int Cin, int K, float gain, int demod,
+                                                       float* __restrict__ wm, float* __restrict__ dcoef) {
+    __shared__ float red[4];
+    const int co = blockIdx.x, n = blockIdx.y, Cout = gridDim.x;
+    const float* w = W + (size_t)co * Cin * K;
+    const float* sn = s + (size_t)n * Cin;
+    float* o = wm + ((size_t)n * Cout + co) * Cin * K;
+    const int E = Cin * K;
+    float d = 1.f;
+    if (demod) {
+        float ss = 0.f;
+        for (int e = threadIdx.x; e < E; e += 256) { const float u = w[e] * (sn[e / K] * gain); ss = fmaf(u, u, ss); }
+        d = rsqrtf(c3_block_sum(ss, red) + 1e-8f);
+    }
+    for (int e = threadIdx.x; e < E; e += 256) o[e] = w[e] * (sn[e / K] * gain) * d;
+    if (threadIdx.x == 0) dcoef[(size_t)n * Cout + co] = d;
+}
+
+// with u = W s g and wm = u d:  d_u = d (d_wm - wm sum(d_wm wm)) (demodulated) | d_wm (not);  dW = sum_n d_u s g;  ds[n][ci] = g sum_{co,k} d_u W.
+// A block owns one output channel and walks its Cin K elements in chunks of 256 rows (ci) x K taps with coalesced accesses: thread t holds
+// elements t + 256 j of the chunk (its dW sums over n stay in registers), the products d_u W go through LDS where thread r sums row r
+// (stride K = 27 words: conflict-free) and adds it to ds[n][ci] with one atomic — Cout adds per address over the launch.
+template <int K>
+__global__ __launch_bounds__(256) void modw_bwd_kernel(const float* __restrict__ d_wm, const float* __restrict__ wm, const float* __restrict__ W,
+                                                       const float* __restrict__ s, const float* __restrict__ dcoef, int N, int Cin, float gain,
+                                                       int demod, float* __restrict__ dW, float* __restrict__ ds) {
+    __shared__ float red[4];
+    __shared__ float t_sh[8];
+    __shared__ float prod[256 * K];
+    const int co = blockIdx.x, Cout = gridDim.x;
+    const int E = Cin * K;
+    if (demod) {
+        for (int n = 0; n < N; ++n) {
+            const float* g = d_wm + ((size_t)n * Cout + co) * E;
+            const float* m = wm + ((size_t)n * Cout + co) * E;
+            float a = 0.f;
+            for (int e = threadIdx.x; e < E; e += 256) a = fmaf(g[e], m[e], a);
+            a = c3_block_sum(a, red);
+            if (threadIdx.x == 0) t_sh[n] = a;
+        }
+        __syncthreads();
+    }
+    const float* w = W + (size_t)co * E;
+    for (int r0 = 0; r0 < Cin; r0 += 256) {
+        const int e0 = r0 * K, ne = min(256, Cin - r0) * K;
+        float acc[K], wv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int el = threadIdx.x + 256 * j;
+            acc[j] = 0.f;
+            wv[j] = el < ne ? w[e0 + el] : 0.f;
+        }
+        for (int n = 0; n < N; ++n) {
+            const size_t base = ((size_t)n * Cout + co) * E + e0;
+            const float dc = dcoef[(size_t)n * Cout + co], tn = demod ? t_sh[n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int el = threadIdx.x + 256 * j;
+                float du = 0.f;
+                if (el < ne) {
+                    du = d_wm[base + el];
+                    if (demod) du = dc * (du - wm[base + el] * tn);
+                    acc[j] = fmaf(du, s[(size_t)n * Cin + r0 + el / K] * gain, acc[j]);
+                }
+                prod[el] = du * wv[j];
+            }
+            __syncthreads();
+            if (r0 + (int)threadIdx.x < Cin) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) a += prod[threadIdx.x * K + k];
+                atomicAdd(&ds[(size_t)n * Cin + r0 + threadIdx.x], a * gain);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int el = threadIdx.x + 256 * j;
+            if (el < ne) dW[(size_t)co * E + e0 + el] = acc[j];
+        }
+    }
+}
+
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int c3_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
@@ -904,6 +1001,28 @@ int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t
     return ASD_OK;
 }
 
+
+int asd_modulated_weights_fwd(const float* weight, const float* styles, int32_t N, int32_t Cout, int32_t Cin, int32_t K, float gain,
+                              int32_t demodulate, float* wm, float* dcoef, void* stream) {
+    ASD_CHECK_ARG(weight && styles && wm && dcoef && N > 0 && N <= 8 && Cout > 0 && Cin > 0 && K > 0, "bad argument (1 <= N <= 8)");
+    hipLaunchKernelGGL(modw_fwd_kernel, dim3(Cout, N), dim3(256), 0, (hipStream_t)stream, weight, styles, Cin, K, gain, demodulate, wm, dcoef);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_modulated_weights_bwd(const float* d_wm, const float* wm, const float* weight, const float* styles, const float* dcoef, int32_t N,
+                              int32_t Cout, int32_t Cin, int32_t K, float gain, int32_t demodulate, float* d_weight, float* d_styles, void* stream) {
+    ASD_CHECK_ARG(d_wm && wm && weight && styles && dcoef && d_weight && d_styles && N > 0 && N <= 8 && Cout > 0 && Cin > 0, "bad argument (1 <= N <= 8)");
+    ASD_CHECK_ARG(K == 1 || K == 27, "kernel volumes of 1 (toRGB) and 27 (3 x 3 x 3) taps");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(d_styles, 0, (size_t)N * Cin * 4, s);
+    if (K == 27)
+        hipLaunchKernelGGL((modw_bwd_kernel<27>), dim3(Cout), dim3(256), 0, s, d_wm, wm, weight, styles, dcoef, N, Cin, gain, demodulate, d_weight, d_styles);
+    else
+        hipLaunchKernelGGL((modw_bwd_kernel<1>), dim3(Cout), dim3(256), 0, s, d_wm, wm, weight, styles, dcoef, N, Cin, gain, demodulate, d_weight, d_styles);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
 
 int asd_absmax_f32(const float* x, int64_t n, uint32_t* amax_out, void* stream) {
     ASD_CHECK_ARG(x && amax_out && n > 0 && n % 4 == 0, "n must be a positive multiple of 4");

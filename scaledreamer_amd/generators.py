@@ -193,6 +193,27 @@ class _ToRGBFn(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.has_add else None)
 
 
+_FUSED_MODULATION = os.environ.get("ASD_FUSED_MODULATION", "1") != "0"      # =0: the tensor-op form (same-box A/B, tools/)
+
+
+class _ModWeightsFn(torch.autograd.Function):
+    """the per-sample weights of modulated_conv3d (stylegan_3dconv_modules.py:64-82): weight * styles * gain, demodulated — one launch
+    forward, two backward (asd_modulated_weights_fwd / _bwd) instead of six / a dozen tensor ops over [N, Cout, Cin, 27] floats"""
+
+    @staticmethod
+    def forward(ctx, weight, styles, gain, demodulate):
+        wm, dcoef = _ops().modulated_weights_fwd(weight, styles, gain, demodulate)
+        ctx.save_for_backward(weight, styles, wm, dcoef)
+        ctx.gain, ctx.demodulate = gain, demodulate
+        return wm
+
+    @staticmethod
+    def backward(ctx, d_wm):
+        weight, styles, wm, dcoef = ctx.saved_tensors
+        d_weight, d_styles = _ops().modulated_weights_bwd(d_wm, wm, weight, styles, dcoef, ctx.gain, ctx.demodulate)
+        return d_weight, d_styles, None, None
+
+
 def _conv3d_cl(x, ax, w, bias=None, noise=None, ns=None, act=False, gain=1.0, clamp=0.0):
     """the convolution node -> (y, ay); volumes below 16 x 16 in-plane (the 4^3 and 8^3 levels: 0.1 % of the generator's flops) are zero-padded
     to the kernel's 16 x 16 patch and cropped, with their layer tail as tensor ops on the cropped volume"""
@@ -235,9 +256,11 @@ class SynthesisLayer(nn.Module):
         """the same layer on a channel-last volume x [N, D, H, W, Cin] through the HIP nodes -> (y, ay); ax / ay: max|.| words (or None);
         add: a volume added to the result (the block's const_bias, which the reference adds right after this layer)"""
         n, cin = x.shape[0], x.shape[4]
-        styles = self.affine(w)
-        wm = self.weight.unsqueeze(0) * styles.reshape(n, 1, cin, 1, 1, 1)
-        wm = wm * (wm.square().sum(dim=[2, 3, 4, 5]) + 1e-8).rsqrt().reshape(n, -1, 1, 1, 1, 1)
+        if _FUSED_MODULATION:
+            wm = _ModWeightsFn.apply(self.weight, self.affine(w), 1.0, True)
+        else:
+            wm = self.weight.unsqueeze(0) * self.affine(w).reshape(n, 1, cin, 1, 1, 1)
+            wm = wm * (wm.square().sum(dim=[2, 3, 4, 5]) + 1e-8).rsqrt().reshape(n, -1, 1, 1, 1, 1)
         r = self.resolution
         if noise_mode == "random":
             noise = torch.randn([n, 1, r, r, r], device=x.device).reshape(n, r, r, r)       # (the reference's draw: same shape, same stream position)
@@ -267,7 +290,10 @@ class ToRGBLayer(nn.Module):
     def forward_cl(self, x, w):
         """channel-last: the 1x1x1 modulated convolution (no demodulation) is a per-sample matrix product on the [voxels, C] view"""
         n, cin = x.shape[0], x.shape[4]
-        wm = self.weight.reshape(1, -1, cin) * (self.affine(w) * self.weight_gain).reshape(n, 1, cin)      # [N, Cout, Cin]
+        if _FUSED_MODULATION:
+            wm = _ModWeightsFn.apply(self.weight.reshape(-1, cin), self.affine(w), self.weight_gain, False)      # [N, Cout, Cin]
+        else:
+            wm = self.weight.reshape(1, -1, cin) * (self.affine(w) * self.weight_gain).reshape(n, 1, cin)
         if wm.shape[1] == 32 and cin % 64 == 0:
             return _ToRGBFn.apply(x, wm, self.bias, None)
         y = torch.baddbmm(self.bias.reshape(1, 1, -1), x.reshape(n, -1, cin), wm.transpose(1, 2))       # other widths: library product

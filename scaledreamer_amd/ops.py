@@ -446,6 +446,34 @@ def layer_act_bwd(dy: torch.Tensor, y: torch.Tensor, gain: float, clamp: float, 
     return dz, d_bias, d_rowsum
 
 
+def modulated_weights_fwd(weight: torch.Tensor, styles: torch.Tensor, gain: float = 1.0, demodulate: bool = True):
+    """weight [Cout, Cin, *k], styles [N, Cin] -> (wm [N, Cout, Cin, *k], dcoef [N, Cout]): weight * styles * gain, demodulated per (n, co)"""
+    _need_cuda(weight, styles)
+    weight, styles = _c(weight), _c(styles)
+    cout, cin = weight.shape[0], weight.shape[1]
+    K = weight.numel() // (cout * cin)
+    N = styles.shape[0]
+    wm = torch.empty((N,) + tuple(weight.shape), device=weight.device, dtype=torch.float32)
+    dcoef = torch.empty((N, cout), device=weight.device, dtype=torch.float32)
+    check(lib().asd_modulated_weights_fwd(ptr(weight), ptr(styles), i32(N), i32(cout), i32(cin), i32(K), f32(gain), i32(int(demodulate)), ptr(wm),
+                                          ptr(dcoef), stream()))
+    return wm, dcoef
+
+
+def modulated_weights_bwd(d_wm: torch.Tensor, wm: torch.Tensor, weight: torch.Tensor, styles: torch.Tensor, dcoef: torch.Tensor, gain: float = 1.0,
+                          demodulate: bool = True):
+    """-> (d_weight like weight, d_styles [N, Cin])"""
+    d_wm, wm, weight, styles = _c(d_wm), _c(wm), _c(weight), _c(styles)
+    cout, cin = weight.shape[0], weight.shape[1]
+    K = weight.numel() // (cout * cin)
+    N = styles.shape[0]
+    d_weight = torch.empty_like(weight)
+    d_styles = torch.empty_like(styles)
+    check(lib().asd_modulated_weights_bwd(ptr(d_wm), ptr(wm), ptr(weight), ptr(styles), ptr(dcoef), i32(N), i32(cout), i32(cin), i32(K), f32(gain),
+                                          i32(int(demodulate)), ptr(d_weight), ptr(d_styles), stream()))
+    return d_weight, d_styles
+
+
 def upsample3d_fwd(x: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0,
                    add: Optional[torch.Tensor] = None, amax_out=None) -> torch.Tensor:
     """x [N,r,r,r,C] -> act(trilinear 2x (align_corners) + noise * ns + bias) + add, [N,2r,2r,2r,C]"""

@@ -53,6 +53,64 @@ def test_conv3d_forward_input_gradient_weight_gradient_vs_float64(N, D, H, W, ci
     assert e_y < max(4 * e_lib, 1e-6)
 
 
+@pytest.mark.parametrize("N,cout,cin,k,gain,demod", [(2, 64, 128, 3, 1.0, True), (1, 512, 512, 3, 1.0, True), (3, 32, 64, 1, 0.125, False), (8, 7, 5, 3, 1.0, True)])
+def test_modulated_weights_and_their_gradients_vs_float64(N, cout, cin, k, gain, demod):
+    """asd_modulated_weights_fwd / _bwd against the tensor-op form of the reference (stylegan_3dconv_modules.py:64-82: w = weight * styles;
+    dcoefs = (w.square().sum(dim=[2,3,4,5]) + 1e-8).rsqrt(); w = w * dcoefs) evaluated in float64"""
+    from scaledreamer_amd.generators import _ModWeightsFn
+
+    g = torch.Generator().manual_seed(cout + cin)
+    weight = torch.randn(cout, cin, k, k, k, generator=g)
+    styles = torch.randn(N, cin, generator=g) + 1.0
+    d_wm = torch.randn(N, cout, cin, k, k, k, generator=g)
+    w64, s64 = weight.double().requires_grad_(True), styles.double().requires_grad_(True)
+    ref = w64.unsqueeze(0) * (s64 * gain).reshape(N, 1, cin, 1, 1, 1)
+    if demod:
+        ref = ref * (ref.square().sum(dim=[2, 3, 4, 5]) + 1e-8).rsqrt().reshape(N, -1, 1, 1, 1, 1)
+    ref.backward(d_wm.double())
+    wd, sd = weight.cuda().requires_grad_(True), styles.cuda().requires_grad_(True)
+    wm = _ModWeightsFn.apply(wd, sd, gain, demod)
+    wm.backward(d_wm.cuda())
+    torch.cuda.synchronize()
+    e = _relerr(wm.cpu(), ref), _relerr(wd.grad.cpu(), w64.grad), _relerr(sd.grad.cpu(), s64.grad)
+    print(f"modulated weights {cin}->{cout} k={k} N={N}: rel. error vs float64  wm {e[0]:.2e}  d_weight {e[1]:.2e}  d_styles {e[2]:.2e}")
+    assert max(e) < 2e-6
+
+
+def test_conv3d_one_outlier_voxel_far_above_the_rest():
+    """the split-fp16 operands carry ONE power-of-two scale per tensor (csrc/conv3d.hip: x s = hi + lo): an element 2^20 times the rest pushes
+    every other element's low half into fp16's subnormal range (19 instead of 22 bits).  The outputs the outlier does not reach — every
+    weight-gradient entry of the other input channels, every output voxel outside its 3x3x3 neighbourhood — are compared on their own
+    scale against float64; what the outlier reaches, on the scale of the whole tensor."""
+    from scaledreamer_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    N, cin, cout, D, H, W = 1, 64, 64, 4, 16, 16
+    x = torch.randn(N, cin, D, H, W, generator=g)
+    w = torch.randn(N, cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    dy = torch.randn(N, cout, D, H, W, generator=g) * 1e-4
+    oc, od, oh, ow = 5, 2, 7, 9
+    x[0, oc, od, oh, ow] = float(2 ** 20)
+    x64, w64, dy64 = x.double().requires_grad_(True), w.double().requires_grad_(True), dy.double()
+    y64 = F.conv3d(x64, w64[0], padding=1)
+    y64.backward(dy64)
+    xd, wd, dyd = _cl(x).cuda(), w.cuda(), _cl(dy).cuda()
+    y = _cf(ops.conv3d_fwd(xd, wd).cpu())
+    dw = ops.conv3d_wgrad(xd, dyd).cpu()
+    torch.cuda.synchronize()
+    y32 = F.conv3d(x.cuda(), w[0].cuda(), padding=1).cpu()
+    far = torch.ones(D, H, W, dtype=torch.bool)
+    far[od - 1:od + 2, oh - 1:oh + 2, ow - 1:ow + 2] = False
+    others = [c for c in range(cin) if c != oc]
+    e_y_all, e_dw_all = _relerr(y, y64.detach()), _relerr(dw, w64.grad)
+    e_y_far, e_y_far_lib = _relerr(y[0][:, far], y64.detach()[0][:, far]), _relerr(y32[0][:, far], y64.detach()[0][:, far])
+    e_dw_far = _relerr(dw[0][:, others], w64.grad[0][:, others])
+    print(f"conv3d with one voxel 2^20 x the rest: fwd {e_y_all:.2e} (whole tensor) {e_y_far:.2e} (voxels it does not reach; library fp32 {e_y_far_lib:.2e})"
+          f"  wgrad {e_dw_all:.2e} (whole) {e_dw_far:.2e} (other input channels)")
+    assert e_y_all < 3e-6 and e_dw_all < 3e-6               # on the scale of the tensor: as without the outlier
+    assert e_y_far < 3e-5 and e_dw_far < 3e-5               # on their own scale: 19-bit operands (2^-19 = 1.9e-6 per element, K = 27 cin terms)
+
+
 def test_conv3d_fused_layer_tail_and_its_gradient():
     from scaledreamer_amd import ops
     from scaledreamer_amd.generators import _Conv3dFn
