@@ -108,7 +108,8 @@ def test_conv3d_one_outlier_voxel_far_above_the_rest():
     print(f"conv3d with one voxel 2^20 x the rest: fwd {e_y_all:.2e} (whole tensor) {e_y_far:.2e} (voxels it does not reach; library fp32 {e_y_far_lib:.2e})"
           f"  wgrad {e_dw_all:.2e} (whole) {e_dw_far:.2e} (other input channels)")
     assert e_y_all < 3e-6 and e_dw_all < 3e-6               # on the scale of the tensor: as without the outlier
-    assert e_y_far < 3e-5 and e_dw_far < 3e-5               # on their own scale: 19-bit operands (2^-19 = 1.9e-6 per element, K = 27 cin terms)
+    # on their own scale: 19-bit operands (2^-19 = 1.9e-6 per element, errors of K = 27 cin terms adding at random); measured 1.4e-6 / 1.2e-6
+    assert e_y_far < 6e-6 and e_dw_far < 6e-6
 
 
 def test_conv3d_fused_layer_tail_and_its_gradient():

@@ -19,3 +19,5 @@ for ln in open("$O/secondary_bench_lines.jsonl"):
     d = json.loads(ln); print(d["metric"], d["value"], d["ms_per_step"], d["config"].get("render", ""))
 PY
 bash tools/workload_breakdown.sh ${1:-r5_final}_c5 asd_mv_triplane 8 8 > /dev/null 2>&1; head -3 gpurun_out/${1:-r5_final}_c5/asd_mv_triplane_step_breakdown.txt
+bash tools/workload_breakdown.sh ${1:-r5_final}_c4 asd_sd_3dconv_net 8 8 > /dev/null 2>&1; head -3 gpurun_out/${1:-r5_final}_c4/asd_sd_3dconv_net_step_breakdown.txt
+bash tools/tritx_pmc.sh ${1:-r5_final}_tritx > /dev/null 2>&1; head -12 gpurun_out/${1:-r5_final}_tritx/tritx_sq_counters.txt | cut -c1-160

@@ -3,7 +3,7 @@ O=gpurun_out/${1:-tritx_pmc}; mkdir -p $O
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tx_pmc; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/tx_pmc -- python $R/tools/tritx_time.py > $R/$O/time.txt 2>&1
 python $R/tools/pmc_table.py /tmp/tx_pmc | grep -E "tx_attn_(fwd|bwd)|gemm_f16" > $R/$O/tritx_sq_counters.txt
-python - "$R/$O/tritx_sq_counters.txt" <<'PY'
+python - "$R/$O/tritx_sq_counters.txt" <<'PY' | tee $R/$O/tritx_sq_summary.txt
 import sys, re, collections
 rows = collections.defaultdict(dict)
 for ln in open(sys.argv[1]):
