@@ -310,6 +310,7 @@ typedef struct asd_render_layout {      /* byte offsets into the workspace */
     int64_t kept, koff, n_kept;                                     /* kept per ray, exclusive scan, sum [1] */
     int64_t ray_idx /* int64 */, t0, t1, pts, dirs, sigma, feats /* raw */, enc, weights;   /* kept samples [capacity] */
     int64_t opacity, depth, z_var, rgb_fg, comp_rgb;                /* per ray */
+    int64_t c_feats, c_enc;                                         /* candidates [capacity]: the field's outputs before the compaction */
 } asd_render_layout;
 int asd_render_layout_init(int32_t n_rays, int32_t capacity, asd_render_layout* layout);   /* [host] */
 int asd_render_fwd(const asd_render_params* p, void* workspace, void* stream);

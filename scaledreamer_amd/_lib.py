@@ -94,7 +94,8 @@ class RenderParams(C.Structure):
 
 
 RENDER_LAYOUT_FIELDS = ["total_bytes", "count", "offset", "total", "c_ray_idx", "c_t0", "c_t1", "c_pts", "c_sigma", "keep", "kept", "koff", "n_kept",
-                        "ray_idx", "t0", "t1", "pts", "dirs", "sigma", "feats", "enc", "weights", "opacity", "depth", "z_var", "rgb_fg", "comp_rgb"]
+                        "ray_idx", "t0", "t1", "pts", "dirs", "sigma", "feats", "enc", "weights", "opacity", "depth", "z_var", "rgb_fg", "comp_rgb",
+                        "c_feats", "c_enc"]
 
 
 class RenderLayout(C.Structure):

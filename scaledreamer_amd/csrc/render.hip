@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
                                                       const int* __restrict__ kept_offset,
                                                       int64_t* __restrict__ ray_idx_out, float* __restrict__ t0_out,
                                                       float* __restrict__ t1_out, float* __restrict__ points_out,
-                                                      float* __restrict__ dirs_out) {
+                                                      float* __restrict__ dirs_out, const float* __restrict__ c_sigma,
+                                                      const float* __restrict__ c_feats, const float* __restrict__ c_enc,
+                                                      float* __restrict__ sigma_out, float* __restrict__ feats_out, float* __restrict__ enc_out) {
     const int r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= n_rays) return;
     const int lane = asd_lane();
@@ -195,6 +197,25 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
                 dirs_out[3 * (size_t)dst] = dx;
                 dirs_out[3 * (size_t)dst + 1] = dy;
                 dirs_out[3 * (size_t)dst + 2] = dz;
+            }
+            if (c_sigma) {      // the field was evaluated on the candidates: its outputs move with the sample
+                sigma_out[dst] = c_sigma[b + j];
+                feats_out[3 * (size_t)dst] = c_feats[3 * (size_t)(b + j)];
+                feats_out[3 * (size_t)dst + 1] = c_feats[3 * (size_t)(b + j) + 1];
+                feats_out[3 * (size_t)dst + 2] = c_feats[3 * (size_t)(b + j) + 2];
+            }
+        }
+        if (c_enc) {
+            // the 128-byte encoding rows: eight lanes per row (16 bytes each), eight kept samples of this trip per pass
+            const int my_src = k ? b + j : -1, my_dst = k ? dst0 + asd_ballot_rank(mask) : 0;
+            for (int s0 = 0; s0 < 64; s0 += 8) {
+                if (!((mask >> s0) & 0xffull)) continue;                     // wave-uniform
+                const int sl = s0 + (lane >> 3);
+                const int src = __shfl(my_src, sl), dd = __shfl(my_dst, sl);
+                if (src >= 0) {
+                    const float4 v = reinterpret_cast<const float4*>(c_enc + (size_t)src * 32)[lane & 7];
+                    reinterpret_cast<float4*>(enc_out + (size_t)dd * 32)[lane & 7] = v;
+                }
             }
         }
         dst0 += __popcll(mask);
@@ -493,7 +514,8 @@ int asd_compact(const float* rays_o, const float* rays_d, int32_t n_rays, const 
     if (n_rays == 0) return ASD_OK;
     hipLaunchKernelGGL(compact_kernel, dim3(asd_div_up(n_rays, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, rays_o,
                        rays_d, n_rays, offset, count, keep, t_start, t_end, kept_offset, ray_idx_out, t_start_out,
-                       t_end_out, points_out, dirs_out);
+                       t_end_out, points_out, dirs_out, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -551,6 +573,7 @@ int asd_render_layout_init(int32_t n_rays, int32_t capacity, asd_render_layout* 
     L->ray_idx = take(cap * 8); L->t0 = take(cap * 4); L->t1 = take(cap * 4); L->pts = take(cap * 12); L->dirs = take(cap * 12);
     L->sigma = take(cap * 4); L->feats = take(cap * 12); L->enc = take(cap * 128); L->weights = take(cap * 4);
     L->opacity = take(nr * 4); L->depth = take(nr * 4); L->z_var = take(nr * 4); L->rgb_fg = take(nr * 12); L->comp_rgb = take(nr * 12);
+    L->c_feats = take(cap * 12); L->c_enc = take(cap * 128);       // (behind the per-ray outputs: the tail a caller copies out stays short)
     L->total_bytes = o;
     return ASD_OK;
 }
@@ -578,13 +601,30 @@ int asd_render_fwd(const asd_render_params* p, void* workspace, void* stream) {
     STEP(asd_march_write(&p->march, p->rays_o, p->rays_d, nr, p->occ_bits, p->jitter, AT(int32_t, offset), AT(int32_t, c_ray_idx), AT(float, c_t0), AT(float, c_t1),
                          AT(float, c_pts), stream));
     const int32_t *k_off, *k_cnt, *n_kept;
+    // ASD_RENDER_CANDIDATE_FIELD=0 (A/B): densities of the candidates, then the whole field again at the kept samples (the reference's order:
+    // nerfacc's sigma_fn inside the sampling, then geometry(positions)).  Default: the field ONCE, on the candidates — the hash-grid gathers
+    // are what a sample costs, the feature head on the pruned candidates is cheap beside a second encode of the kept ones — and the
+    // compaction carries sigma / features / encoding rows along (bit-identical values: same function of the same positions).
+    static const bool candidate_field = !(getenv("ASD_RENDER_CANDIDATE_FIELD") && getenv("ASD_RENDER_CANDIDATE_FIELD")[0] == '0');
+    const bool fused = p->prune && candidate_field;
     if (p->prune) {
-        STEP(asd_field_density(p->meta, p->field, p->grid, p->w1d, p->w2d, AT(float, c_pts), cap, AT(int32_t, total), AT(float, c_sigma), stream));
+        if (fused)
+            STEP(asd_field_fwd(p->meta, p->field, p->grid, p->w1d, p->w2d, p->w1f, p->w2f, AT(float, c_pts), cap, AT(int32_t, total), AT(float, c_sigma),
+                               AT(float, c_feats), nullptr, nullptr, AT(float, c_enc), stream));
+        else
+            STEP(asd_field_density(p->meta, p->field, p->grid, p->w1d, p->w2d, AT(float, c_pts), cap, AT(int32_t, total), AT(float, c_sigma), stream));
         STEP(asd_prune_count(AT(float, c_sigma), AT(float, c_t0), AT(float, c_t1), AT(int32_t, offset), AT(int32_t, count), nr, p->early_stop_eps, p->alpha_thre,
                              AT(uint8_t, keep), AT(int32_t, kept), stream));
         STEP(asd_scan_i32(AT(int32_t, kept), nr, AT(int32_t, koff), AT(int32_t, n_kept), stream));
-        STEP(asd_compact(p->rays_o, p->rays_d, nr, AT(int32_t, offset), AT(int32_t, count), AT(uint8_t, keep), AT(float, c_t0), AT(float, c_t1), AT(int32_t, koff),
-                         AT(int64_t, ray_idx), AT(float, t0), AT(float, t1), AT(float, pts), AT(float, dirs), stream));
+        if (fused) {
+            hipLaunchKernelGGL(compact_kernel, dim3(asd_div_up(nr, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, p->rays_o, p->rays_d, nr, AT(int32_t, offset),
+                               AT(int32_t, count), AT(uint8_t, keep), AT(float, c_t0), AT(float, c_t1), AT(int32_t, koff), AT(int64_t, ray_idx), AT(float, t0),
+                               AT(float, t1), AT(float, pts), AT(float, dirs), AT(float, c_sigma), AT(float, c_feats), AT(float, c_enc), AT(float, sigma),
+                               AT(float, feats), AT(float, enc));
+        } else {
+            STEP(asd_compact(p->rays_o, p->rays_d, nr, AT(int32_t, offset), AT(int32_t, count), AT(uint8_t, keep), AT(float, c_t0), AT(float, c_t1), AT(int32_t, koff),
+                             AT(int64_t, ray_idx), AT(float, t0), AT(float, t1), AT(float, pts), AT(float, dirs), stream));
+        }
         k_off = AT(int32_t, koff); k_cnt = AT(int32_t, kept); n_kept = AT(int32_t, n_kept);
     } else {
         STEP(asd_compact(p->rays_o, p->rays_d, nr, AT(int32_t, offset), AT(int32_t, count), nullptr, AT(float, c_t0), AT(float, c_t1), AT(int32_t, offset),
@@ -594,8 +634,9 @@ int asd_render_fwd(const asd_render_params* p, void* workspace, void* stream) {
         (void)hipMemcpyAsync(AT(int32_t, n_kept), AT(int32_t, total), 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
         k_off = AT(int32_t, koff); k_cnt = AT(int32_t, kept); n_kept = AT(int32_t, n_kept);
     }
-    STEP(asd_field_fwd(p->meta, p->field, p->grid, p->w1d, p->w2d, p->w1f, p->w2f, AT(float, pts), cap, n_kept, AT(float, sigma), AT(float, feats), nullptr, nullptr,
-                       AT(float, enc), stream));
+    if (!fused)
+        STEP(asd_field_fwd(p->meta, p->field, p->grid, p->w1d, p->w2d, p->w1f, p->w2f, AT(float, pts), cap, n_kept, AT(float, sigma), AT(float, feats), nullptr,
+                           nullptr, AT(float, enc), stream));
     hipLaunchKernelGGL((composite_fwd_kernel<0>), dim3(asd_div_up(nr, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, AT(float, sigma), AT(float, t0), AT(float, t1),
                        AT(float, feats), k_off, k_cnt, nr, p->bg, AT(float, weights), AT(float, opacity), AT(float, depth), AT(float, rgb_fg), AT(float, z_var),
                        AT(float, comp_rgb), p->color_act);

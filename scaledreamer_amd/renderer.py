@@ -226,7 +226,7 @@ class _RenderFn(torch.autograd.Function):
         # five per-ray outputs (they are the contiguous tail of the layout: one n_rays * ~36 B copy), so an in-place op on a returned tensor
         # cannot corrupt the gradients and a surviving output does not pin the n_rays * max_steps * ~217 B workspace
         L, n = st.layout, st.n_rays
-        tail = st.ws[L.opacity:L.total_bytes].clone()
+        tail = st.ws[L.opacity:L.c_feats].clone()
 
         def out(off, cols):
             t = tail[off - L.opacity:off - L.opacity + n * max(cols, 1) * 4].view(torch.float32)

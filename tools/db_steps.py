@@ -7,7 +7,7 @@ db = sys.argv[1]
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 10
 c = sqlite3.connect(db)
 rows = c.execute("select start, end, name from kernels order by start").fetchall()
-short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "")).replace("at::native::", "")[:64]
+short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", "")).replace("at::native::", "")[:64]
 # --marker NAME: the kernel that opens a step (default the marcher; the amortized workloads have none: use e.g. score_fwd_kernel,
 # which runs once per step — the step boundaries are then shifted, the per-step sums are not)
 marker = sys.argv[sys.argv.index("--marker") + 1] if "--marker" in sys.argv else "march_kernel"
