@@ -574,6 +574,10 @@ int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_d
 /* d loss / d moments (fp32 [B,hl,wl,2C]) given grad: d z = upstream * grad / B (upstream: device scalar or NULL = 1) */
 int asd_latents_bwd(const float* grad, const float* moments_nhwc, const float* post_noise, const float* upstream, int32_t B, int32_t C,
                     int32_t hl, int32_t wl, float scaling, float* d_moments_nhwc, void* stream);
+/* t_plus = clamp(t + (int64)(u * clamp(plus_ratio * (t - min_step), 0, T - 1 - t)), 1, T - 1) in the reference's float32 arithmetic
+ * (stable_diffusion_asd_guidance.py:294-316 get_t_plus); u: fp32 [n] uniform draws, or NULL (plus_random off: u = 1) */
+int asd_timestep_plus(const int64_t* t, const float* u, int32_t n, int64_t min_step, int64_t num_train_timesteps, float plus_ratio,
+                      int64_t* t_plus, void* stream);
 /* loss assembly of training_step (scaledreamer.py:62-126) in one launch each way:
  *   total = sum_j weights[j] * terms[j][0] + lambda_sparsity * mean(sqrt(opacity^2 + 0.01))
  *         + lambda_opaque * mean(-(x log x + (1 - x) log(1 - x))), x = clamp(opacity, 1e-3, 1 - 1e-3)   (threestudio/utils/ops.py:365-369)

@@ -167,7 +167,7 @@ SYMBOLS = [
     "asd_tx_attention_workspace", "asd_tx_attention_fwd", "asd_tx_attention_bwd",
     "asd_tritx_packed_floats", "asd_tritx_save_floats", "asd_tritx_workspace_floats", "asd_tritx_pack", "asd_tritx_fwd", "asd_tritx_bwd",
     "asd_comm_unique_id", "asd_comm_create", "asd_comm_destroy", "asd_allreduce_mean_f32",
-    "asd_version", "asd_last_error", "asd_modulated_weights_fwd", "asd_modulated_weights_bwd", "asd_loss_tail_fwd", "asd_loss_tail_bwd", "asd_probe_events", "asd_probe_mark",
+    "asd_version", "asd_last_error", "asd_modulated_weights_fwd", "asd_modulated_weights_bwd", "asd_timestep_plus", "asd_loss_tail_fwd", "asd_loss_tail_bwd", "asd_probe_events", "asd_probe_mark",
 ]
 
 

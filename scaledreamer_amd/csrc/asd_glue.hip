@@ -220,6 +220,22 @@ __global__ __launch_bounds__(256) void latents_bwd_kernel(const float* __restric
 }
 
 
+// t+ = clamp(t + (long)(u * clamp(plus_ratio * (t - min_step), 0, T - 1 - t)), 1, T - 1), u = 1 without plus_random
+// (stable_diffusion_asd_guidance.py:294-316): the tensor-op form's float32 arithmetic — the product in float32, clamp as min(max(x, lo), hi),
+// truncation toward zero — in one launch instead of a dozen one-element ones
+__global__ void timestep_plus_kernel(const long long* __restrict__ t, const float* __restrict__ u, int n, long long min_step, long long T, float plus_ratio,
+                                     long long* __restrict__ t_plus) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long ti = t[i];
+    float room = plus_ratio * (float)(ti - min_step);
+    room = fminf(fmaxf(room, 0.f), (float)(T - ti - 1));
+    if (u) room = room * u[i];
+    long long tp = ti + (long long)room;
+    tp = tp < 1 ? 1 : (tp > T - 1 ? T - 1 : tp);
+    t_plus[i] = tp;
+}
+
 // ---- loss assembly: weighted scalar terms + the per-ray regularisers, one launch forward and one backward --------------------------
 // scaledreamer.py:62-126 (training_step): loss = sum_j lambda_j loss_j + lambda_sparsity mean(sqrt(opacity^2 + 0.01))
 //   + lambda_opaque BCE(clamp(opacity, 1e-3, 1 - 1e-3)) (threestudio/utils/ops.py:365-369, the clamped opacity as input AND target, both
@@ -418,6 +434,15 @@ int asd_prompt_context(const float* text_vd, const float* uncond_vd, int32_t n_d
     const int slots = (layout == 0 ? 3 : 5) * batch;
     hipLaunchKernelGGL(prompt_context_kernel, dim3(slots * n_tok), dim3(128), 0, (hipStream_t)stream, text_vd, uncond_vd, n_dir, n_tok, dim, elevation,
                        azimuth, batch, layout, pp, neg_scale, (half_t*)context_f16, ctx_stride, neg_w);
+    ASD_LAUNCH_CHECK();
+    return ASD_OK;
+}
+
+int asd_timestep_plus(const int64_t* t, const float* u, int32_t n, int64_t min_step, int64_t num_train_timesteps, float plus_ratio, int64_t* t_plus,
+                      void* stream) {
+    ASD_CHECK_ARG(t && t_plus && n > 0 && num_train_timesteps > 1 && plus_ratio >= 0.f, "bad argument");
+    hipLaunchKernelGGL(timestep_plus_kernel, dim3(asd_div_up(n, 64)), dim3(64), 0, (hipStream_t)stream, (const long long*)t, u, n, (long long)min_step,
+                       (long long)num_train_timesteps, plus_ratio, (long long*)t_plus);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

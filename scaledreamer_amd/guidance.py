@@ -296,6 +296,17 @@ class _AsdGuidanceBase(BaseObject):
         if self.cfg.plus_ratio < 0.0:
             raise AssertionError("plus_ratio must be >= 0")
         T = self.num_train_timesteps
+        if t.is_cuda and t.dtype == torch.long:        # one launch (asd_timestep_plus) instead of a dozen one-element tensor ops
+            import ctypes as C
+
+            from . import _lib
+
+            t = t.contiguous()
+            u = self.rand_fn(t.shape, t.device).float().contiguous() if self.cfg.plus_random else None
+            out = torch.empty_like(t)
+            _lib.check(_lib.lib().asd_timestep_plus(_lib.ptr(t), _lib.ptr(u), _lib.i32(t.numel()), C.c_int64(int(self.min_step)), C.c_int64(int(T)),
+                                                    _lib.f32(float(self.cfg.plus_ratio)), _lib.ptr(out), _lib.stream()))
+            return out
         room = (self.cfg.plus_ratio * (t - self.min_step)).clamp(torch.zeros_like(t), T - t - 1)
         if self.cfg.plus_random:
             room = room * self.rand_fn(t.shape, t.device)

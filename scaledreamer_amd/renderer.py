@@ -238,7 +238,13 @@ class _RenderFn(torch.autograd.Function):
         grid, w1d, w2d, w1f, w2f, bg = ctx.saved_tensors
         st = ctx.st
         d_grid = torch.zeros_like(grid)
-        dws = [torch.zeros_like(w) for w in (w1d, w2d, w1f, w2f)]
+        ws_ = (w1d, w2d, w1f, w2f)           # the four small gradients: views of ONE zeroed buffer (16-byte aligned pieces)
+        offs, total = [], 0
+        for w in ws_:
+            offs.append(total)
+            total += (w.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, device=grid.device, dtype=torch.float32)
+        dws = [flat[o:o + w.numel()].view_as(w) for o, w in zip(offs, ws_)]
         if all(g is None for g in (d_comp, d_fg, d_op, d_dp, d_zv)):
             return (d_grid, *dws, None, None)
         p = st.params(grid, w1d, w2d, w1f, w2f, bg)

@@ -282,3 +282,32 @@ def test_loss_tail_z_variance_without_a_ray_above_one_half_is_nan_like_the_empty
     total, values = _LossTailFn.apply(op, zv, (0.0, 0.0, 2.0), ())
     assert torch.isnan(total) and torch.isnan(values[2])
     assert torch.isnan(zv[op > 0.5].mean())                            # what the tensor-op form gives
+
+
+def test_timestep_plus_kernel_matches_the_tensor_op_form():
+    """asd_timestep_plus (one launch) against get_t_plus' tensor-op form evaluated on the CPU (stable_diffusion_asd_guidance.py:294-316): every
+    timestep of the schedule x several uniform draws incl. 0 and the largest float below 1, with and without plus_random — bit-exact"""
+    from scaledreamer_amd.guidance import _AsdGuidanceBase
+
+    class G(_AsdGuidanceBase):
+        def __init__(self, plus_random, min_step, u):
+            self.cfg = type("Cfg", (), {"plus_ratio": 0.1, "plus_random": plus_random})()
+            self.num_train_timesteps, self.min_step = 1000, min_step
+            self.rand_fn = lambda shape, device: u.to(device)
+
+    T = 1000
+    t = torch.arange(0, T, dtype=torch.long).repeat(7)
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(t.shape, generator=g)
+    u[:T] = 0.0
+    u[T:2 * T] = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+    for plus_random in (False, True):
+        for min_step in (20, 500, 979):
+            want = G(plus_random, min_step, u).get_t_plus(t)                       # CPU tensors: the tensor-op form
+            got = G(plus_random, min_step, u).get_t_plus(t.cuda())                 # device tensors: the kernel
+            assert got.dtype == torch.long and torch.equal(got.cpu(), want), (plus_random, min_step)
+    # other plus_ratio values round differently in float32: sweep a few
+    for ratio in (0.0, 0.05, 0.3, 1.0, 2.5):
+        a, b = G(True, 20, u), G(True, 20, u)
+        a.cfg.plus_ratio = b.cfg.plus_ratio = ratio
+        assert torch.equal(b.get_t_plus(t.cuda()).cpu(), a.get_t_plus(t)), ratio
