@@ -715,12 +715,13 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
     constexpr int NIN = 2 * L;
     // weight gradients: wave sums -> per-block LDS cells -> one global atomic per weight and block (64 wave leaders hammering the
     // same 432 addresses ran at the hot-address atomic rate)
+    static_assert(H <= 16 && NIN <= 16, "factor rows of 17 words");
     __shared__ float w_acc[3 * H + H * H + H * NIN];
+    __shared__ float xch[4 * 2 * 64 * 17];
     for (int q = threadIdx.x; q < 3 * H + H * H + H * NIN; q += 256) w_acc[q] = 0.f;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n;
-    const bool lead = (threadIdx.x & 63) == 0;
     float enc[NIN], a0[H], a1[H], dout[3], dh1[H], dh0[H], denc[NIN];
     float x = 0.f, y = 0.f, z = 0.f;
     if (active) {
@@ -752,37 +753,55 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
         const float s = asd_sigmoid(a);
         dout[o] = active ? d_color[3 * (size_t)i + o] * s * (1.f - s) : 0.f;
     }
+    // Weight gradients = sums over rays of outer products.  One wave_sum per entry (432 six-step shuffle reductions, each followed by a
+    // lead-lane LDS atomic) was the critical path of this 16-block launch; instead the lanes park the two factor vectors of a layer in
+    // the wave's LDS rows (pitch 17 words: conflict-free) and every lane sums a few ENTRIES over the wave's 64 rays.
+    float* const fa = xch + (threadIdx.x >> 6) * (2 * 64 * 17);      // [ray][17]: the gradient factor
+    float* const fb = fa + 64 * 17;                                   // [ray][17]: the activation factor
+    const int lane = threadIdx.x & 63;
+    auto outer_sums = [&](int n_out, int n_in, float* dst) __attribute__((always_inline)) {
+        __syncthreads();                                              // the factors of this layer are in place
+        for (int e = lane; e < n_out * n_in; e += 64) {
+            const int o = e / n_in, k = e - o * n_in;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) acc = fmaf(fa[r * 17 + o], fb[r * 17 + k], acc);
+            atomicAdd(&dst[e], acc);                                  // the block's four waves meet here (distinct cells within a wave)
+        }
+        __syncthreads();                                              // before the rows are overwritten
+    };
+#pragma unroll
+    for (int o = 0; o < 3; ++o) fa[lane * 17 + o] = dout[o];
+#pragma unroll
+    for (int k = 0; k < H; ++k) fb[lane * 17 + k] = fmaxf(a1[k], 0.f);
+    outer_sums(3, H, w_acc);                                          // dw2[o][k]
 #pragma unroll
     for (int k = 0; k < H; ++k) {
         float acc = 0.f;
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const float v = asd_wave_sum(dout[o] * fmaxf(a1[k], 0.f));
-            if (lead) atomicAdd(&w_acc[o * H + k], v);
-            acc = fmaf(dout[o], w2[o * H + k], acc);
-        }
+        for (int o = 0; o < 3; ++o) acc = fmaf(dout[o], w2[o * H + k], acc);
         dh1[k] = a1[k] > 0.f ? acc : 0.f;
     }
 #pragma unroll
+    for (int k = 0; k < H; ++k) { fa[lane * 17 + k] = dh1[k]; fb[lane * 17 + k] = fmaxf(a0[k], 0.f); }
+    outer_sums(H, H, w_acc + 3 * H);                                  // dw1[h][k]
+#pragma unroll
     for (int k = 0; k < H; ++k) {
         float acc = 0.f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float v = asd_wave_sum(dh1[h] * fmaxf(a0[k], 0.f));
-            if (lead) atomicAdd(&w_acc[3 * H + h * H + k], v);
-            acc = fmaf(dh1[h], w1[h * H + k], acc);
-        }
+        for (int h = 0; h < H; ++h) acc = fmaf(dh1[h], w1[h * H + k], acc);
         dh0[k] = a0[k] > 0.f ? acc : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < H; ++k) fa[lane * 17 + k] = dh0[k];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) fb[lane * 17 + k] = enc[k];
+    outer_sums(H, NIN, w_acc + 3 * H + H * H);                        // dw0[h][k]
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         float acc = 0.f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float v = asd_wave_sum(dh0[h] * enc[k]);
-            if (lead) atomicAdd(&w_acc[3 * H + H * H + h * NIN + k], v);
-            acc = fmaf(dh0[h], w0[h * NIN + k], acc);
-        }
+        for (int h = 0; h < H; ++h) acc = fmaf(dh0[h], w0[h * NIN + k], acc);
         denc[k] = acc;
     }
     // a wave is 64 consecutive pixels of an image row: on the three coarse levels (cells of 1/4 .. 1/64 of the direction cube) its
