@@ -70,6 +70,8 @@ class MultiPromptUtils:
         assert view_dependent_prompting, "Perp-Neg only works with view-dependent prompting"
         B = len(self.global_text_embeddings)
         gs = -1 if guidance_scale_neg is None else guidance_scale_neg
+        if elevation.is_cuda and os.environ.get("ASD_PERP_NEG_ON_DEVICE", "1") != "0":      # =0: the branching form (same-box A/B)
+            return self._perp_neg_on_device(elevation, azimuth, gs)
         idx = self.direction_idx(elevation, azimuth, camera_distances)
         pos, neg, uncond, weights = [], [], [], []
         for b in range(B):
@@ -93,6 +95,41 @@ class MultiPromptUtils:
                 weights += [shifted_expotional_decay(*self.perp_neg_f_sb, r) * gs, shifted_expotional_decay(*self.perp_neg_f_fsb, r) * gs]
         text = torch.cat([torch.stack(pos, 0), torch.stack(uncond, 0), torch.stack(neg, 0)], dim=0)
         return text, torch.as_tensor(weights, device=elevation.device).reshape(B, 2)
+
+
+def _perp_neg_on_device(self, elevation, azimuth, gs):
+    """get_text_embeddings_perp_neg for device tensors WITHOUT reading the angles back: the reference (prompt_processors/base.py:470-533)
+    branches on `int(idx[b])` / `torch.abs(azi) < 90` per batch element — one host synchronisation per element and step, after which the
+    device idles until the host has caught up.  Here the three cases are evaluated with the same elementwise expressions on [B, 1, 1]
+    coefficients and selected with torch.where: bit-identical embeddings and weights (tests/test_gpu_asd_glue.py)."""
+    vd = torch.stack(list(self.text_embeddings_vd), dim=0)                     # [B, 4, 77, D]: side / front / back / overhead
+    side, front, back, overhead = vd[:, 0], vd[:, 1], vd[:, 2], vd[:, 3]
+    azi = shift_azimuth_deg(azimuth)
+    a = torch.abs(azi)
+    # direction_idx's masked assignments in their order of precedence (overhead over back over front over side) as selections
+    one, two, three = (torch.full_like(elevation, k, dtype=torch.long) for k in (1, 2, 3))
+    idx = torch.where((azi > -self.front_threshold) & (azi < self.front_threshold), one, torch.zeros_like(one))
+    idx = torch.where((azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold), two, idx)
+    idx = torch.where(elevation > self.overhead_threshold, three, idx)
+    unc = self.uncond_text_embeddings_vd[idx]                                   # [B, 77, D]
+    is_over = (idx == 3)
+    near = a < 90
+    r1 = (1 - a / 90).view(-1, 1, 1)                                            # front half: r * front + (1 - r) * side
+    r2 = (2.0 - a / 90).view(-1, 1, 1)                                          # back half:  r * side + (1 - r) * back
+    o3, n3 = is_over.view(-1, 1, 1), near.view(-1, 1, 1)
+    pos = torch.where(o3, overhead, torch.where(n3, r1 * front + (1 - r1) * side, r2 * side + (1 - r2) * back))
+    neg0 = torch.where(o3, unc, torch.where(n3, front, side))
+    neg1 = torch.where(o3, unc, torch.where(n3, side, front))
+    q1, q2 = r1.view(-1), r2.view(-1)
+    w0 = torch.where(near, shifted_expotional_decay(*self.perp_neg_f_fs, q1) * gs, shifted_expotional_decay(*self.perp_neg_f_sb, q2) * gs)
+    w1 = torch.where(near, shifted_expotional_decay(*self.perp_neg_f_sf, 1 - q1) * gs, shifted_expotional_decay(*self.perp_neg_f_fsb, q2) * gs)
+    zero = torch.zeros_like(w0)
+    weights = torch.stack([torch.where(is_over, zero, w0), torch.where(is_over, zero, w1)], dim=1)
+    neg = torch.stack([neg0, neg1], dim=1).reshape(-1, *neg0.shape[1:])         # (b, k) order: two negatives per sample, interleaved
+    return torch.cat([pos, unc, neg], dim=0), weights
+
+
+MultiPromptUtils._perp_neg_on_device = _perp_neg_on_device
 
 
 class SyntheticMultiPromptProcessor:

@@ -311,3 +311,24 @@ def test_timestep_plus_kernel_matches_the_tensor_op_form():
         a, b = G(True, 20, u), G(True, 20, u)
         a.cfg.plus_ratio = b.cfg.plus_ratio = ratio
         assert torch.equal(b.get_t_plus(t.cuda()).cpu(), a.get_t_plus(t)), ratio
+
+
+def test_multiprompt_perp_neg_conditioning_without_read_back_is_bit_identical():
+    """MultiPromptUtils.get_text_embeddings_perp_neg on device tensors (selections instead of per-element host branches) against the
+    branching form (the reference's, prompt_processors/base.py:470-533) evaluated on the same values: every direction class, the
+    class boundaries, the 90-degree switch between the two blends"""
+    from scaledreamer_amd.multiprompt import SyntheticMultiPromptProcessor
+
+    prompts = [f"p{i}" for i in range(12)]
+    pu_dev = SyntheticMultiPromptProcessor(prompts, device="cuda")(prompts)
+    pu_cpu = SyntheticMultiPromptProcessor(prompts, device="cpu")(prompts)
+    az = torch.tensor([0.0, 30.0, 45.0, -45.0, 89.99, 90.0, 120.0, 135.0, -135.0, 179.0, -100.0, 10.0])
+    el = torch.tensor([0.0, 10.0, 59.0, 60.0, 60.01, 75.0, -5.0, 20.0, 30.0, 61.0, 5.0, 89.0])
+    got, w = pu_dev.get_text_embeddings_perp_neg(el.cuda(), az.cuda(), torch.ones(12).cuda(), True)
+    want, ww = pu_cpu.get_text_embeddings_perp_neg(el, az, torch.ones(12), True)
+    assert torch.equal(got.cpu(), want)
+    torch.testing.assert_close(w.cpu(), ww, rtol=1e-6, atol=1e-7)           # exp() of the host's libm vs the device's
+    got2, w2 = pu_dev.get_text_embeddings_perp_neg(el.cuda(), az.cuda(), None, True, guidance_scale_neg=-3.0)
+    want2, ww2 = pu_cpu.get_text_embeddings_perp_neg(el, az, None, True, guidance_scale_neg=-3.0)
+    assert torch.equal(got2.cpu(), want2)
+    torch.testing.assert_close(w2.cpu(), ww2, rtol=1e-6, atol=1e-7)
