@@ -14,4 +14,4 @@ finally:
     st.sort_stats('tottime').print_stats(60)
     st.sort_stats('cumtime').print_stats(70)
 " > $O/$2_bench.json 2> $O/$2_err.txt
-head -75 $O/$2_host_profile.txt | cut -c1-150
+grep -v "weights.py\|engine.py\|importlib\|sympy\|tokenize\|marshal" $O/$2_host_profile.txt | head -45 | cut -c1-150
