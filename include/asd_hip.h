@@ -645,11 +645,12 @@ int asd_conv3d_dgrad(const asd_conv3d_desc* desc, const float* dy, const float* 
                      int64_t ws_bytes, void* stream);
 int asd_conv3d_wgrad(const asd_conv3d_desc* desc, const float* x, const float* dy, float* dw /* [N][Cout][Cin][27] */,
                      int64_t dw_sample_stride, void* ws, int64_t ws_bytes, void* zero_page /* >= 16 B of zeros */, void* stream);
-/* gradient through the layer tail, read off the OUTPUT y (minus `sub` when the layer output was act(.) + sub): dz = dy * act'(y - sub);
+/* gradient through the layer tail, read off the OUTPUT y (minus `sub` when the layer output was act(.) + sub): dz = dy * act'(y - sub) — or,
+ * with act_mask (asd_upsample3d_fwd), off the branch bits the forward pass recorded (y may then be NULL);
  * d_bias[C] = sum over rows of dz (optional); d_rowsum[rows] = sum over channels of dz (optional: the gradient of the per-voxel noise
  * term); amax_out (optional, zeroed by the caller): max|dz| for asd_conv3d_desc.amax_dy */
-int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t rows, int32_t C, float gain, float clamp, float* dz,
-                      float* d_bias, float* d_rowsum, uint32_t* amax_out, void* stream);
+int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, const uint8_t* act_mask, int64_t rows, int32_t C, float gain, float clamp,
+                      float* dz, float* d_bias, float* d_rowsum, uint32_t* amax_out, void* stream);
 /* the per-sample weights of a modulated convolution (custom/amortized/extern/stylegan_3dconv_modules.py:64-82 modulated_conv3d):
  *   wm[n][co][ci][k] = weight[co][ci][k] * styles[n][ci] * gain * dcoef[n][co],
  *   dcoef = rsqrt(sum_{ci,k} (weight styles gain)^2 + 1e-8) when demodulate, 1 otherwise (toRGB: gain = its weight_gain).  1 <= N <= 8.
@@ -670,6 +671,8 @@ int asd_torgb_bwd(const float* x, const float* dy, int64_t rows, int32_t Cin, co
                   float* d_bias, void* stream);
 /* y[N][2r][2r][2r][C] = act(trilinear_2x(x[N][r][r][r][C], align_corners) + noise * ns + bias) + add   (ep and add optional) */
 int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const asd_conv3d_epilogue* ep, const float* add, float* y,
+                       uint8_t* act_mask /* optional, [N (2r)^3 C / 4] bytes: with ep->act, two bits per element (slope 1 | clamped) for
+                                            asd_layer_act_bwd — exact where y = act(.) + add does not give the branch back */,
                        void* stream);
 /* dx = transpose of the upsampling applied to dy; ws: 6 * N * r^3 * C floats */
 int asd_upsample3d_bwd(const float* dy, int32_t N, int32_t r, int32_t C, float* dx, float* ws, void* stream);

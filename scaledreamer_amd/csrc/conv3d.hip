@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // gradient through the layer's activation: y = clamp(lrelu(z) * gain, +-clamp), z = conv + noise * ns + bias.  dz = dy * act'(y), read off
 // the OUTPUT (sign(y) = sign(z); |y| == clamp where the clamp cut).  Also leaves d_bias[c] = sum_rows dz (atomics of block partials) and
 // d_noise[row] = sum_c dz (the gradient of noise * ns w.r.t. the per-voxel term; the caller contracts it with the noise it drew).
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ sub, size_t rows, int C,
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ sub,
+                                                      const unsigned char* __restrict__ act_mask, size_t rows, int C,
                                                       float gain, float clamp, float* __restrict__ dz, float* __restrict__ d_bias, float* __restrict__ d_rowsum,
                                                       unsigned* __restrict__ amax_out) {
     extern __shared__ float cb[];                     // [C] block partial of d_bias
@@ -446,15 +447,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         float rs = 0.f;
         if (r < rows) {
             const floatx4 g = *(const floatx4*)(dy + r * C + c);
-            floatx4 o = *(const floatx4*)(y + r * C + c);
-            if (sub) {        // y = act(.) + sub: the activation's own output
-                const floatx4 sb = *(const floatx4*)(sub + r * C + c);
-                o[0] -= sb[0]; o[1] -= sb[1]; o[2] -= sb[2]; o[3] -= sb[3];
+            floatx4 o = {0.f, 0.f, 0.f, 0.f};
+            unsigned mk = 0;
+            if (act_mask) {   // the forward pass left the branch of every element (y = act(.) + sub: (y - sub) is not exact in fp32)
+                mk = act_mask[(r * C + c) >> 2];
+            } else {
+                o = *(const floatx4*)(y + r * C + c);
+                if (sub) {    // y = act(.) + sub: the activation's own output, up to the rounding of the sum
+                    const floatx4 sb = *(const floatx4*)(sub + r * C + c);
+                    o[0] -= sb[0]; o[1] -= sb[1]; o[2] -= sb[2]; o[3] -= sb[3];
+                }
             }
             floatx4 z;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float sl = fabsf(o[k]) >= clamp ? 0.f : (o[k] >= 0.f ? gain : 0.2f * gain);
+                float sl;
+                if (act_mask) sl = ((mk >> (2 * k + 1)) & 1u) ? 0.f : (((mk >> (2 * k)) & 1u) ? gain : 0.2f * gain);
+                else sl = fabsf(o[k]) >= clamp ? 0.f : (o[k] >= 0.f ? gain : 0.2f * gain);
                 z[k] = g[k] * sl;
                 rs += z[k];
                 bs[k] += z[k];
@@ -493,7 +502,8 @@ __device__ __forceinline__ float layer_act(float u, int act, float gain, float c
 // source coordinate of output index a: a * (r - 1) / (2 r - 1)
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int N, int r, int C, const float* __restrict__ noise,
                                                            const float* __restrict__ noise_strength, const float* __restrict__ bias, int act, float gain,
-                                                           float clamp, const float* __restrict__ add, float* __restrict__ y, unsigned* __restrict__ amax_out) {
+                                                           float clamp, const float* __restrict__ add, float* __restrict__ y, unsigned* __restrict__ amax_out,
+                                                           unsigned char* __restrict__ act_mask) {
     const int R = 2 * r, c4 = C / 4;
     const size_t total = (size_t)N * R * R * R * c4;
     const float sc = (float)(r - 1) / (float)(R - 1);
@@ -538,8 +548,16 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         if (bias) bb = *(const floatx4*)(bias + c);
         floatx4 ad = {0.f, 0.f, 0.f, 0.f};
         if (add) ad = *(const floatx4*)(add + row * C + c);
+        unsigned mk = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = layer_act(o[q] + nz + bb[q], act, gain, clamp) + ad[q];
+        for (int q = 0; q < 4; ++q) {
+            const float u = o[q] + nz + bb[q];
+            // two bits per element for the backward pass: slope 1 (u >= 0) | clamped (the gradient of torch.clamp is zero outside [-c, c])
+            mk |= (u >= 0.f ? 1u : 0u) << (2 * q);
+            mk |= (fabsf((u >= 0.f ? u : 0.2f * u) * gain) > clamp ? 1u : 0u) << (2 * q + 1);
+            o[q] = layer_act(u, act, gain, clamp) + ad[q];
+        }
+        if (act_mask) act_mask[i] = (unsigned char)mk;
         am = abs4max(o, am);
         *(floatx4*)(y + row * C + c) = o;
     }
@@ -987,16 +1005,16 @@ int asd_conv3d_wgrad(const asd_conv3d_desc* d, const float* x, const float* dy, 
     return ASD_OK;
 }
 
-int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, int64_t rows, int32_t C, float gain, float clamp, float* dz, float* d_bias,
-                      float* d_rowsum, uint32_t* amax_out, void* stream) {
-    ASD_CHECK_ARG(dy && y && dz && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0, "C / 4 must divide 256");
+int asd_layer_act_bwd(const float* dy, const float* y, const float* sub, const uint8_t* act_mask, int64_t rows, int32_t C, float gain, float clamp,
+                      float* dz, float* d_bias, float* d_rowsum, uint32_t* amax_out, void* stream) {
+    ASD_CHECK_ARG(dy && (y || act_mask) && dz && rows > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0, "C / 4 must divide 256");
     hipStream_t s = (hipStream_t)stream;
     if (d_bias) (void)hipMemsetAsync(d_bias, 0, (size_t)C * 4, s);
     if (d_rowsum && C / 4 > 64) (void)hipMemsetAsync(d_rowsum, 0, (size_t)rows * 4, s);
     const int rpb = 256 / (C / 4);
     int grid = asd_div_up(rows, rpb);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), (size_t)C * 4, s, dy, y, sub, (size_t)rows, C, gain, clamp, dz, d_bias, d_rowsum, amax_out);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), (size_t)C * 4, s, dy, y, sub, act_mask, (size_t)rows, C, gain, clamp, dz, d_bias, d_rowsum, amax_out);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -1054,13 +1072,14 @@ int asd_torgb_bwd(const float* x, const float* dy, int64_t rows, int32_t Cin, co
     return ASD_OK;
 }
 
-int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const asd_conv3d_epilogue* ep, const float* add, float* y, void* stream) {
+int asd_upsample3d_fwd(const float* x, int32_t N, int32_t r, int32_t C, const asd_conv3d_epilogue* ep, const float* add, float* y, uint8_t* act_mask,
+                       void* stream) {
     ASD_CHECK_ARG(x && y && N > 0 && r > 0 && C % 4 == 0 && C > 0, "bad argument");
     ASD_CHECK_ARG(!ep || (ep->act >= 0 && ep->act <= 1 && (!ep->noise || ep->noise_strength)), "bad epilogue");
     const size_t total = (size_t)N * 8 * r * r * r * (C / 4);
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3(c3_grid(total) * 2), dim3(256), 0, (hipStream_t)stream, x, N, r, C, ep ? ep->noise : nullptr,
                        ep ? ep->noise_strength : nullptr, ep ? ep->bias : nullptr, ep ? ep->act : 0, ep ? ep->gain : 1.f, ep ? ep->clamp : 0.f, add, y,
-                       ep ? ep->amax_out : nullptr);
+                       ep ? ep->amax_out : nullptr, act_mask);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }

@@ -150,25 +150,30 @@ class _Conv3dFn(torch.autograd.Function):
 
 class _UpsampleFn(torch.autograd.Function):
     """y = act(trilinear_2x(x) + noise * ns + bias) + add on channel-last volumes (asd_upsample3d_fwd / _bwd; the activation's gradient is
-    read off y - add); returns (y, ay) like _Conv3dFn"""
+    read off y, or with an added volume off the branch bits the forward kernel records); returns (y, ay) like _Conv3dFn"""
 
     @staticmethod
     def forward(ctx, x, bias, noise, ns, act, gain, clamp, add):
         ops = _ops()
         ay = ops.new_amax(x.device)
-        y = ops.upsample3d_fwd(x, bias, noise, ns, act, gain, clamp, add, amax_out=ay)
-        ctx.save_for_backward(y if act else None, noise, add if act else None)
+        # with an added volume (the block's const_bias) the activation's branch cannot be read off y - add exactly (a value clamped at
+        # +-256 gain comes back as 255.9999, one below ulp(add) / 2 loses its sign): the kernel records two bits per element instead
+        mask = (torch.empty(x.shape[0] * 8 * x.shape[1] ** 3 * x.shape[4] // 4, dtype=torch.uint8, device=x.device)
+                if act and add is not None else None)
+        y = ops.upsample3d_fwd(x, bias, noise, ns, act, gain, clamp, add, amax_out=ay, act_mask=mask)
+        ctx.save_for_backward(y if act and mask is None else None, noise, mask)
         ctx.act, ctx.gain, ctx.clamp, ctx.has_bias, ctx.has_noise, ctx.has_add = act, gain, clamp, bias is not None, noise is not None, add is not None
         ctx.mark_non_differentiable(ay)
         return y, ay
 
     @staticmethod
     def backward(ctx, dy, _):
-        y, noise, add = ctx.saved_tensors
+        y, noise, mask = ctx.saved_tensors
         ops = _ops()
         d_bias = d_ns = None
         if ctx.act:
-            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise, sub=add)
+            dz, d_bias, d_rows = ops.layer_act_bwd(dy, y if mask is None else dy, ctx.gain, ctx.clamp, want_bias=ctx.has_bias, want_rowsum=ctx.has_noise,
+                                                   act_mask=mask)
             if ctx.has_noise:
                 d_ns = torch.dot(d_rows, noise.reshape(-1)).reshape(1)
         else:

@@ -433,16 +433,17 @@ def conv3d_wgrad(x: torch.Tensor, dy: torch.Tensor, amax_x=None, amax_dy=None) -
 
 
 def layer_act_bwd(dy: torch.Tensor, y: torch.Tensor, gain: float, clamp: float, want_bias: bool = True, want_rowsum: bool = True,
-                  sub: Optional[torch.Tensor] = None, amax_out=None):
-    """dz = dy * act'(y - sub) on [..., C]; -> (dz, d_bias [C] | None, d_rowsum [rows] | None)"""
+                  sub: Optional[torch.Tensor] = None, amax_out=None, act_mask: Optional[torch.Tensor] = None):
+    """dz = dy * act'(y - sub) on [..., C] (act_mask: the branch bits upsample3d_fwd recorded, instead of reading them off y - sub);
+    -> (dz, d_bias [C] | None, d_rowsum [rows] | None)"""
     dy, y, sub = _c(dy), _c(y), _c(sub)
     Cc = y.shape[-1]
     rows = y.numel() // Cc
     dz = torch.empty_like(y)
     d_bias = torch.empty(Cc, device=y.device, dtype=torch.float32) if want_bias else None
     d_rowsum = torch.empty(rows, device=y.device, dtype=torch.float32) if want_rowsum else None
-    check(lib().asd_layer_act_bwd(ptr(dy), ptr(y), ptr(sub), C.c_int64(rows), i32(Cc), f32(gain), f32(clamp), ptr(dz), ptr(d_bias), ptr(d_rowsum),
-                                  _ap(amax_out), stream()))
+    check(lib().asd_layer_act_bwd(ptr(dy), ptr(y), ptr(sub), ptr(act_mask), C.c_int64(rows), i32(Cc), f32(gain), f32(clamp), ptr(dz), ptr(d_bias),
+                                  ptr(d_rowsum), _ap(amax_out), stream()))
     return dz, d_bias, d_rowsum
 
 
@@ -475,15 +476,16 @@ def modulated_weights_bwd(d_wm: torch.Tensor, wm: torch.Tensor, weight: torch.Te
 
 
 def upsample3d_fwd(x: torch.Tensor, bias=None, noise=None, noise_strength=None, act: bool = False, gain: float = 1.0, clamp: float = 0.0,
-                   add: Optional[torch.Tensor] = None, amax_out=None) -> torch.Tensor:
-    """x [N,r,r,r,C] -> act(trilinear 2x (align_corners) + noise * ns + bias) + add, [N,2r,2r,2r,C]"""
+                   add: Optional[torch.Tensor] = None, amax_out=None, act_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,r,r,r,C] -> act(trilinear 2x (align_corners) + noise * ns + bias) + add, [N,2r,2r,2r,C]; act_mask: uint8 [N (2r)^3 C / 4] that
+    receives the activation's branch per element (for layer_act_bwd)"""
     _need_cuda(x)
     x, add = _c(x), _c(add)
     N, r, r2, r3, Cc = x.shape
     assert r == r2 == r3, "cubic volumes"
     y = torch.empty((N, 2 * r, 2 * r, 2 * r, Cc), device=x.device, dtype=torch.float32)
     ep, keep = _epilogue(bias, noise, noise_strength, act, gain, clamp, amax_out)
-    check(lib().asd_upsample3d_fwd(ptr(x), i32(N), i32(r), i32(Cc), C.byref(ep), ptr(add), ptr(y), stream()))
+    check(lib().asd_upsample3d_fwd(ptr(x), i32(N), i32(r), i32(Cc), C.byref(ep), ptr(add), ptr(y), ptr(act_mask), stream()))
     return y
 
 

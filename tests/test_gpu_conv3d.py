@@ -171,8 +171,37 @@ def test_upsample_matches_trilinear_align_corners_and_its_transpose(r, C):
         assert _relerr(y, yr.detach()) < 2e-6
         for k, t in (("x", x), ("bias", bias), ("ns", ns), ("add", add)):
             if t.grad is not None:
-                assert (_rel_l2 if act else _relerr)(got[k], t.grad) < (5e-4 if act else 2e-5), (act, with_add, k)      # (with `add`, act' is read off fl(y) - add: +-1 ulp of |add| around the kink)
+                assert (_rel_l2 if act else _relerr)(got[k], t.grad) < (5e-4 if act else 2e-5), (act, with_add, k)      # (without `add`, act' is read off y: the fp32 reference may take the other branch within rounding distance of the kink)
             t.grad = None
+
+
+def test_upsample_with_added_volume_takes_the_activation_branch_from_recorded_bits():
+    """y = act(.) + const_bias: (y - const_bias) does not give the activation back exactly — a value clamped at +-256 gain returns as
+    255.9999 (gradient 0 in the reference, slope 1 read off the difference), one smaller than ulp(const_bias) / 2 loses its sign (slope
+    0.2 vs 1).  The forward kernel records the branch of every element; the gradient equals torch autograd's on exactly those cases."""
+    from scaledreamer_amd.generators import _UpsampleFn
+
+    r, C, gain, clamp = 4, 8, 2 ** 0.5, 256.0
+    # constant volumes upsample to themselves: channel 0 far above the clamp, 1 far below -clamp, 2 tiny positive, 3 tiny negative,
+    # 4 ordinary positive, 5 ordinary negative, 6 just inside the clamp, 7 just outside
+    vals = torch.tensor([1.0e4, -1.0e4, 1.0e-9, -1.0e-9, 0.7, -0.7, 255.9 / gain, 256.1 / gain])
+    x = torch.zeros(1, r, r, r, C) + vals
+    bias = torch.zeros(C)
+    add = torch.full((1, 2 * r, 2 * r, 2 * r, C), 1234.567)
+    dy = torch.randn(1, 2 * r, 2 * r, 2 * r, C, generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_(True)
+    up = F.interpolate(xr.permute(0, 4, 1, 2, 3), scale_factor=2, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
+    ref = torch.clamp(F.leaky_relu(up + bias, 0.2) * gain, -clamp, clamp) + add
+    ref.backward(dy)
+    xd = x.cuda().requires_grad_(True)
+    y, _ = _UpsampleFn.apply(xd, bias.cuda(), None, None, True, gain, clamp, add.cuda())
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-6, atol=0)
+    per_ch_ref, per_ch = xr.grad.sum(dim=(0, 1, 2, 3)), xd.grad.cpu().sum(dim=(0, 1, 2, 3))
+    assert float(per_ch_ref[0].abs()) == 0.0 and float(per_ch_ref[7].abs()) == 0.0 and float(per_ch_ref[2].abs()) > 0.0      # the cases are in there
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(per_ch, per_ch_ref, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("cin,rows_shape", [(64, (2, 5, 16, 16)), (512, (1, 4, 4, 4)), (128, (1, 3, 8, 40))])
