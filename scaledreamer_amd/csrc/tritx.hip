@@ -1058,8 +1058,9 @@ int64_t asd_tx_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
 // dw [N, K] = dy [M, N]^T . x [M, K]  (contraction over the M rows), db [N] = column sums of dy (optional)
 // x_planes / x_inv: the transposed planes of x made earlier (the text tokens serve all twelve layers); x_bound: per-column bounds of |x|
 // known without looking at x (LayerNorm outputs: sqrt(D - 1) |gamma_c| + |beta_c|; ...) — either spares the statistics pass over x
+// accumulate: dw += the product (the epilogue reads the old value as its residual: no staging buffer, no add launch), db += its column sums
 static int tx_wgrad_core(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* dw, float* db, float* ws,
-                         const h16* x_planes, const float* x_inv, const unsigned* x_bound, void* stream) {
+                         const h16* x_planes, const float* x_inv, const unsigned* x_bound, void* stream, bool accumulate = false) {
     ASD_CHECK_ARG(dy && (x || x_planes) && dw && ws && M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int Mp = tx_rp(M);
@@ -1074,7 +1075,7 @@ static int tx_wgrad_core(const float* dy, int32_t ldy, const float* x, int32_t l
     float* c32 = p;
     cmax_a = tx_zeroed(cmax_a, (size_t)(tx_al(N) + tx_al(K)), s);
     unsigned* cmax_w = cmax_a + tx_al(N);
-    if (db && !tx_pool.outputs_zeroed) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
+    if (db && !tx_pool.outputs_zeroed && !accumulate) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(N, 64), asd_div_up(M, 256)), dim3(256), 0, s, dy, M, N, ldy, 256, cmax_a, db);
     hipLaunchKernelGGL((tx_split_cols_kernel<0>), dim3(asd_div_up(N, 64), Mp / 64), dim3(256), 0, s, dy, M, N, ldy, Mp, cmax_a, pa, ia);
     if (!x_planes) {
@@ -1086,7 +1087,7 @@ static int tx_wgrad_core(const float* dy, int32_t ldy, const float* x, int32_t l
     const int rc = tx_gemm(pa, x_planes ? x_planes : pw, N, K, 3 * Mp, c32, c32 + tx_al((int64_t)N * K), &res, &nslab, s);
     if (rc != ASD_OK) return rc;
     hipLaunchKernelGGL(tx_epilogue_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, res, nslab, N, K, ia, x_planes ? x_inv : iw, (const float*)nullptr, 0,
-                       (float*)nullptr, 0, (const float*)nullptr, 0, dw, K);
+                       (float*)nullptr, 0, accumulate ? (const float*)dw : (const float*)nullptr, K, dw, K);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
 }
@@ -1497,8 +1498,7 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     h16* cond_planes = reinterpret_cast<h16*>(p); p += tx_al((int64_t)d.Dc * 3 * tx_rp(d.Tc) / 2 + 64);      // text tokens^T [Dc, 3 Tcp]: one split for all layers
     float* cond_inv = p; p += tx_al(d.Dc);
     unsigned* cond_max = reinterpret_cast<unsigned*>(p); p += tx_al(d.Dc);
-    float* stage = p;
-    float* stage_b = stage + (tx_stage_floats(d) - tx_al(tx_max64(d.F, 3 * d.D)));
+    (void)p;      // (a staging area follows in the workspace layout: unused since the weight gradients accumulate in their epilogue)
     // LayerNorm gradients accumulate over layers' rows and the batch, bias gradients are atomic column sums: zero them once — or take the
     // caller's word that it did (desc->grads_prezeroed: the Python side carves all of them out of one zeroed buffer)
     float* const* GH = grads + 17 * d.layers;       // pos_embed, norm.w, norm.b, deconv.w
@@ -1512,20 +1512,14 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     }
     struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
     unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
-    // weight gradients of batch element n > 0 are added to those of the elements before it: staged through `stage`
+    // weight gradients of batch element n > 0 are added to those of the elements before it — in the product's own epilogue (residual = dw)
     const h16* xpl = nullptr;          // precomputed transposed planes of x (+ scales) / column bounds of x for the NEXT wgrad call
     const float* xinv = nullptr;
     const unsigned* xbound = nullptr;
     auto wgrad = [&](const float* dyp, int ldy, const float* xp, int ldx, int M, int N, int K, float* dw, float* db, bool acc) -> int {
         const h16* pl = xpl; const float* pi = xinv; const unsigned* pb = xbound;
         xpl = nullptr; xinv = nullptr; xbound = nullptr;
-        if (!acc) return tx_wgrad_core(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, pl, pi, pb, stream);
-        float* tmp = stage;
-        float* tb = stage_b;
-        TXS(tx_wgrad_core(dyp, ldy, xp, ldx, M, N, K, tmp, db ? tb : nullptr, ws, pl, pi, pb, stream));
-        hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for((int64_t)N * K / 4, 256)), dim3(256), 0, s, dw, tmp, (size_t)((int64_t)N * K / 4), 1);
-        if (db) hipLaunchKernelGGL(tx_add_kernel, dim3(asd_grid_for(N / 4, 256)), dim3(256), 0, s, db, tb, (size_t)(N / 4), 1);
-        return ASD_OK;
+        return tx_wgrad_core(dyp, ldy, xp, ldx, M, N, K, dw, db, ws, pl, pi, pb, stream, acc);
     };
     for (int n = 0; n < batch; ++n) {
         const bool acc = n > 0;
