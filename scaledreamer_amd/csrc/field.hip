@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
                                 // clock and CU on gfx950, which made them, not the arithmetic, the bound of this kernel (round 5).
 #endif
 #ifndef ASD_FIELD_NAGG
-#define ASD_FIELD_NAGG 6   // levels scattered with wave-level run aggregation (asd_scatter_runs)
+#define ASD_FIELD_NAGG 5   // levels scattered with wave-level run aggregation (asd_scatter_runs): the dense ones.  Level 5 (102^3 cells in a 2^19-entry
+                           // hashed table) was the bulk of this kernel's atomic requests (runs of ~2.5 samples); it is paged with the finer ones
 #endif
 #ifndef ASD_FIELD_NPRIV
 #define ASD_FIELD_NPRIV 3   // levels whose gradient is accumulated in per-XCD copies first (asd_scatter_runs)
@@ -532,11 +533,15 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                 if (active) {
                     constexpr int NFINE = L - ASD_FIELD_NAGG;
                     const size_t rr = (size_t)pt * n + i;
-                    float4* dst = reinterpret_cast<float4*>(pg_g + rr * (2 * NFINE));
+                    float4* dst = reinterpret_cast<float4*>(pg_g + rr * (2 * ASD_PG_NF_PAD));
+                    static_assert(NFINE == ASD_PG_NF && ASD_PG_NF_PAD >= ASD_PG_NF && ASD_PG_NF_PAD % 2 == 0, "paged levels");
+                    float row[2 * ASD_PG_NF_PAD];                        // (rows of ASD_PG_NF_PAD levels: the pair behind the last level is zero)
 #pragma unroll
-                    for (int q = 0; q < NFINE / 2; ++q)
-                        dst[q] = make_float4(denc[2 * ASD_FIELD_NAGG + 4 * q], denc[2 * ASD_FIELD_NAGG + 4 * q + 1],
-                                             denc[2 * ASD_FIELD_NAGG + 4 * q + 2], denc[2 * ASD_FIELD_NAGG + 4 * q + 3]);
+                    for (int k = 0; k < 2 * ASD_PG_NF_PAD; ++k) row[k] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 2 * NFINE; ++k) row[k] = denc[2 * ASD_FIELD_NAGG + k];
+#pragma unroll
+                    for (int q = 0; q < ASD_PG_NF_PAD / 2; ++q) dst[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
                     pg_pos[3 * rr] = asd_unit(ux); pg_pos[3 * rr + 1] = asd_unit(uy); pg_pos[3 * rr + 2] = asd_unit(uz);
                 }
             } else {
@@ -941,7 +946,7 @@ int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_no
     //   + the paged scatter of the fine levels (field_paged.h): their feature gradients [rows, 20], positions [rows, 3], item lists
     *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 +
                 (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0) +
-                rows * (2 * ASD_PG_NF + 3) + asd_paged_workspace_floats(rows);
+                rows * (2 * ASD_PG_NF_PAD + 3) + asd_paged_workspace_floats(rows);
     return ASD_OK;
 }
 
@@ -983,7 +988,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     asd_paged_plan plan;
     const bool paged = paged_on && asd_paged_plan_init(meta, ASD_FIELD_NAGG, &plan);
     float* pg_g = slabs + (int64_t)chunks * 128 * 32 + 64 + (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0);
-    float* pg_pos = pg_g + rows * (2 * ASD_PG_NF);
+    float* pg_pos = pg_g + rows * (2 * ASD_PG_NF_PAD);
     float* pg_ws = pg_pos + rows * 3;
     const dim3 grid(asd_div_up(n, 256)), block(256);
     ASD_PROBE_START(s);

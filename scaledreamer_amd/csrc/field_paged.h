@@ -19,7 +19,10 @@
 #define ASD_PG_SHIFT 13                    // log2(entries per page): 8192 entries x 2 floats = 64 KB of LDS
 #define ASD_PG_ENTRIES (1 << ASD_PG_SHIFT)
 #define ASD_PG_MAX_BINS 1024               // levels x pages per level (one block scans them)
-#define ASD_PG_NF 10                       // fine levels of the 16-level grid (levels >= ASD_FIELD_NAGG = 6)
+#ifndef ASD_PG_NF
+#define ASD_PG_NF 11                       // hashed levels of the 16-level grid (levels >= ASD_FIELD_NAGG = 5: all of them have 2^19 entries)
+#endif
+#define ASD_PG_NF_PAD ((ASD_PG_NF + 1) / 2 * 2)   // levels per row of `g` (24 floats: 16-byte aligned rows; the pad pair is zero)
 #define ASD_PG_CHUNK_ROWS (2 << 20)        // rows binned per pass (item slots: 800 B per row)
 
 struct asd_paged_plan {
@@ -32,7 +35,7 @@ struct asd_paged_plan {
 int asd_paged_plan_init(const asd_grid_meta* m, int first_level, asd_paged_plan* plan);
 // floats behind the row buffers: items of one chunk + counters
 int64_t asd_paged_workspace_floats(int64_t rows);
-// upos [rows, 3] unit-cube positions, g [rows, 2 * ASD_PG_NF] gradients w.r.t. the fine levels' features; row = pt * n + i is live iff
+// upos [rows, 3] unit-cube positions, g [rows, 2 * ASD_PG_NF_PAD] gradients w.r.t. the fine levels' features; row = pt * n + i is live iff
 // i < min(*n_dev, n).  d_grid += the fine levels' scatter.  ws: asd_paged_workspace_floats(rows) floats.
 int asd_paged_scatter(const asd_grid_meta* m, const asd_paged_plan* plan, const float* upos, const float* g, int32_t n, int32_t n_pts,
                       const int32_t* n_dev, float* d_grid, float* ws, hipStream_t s);

@@ -53,15 +53,18 @@ __global__ __launch_bounds__(256) void pg_fill_kernel(const asd_grid_meta m, con
     for (int q = threadIdx.x; q < plan.bins; q += 256) hist[q] = 0u;
     __syncthreads();
     float x = 0.f, y = 0.f, z = 0.f;
-    float gv[2 * NF];
+    constexpr int NFP = (NF + 1) / 2 * 2;       // levels per row of g (= ASD_PG_NF_PAD)
+    float gv[2 * NFP];
     uint32_t rk[2 * NF];            // ranks inside the block's range of a bin: two 16-bit ranks per word (<= 1024 items per block and bin)
 #pragma unroll
-    for (int q = 0; q < 2 * NF; ++q) { gv[q] = 0.f; rk[q] = 0u; }
+    for (int q = 0; q < 2 * NFP; ++q) gv[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2 * NF; ++q) rk[q] = 0u;
     if (live) {
         x = upos[3 * rr]; y = upos[3 * rr + 1]; z = upos[3 * rr + 2];
-        const float4* src = reinterpret_cast<const float4*>(g + rr * (2 * NF));
+        const float4* src = reinterpret_cast<const float4*>(g + rr * (2 * NFP));
 #pragma unroll
-        for (int q = 0; q < NF / 2; ++q) {
+        for (int q = 0; q < NFP / 2; ++q) {
             const float4 v = src[q];
             gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
         }
