@@ -686,3 +686,30 @@ def test_trainer_keys_of_the_presets_reach_the_system():
 
     s = presets.apply_trainer(S(), {"trainer": {"accumulate_grad_batches": 4}})
     assert s.accumulate_grad_batches == 4 and presets.apply_trainer(S(), {}).accumulate_grad_batches == 1
+
+
+def test_multiprompt_perp_neg_selection_form_equals_the_branching_form():
+    """MultiPromptUtils._perp_neg_on_device (what device tensors take: no read-back of the angles) evaluated on CPU tensors against the
+    branching form of the reference (prompt_processors/base.py:470-533) — every direction class, its boundaries, the 90-degree switch"""
+    from scaledreamer_amd.multiprompt import SyntheticMultiPromptProcessor, _perp_neg_on_device
+
+    prompts = [f"p{i}" for i in range(12)]
+    pu = SyntheticMultiPromptProcessor(prompts, device="cpu")(prompts)
+    az = torch.tensor([0.0, 30.0, 45.0, -45.0, 89.99, 90.0, 120.0, 135.0, -135.0, 179.0, -100.0, 10.0])
+    el = torch.tensor([0.0, 10.0, 59.0, 60.0, 60.01, 75.0, -5.0, 20.0, 30.0, 61.0, 5.0, 89.0])
+    for gs in (-1, -3.0):
+        want, ww = pu.get_text_embeddings_perp_neg(el, az, None, True, guidance_scale_neg=None if gs == -1 else gs)
+        got, w = _perp_neg_on_device(pu, el, az, gs)
+        assert torch.equal(got, want) and torch.equal(w, ww)
+
+
+def test_fused_optimizer_table_matches_the_c_struct():
+    """the numpy record the fused optimizers fill per step is include/asd_hip.h's asd_opt_tensor field for field"""
+    import ctypes as C
+
+    from scaledreamer_amd._lib import OptTensor
+    from scaledreamer_amd.optimizers import _OPT_DTYPE
+
+    assert _OPT_DTYPE.itemsize == C.sizeof(OptTensor)
+    for name, _ in OptTensor._fields_:
+        assert _OPT_DTYPE.fields[name][1] == getattr(OptTensor, name).offset, name
