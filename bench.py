@@ -420,11 +420,11 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     bytes_per_sample = 128 * 8 + 128 + 16
     achieved = n * bytes_per_sample / (ms * 1e-3) / 1e9
     # PMC: the span is field_bwd_sample_kernel (MLP backward + the coarse levels' run-aggregated atomics) + pg_fill_kernel + pg_accum_kernel (the
-    # paged scatter of the ten hashed levels); bytes per launch from this round's per-kernel passes, where every launch of these kernels has
+    # paged scatter of the eleven hashed levels); bytes per launch from this round's per-kernel passes, where every launch of these kernels has
     # the step's sample count
     traffic = pmc_traffic_of("field_bwd_sample_kernel", "pg_fill_kernel", "pg_accum_kernel")
-    return {"kernel": "asd_field_bwd's gradient span: field_bwd_sample_kernel<16,64,3> (MLP backward, coarse levels 0-5 as run-aggregated fp32 atomics with per-XCD "
-                      "copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the ten hashed levels binned by 64 KB table page, one workgroup "
+    return {"kernel": "asd_field_bwd's gradient span: field_bwd_sample_kernel<16,64,3> (MLP backward, the dense levels 0-4 as run-aggregated fp32 atomics with per-XCD "
+                      "copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the eleven hashed levels 5-15 binned by 64 KB table page, one workgroup "
                       "per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None if traffic is None else round(traffic),
