@@ -237,7 +237,7 @@ __device__ __forceinline__ void tfm_interp(const tfm_raw& r, float (&e)[8]) {
 // through every linear step — enc_k - enc_0 here, formed in fp32 in the lane that holds both — and are made whole (z_k = z_0 + dz_k) only where
 // a ReLU needs them.  A finite difference (s_k - s_0) / eps and the backward pass's (g_k a_k (x) b_k - g_k a_0 (x) b_0) cancel 2-3 digits; on
 // whole values the 22-bit split products would leave that cancellation 4x the noise of fp32 arithmetic, on differences they leave none.
-template <bool FD, typename F, typename Z>
+template <bool FD, bool DEEP = true, typename F, typename Z>
 __device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __restrict__ planes, const float (&N)[4][3], int lg, float sE, F&& consume, Z&& zero) {
     // one scheduling region per unit: the matrix products of unit u next to the interpolation / split of unit u + 1 (loads issued one unit ago) and
     // the tap setup + loads of unit u + 2 — three independent strands for the scheduler to interleave.
@@ -254,6 +254,38 @@ __device__ __forceinline__ void tfm_layer1(const tf_geom& g, const float* __rest
         dead[3] = all_same(3, 0, 1);                // plane 0 = (x, y), probe + z
         dead[6] = all_same(2, 0, 2);                // plane 1 = (x, z), probe + y
         dead[9] = all_same(1, 2, 1);                // plane 2 = (z, y), probe + x
+    }
+    if constexpr (!DEEP) {
+        // one unit ahead only (the weight-gradient kernel: 176 accumulator registers leave no room for two units of taps in flight)
+        tfm_raw r1;
+        half8 bh1, bl1;
+        float e0[8];
+        tfm_issue(g, planes, 0, N[0], 8 * lg, sE, r1);
+        tfm_interp(r1, e0);
+        tfm_split8(e0, bh1, bl1);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const bool nxt = u + 1 < 12 && !dead[u + 1 < 12 ? u + 1 : 0];
+            if (nxt) tfm_issue(g, planes, (u + 1) / 4, N[(u + 1) % 4], 8 * lg, sE, r1);
+            if (dead[u]) zero(u / 4, u % 4);
+            else consume(u / 4, u % 4, bh1, bl1);
+            if (nxt) {
+                float e[8];
+                tfm_interp(r1, e);
+                if (FD) {
+                    if ((u + 1) % 4 == 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) e0[k] = e[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) e[k] -= e0[k];
+                    }
+                }
+                tfm_split8(e, bh1, bl1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
     }
     tfm_raw r[2];
     half8 bh[2], bl[2];
@@ -716,6 +748,9 @@ __global__ __launch_bounds__(256, 2) void tfm_bwd_data_kernel(const tfm_bwd_args
 // numbers).  The rows' G spans many orders of magnitude across a chunk: a wave keeps a RUNNING power-of-two scale S >= every |G| it has seen
 // (operands carry G / S, the accumulators are rescaled when S grows — exact), so the fp16 operands stay in range without a pass over the
 // gradients.  One wave per SIMD (176 accumulator registers + the chain); per-wave LDS: the lookup fragments of the tile (24 KB), the rows' G.
+#ifndef TFM_W_DEEP
+#define TFM_W_DEEP false    // lookup pipeline of this kernel one unit deep (two in the forward / data kernels): same-box A/B of C5 at the 256 x 256 render
+#endif                      // 267.7 vs 271.6 ms per step (tools/r5_tfm_ab.sh)
 template <int O, bool FD>
 __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_args a) {
     constexpr int head = O == 3;
@@ -782,7 +817,7 @@ __global__ __launch_bounds__(256, 1) void tfm_bwd_weights_kernel(const tfm_bwd_a
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) zt[mb][nb] = floatx4{0.f, 0.f, 0.f, 0.f};
-            tfm_layer1<FD>(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
+            tfm_layer1<FD, TFM_W_DEEP>(a.g, a.planes, N, lg, sE, [&](int plane, int nb, const half8& bh, const half8& bl) __attribute__((always_inline)) {
                 encbuf[((plane * 4 + nb) * 2 + 0) * 64 + lane] = bh;
                 encbuf[((plane * 4 + nb) * 2 + 1) * 64 + lane] = bl;
 #pragma unroll
