@@ -44,12 +44,13 @@ class MultiPromptUtils:
     use_local_text_embeddings: bool = False
 
     def direction_idx(self, elevation, azimuth, camera_distances):
-        idx = torch.zeros_like(elevation, dtype=torch.long)
+        """side 0 / front 1 / back 2 / overhead 3, later rules overriding earlier ones (prompt_processors/base.py:262-294) — as selections, so
+        that device tensors are never read back (same values as the reference's masked assignments)"""
         azi = shift_azimuth_deg(azimuth)
-        idx[(azi > -self.front_threshold) & (azi < self.front_threshold)] = 1
-        idx[(azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold)] = 2
-        idx[elevation > self.overhead_threshold] = 3
-        return idx
+        one, two, three = (torch.full_like(elevation, k, dtype=torch.long) for k in (1, 2, 3))
+        idx = torch.where((azi > -self.front_threshold) & (azi < self.front_threshold), one, torch.zeros_like(one))
+        idx = torch.where((azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold), two, idx)
+        return torch.where(elevation > self.overhead_threshold, three, idx)
 
     def get_global_text_embeddings(self) -> torch.Tensor:
         return torch.stack(self.local_text_embeddings if self.use_local_text_embeddings else self.global_text_embeddings, dim=0)
@@ -58,7 +59,8 @@ class MultiPromptUtils:
         B = len(self.global_text_embeddings)
         if view_dependent_prompting:
             idx = self.direction_idx(elevation, azimuth, camera_distances)
-            text = torch.stack([self.text_embeddings_vd[i][idx[i]] for i in range(B)], dim=0)
+            # (one gather with tensor indices: `self.text_embeddings_vd[i][idx[i]]` reads every idx[i] back to the host on a device tensor)
+            text = torch.stack(list(self.text_embeddings_vd), dim=0)[torch.arange(B, device=idx.device), idx]
             uncond = self.uncond_text_embeddings_vd[idx]
         else:
             text = torch.stack(list(self.local_text_embeddings), dim=0)
@@ -106,11 +108,7 @@ def _perp_neg_on_device(self, elevation, azimuth, gs):
     side, front, back, overhead = vd[:, 0], vd[:, 1], vd[:, 2], vd[:, 3]
     azi = shift_azimuth_deg(azimuth)
     a = torch.abs(azi)
-    # direction_idx's masked assignments in their order of precedence (overhead over back over front over side) as selections
-    one, two, three = (torch.full_like(elevation, k, dtype=torch.long) for k in (1, 2, 3))
-    idx = torch.where((azi > -self.front_threshold) & (azi < self.front_threshold), one, torch.zeros_like(one))
-    idx = torch.where((azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold), two, idx)
-    idx = torch.where(elevation > self.overhead_threshold, three, idx)
+    idx = self.direction_idx(elevation, azimuth, None)
     unc = self.uncond_text_embeddings_vd[idx]                                   # [B, 77, D]
     is_over = (idx == 3)
     near = a < 90
