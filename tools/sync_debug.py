@@ -1,25 +1,37 @@
-"""Which Python lines synchronise the host with the GPU inside a training step: torch.cuda.set_sync_debug_mode("warn") over two steps."""
-import sys, warnings, traceback
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+"""every host<->device synchronisation inside the steady-state steps of a workload (torch.cuda.set_sync_debug_mode('warn')):
+    python tools/sync_debug.py [workload]"""
+import os, sys, warnings, collections, traceback
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-cfg, system, data = bench.build_system("hip", seed=10)
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "asd_sd_3dconv_net"
+torch.cuda.set_device(0)
+torch.set_num_threads(1)
+cfg, system, data = bench.build_system("hip", seed=10, workload=wl)
 dev = torch.device("cuda", 0)
-for _ in range(18):
-    system.train_one_step(bench.to_device(data.collate(), dev))
+to_device = bench.to_device
+batch = to_device(data.collate(), dev)
+for _ in range(6):
+    system.train_one_step(batch)
+    batch = to_device(data.collate(), dev)
 torch.cuda.synchronize()
-seen = {}
-def show(message, category, filename, lineno, file=None, line=None):
-    st = [f for f in traceback.extract_stack() if "/root/repo" in f.filename or "scaledreamer_amd" in f.filename]
-    if not st:                                  # no frame of this repository on the stack: show where it comes from anyway
-        st = traceback.extract_stack()[:-1]
-    key = tuple((f.filename.split("/")[-1], f.lineno) for f in st[-5:])
-    seen[key] = seen.get(key, 0) + 1
-warnings.showwarning = show
+seen = collections.Counter()
+def hook(message, category, filename, lineno, file=None, line=None):
+    if "synchroniz" in str(message):
+        st = [f for f in traceback.extract_stack() if "/repo/" in f.filename and "sync_debug" not in f.filename]
+        where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-3:])
+        seen[where] += 1
+warnings.showwarning = hook
 warnings.simplefilter("always")
 torch.cuda.set_sync_debug_mode("warn")
-for _ in range(2):
-    system.train_one_step(bench.to_device(data.collate(), dev))
+for _ in range(4):
+    system.train_one_step(batch)
+    batch = to_device(data.collate(), dev)
 torch.cuda.set_sync_debug_mode("default")
-for k, v in sorted(seen.items(), key=lambda kv: -kv[1]):
-    print(v, "x", " <- ".join(f"{a}:{b}" for a, b in reversed(k)))
+torch.cuda.synchronize()
+print(f"{wl}: synchronising calls over 4 steps")
+for k, v in seen.most_common():
+    print(f"  {v:3d} x  {k}")
+if not seen:
+    print("  none")
