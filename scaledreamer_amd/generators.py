@@ -585,6 +585,7 @@ class TriplaneTransformer(nn.Module):
 
     def _tritx_state(self, params):
         """(descriptor, pointer table, packed operand planes); the planes are rebuilt when a weight has changed (optimizer step, checkpoint load)"""
+        # the fused optimizers write parameters through raw pointers and bump `_version` themselves (optimizers._Table.launch)
         key = (self._cond_tokens,) + tuple((p.data_ptr(), p._version) for p in params)
         st = getattr(self, "_tritx_cache", None)
         if st is not None and st[0] == key:

@@ -351,7 +351,7 @@ def free_workspaces() -> None:
     """release the grow-only convolution workspaces (e.g. before evaluation or torch.cuda.empty_cache()): the 128^3 weight-gradient planes and
     slabs otherwise stay resident for the life of the process"""
     for key, buf in list(_conv3d_ws.items()):
-        buf.record_stream(torch.cuda.current_stream(key[0]))
+        buf.record_stream(torch.cuda.ExternalStream(key[1], device=key[0]))     # the stream the workspace was keyed by, not the current one
     _conv3d_ws.clear()
 
 

@@ -56,6 +56,9 @@ class _Table:
         """the table still describes these parameters and these state tensors (identity, not value)"""
         if len(params) != len(self.params) or any(a is not b for a, b in zip(params, self.params)):
             return False
+        # a Parameter whose storage was replaced (`p.data = ...`, `module.to()`, `set_`) keeps its identity: compare the addresses too
+        if any(p.data_ptr() != int(q) or p.numel() != int(n) for p, q, n in zip(params, self.arr["p"], self.arr["n"])):
+            return False
         return all(len(c) == len(k) and all(a is b for a, b in zip(c, k)) for c, k in zip(state_cols, self.keep))
 
     def launch(self, grads, lr, wd, bc1, bc2, bc2s, *scalars) -> None:
@@ -68,6 +71,9 @@ class _Table:
         a["g"] = [g.data_ptr() for g in grads]
         a["lr"], a["weight_decay"], a["bias_correction1"], a["bias_correction2"], a["bias_correction2_sqrt"] = lr, wd, bc1, bc2, bc2s
         check(getattr(lib(), self.fn_name)(C.c_void_p(a.ctypes.data), C.c_int32(len(a)), *scalars, stream()))
+        # the kernel wrote the parameters through raw pointers: tell autograd (saved-tensor checks) and every cache keyed on
+        # `p._version` (the tri-plane transformer's packed operand planes, generators.TriplaneTransformer._tritx_state)
+        torch.autograd.graph.increment_version(self.params)
 
 
 class AdamW(Optimizer):

@@ -115,6 +115,14 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
         out.update(normal=normal, shading_normal=normal, sdf_grad=sdf_grad)
         return out
 
+    @staticmethod
+    def _gate(space_cache, cache_cl, b):
+        """(cache as the fused field node reads it, entry, gradient slot) — see _GradSlot"""
+        if not cache_cl.requires_grad:
+            return cache_cl, b, None
+        gated, slot = _gate_of(space_cache, cache_cl)
+        return gated, b, slot
+
     def forward_sdf(self, points: torch.Tensor, space_cache: Any) -> torch.Tensor:
         batch_size = points.shape[0]
         pts = contract_to_unisphere_custom(points, self.bbox, self.unbounded)
@@ -146,39 +154,58 @@ class _SampledSdfGeometry(BaseImplicitGeometry):
 
 
 class _GradSlot:
-    """ONE gradient buffer per feature volume (batch entry) and backward pass.  The VolSDF renderer evaluates the field chunk by chunk and
-    pass by pass (proposal sdf, main samples): every evaluation is its own autograd node, and a node that returned a fresh
-    zeros_like(volume) — 268 MB at 128^3 x 32 — had autograd memset, fill and sum one volume per chunk.  The scatter kernels accumulate, so the
-    first node of a backward pass allocates the buffer and hands it to autograd, the later ones add into it in place and return None.
-    That is sound because (a) the buffer is the gradient of the WHOLE channel-last cache, which reaches the cache's producer only through
-    view nodes (permute) or through the one shared relayout node — no node in between copies it early (a per-entry `cache[b]` select would:
-    its backward copies as soon as its own consumer has run, which is why the field functions take the whole cache and an index), (b) the
-    producer cannot run before every node that reads the cache has run (autograd's dependency count), and (c) the buffer of a pass is
-    never reused by another one (keyed by the engine's graph-task id)."""
+    """ONE gradient buffer per feature volume and backward pass.  The VolSDF renderer evaluates the field chunk by chunk and pass by pass
+    (proposal sdf, main samples): every evaluation is its own autograd node, and a node that returned a fresh zeros_like(volume) — 268 MB at
+    128^3 x 32 — had autograd memset, fill and sum one volume per chunk.  The scatter kernels accumulate, so the first node of a backward
+    pass allocates the buffer and hands it to autograd, the later ones add into it in place and return None.
 
-    __slots__ = ("task", "buf")
+    The invariant that makes this sound is structural since round 6 (`_CacheGate` below): the field nodes never see the cache itself but the
+    output of ONE identity node per cache whose only consumers they are.  The gate's gradient edge therefore receives exactly one defined
+    gradient — the buffer — and the gate runs after every field node has run (autograd's dependency count), checks that what arrives IS the
+    buffer, hands it on and drops the slot's reference.  Other consumers of the cache (a regulariser on the planes, a second relayout) meet the
+    gate's result at the cache's own edge, after the last scatter, through autograd's normal accumulation."""
+
+    __slots__ = ("buf",)
 
     def __init__(self):
-        self.task, self.buf = None, None
+        self.buf = None
 
     def acquire(self, like: torch.Tensor):
         """(buffer, first): `first` tells the caller to return the buffer as its gradient"""
-        task = torch._C._current_graph_task_id()
-        if task < 0 or task != self.task or self.buf is None or self.buf.shape != like.shape:
-            self.task, self.buf = task, torch.zeros_like(like)
+        if self.buf is None or self.buf.shape != like.shape:
+            self.buf = torch.zeros_like(like)
             return self.buf, True
-        return self.buf, task < 0
+        return self.buf, False
 
     def release(self):
         self.buf = None
 
 
-def _grad_slot(owner: torch.Tensor) -> _GradSlot:
-    """the slot of a space cache: lives on the cache tensor itself (one Python object per step)"""
-    slot = owner.__dict__.get("_asd_grad_slot")
-    if slot is None:
-        slot = owner.__dict__["_asd_grad_slot"] = _GradSlot()
-    return slot
+class _CacheGate(torch.autograd.Function):
+    """identity on the channel-last cache; its output is private to the fused field nodes of this cache (see _GradSlot)"""
+
+    @staticmethod
+    def forward(ctx, cache_cl, slot):
+        ctx.slot = slot
+        return cache_cl.view_as(cache_cl)
+
+    @staticmethod
+    def backward(ctx, grad):
+        buf = ctx.slot.buf
+        ctx.slot.release()                               # the next backward pass over this graph (retain_graph) starts from a fresh buffer
+        if grad is not None and buf is not None and grad.data_ptr() != buf.data_ptr():
+            raise RuntimeError("fused field: the gated cache alias received a gradient that is not the shared buffer — the alias is private "
+                               "to the field nodes, read the cache itself instead")
+        return grad, None
+
+
+def _gate_of(owner: torch.Tensor, cache_cl: torch.Tensor):
+    """(gated alias of the channel-last cache, its slot): one gate per cache tensor and autograd graph, kept on the cache object itself"""
+    st = owner.__dict__.get("_asd_gate")
+    if st is None or st[2] != owner._version or st[0].shape != cache_cl.shape:
+        slot = _GradSlot()
+        st = owner.__dict__["_asd_gate"] = (_CacheGate.apply(cache_cl, slot), slot, owner._version)
+    return st[0], st[1]
 
 
 class _VoxFieldFn(torch.autograd.Function):
@@ -186,7 +213,7 @@ class _VoxFieldFn(torch.autograd.Function):
     lookup, heads, bias and finite differences in one kernel each way (include/asd_hip.h: asd_voxfield_fwd / _bwd)"""
 
     @staticmethod
-    def forward(ctx, points, vol_cl, b, w1s, w2s, w1f, w2f, fcfg, want_normal, slot=None):
+    def forward(ctx, points, vol_cl, b, slot, w1s, w2s, w1f, w2f, fcfg, want_normal):
         """vol_cl: the WHOLE channel-last cache [B, D, H, W, C] (contiguous), b: the entry these points sample"""
         sdf, feats, normal, fdg, enc = ops.voxfield_fwd(vol_cl[b], fcfg, w1s, w2s, w1f, w2f, points, want_normal)
         if not want_normal:
@@ -206,7 +233,7 @@ class _VoxFieldFn(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()
         dw = ops.voxfield_bwd(vol_cl[ctx.b], ctx.fcfg, w1s, w2s, w1f, w2f, points, enc, sdf, c(d_sdf), c(d_feats),
                               c(d_normal) if ctx.want_normal else None, c(d_fdg) if ctx.want_normal else None, d_vol[ctx.b])
-        return None, (d_vol if first else None), None, dw[0], dw[1], dw[2], dw[3], None, None, None
+        return None, (d_vol if first else None), None, None, dw[0], dw[1], dw[2], dw[3], None, None
 
 
 @register("3DConv-net")
@@ -306,7 +333,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_VoxFieldFn.apply(pts, vol, b, *w, self._fcfg, bool(output_normal), _grad_slot(space_cache)))
+                outs.append(_VoxFieldFn.apply(pts, *self._gate(space_cache, vol, b), *w, self._fcfg, bool(output_normal)))
             else:
                 with torch.no_grad():
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, pts, bool(output_normal), save_enc=False)[:4])
@@ -329,7 +356,7 @@ class Voxel_3d_Sdf(_SampledSdfGeometry):
             for b in range(B):
                 p = pts[b].contiguous().float()
                 if need_grad:
-                    outs.append(_VoxFieldFn.apply(p, vol, b, *w, self._fcfg, False, _grad_slot(space_cache))[0])
+                    outs.append(_VoxFieldFn.apply(p, *self._gate(space_cache, vol, b), *w, self._fcfg, False)[0])
                 else:
                     outs.append(ops.voxfield_fwd(vol[b], self._fcfg, *w, p, False, want_features=False, save_enc=False)[0])
         return torch.stack(outs, 0).reshape(*points.shape[:-1], 1)
@@ -340,7 +367,7 @@ class _TriFieldFn(torch.autograd.Function):
     heads (include/asd_hip.h: asd_trifield_fwd / _bwd); nothing but the points and the sdf is kept for the backward pass"""
 
     @staticmethod
-    def forward(ctx, points, planes_cl, b, s1, s2, s3, f1, f2, f3, fcfg, want_normal, slot=None):
+    def forward(ctx, points, planes_cl, b, slot, s1, s2, s3, f1, f2, f3, fcfg, want_normal):
         """planes_cl: the WHOLE channel-last cache [B, 3, H, W, 32] (contiguous), b: the entry these points sample"""
         w6 = (s1.t().contiguous(), s2.contiguous(), s3.contiguous(), f1.t().contiguous(), f2.contiguous(), f3.contiguous())
         sdf, feats, normal, fdg = ops.trifield_fwd(planes_cl[b], fcfg, w6, points, want_normal)
@@ -361,7 +388,7 @@ class _TriFieldFn(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()
         dws = ops.trifield_bwd(planes_cl[ctx.b], ctx.fcfg, w6, points, sdf, c(d_sdf), c(d_feats), c(d_normal) if ctx.want_normal else None,
                                c(d_fdg) if ctx.want_normal else None, d_pl[ctx.b])
-        return (None, (d_pl if first else None), None, *dws, None, None, None)
+        return (None, (d_pl if first else None), None, None, *dws, None, None)
 
 
 @register("Triplane-transformer-sdf")
@@ -444,7 +471,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(points.shape[0]):
             pts = points[b].reshape(-1, 3).contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(pts, planes, b, *w, self._fcfg, bool(output_normal), _grad_slot(space_cache)))
+                outs.append(_TriFieldFn.apply(pts, *self._gate(space_cache, planes, b), *w, self._fcfg, bool(output_normal)))
             else:
                 with torch.no_grad():
                     w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
@@ -467,7 +494,7 @@ class TriplaneTransformerSDF(_SampledSdfGeometry):
         for b in range(B):
             p = pts[b].contiguous().float()
             if need_grad:
-                outs.append(_TriFieldFn.apply(p, planes, b, *w, self._fcfg, False, _grad_slot(space_cache))[0])
+                outs.append(_TriFieldFn.apply(p, *self._gate(space_cache, planes, b), *w, self._fcfg, False)[0])
             else:
                 w6 = (w[0].t().contiguous(), w[1], w[2], w[3].t().contiguous(), w[4], w[5])
                 outs.append(ops.trifield_fwd(planes[b], self._fcfg, w6, p, False, want_features=False)[0])

@@ -238,15 +238,23 @@ class StableDreamer(nn.Module, Updateable):
                 self.log("train/inv_std", out["inv_std"])
         return terms, lams
 
-    def _assemble_loss(self, terms, out, lams):
-        """sum of weight * value over `terms` plus the fused per-ray regularisers `lams`; in the reference's order of additions when
-        nothing is fused (CPU tensors: the host-logic tests)"""
-        if not lams and not (terms and terms[0][0].is_cuda):
+    def _assemble_loss(self, terms, out, lams, fused: bool):
+        """sum of weight * value over `terms` plus the fused per-ray regularisers `lams`; in the reference's order of additions (tensor
+        ops) when `fused` is off — CPU tensors, ASD_LOSS_TAIL=0, no fp32 device opacity, more terms than one launch takes"""
+        ASD_LOSS_MAX_TERMS = 8                     # csrc/asd_glue.hip: the term table of one asd_loss_tail launch
+
+        opacity = out.get("opacity") if fused else None
+        if (not fused or not torch.is_tensor(opacity) or not opacity.is_cuda or opacity.dtype != torch.float32 or len(terms) > ASD_LOSS_MAX_TERMS
+                or not all(torch.is_tensor(v) and v.is_cuda for v, _ in terms)):
+            terms = list(terms)
+            for name, lam in lams.items():          # regularisers that were left to the fused tail: as tensor ops after all
+                value = self.REGULARISERS[name][2](out)
+                self.log(f"train/loss_{name}", value)
+                terms.append((value, lam))
             total = 0.0
             for value, w in terms:
                 total = total + value * w
             return total
-        opacity = out["opacity"]
         z_var = out["z_variance"] if "z_variance" in lams else None
         lam3 = tuple(float(lams.get(k, 0.0)) for k in self.FUSED_REGULARISERS)
         total, values = _LossTailFn.apply(opacity, z_var, lam3, tuple(float(w) for _, w in terms), *[v for v, _ in terms])
@@ -272,7 +280,7 @@ class StableDreamer(nn.Module, Updateable):
         if stage == "coarse+geometry":   # second guidance pass on the normal image
             normal_img = torch.nan_to_num(out["comp_normal"], nan=0.0, posinf=0.0, neginf=0.0)
             terms = terms + self._guidance_terms(normal_img, batch, "shape_", self.GEOMETRY_PASS_WEIGHT)
-        return {"loss": self._assemble_loss(terms, out, lams)}
+        return {"loss": self._assemble_loss(terms, out, lams, fused)}
 
     def gradient_exchange(self):
         """the DP exchange object of this system (None on a single process): created on first use, after the process group."""

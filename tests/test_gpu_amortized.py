@@ -274,7 +274,8 @@ def test_generator_backed_amortized_step_runs(kind):
         local = False
     else:
         cfg = presets.asd_mv_triplane_transformer()
-        cfg["system"]["geometry"]["space_generator_config"].update(num_layers=2, inner_dim=256, num_heads=4, condition_dim=128)
+        # head dimension 48 (192 / 4) as in the shipped YAML: the generator must run on csrc/tritx.hip, not on the library restatement
+        cfg["system"]["geometry"]["space_generator_config"].update(num_layers=2, inner_dim=192, num_heads=4, condition_dim=128)
         backend = HipBackend(dev, unet_cfg=W.UNetConfig(model_channels=128, context_dim=128, camera_dim=16), vae_cfg=W.VAEConfig(), seed=3)
         local = True
     proc = SyntheticMultiPromptProcessor(cfg["data"]["prompt_library"]["train"], seed=2, device=dev, ctx_dim=128, global_dim=1024,
@@ -285,9 +286,13 @@ def test_generator_backed_amortized_step_runs(kind):
     data = find(cfg["data_type"])(cfg["data"], rank=0, n_ranks=1)
     gen_w = next(p for n, p in system.geometry.space_generator.named_parameters() if p.ndim >= 2)
     before = gen_w.detach().clone()
-    for _ in range(2):
-        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
-        loss = system.train_one_step(batch)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message=".*library-op restatement.*")      # a silent drop to library ops fails this test
+        for _ in range(2):
+            batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+            loss = system.train_one_step(batch)
     assert torch.isfinite(loss).item()
     assert (gen_w.detach() != before).any().item(), "no gradient reached the generator"
 
@@ -449,7 +454,9 @@ def test_fused_field_several_evaluations_of_one_cache_share_one_gradient_buffer(
             for k in gs:
                 gk = gs[k].view(2, n, -1)[:, a:b].reshape(2 * (b - a), -1)
                 total = total + (out[k] * gk).sum()
-        return total + (geo.forward_sdf(pts_sdf, c) * g_sdf).sum()
+        # two consumers of another kind on the same cache — one created before the field nodes (runs last in the backward pass), one after
+        # (runs first): their gradients must meet the shared buffer at the cache's own edge, after the last scatter (round-5 advisor finding)
+        return (c * c).sum() * 0.05 + total + (geo.forward_sdf(pts_sdf, c) * g_sdf).sum() + (c.roll(1, -1) - c).abs().sum() * 0.02
 
     def grads(chunks):
         for p in geo.parameters():

@@ -243,3 +243,80 @@ def test_whole_generator_matches_the_reference_module():
     print("planes: hip", e_hip, "library fp32", e_lib, "| worst parameter gradient: hip", worst, "library fp32", worst_lib)
     assert e_hip < max(2e-5, 3 * e_lib), (e_hip, e_lib)
     assert worst[1] < max(5e-5, 3 * worst_lib[1]), (worst, worst_lib)
+
+
+def test_packed_planes_follow_a_fused_optimizer_step():
+    """The operand planes of the Linear / deconvolution weights are cached across steps (`_tritx_state`); the fused Adan / AdamW kernels write the
+    parameters through raw pointers.  forward -> backward -> fused Adan.step() -> forward must equal the library module loaded from the UPDATED
+    state dict (round-5 advisor finding: the cache key did not see the update, the generator trained against its step-0 weights)."""
+    from scaledreamer_amd.generators import TriplaneTransformer
+    from scaledreamer_amd.optimizers import Adan
+
+    tt = TriplaneTransformer(**TRI_HD48)
+    with torch.no_grad():
+        for k, p in tt.named_parameters():
+            scale = 1.0 if "norm" in k and k.endswith("weight") else 0.2
+            p.copy_(_seeded(f"opt.{k}", tuple(p.shape), 5, scale))
+    tt = tt.cuda()
+    te = _seeded("opt.text", (2, 77, 128), 5).cuda()
+    opt = Adan(tt.parameters(), lr=2e-2, betas=(0.98, 0.92, 0.99), eps=1e-15)
+    p0 = tt(te)
+    gp = _seeded("opt.g", tuple(p0.shape), 5).cuda()
+    (p0 * gp).sum().backward()
+    w_before = tt.layers[0].mlp[0].weight.detach().clone()
+    v_before = tt.layers[0].mlp[0].weight._version
+    opt.step()
+    assert tt.layers[0].mlp[0].weight._version > v_before, "the fused optimizer must bump parameter versions"
+    assert (tt.layers[0].mlp[0].weight.detach() != w_before).any().item()
+    opt.zero_grad(set_to_none=True)
+    p1 = tt(te)
+    tl = TriplaneTransformer(**TRI_HD48, backend="library").cuda().double()
+    tl.load_state_dict(tt.state_dict())
+    want1 = tl(te.double())
+    assert rel(p1.detach(), want1.detach()) < 5e-5, rel(p1.detach(), want1.detach())
+    assert rel(p0.detach(), want1.detach()) > 1e-3, "the step did not change the planes: the test proves nothing"
+    # and the second backward pass runs on the updated planes too (input gradient products use the packed W^T)
+    (p1 * gp).sum().backward()
+    (want1 * gp.double()).sum().backward()
+    lib_grads = dict(tl.named_parameters())
+    for k, p in tt.named_parameters():
+        assert rel(p.grad, lib_grads[k].grad) < 3e-4, (k, rel(p.grad, lib_grads[k].grad))
+
+
+TRI_FULL = dict(inner_dim=768, condition_dim=1024, triplane_low_res=32, triplane_high_res=64, triplane_dim=32, num_layers=12, num_heads=16, local_text=True,
+                mlp_ratio=4)
+
+
+def test_shipped_size_generator_against_float64():
+    """The generator at the size the shipped YAML trains (asd_mv_triplane_transformer_10k.yaml: 12 layers x 768 wide, 16 heads x 48, 3 x 32^2 = 3072
+    tokens, 77 text tokens x 1024) through `_TritxFn`, against the SAME module on backend="library" evaluated in float64 on the device: planes and
+    every one of the 244 parameter gradients, with ABSOLUTE bounds (relative to each tensor's own range) — error growth through twelve split-fp16
+    layers at full width, which the 2-layer / 192-wide golden cannot show."""
+    from scaledreamer_amd.generators import TriplaneTransformer
+
+    tt = TriplaneTransformer(**TRI_FULL)
+    with torch.no_grad():
+        for k, p in tt.named_parameters():
+            if "norm" in k and k.endswith("weight"):
+                p.copy_(1.0 + 0.1 * _seeded(f"full.{k}", tuple(p.shape), 11))
+            elif p.ndim >= 2 and k != "pos_embed":
+                p.copy_(_seeded(f"full.{k}", tuple(p.shape), 11, 1.0 / p.shape[1] ** 0.5))      # the layers keep the activations O(1)
+            elif k != "pos_embed":
+                p.copy_(_seeded(f"full.{k}", tuple(p.shape), 11, 0.1))
+    tt = tt.cuda()
+    te = _seeded("full.text", (1, 77, 1024), 11).cuda()
+    planes = tt(te)
+    assert planes.shape == (1, 3, 32, 64, 64)
+    gp = _seeded("full.g", tuple(planes.shape), 11).cuda()
+    (planes * gp).sum().backward()
+    tl = TriplaneTransformer(**TRI_FULL, backend="library").cuda().double()
+    tl.load_state_dict(tt.state_dict())
+    want = tl(te.double())
+    (want * gp.double()).sum().backward()
+    e_planes = rel(planes.detach(), want.detach())
+    lib_grads = dict(tl.named_parameters())
+    errs = sorted(((rel(p.grad, lib_grads[k].grad), k) for k, p in tt.named_parameters()), reverse=True)
+    print("shipped-size tri-plane transformer vs float64: planes", e_planes, "| worst parameter gradients", errs[:4], "| median", errs[len(errs) // 2])
+    assert len(errs) == 12 * 20 + 4
+    assert e_planes < 2e-5, e_planes
+    assert errs[0][0] < 2e-4, errs[:4]

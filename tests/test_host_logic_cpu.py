@@ -632,13 +632,16 @@ def test_presets_do_not_allow_a_random_prior_unless_asked():
 
 
 def test_grad_slot_shares_one_buffer_per_backward_pass_cpu():
-    """sampled_geometry._GradSlot on CPU tensors with a stand-in for the fused field nodes: several autograd nodes read one cache through
-    their own view of it and ACCUMULATE into one gradient buffer (first node of a backward pass hands it to autograd, the others add in place
-    and return None).  The cache gradient must equal the plain sum, for two backward passes in a row, and a consumer of another kind on the
-    same cache (its gradient arrives through the normal accumulation) must still be added."""
+    """sampled_geometry._GradSlot / _CacheGate on CPU tensors with a stand-in for the fused field nodes: several autograd nodes read one cache
+    through ONE gated alias and ACCUMULATE into one gradient buffer (first node of a backward pass hands it to autograd, the others add in place
+    and return None; the gate runs after all of them).  The cache gradient must equal the plain sum, for two backward passes over the SAME
+    graph and over fresh graphs, with consumers of another kind on the cache created before AND after the field nodes (the engine runs the
+    later-created one first: its gradient must not make autograd sum the buffer away before the last scatter), and a foreign consumer of the
+    gated alias itself must raise instead of losing gradient silently."""
+    import pytest
     import torch
 
-    from scaledreamer_amd.sampled_geometry import _GradSlot
+    from scaledreamer_amd.sampled_geometry import _gate_of
 
     class Node(torch.autograd.Function):
         @staticmethod
@@ -657,19 +660,34 @@ def test_grad_slot_shares_one_buffer_per_backward_pass_cpu():
     torch.manual_seed(0)
     base = torch.randn(2, 3, 4, 5)
     ws = [torch.randn(4, 5) for _ in range(5)]
-    for _ in range(2):                                   # second round: a new graph task must not see the first one's buffer
-        cache = base.clone().requires_grad_(True)
-        slot = _GradSlot()
-        total = (cache * 0.5).sum()                      # another consumer of the cache
-        for i, w in enumerate(ws):
-            total = total + Node.apply(cache.permute(0, 2, 3, 1), i % 2, w.unsqueeze(-1).expand(4, 5, 3), slot).sum()
-        total.backward()
+
+    def reference():
         ref = base.clone().requires_grad_(True)
         t2 = (ref * 0.5).sum()
         for i, w in enumerate(ws):
             t2 = t2 + (ref.permute(0, 2, 3, 1)[i % 2] * w.unsqueeze(-1)).sum()
-        t2.backward()
-        torch.testing.assert_close(cache.grad, ref.grad)
+        (t2 + (ref * ref).sum() * 0.25).backward()
+        return ref.grad
+
+    for _ in range(2):                                   # second round: a new graph must not see the first one's buffer
+        cache = base.clone().requires_grad_(True)
+        total = (cache * 0.5).sum()                      # a consumer created before the field nodes
+        for i, w in enumerate(ws):
+            gated, slot = _gate_of(cache, cache.permute(0, 2, 3, 1))
+            total = total + Node.apply(gated, i % 2, w.unsqueeze(-1).expand(4, 5, 3), slot).sum()
+        total = total + (cache * cache).sum() * 0.25     # and one created after them: the engine runs it first
+        total.backward(retain_graph=True)
+        torch.testing.assert_close(cache.grad, reference())
+        assert slot.buf is None                           # released by the gate
+        cache.grad = None
+        total.backward()                                 # the same graph once more: a fresh buffer, the same gradient
+        torch.testing.assert_close(cache.grad, reference())
+
+    cache = base.clone().requires_grad_(True)
+    gated, slot = _gate_of(cache, cache.permute(0, 2, 3, 1))
+    out = Node.apply(gated, 0, ws[0].unsqueeze(-1).expand(4, 5, 3), slot).sum() + Node.apply(gated, 1, ws[1].unsqueeze(-1).expand(4, 5, 3), slot).sum()
+    with pytest.raises(RuntimeError, match="private"):
+        (out + (gated * 2.0).sum()).backward()
 
 
 def test_trainer_keys_of_the_presets_reach_the_system():
