@@ -507,15 +507,42 @@ def cpu_baseline(system, batch, seed: int):
             "step_seconds": round(total, 2), "step_seconds_all": [round(t, 2) for t in totals], "cpu_model": cpu_model, "host_threads_available": os.cpu_count(), "phases_s": {k: round(v, 3) for k, v in tm.items()}}
 
 
+def dist_evidence(world, rank, local_rank, dev, ex):
+    """What a multi-GPU line must carry so that it proves itself: the world size as an all-reduce of ones sees it (RCCL, not the
+    environment), every rank's device, the bytes one gradient exchange moves per rank and how the exchange is cut (launch.py:233-240:
+    the reference's DDP all-reduce of the field parameters).  On one GPU: the same keys with the trivial values."""
+    import socket
+
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": int(torch.cuda.current_device()) if dev.type == "cuda" else -1,
+            "device": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu", "host": socket.gethostname(),
+            "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None) if dev.type == "cuda" else None}
+    out = {"rccl_ranks": 1, "ranks": [mine], "allreduce_bytes": None, "allreduce_units": None, "collective_backend": None}
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        every = [None] * world
+        torch.distributed.all_gather_object(every, mine)
+        out.update(rccl_ranks=int(ones.item()), ranks=every, collective_backend=torch.distributed.get_backend())
+    if ex is not None:
+        sizes = [int((u["flat"] if u["flat"] is not None else u["params"][0]).numel() * 4) for u in ex.units]
+        out.update(allreduce_bytes=sum(sizes), allreduce_units=len(sizes),
+                   collective_backend=("asd_allreduce_mean_f32 (library communicator, RCCL)" if getattr(ex, "_own", None) is not None
+                                       else out["collective_backend"]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: a timed region of >= 5 s at ~14 ms per step, so that a sampler outside this process (rocm-smi, the driver's gpu_busy
+    # probe at 5-s intervals) sees the GPU work of the timed steps and not only the weight generation and roofline legs around them
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--backend", default=os.environ.get("ASD_BACKEND", "hip"), choices=["hip", "eager"])
     ap.add_argument("--workload", default="asd_sd_nerf", choices=["asd_sd_nerf", "asd_mv_nerf", "asd_sd_hyper_ingp", "asd_sd_3dconv_net", "asd_mv_triplane"],
                     help="asd_sd_nerf = BASELINE configs[1] (the headline metric); asd_mv_nerf = SURVEY C3 (MVDream, 4 views), secondary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="same-box A/B runs (tools/r6_ab_env.sh): the step line only, no roofline legs")
     ap.add_argument("--render", type=int, default=0, help="secondary workloads only: render size override (e.g. 256 for BASELINE's wording of configs[4])")
     ap.add_argument("--phases", action="store_true", help="also report per-phase milliseconds (adds syncs; untimed extra steps)")
     args = ap.parse_args()
@@ -580,6 +607,7 @@ def main():
     pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 3)
     ex = system.gradient_exchange() if hasattr(system, "gradient_exchange") else None
     allreduce_ms = round(ex.exposed_ms(), 3) if ex is not None else None
+    evidence = dist_evidence(world, rank, local_rank, dev, ex)
     phases = None
     if args.phases and rank == 0:
         # untimed extra steps with events around the phases of train_one_step (adds host syncs: not part of `value`)
@@ -626,7 +654,7 @@ def main():
                                                "cross-attention computed once per distinct (x, t) of the batch of 5 (2 distinct) — same eps within fp16 rounding, "
                                                "tests/test_gpu_unet_engine.py, tests/test_gpu_diffusion_ops.py"},
             "step_ms_gpu": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9)},
-            "allreduce_exposed_ms": allreduce_ms,
+            "allreduce_exposed_ms": allreduce_ms, **evidence,
             "loss": float(loss.item()), "kept_samples_last_step": int(system.renderer.last_n_samples) if hasattr(system.renderer, "last_n_samples") else None,
         }
         if args.workload == "asd_mv_nerf":  # secondary line (not BASELINE's metric): 4 views / step / GPU
@@ -657,6 +685,9 @@ def main():
         if phases:
             out["phases_ms"] = phases
         # `roofline` = the kernel rocprofv3 ranks first for this step (profiles/: see DOMINANT above); the other families follow
+        if args.no_roofline:
+            print(json.dumps(out), flush=True)
+            return
         lines = {"gemm": roofline_gemm_kernel(), "vae_conv": roofline_conv_kernel("vae512"), "unet_conv": roofline_conv_kernel("unet64")}
         if args.workload == "asd_sd_nerf":
             lines["pp_conv"] = roofline_pp_kernel()
@@ -707,6 +738,7 @@ def main_stub(args, rank, world):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     ex = system.gradient_exchange()
+    evidence = dist_evidence(world, rank, int(os.environ.get("LOCAL_RANK", "0")), torch.device("cpu"), ex)
     digest = torch.cat([p.detach().reshape(-1)[:64] for p in system.renderer.parameters()]).double().sum()
     if world > 1:       # replicas must have stayed identical
         lo, hi = digest.clone(), digest.clone()
@@ -718,7 +750,7 @@ def main_stub(args, rank, world):
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
                           "config": {"workload": "stub", "parallelism": f"dp{world}"},
-                          "allreduce_exposed_ms": None if ex is None else round(ex.exposed_ms(), 3),
+                          "allreduce_exposed_ms": None if ex is None else round(ex.exposed_ms(), 3), **evidence,
                           "exchange_units": None if ex is None else len(ex.units), "exchange_steps": None if ex is None else ex.prepare_called,
                           "loss": float(loss.item())}), flush=True)
     if world > 1:

@@ -386,9 +386,22 @@ typedef struct asd_gemm_args {
     int32_t a_seg_rows, w_seg_rows;
     int32_t a_seg_off[9], w_seg_off[6];
     int32_t partials_only;  /* split_k > 1: leave the fp32 slabs workspace[split_k, M, N] unreduced (no epilogue launch; the caller sums them) */
+    /* GroupNorm(32)(+SiLU) of C applied by the PRODUCER (ResBlock: GroupNorm32 -> SiLU -> conv, openaimodel.py:206-222, when C has no
+     * other reader of its statistics): on a split-K launch the reduction kernel owns whole (batch element, group) blocks, so it stores C,
+     * takes the group statistics of the stored values and writes gn_apply_y[M, N] = silu?((C - mean) * rstd * gamma + beta) in the same
+     * launch — no records, no apply launch.  asd_gemm_gn_applies() tells whether a launch does (plan-dependent); when it does not,
+     * the fields are ignored.  gn_cg / gn_rows as above; gn_apply_stats (optional) receives [batch*64] {sum, sumsq} per group. */
+    int32_t gn_apply;
+    void*   gn_apply_y;
+    const void* gn_apply_gamma; const void* gn_apply_beta;   /* fp16 [N] */
+    float   gn_apply_eps;
+    int32_t gn_apply_silu;
+    float*  gn_apply_stats;
 } asd_gemm_args;
 /* records per batch element asd_gemm_f16(args) will write to args->gn_partials under the current plan; 0 = none */
 int32_t asd_gemm_gn_records(const asd_gemm_args* args);
+/* 1 when asd_gemm_f16(args) with args->gn_apply set will write args->gn_apply_y itself under the current plan (pointers may be null) */
+int32_t asd_gemm_gn_applies(const asd_gemm_args* args);
 int asd_gemm_f16(const asd_gemm_args* args, void* stream);
 /* Tuning hook (tools/gemm_sweep.py): force tile configuration `cfg` (index into the table of csrc/gemm.hip: 128x64, 128x128,
  * 256x64, 256x128, 128x320, 256x256, 256x320, 320x128, and for 3x3 stride-1 convolutions the LDS-window kernel with

@@ -83,6 +83,8 @@ class GemmArgs(C.Structure):
         ("ln_mode", C.c_int32), ("ln_eps", C.c_float), ("ln_sc", C.c_void_p), ("ln_stats", C.c_void_p),
         ("a_seg_rows", C.c_int32), ("w_seg_rows", C.c_int32), ("a_seg_off", C.c_int32 * 9), ("w_seg_off", C.c_int32 * 6),
         ("partials_only", C.c_int32),
+        ("gn_apply", C.c_int32), ("gn_apply_y", C.c_void_p), ("gn_apply_gamma", C.c_void_p), ("gn_apply_beta", C.c_void_p),
+        ("gn_apply_eps", C.c_float), ("gn_apply_silu", C.c_int32), ("gn_apply_stats", C.c_void_p),
     ]
 
 
@@ -151,7 +153,7 @@ SYMBOLS = [
     "asd_occgrid_update", "asd_composite_fwd", "asd_composite_bwd",
     "asd_gemm_f16", "asd_gemm_force_tile", "asd_groupnorm_f16", "asd_groupnorm_bwd_f16", "asd_transpose_f16", "asd_layernorm_f16", "asd_softmax_f16", "asd_softmax_bwd_f16", "asd_geglu_f16", "asd_silu_f16",
     "asd_timestep_embedding_f16", "asd_concat_f16", "asd_attention_f16",
-    "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_generation", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune", "asd_gemm_gn_records", "asd_groupnorm_apply_f16", "asd_groupnorm_bwd_apply_f16",
+    "asd_gemm_plan_set", "asd_gemm_plan_get", "asd_gemm_plan_count", "asd_gemm_plan_generation", "asd_gemm_plan_entry", "asd_gemm_workspace_bytes", "asd_gemm_tune", "asd_gemm_gn_records", "asd_gemm_gn_applies", "asd_groupnorm_apply_f16", "asd_groupnorm_bwd_apply_f16",
     "asd_pad_cast_f16",
     "asd_image_prep_fwd", "asd_image_prep_bwd", "asd_latents_fwd", "asd_score_fwd", "asd_latents_bwd", "asd_prompt_context",
     "asd_unet_create", "asd_unet_destroy", "asd_unet_num_weights", "asd_unet_weight_info", "asd_unet_bind_weights",

@@ -914,10 +914,144 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const asd_gemm_
     if (threadIdx.x < 64) p.gn_partials[(size_t)blockIdx.x * 64 + threadIdx.x] = lds64[threadIdx.x];
 }
 
+// Split-K epilogue of a layer whose ONLY consumer is GroupNorm(32)(+SiLU) (asd_gemm_args.gn_apply): a block owns ALL rows of one batch
+// element x ONE group, so after summing the slabs and storing C it holds every value of its group — mean / rstd come from one block
+// reduction and the normalised tensor gn_apply_y = silu?(C * a + b) leaves in the same launch.  Replaces splitk_epilogue_gn_kernel +
+// gn_apply_kernel (two launches, the records, and a second trip of C through HBM) on the UNet's 8x8 / 16x16 / 32x32 split-K
+// convolutions (ResBlock: GroupNorm32 -> SiLU -> conv, openaimodel.py:206-222).  Statistics are taken from the STORED fp16 values
+// with fp32 sums, var = max(E[x^2] - mean^2, 0): the arithmetic of gn_stats_kernel / gn_apply_kernel (nn_ops.hip).
+// 1024 threads per block (the block is alone with its group: 160 blocks per launch at batch 5, so the memory parallelism has to come
+// from waves per CU — with 256 threads the launch took longer than the two it replaces); NV: float4 items per thread
+// (>= rows * (cg / 4) / 1024), four slabs in flight per trip.
+#define GNA_THREADS 1024
+template <int NV>
+__global__ __launch_bounds__(GNA_THREADS) void splitk_epilogue_gnapply_kernel(const asd_gemm_args p, int splits) {
+    __shared__ float red[2 * (GNA_THREADS / 64)];
+    const int cg = p.gn_cg, g4 = cg >> 2, rows = p.gn_rows;
+    const int b = blockIdx.x >> 5, g = blockIdx.x & 31;
+    const int n0 = g * cg, total = rows * g4, tid = threadIdx.x;
+    floatx4 v[NV];
+    int mrow[NV], ncol[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = min(tid + GNA_THREADS * i, total - 1);
+        const int r = e / g4;
+        mrow[i] = b * rows + r;
+        ncol[i] = n0 + (e - r * g4) * 4;
+        v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // operands of the epilogue that do not depend on the slabs: requested first
+    half4 bias[NV], rbias[NV], resid[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int m = mrow[i], n = ncol[i];
+        bias[i] = p.bias ? *(const half4*)((const half_t*)p.bias + n) : half4{0, 0, 0, 0};
+        rbias[i] = p.row_bias ? *(const half4*)((const half_t*)p.row_bias + (size_t)(m / p.rows_per_group) * p.ld_row_bias + n) : half4{0, 0, 0, 0};
+        resid[i] = p.residual ? *(const half4*)((const half_t*)p.residual + (size_t)m * p.ldr + n) : half4{0, 0, 0, 0};
+    }
+    // four slabs per trip: 4 NV independent 16-byte loads in flight (a 10-way split is three dependent round trips, not ten)
+    for (int s = 0; s < splits; s += 4) {
+        floatx4 t[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int su = min(s + u, splits - 1);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t[u][i] = *(const floatx4*)(p.workspace + ((size_t)su * p.M + mrow[i]) * p.N + ncol[i]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float on = s + u < splits ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                v[i][0] = fmaf(t[u][i][0], on, v[i][0]); v[i][1] = fmaf(t[u][i][1], on, v[i][1]);
+                v[i][2] = fmaf(t[u][i][2], on, v[i][2]); v[i][3] = fmaf(t[u][i][3], on, v[i][3]);
+            }
+        }
+    }
+    float cs = 0.f, cq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int m = mrow[i], n = ncol[i];
+        floatx4 w = v[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] += (float)bias[i][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] += (float)rbias[i][r];
+        if (p.act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = w[r] / (1.f + __expf(-w[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] += (float)resid[i][r];
+        const half4 o = {(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
+        const bool live = tid + GNA_THREADS * i < total;
+        if (live) *(half4*)((half_t*)p.C + (size_t)m * p.ldc + n) = o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float f = (float)o[r];
+            v[i][r] = f;                              // the stored value: what GroupNorm sees
+            if (live) { cs += f; cq = fmaf(f, f, cq); }
+        }
+    }
+    // block sum of (cs, cq): wave reduction by shuffles, sixteen waves through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { cs += __shfl_xor(cs, off, 64); cq += __shfl_xor(cq, off, 64); }
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = cs; red[(tid >> 6) * 2 + 1] = cq; }
+    __syncthreads();
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GNA_THREADS / 64; ++w) { sum += red[2 * w]; sq += red[2 * w + 1]; }
+    if (p.gn_apply_stats && tid == 0) { p.gn_apply_stats[b * 64 + g * 2] = sum; p.gn_apply_stats[b * 64 + g * 2 + 1] = sq; }
+    const float inv_cnt = 1.f / ((float)rows * (float)cg);
+    const float mean = sum * inv_cnt;
+    const float var = fmaxf(sq * inv_cnt - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.gn_apply_eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (tid + GNA_THREADS * i >= total) continue;
+        const int m = mrow[i], n = ncol[i];
+        const half4 gm = *(const half4*)((const half_t*)p.gn_apply_gamma + n), bt = *(const half4*)((const half_t*)p.gn_apply_beta + n);
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sa = rstd * (float)gm[r];
+            float f = fmaf(v[i][r], sa, (float)bt[r] - mean * sa);
+            if (p.gn_apply_silu) f = f / (1.f + __expf(-f));
+            o[r] = (half_t)f;
+        }
+        *(half4*)((half_t*)p.gn_apply_y + (size_t)m * p.N + n) = o;
+    }
+}
+
+#define ASD_GNAPPLY_MAX_NV 5
+// float4 items per thread of splitk_epilogue_gnapply_kernel for this (plan-resolved) launch; 0 = the fused form does not apply
+static int asd_gemm_gn_apply_nv(const asd_gemm_args* a) {
+    if (!a->gn_apply || a->split_k <= 1 || a->partials_only || a->out_f32 || a->act == 2 || a->gn_bwd_x) return 0;
+    if (a->gn_cg < 4 || a->gn_cg % 4 || a->N != 32 * a->gn_cg || a->gn_rows < 1 || a->M % a->gn_rows || a->ldc % 4) return 0;
+    if (a->conv && a->upsample == 3) return 0;      // parity-major row order
+    const int need = (a->gn_rows * (a->gn_cg / 4) + GNA_THREADS - 1) / GNA_THREADS;
+    return need <= 1 ? 1 : need <= 3 ? 3 : need <= ASD_GNAPPLY_MAX_NV ? ASD_GNAPPLY_MAX_NV : 0;
+}
+
+// the reduction launch behind a split-K main kernel
+static void asd_launch_splitk_epilogue(const asd_gemm_args* a, hipStream_t s) {
+    const int nv = a->gn_apply_y ? asd_gemm_gn_apply_nv(a) : 0;
+    if (nv > 0) {
+        const dim3 grid((a->M / a->gn_rows) * 32);
+        if (nv == 1) hipLaunchKernelGGL(splitk_epilogue_gnapply_kernel<1>, grid, dim3(GNA_THREADS), 0, s, *a, a->split_k);
+        else if (nv == 3) hipLaunchKernelGGL(splitk_epilogue_gnapply_kernel<3>, grid, dim3(GNA_THREADS), 0, s, *a, a->split_k);
+        else hipLaunchKernelGGL(splitk_epilogue_gnapply_kernel<ASD_GNAPPLY_MAX_NV>, grid, dim3(GNA_THREADS), 0, s, *a, a->split_k);
+        return;
+    }
+    const size_t total4 = (size_t)a->M * a->N / 4;
+    if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, s, *a, a->split_k);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);
+}
+
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn, nst, kg; };   // nst: stages of the operand ring (0 = the default two); kg: k-groups (0 = one)
-#define ASD_GEMM_NCFG 25
+#define ASD_GEMM_NCFG 26
 #define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
                           // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 #define ASD_GEMM_PP0 20   // configurations 20-24: the ping-pong window convolution of gemm_pp.hip (eight waves, two per SIMD staggered by a
@@ -932,12 +1066,22 @@ static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     // 64x64 x 2 groups, 64x64 x 4 groups, 128x64 x 2, 128x128 x 2
     {64, 64, 2, 2, 4, 1}, {64, 64, 2, 2, 2, 2}, {64, 64, 2, 2, 2, 4}, {128, 64, 2, 2, 2, 2}, {128, 128, 2, 2, 2, 2},
     // 20-24: ping-pong window convolution: 32x16 px x 128 ch, 16x16 px x 256 / 320 / 128 / 160 ch
-    {512, 128, 4, 2}, {256, 256, 4, 2}, {256, 320, 4, 2}, {256, 128, 4, 2}, {256, 160, 4, 2}};
+    {512, 128, 4, 2}, {256, 256, 4, 2}, {256, 320, 4, 2}, {256, 128, 4, 2}, {256, 160, 4, 2},
+    // 25: weight-streaming 3x3 convolution of the 8x8 level (gemm_ws.hip): all <= 320 rows x 64 channels x one channel slice per block
+    {320, 64, 2, 2}};
+#define ASD_GEMM_WS 25
 static int asd_cfg_stages(int cfg) { return asd_gemm_tiles[cfg].nst > 2 ? asd_gemm_tiles[cfg].nst : 2; }
 static int asd_cfg_kgroups(int cfg) { return asd_gemm_tiles[cfg].kg > 1 ? asd_gemm_tiles[cfg].kg : 1; }
 static bool asd_cfg_is_pp(int cfg) { return cfg >= ASD_GEMM_PP0 && cfg < ASD_GEMM_PP0 + 5; }
 static bool asd_cfg_is_window(int cfg) { return (cfg >= ASD_GEMM_WIN0 && cfg < ASD_GEMM_WIN0 + 4) || cfg == 13 || cfg == 14 || asd_cfg_is_pp(cfg); }
 static bool asd_cfg_is_win2(int cfg) { return cfg == ASD_GEMM_WIN0 + 2 || cfg == ASD_GEMM_WIN0 + 3 || cfg == 13 || cfg == 14; }
+static bool asd_cfg_is_ws(int cfg) { return cfg == ASD_GEMM_WS; }
+int asd_conv_ws_launch(const asd_gemm_args* a, hipStream_t s);                                 // gemm_ws.hip
+// (split_k resolved) 3x3 stride-1 pad-1 convolution on <= 5 images of 8 x 8 pixels, whole 32-channel chunks per slice, fp32 slabs
+static bool asd_conv_ws_ok(const asd_gemm_args* a) {
+    return a->conv && a->stride == 1 && a->pad == 1 && a->upsample == 0 && a->Hin == 8 && a->Win == 8 && a->Hout == 8 && a->Wout == 8 &&
+           a->M % 64 == 0 && a->M / 64 <= 5 && a->N % 64 == 0 && a->split_k >= 2 && a->Cin % (32 * a->split_k) == 0 && !a->gn_bwd_x && !a->ln_mode;
+}
 size_t asd_conv_pp_lds_bytes(int variant);                                                    // gemm_pp.hip
 int asd_conv_pp_launch(int variant, const asd_gemm_args* a, int blocks, hipStream_t s);
 
@@ -1103,6 +1247,17 @@ int32_t asd_gemm_gn_records(const asd_gemm_args* a_in) {
     return asd_gemm_gn_records_cfg(&a, asd_gemm_resolve_cfg(&a), false);
 }
 
+int32_t asd_gemm_gn_applies(const asd_gemm_args* a_in) {
+    if (!a_in || a_in->M <= 0 || a_in->N <= 0 || a_in->K <= 0) return 0;
+    asd_gemm_args a = *a_in;
+    if (a.split_k == 0) {
+        int32_t t = 0, sk = 1;
+        asd_gemm_plan_get(&a, &t, &sk);
+        a.split_k = sk;
+    }
+    return asd_gemm_gn_apply_nv(&a) > 0 ? 1 : 0;
+}
+
 int asd_gemm_plan_count(void) {
     std::lock_guard<std::mutex> lk(g_plans_mu);
     return (int)g_plans.size();
@@ -1184,6 +1339,14 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         fprintf(stderr, "ASD_GEMM %d %d %d conv=%d %d %d %d %d %d s=%d p=%d u=%d cfg=%d split=%d act=%d res=%d f32=%d gn=%d\n", a->M, a->N, a->K, a->conv, a->Hin,
                 a->Win, a->Cin, a->Hout, a->Wout, a->stride, a->pad, a->upsample, cfg, a->split_k, a->act, a->residual != nullptr, a->out_f32,
                 a->gn_partials ? (a->gn_bwd_x ? 2 : 1) : 0);
+    if (asd_cfg_is_ws(cfg)) {
+        ASD_CHECK_ARG(asd_conv_ws_ok(a), "weight-streaming convolution: 3x3 stride-1 pad-1 on <= 5 images of 8x8, N % 64 == 0, split_k >= 2, Cin % (32 split_k) == 0");
+        hipStream_t sws = (hipStream_t)stream;
+        if (asd_conv_ws_launch(a, sws) != ASD_OK) { asd_set_error("weight-streaming convolution: bad image count"); return ASD_ERR_ARG; }
+        if (!a->partials_only) asd_launch_splitk_epilogue(a, sws);
+        ASD_LAUNCH_CHECK();
+        return ASD_OK;
+    }
     if (asd_cfg_is_window(cfg)) {
         ASD_CHECK_ARG(asd_cfg_is_pp(cfg) ? asd_conv_pp_ok(a, cfg) : asd_conv_window_ok(a),
                       "window convolution needs a 3x3 stride-1 pad-1 conv with Cin % 64 == 0 (ping-pong: % 32) and H, W % 16 == 0");
@@ -1195,9 +1358,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
             hipStream_t sp = (hipStream_t)stream;
             if (asd_conv_pp_launch(cfg - ASD_GEMM_PP0, a, 8 * asd_div_up(tiles_mp * tiles_np * a->split_k, 8), sp) != ASD_OK) { asd_set_error("bad ping-pong variant"); return ASD_ERR_ARG; }
             if (a->split_k > 1) {
-                const size_t total4 = (size_t)a->M * a->N / 4;
-                if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, sp, *a, a->split_k);
-                else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sp, *a, a->split_k);
+                asd_launch_splitk_epilogue(a, sp);
             }
             ASD_LAUNCH_CHECK();
             return ASD_OK;
@@ -1224,9 +1385,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
             else WIN2_LAUNCH(128, 8);
 #undef WIN2_LAUNCH
             if (a->split_k > 1) {
-                const size_t total4 = (size_t)a->M * a->N / 4;
-                if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, sw, *a, a->split_k);
-                else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+                asd_launch_splitk_epilogue(a, sw);
             }
             ASD_LAUNCH_CHECK();
             return ASD_OK;
@@ -1240,9 +1399,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
             hipLaunchKernelGGL((conv3x3_win_kernel<128>), dim3(tiles_w), dim3(512), lds_w, sw, *a);
         }
         if (a->split_k > 1) {
-            const size_t total4 = (size_t)a->M * a->N / 4;
-            if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, sw, *a, a->split_k);
-                else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, sw, *a, a->split_k);
+            asd_launch_splitk_epilogue(a, sw);
         }
         ASD_LAUNCH_CHECK();
         return ASD_OK;
@@ -1290,9 +1447,7 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
 #undef GEMM_CASE_N
 #undef GEMM_LAUNCH
     if (a->split_k > 1 && !a->partials_only) {
-        const size_t total4 = (size_t)a->M * a->N / 4;
-        if (a->gn_partials) hipLaunchKernelGGL(splitk_epilogue_gn_kernel, dim3((a->M / 64) * (a->N / 64)), dim3(256), 0, s, *a, a->split_k);
-        else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(asd_div_up(total4, 256)), dim3(256), 0, s, *a, a->split_k);
+        asd_launch_splitk_epilogue(a, s);
     }
     ASD_LAUNCH_CHECK();
     return ASD_OK;
@@ -1306,6 +1461,16 @@ static int asd_tune_candidates(const asd_gemm_args* a, int (*out)[2], int max_ou
     int n = 0;
     for (int t = 0; t < ASD_GEMM_NCFG && n < max_out; ++t) {
         const int bm = asd_gemm_tiles[t].bm, bn = asd_gemm_tiles[t].bn;
+        if (asd_cfg_is_ws(t)) {
+            static const int sk_ws[] = {2, 4, 5, 8, 10, 16, 20};
+            for (int sk : sk_ws) {
+                asd_gemm_args q = *a;
+                q.split_k = sk;
+                if (!asd_conv_ws_ok(&q) || (a->N / 64) * sk > 512 || (a->N / 64) * sk < 64) continue;
+                if (n < max_out) { out[n][0] = t + 1; out[n][1] = sk; ++n; }
+            }
+            continue;
+        }
         if (asd_cfg_is_window(t)) {
             if (asd_cfg_is_pp(t) ? !asd_conv_pp_ok(a, t) : (!window_ok || (bn != 64 && a->N % bn != 0))) continue;
             const int tiles = (a->M / bm) * asd_div_up(a->N, bn);

@@ -58,6 +58,13 @@ struct Act {                // an activation and, when its producer left them, i
     const half_t* p = nullptr;
     const float* rec = nullptr;
     int nrec = 0;           // records per batch element (0: none — the consumer runs its own statistics pass)
+    // GroupNorm(+SiLU) of p already applied by the producer's split-K reduction (asd_gemm_args.gn_apply) with these parameters
+    const half_t* applied = nullptr; const half_t* applied_gamma = nullptr; const half_t* applied_beta = nullptr;
+    float applied_eps = 0.f; int applied_silu = 0;
+};
+
+struct GnNext {             // the GroupNorm that consumes a layer's output, when the schedule knows it
+    const half_t* gamma = nullptr; const half_t* beta = nullptr; float eps = 0.f; int silu = 0;
 };
 
 struct Net {
@@ -94,6 +101,9 @@ struct GemmOpt {
     // LayerNorm folded into this GEMM (asd_gemm_args.ln_mode): 1 = the rows of A are normalised (statistics reduced in the main loop,
     // optionally exported to ln_stats), 2 = the rows of the W operand are (statistics read from ln_stats)
     int ln_mode = 0; const float* ln_sc = nullptr; float* ln_stats = nullptr;
+    // the GroupNorm that consumes this output (with gn_rows / out): a split-K launch applies it in its reduction kernel and leaves the
+    // normalised tensor in out->applied (asd_gemm_args.gn_apply); otherwise the records path above
+    const GnNext* gn_next = nullptr;
 };
 
 void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
@@ -101,7 +111,7 @@ void set_gn_bwd(asd_gemm_args& g, const GemmOpt& o) {
     g.gn_eps = 1e-6f; g.gn_silu = o.gn_silu;
 }
 
-void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr, bool gn_bwd_form = false) {
+void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr, bool gn_bwd_form = false, const GnNext* gn_next = nullptr) {
     g.zero_page = r.zero_page;
     g.split_k = 0;          // auto: tuned plan of this shape (asd_gemm_plan_*), else cost model
     g.tile_cfg = 0;
@@ -120,6 +130,22 @@ void launch_gemm(Run& r, asd_gemm_args& g, Act* gn_out = nullptr, bool gn_bwd_fo
     // A/B 15.58 vs 15.64 ms per step (gpurun_out/gnb).  ASD_GN_BWD_EPILOGUE=1 switches it back on.
     static const bool gn_bwd_epilogue = getenv("ASD_GN_BWD_EPILOGUE") && getenv("ASD_GN_BWD_EPILOGUE")[0] == '1';
     if (gn_bwd_form && !gn_bwd_epilogue) { gn_out = nullptr; g.gn_bwd_x = nullptr; g.gn_bwd_fstats = nullptr; g.gn_bwd_gamma = nullptr; g.gn_bwd_beta = nullptr; }
+    static const bool gn_fused_apply = !(getenv("ASD_GN_FUSED_APPLY") && getenv("ASD_GN_FUSED_APPLY")[0] == '0');          // A/B switch (tools)
+    if (gn_fused_apply && gn_epilogue && gn_next && gn_next->gamma && gn_out && !gn_bwd_form && g.gn_rows > 0 && g.N % 32 == 0 && !r.rec_replay && !r.rec_log) {
+        // GroupNorm applied by the producer: decided by shape and plan only (dry passes carry null pointers)
+        asd_gemm_args q = g;
+        q.gn_cg = g.N / 32; q.gn_apply = 1;
+        const bool applies = asd_gemm_gn_applies(&q) != 0;
+        // while tuning the plan of this shape may still change between the sizing pass and the launch: always reserve the buffer
+        half_t* y = (applies || r.tune) ? r.mem.halfs((size_t)g.M * g.N) : nullptr;
+        if (applies) {
+            g.gn_cg = g.N / 32; g.gn_apply = 1; g.gn_apply_y = y;
+            g.gn_apply_gamma = gn_next->gamma; g.gn_apply_beta = gn_next->beta; g.gn_apply_eps = gn_next->eps; g.gn_apply_silu = gn_next->silu;
+            gn_out->applied = y; gn_out->applied_gamma = gn_next->gamma; gn_out->applied_beta = gn_next->beta;
+            gn_out->applied_eps = gn_next->eps; gn_out->applied_silu = gn_next->silu;
+            gn_out = nullptr;           // no records: nothing else reads this tensor's statistics
+        }
+    }
     if (gn_epilogue && gn_out && g.gn_rows > 0 && g.N % 32 == 0) {     // statistics records of the output, produced in the epilogue when the plan allows
         g.gn_cg = g.N / 32;
         const int batch = g.M / g.gn_rows;
@@ -158,8 +184,8 @@ void gemm(Run& r, const void* A, int M, int lda, const void* W, int N, int K, in
     g.gn_rows = o.gn_rows;
     g.ln_mode = o.ln_mode; g.ln_sc = o.ln_sc; g.ln_stats = o.ln_stats; g.ln_eps = 1e-5f;
     if (o.gn_x) set_gn_bwd(g, o);
-    if (o.out) *o.out = Act{(const half_t*)C, nullptr, 0};
-    launch_gemm(r, g, o.out, o.gn_bwd_form);
+    if (o.out) { *o.out = Act{}; o.out->p = (const half_t*)C; }
+    launch_gemm(r, g, o.out, o.gn_bwd_form, o.gn_next);
 }
 
 // 3x3 convolution on NHWC [B,Hin,Win,Cin] with packed weights [Cout, 9*Cin]; upsample: 0 plain, 1 nearest-2x fused, 2 transposed stride-2,
@@ -174,8 +200,8 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
     g.conv = 1; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.Hout = Hout; g.Wout = Wout; g.stride = stride; g.pad = pad; g.upsample = upsample;
     g.gn_rows = o.gn_rows;
     if (o.gn_x) set_gn_bwd(g, o);
-    if (o.out) *o.out = Act{(const half_t*)y, nullptr, 0};
-    launch_gemm(r, g, o.out, o.gn_bwd_form);
+    if (o.out) { *o.out = Act{}; o.out->p = (const half_t*)y; }
+    launch_gemm(r, g, o.out, o.gn_bwd_form, o.gn_next);
 }
 
 #define LEAF(call)                                              \
@@ -189,6 +215,9 @@ void conv3x3(Run& r, const void* x, int B, int Hin, int Win, int Cin, const void
 // GroupNorm(32)(+SiLU) of x1 (|| x2 along channels); returns y, optionally the statistics buffer (kept for a backward pass)
 half_t* groupnorm(Run& r, const void* x1, int c1, const void* x2, int c2, int B, int hw, const half_t* gamma, const half_t* beta, float eps,
                   int silu, half_t* y = nullptr, float** stats_out = nullptr, const Act* src = nullptr) {
+    if (src && src->applied && !x2 && !y && !stats_out && src->applied_gamma == gamma && src->applied_beta == beta && src->applied_eps == eps &&
+        src->applied_silu == silu)
+        return const_cast<half_t*>(src->applied);          // the producer's split-K reduction already wrote GroupNorm(x)
     if (!y) y = r.mem.halfs((size_t)B * hw * (c1 + c2));
     float* stats = r.mem.floats(ASD_GN_STATS_FLOATS(B));
     if (src && src->nrec > 0 && !x2) {       // the producer's epilogue already reduced the statistics: no pass over x for them
@@ -344,7 +373,7 @@ half_t* gather_rows(Run& r, const half_t* src, const int* idx, int n_out, size_t
     return dst;
 }
 
-Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int cin, int cout, int Hh, int Ww) {
+Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act& xin, int cin, int cout, int Hh, int Ww, const GnNext* next = nullptr) {
     const int B = s.B, hw = Hh * Ww, M = B * hw;
     const half_t* x = xin.p;
     half_t* t1 = groupnorm(r, x, cin, nullptr, 0, B, hw, n.w(p + ".in_layers.0.weight"), n.w(p + ".in_layers.0.bias"), 1e-5f, 1, nullptr, nullptr, &xin);
@@ -354,6 +383,8 @@ Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act
     o1.bias = n.w(p + ".in_layers.2.bias");
     o1.row_bias = s.emb_all + n.emb_off[p]; o1.rows_per_group = hw; o1.ld_row_bias = s.emb_ld;   // + emb_layers(emb)[:, :, None, None]
     o1.gn_rows = hw; o1.out = &a2;
+    const GnNext gn2{n.w(p + ".out_layers.0.weight"), n.w(p + ".out_layers.0.bias"), 1e-5f, 1};
+    o1.gn_next = &gn2;
     conv3x3(r, t1, B, Hh, Ww, cin, n.w(p + ".in_layers.2.weight"), cout, t2, Hh, Ww, 1, 1, 0, o1);
     half_t* t3 = groupnorm(r, t2, cout, nullptr, 0, B, hw, n.w(p + ".out_layers.0.weight"), n.w(p + ".out_layers.0.bias"), 1e-5f, 1, nullptr, nullptr, &a2);
     const half_t* skip = x;
@@ -367,7 +398,7 @@ Act u_resblock(UNet& n, Run& r, const UState& s, const std::string& p, const Act
     half_t* out = r.mem.halfs((size_t)M * cout);
     Act ao;
     GemmOpt o2;
-    o2.bias = n.w(p + ".out_layers.3.bias"); o2.residual = skip; o2.ldr = cout; o2.gn_rows = hw; o2.out = &ao;
+    o2.bias = n.w(p + ".out_layers.3.bias"); o2.residual = skip; o2.ldr = cout; o2.gn_rows = hw; o2.out = &ao; o2.gn_next = next;
     conv3x3(r, t3, B, Hh, Ww, cout, n.w(p + ".out_layers.3.weight"), cout, out, Hh, Ww, 1, 1, 0, o2);
     return ao;
 }
@@ -378,7 +409,7 @@ half_t* layernorm(Run& r, const half_t* x, int rows, int c, const half_t* g, con
     return y;
 }
 
-Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, const Act& xin, int C, int Hh, int Ww) {
+Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, const Act& xin, int C, int Hh, int Ww, const GnNext* next = nullptr) {
     const UState* sp = &s_in;
     int B = sp->B, L = Hh * Ww, M = B * L;
     const int heads = C / 64, F = sp->F;
@@ -447,14 +478,26 @@ Act u_transformer(UNet& n, Run& r, const UState& s_in, const std::string& p, con
     }
     half_t* out = r.mem.halfs((size_t)M * C);
     Act ao;
-    GemmOpt o; o.bias = n.w(p + ".proj_out.bias"); o.residual = x; o.ldr = C; o.gn_rows = L; o.out = &ao;
+    GemmOpt o; o.bias = n.w(p + ".proj_out.bias"); o.residual = x; o.ldr = C; o.gn_rows = L; o.out = &ao; o.gn_next = next;
     gemm(r, h, M, C, n.w(p + ".proj_out.weight"), C, C, C, out, C, o);
     return ao;
 }
 
-Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh, int* Ww) {
-    for (const ULayer& l : blk.layers) {
+// the GroupNorm a layer opens with (ResBlock in_layers.0: GroupNorm32 + SiLU; SpatialTransformer.norm: GroupNorm, eps 1e-6), if any
+bool u_first_norm(UNet& n, const ULayer* l, GnNext* out) {
+    if (!l) return false;
+    if (l->kind == 1) { *out = GnNext{n.w(l->name + ".in_layers.0.weight"), n.w(l->name + ".in_layers.0.bias"), 1e-5f, 1}; return true; }
+    if (l->kind == 2) { *out = GnNext{n.w(l->name + ".norm.weight"), n.w(l->name + ".norm.bias"), 1e-6f, 0}; return true; }
+    return false;
+}
+
+// `after`: the layer that consumes this block's output directly (no concatenation in between), when the caller knows it
+Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh, int* Ww, const ULayer* after = nullptr) {
+    for (size_t li = 0; li < blk.layers.size(); ++li) {
+        const ULayer& l = blk.layers[li];
         const int B = s.B;
+        GnNext gnn;
+        const GnNext* next = u_first_norm(n, li + 1 < blk.layers.size() ? &blk.layers[li + 1] : after, &gnn) ? &gnn : nullptr;
         if (l.kind == 0) {
             half_t* y = r.mem.halfs((size_t)B * *Hh * *Ww * l.cout);
             Act a;
@@ -462,14 +505,14 @@ Act u_apply(UNet& n, Run& r, const UState& s, const UBlock& blk, Act h, int* Hh,
             conv3x3(r, h.p, B, *Hh, *Ww, pad32(l.cin), n.w(l.name + ".weight"), l.cout, y, *Hh, *Ww, 1, 1, 0, o);
             h = a;
         } else if (l.kind == 1) {
-            h = u_resblock(n, r, s, l.name, h, l.cin, l.cout, *Hh, *Ww);
+            h = u_resblock(n, r, s, l.name, h, l.cin, l.cout, *Hh, *Ww, next);
         } else if (l.kind == 2) {
-            h = u_transformer(n, r, s, l.name, h, l.cout, *Hh, *Ww);
+            h = u_transformer(n, r, s, l.name, h, l.cout, *Hh, *Ww, next);
         } else if (l.kind == 3) {
             const int Ho = (*Hh + 2 - 3) / 2 + 1, Wo = (*Ww + 2 - 3) / 2 + 1;
             half_t* y = r.mem.halfs((size_t)B * Ho * Wo * l.cout);
             Act a;
-            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = Ho * Wo; o.out = &a;
+            GemmOpt o; o.bias = n.w(l.name + ".bias"); o.gn_rows = Ho * Wo; o.out = &a; o.gn_next = next;
             conv3x3(r, h.p, B, *Hh, *Ww, l.cin, n.w(l.name + ".weight"), l.cout, y, Ho, Wo, 2, 1, 0, o);
             h = a; *Hh = Ho; *Ww = Wo;
         } else {
@@ -547,7 +590,8 @@ void unet_run(UNet& n, Run& r, const half_t* x, const float* t, const half_t* ct
     }
     for (size_t bi = first; bi < n.inputs.size(); ++bi) {
         const UBlock& b = n.inputs[bi];
-        h = u_apply(n, r, s, b, h, &hh, &ww);
+        const UBlock& nb = bi + 1 < n.inputs.size() ? n.inputs[bi + 1] : n.middle;
+        h = u_apply(n, r, s, b, h, &hh, &ww, nb.layers.empty() ? nullptr : &nb.layers.front());
         hs.push_back(Skip{h.p, b.layers.back().cout});
     }
     h = u_apply(n, r, s, n.middle, h, &hh, &ww);

@@ -32,8 +32,9 @@ def _p(t: Optional[torch.Tensor]):
 # split_k = 0 uses the recorded plan of the shape, else its cost model.  The winners for the shapes of the shipped configs are
 # committed in gemm_plans.json and pushed into the library when this module is imported; a shape met for the first time is tuned
 # once (a few ms, never under graph capture) unless ASD_GEMM_AUTOTUNE=0.
-TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64, 64, 128, 64, 64, 64, 64, 128, 128, 256, 320, 128, 160)
-TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64, 256, 256, 64, 64, 64, 128, 128, 512, 256, 256, 256, 256)
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64, 64, 128, 64, 64, 64, 64, 128, 128, 256, 320, 128, 160, 64)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64, 256, 256, 64, 64, 64, 128, 128, 512, 256, 256, 256, 256, 320)
+WS_TILE = 25                             # weight-streaming 3x3 convolution of the 8x8 level (csrc/gemm_ws.hip): split_k >= 2, Cin % (32 split_k) == 0
 WINDOW_TILES = (8, 9, 10, 11, 13, 14, 20, 21, 22, 23, 24)   # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels); 10, 11: two blocks per CU; 13, 14: + four-wave form
 PP_TILES = (20, 21, 22, 23, 24)          # ping-pong window convolution (csrc/gemm_pp.hip): whole N tiles, image rows % (TILE_BM / 16) == 0
 # 15: 64x64 with a 4-stage operand ring; 16-19: intra-block split-K (64x64 x 2 / x 4 k-groups, 128x64 x 2, 128x128 x 2) — few-block launches
@@ -114,14 +115,18 @@ if os.environ.get("ASD_GEMM_PLAN_FILE", "") != "none" and os.path.exists(L.LIB_P
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_group: int = 0, residual=None, act: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, split_k: Optional[int] = None, conv: Optional[dict] = None,
-         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0, gn_bwd: Optional[dict] = None, ln: Optional[dict] = None):
+         M: Optional[int] = None, tile_cfg: int = 0, gn_rows: int = 0, gn_bwd: Optional[dict] = None, ln: Optional[dict] = None,
+         gn_apply: Optional[dict] = None):
     """C = act(A W^T + bias + row_bias) + residual.  a: [M, K] fp16 (last dim contiguous) or NHWC image when conv.
     gn_rows > 0: also ask the epilogue for the GroupNorm statistics records of C (rows per batch element = gn_rows); returns
     (C, records | None, records_per_batch_element).  gn_bwd = dict(x, fstats, gamma, beta, eps, silu): C is the gradient reaching
     GroupNorm(x)[+SiLU] and the records carry that layer's two backward reductions instead (asd_gemm_args.gn_bwd_x).
     ln = dict(mode, sc, stats=None, eps=1e-5): a LayerNorm folded into this GEMM (asd_gemm_args.ln_mode; w = gamma (.) W and sc = fp32
     [2, rows] {rowsum(w), W beta} from weights._ln_fold): mode 1 normalises the rows of a (stats, if given, receives {mean, rstd} per
-    row), mode 2 the rows of w with the statistics read from stats."""
+    row), mode 2 the rows of w with the statistics read from stats.
+    gn_apply = dict(gamma, beta, eps, silu) with gn_rows: ask the PRODUCER to apply GroupNorm(32)(+SiLU) to C (asd_gemm_args.gn_apply:
+    split-K launches whose reduction kernel owns whole groups); returns (C, y | None, stats | None) — y is None when this launch / plan
+    cannot do it and the caller runs its own GroupNorm."""
     dev = a.device
     N, K = w.shape
     if conv is not None and int(conv.get("upsample", 0)) == 3:     # parity form: w = [4 parities][Cout][4 * Cin]
@@ -169,6 +174,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, row_bias=None, rows_per_gr
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         g.workspace = ws.data_ptr()
     rec, nrec = None, 0
+    if gn_rows > 0 and gn_apply is not None:
+        g.gn_cg, g.gn_rows, g.gn_apply = N // 32, gn_rows, 1
+        y = st = None
+        if lib().asd_gemm_gn_applies(C.byref(g)):
+            y = torch.empty((M, N), device=dev, dtype=torch.float16)
+            st = torch.empty((M // gn_rows, 64), device=dev, dtype=torch.float32)
+            g.gn_apply_y, g.gn_apply_stats = y.data_ptr(), st.data_ptr()
+            g.gn_apply_gamma, g.gn_apply_beta = gn_apply["gamma"].data_ptr(), gn_apply["beta"].data_ptr()
+            g.gn_apply_eps, g.gn_apply_silu = float(gn_apply["eps"]), int(gn_apply["silu"])
+        check(lib().asd_gemm_f16(C.byref(g), stream()))
+        return out, y, st
     if gn_rows > 0:
         g.gn_cg, g.gn_rows = N // 32, gn_rows
         if gn_bwd is not None:

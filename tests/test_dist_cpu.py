@@ -290,3 +290,6 @@ def test_bench_two_ranks_under_torchrun_prints_one_json_line():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak" and out["data"] == "stub"
     assert out["exchange_units"] == 2 and out["exchange_steps"] == 6          # the table in place + one bucket; every step exchanged
     assert out["allreduce_exposed_ms"] is not None and out["value"] > 0
+    # the line proves its own world: size as an all-reduce of ones saw it, one record per rank, the bytes one exchange moves
+    assert out["rccl_ranks"] == 2 and [r_["rank"] for r_ in out["ranks"]] == [0, 1] and out["collective_backend"] == "gloo"
+    assert out["allreduce_units"] == 2 and out["allreduce_bytes"] > 0

@@ -99,7 +99,7 @@ def test_upsample_conv_parity_form(B, hw, cin, cout, tile, sk):
     assert float((got.float() - nine.float()).abs().max()) <= 4e-3 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("tile", list(range(25)))
+@pytest.mark.parametrize("tile", list(range(25)))      # 25 (weight streaming, 8x8 images only) has its own test below
 @pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1), (2, 64, 96, 128, 1), (1, 32, 160, 640, 5),
                                               (1, 64, 32, 128, 1)])
 def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
@@ -128,6 +128,32 @@ def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin
     finally:
         lib().asd_gemm_force_tile(C.c_int32(-1))
     _close(got, ref)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,sk", [(5, 1280, 1280, 10), (5, 2560, 1280, 10), (5, 1280, 1280, 5), (3, 256, 128, 2), (1, 64, 64, 2), (4, 320, 192, 5),
+                                           (2, 128, 64, 4), (5, 640, 1280, 20)])
+def test_weight_streaming_convolution_of_the_8x8_level(B, Cin, Cout, sk):
+    """tile configuration 25 (csrc/gemm_ws.hip: all M <= 320 rows x 64 channels x one channel slice per block, raw 10 x 10 activation
+    windows in LDS) against F.conv2d in fp32 and, bit for bit in the slabs' sum order aside, against the implicit-GEMM tile on the same
+    split; with bias + time-embedding row bias + residual through the split-K reduction, and with the producer-applied GroupNorm"""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    x = _rand(B, Cin, 8, 8, seed=8)
+    w = _rand(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=9)
+    bias, res, temb = _rand(Cout, seed=10), _rand(B, 8, 8, Cout, seed=11), _rand(B, Cout, seed=12)
+    ref = F.conv2d(x.float(), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1) + res.float() + temb.float()[:, None, None, :]
+    xn, wp = x.permute(0, 2, 3, 1).contiguous(), H.pack_conv3x3_weight(w)
+    kw = dict(bias=bias, residual=res.view(-1, Cout), row_bias=temb, rows_per_group=64, split_k=sk)
+    got = H.conv3x3(xn, wp, tile_cfg=H.WS_TILE + 1, **kw)
+    _close(got, ref)
+    other = H.conv3x3(xn, wp, tile_cfg=13, **kw)
+    assert float((got.float() - other.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+    if Cout % 128 == 0:
+        gamma, beta = (_rand(Cout, seed=5) * 0.1 + 1).half(), (_rand(Cout, seed=6) * 0.1).half()
+        c, y, st = H.conv3x3(xn, wp, tile_cfg=H.WS_TILE + 1, gn_rows=64, gn_apply=dict(gamma=gamma, beta=beta, eps=1e-5, silu=True), **kw)
+        assert y is not None and torch.equal(c.reshape(-1), got.reshape(-1))
+        want = H.groupnorm(c.view(B, 64, Cout), gamma, beta, 1e-5, True)
+        assert float((y.view_as(want).float() - want.float()).abs().max()) <= 2e-3
 
 
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(5, 4096, 320, 0, True), (5, 64, 1280, 1280, True), (2, 1024, 640, 320, False),
@@ -320,6 +346,50 @@ def test_groupnorm_statistics_from_the_producers_epilogue(B, hw, cin, cout, tile
         g2, gs2 = H.groupnorm_apply(y2v, gamma, beta, 1e-5, True, r2)
         torch.testing.assert_close(gs2, ws2, rtol=2e-4, atol=1e-2)
         assert float((g2.float() - w2.float()).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("B,hw,cin,cout,split,silu,conv", [(5, 8, 128, 1280, 4, True, True), (5, 16, 64, 1280, 2, True, True), (5, 16, 64, 640, 3, False, True),
+                                                           (2, 32, 128, 640, 2, True, True), (3, 8, 64, 128, 2, True, True), (5, 16, 320, 1280, 5, False, False),
+                                                           (1, 8, 64, 2560, 2, True, True)])
+def test_groupnorm_applied_by_the_split_k_reduction(B, hw, cin, cout, split, silu, conv):
+    """asd_gemm_args.gn_apply: a split-K launch whose only consumer is GroupNorm(32)(+SiLU) lets its reduction kernel own whole
+    (batch element, group) blocks — it stores C, takes the statistics of the stored values and writes the normalised tensor in the same
+    launch.  C must be bit-identical to the plain split-K launch, y must equal GroupNorm of that C (the stand-alone kernels and the
+    torch fp32 op), the statistics the sums of the stored values."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    rows = hw * hw
+    bias, res = _rand(cout, seed=3), _rand(B * rows, cout, seed=4)
+    temb = _rand(B, cout, seed=9)
+    gamma, beta = (_rand(cout, seed=5) * 0.1 + 1).half(), (_rand(cout, seed=6) * 0.1).half()
+    eps = 1e-5 if silu else 1e-6
+    spec = dict(gamma=gamma, beta=beta, eps=eps, silu=silu)
+    if conv:
+        x = _rand(B, hw, hw, cin, seed=1)
+        w = H.pack_conv3x3_weight(_rand(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=2))
+        kw = dict(bias=bias, residual=res, row_bias=temb, rows_per_group=rows, tile_cfg=13, split_k=split)
+        c, y, st = H.conv3x3(x, w, gn_rows=rows, gn_apply=spec, **kw)
+        plain = H.conv3x3(x, w, **kw).view(B * rows, cout)
+    else:
+        a, w = _rand(B * rows, cin, seed=1), _rand(cout, cin, scale=cin ** -0.5, seed=2)
+        kw = dict(bias=bias, residual=res, tile_cfg=13, split_k=split)
+        c, y, st = H.gemm(a, w, gn_rows=rows, gn_apply=spec, **kw)
+        plain = H.gemm(a, w, **kw)
+    cg = cout // 32
+    if cg % 4 or (rows * (cg // 4) + 1023) // 1024 > 5:
+        assert y is None
+        pytest.skip("group width / rows outside the fused reduction's range: the caller runs its own GroupNorm")
+    assert y is not None and st is not None
+    c = c.view(B * rows, cout)
+    assert torch.equal(c, plain)
+    cv = c.view(B, rows, cout)
+    want, wstats = H.groupnorm(cv, gamma, beta, eps, silu, return_stats=True)
+    torch.testing.assert_close(st.view(-1), wstats.view(-1), rtol=2e-4, atol=1e-2)
+    assert float((y.view_as(want).float() - want.float()).abs().max()) <= 2e-3
+    ref = F.group_norm(cv.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    _close(y.view(B, rows, cout), ref, tol=4e-3)
 
 
 @pytest.mark.parametrize("B,hw,c,tile,silu", [(2, 64, 128, 11, True), (1, 64, 128, 14, True), (2, 32, 256, 8, True), (1, 32, 128, 1, False),
