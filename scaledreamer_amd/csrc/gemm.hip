@@ -1051,7 +1051,7 @@ static void asd_launch_splitk_epilogue(const asd_gemm_args* a, hipStream_t s) {
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
 struct asd_gemm_tile { int bm, bn, wm, wn, nst, kg; };   // nst: stages of the operand ring (0 = the default two); kg: k-groups (0 = one)
-#define ASD_GEMM_NCFG 26
+#define ASD_GEMM_NCFG 29
 #define ASD_GEMM_WIN0 8   // configurations >= this are the LDS-window 3x3 convolution (16x16-pixel patch x BN): 8, 9 one block per
                           // CU (double-buffered window, pipelined loop), 10, 11 two blocks per CU (conv3x3_win2_kernel)
 #define ASD_GEMM_PP0 20   // configurations 20-24: the ping-pong window convolution of gemm_pp.hip (eight waves, two per SIMD staggered by a
@@ -1068,7 +1068,11 @@ static const asd_gemm_tile asd_gemm_tiles[ASD_GEMM_NCFG] = {
     // 20-24: ping-pong window convolution: 32x16 px x 128 ch, 16x16 px x 256 / 320 / 128 / 160 ch
     {512, 128, 4, 2}, {256, 256, 4, 2}, {256, 320, 4, 2}, {256, 128, 4, 2}, {256, 160, 4, 2},
     // 25: weight-streaming 3x3 convolution of the 8x8 level (gemm_ws.hip): all <= 320 rows x 64 channels x one channel slice per block
-    {320, 64, 2, 2}};
+    {320, 64, 2, 2},
+    // 26-28: deeper operand rings for the one-block-per-CU launches of the 16x16 / 8x8 levels (K >= 1280 linears that take 13 us for 1.7 us
+    // of MFMA work: with NST - 1 tiles in flight a k-step costs 1 / (NST - 1) of an L2 / HBM round trip): 128x64 x 6 stages (144 KB),
+    // 64x64 x 8 (128 KB), 128x128 x 4 (128 KB)
+    {128, 64, 2, 2, 6, 1}, {64, 64, 2, 2, 8, 1}, {128, 128, 2, 2, 4, 1}};
 #define ASD_GEMM_WS 25
 static int asd_cfg_stages(int cfg) { return asd_gemm_tiles[cfg].nst > 2 ? asd_gemm_tiles[cfg].nst : 2; }
 static int asd_cfg_kgroups(int cfg) { return asd_gemm_tiles[cfg].kg > 1 ? asd_gemm_tiles[cfg].kg : 1; }
@@ -1441,6 +1445,9 @@ int asd_gemm_f16(const asd_gemm_args* a_in, void* stream) {
         GEMM_CASE_N(17, 64, 64, 2, 2, 2, 4);
         GEMM_CASE_N(18, 128, 64, 2, 2, 2, 2);
         GEMM_CASE_N(19, 128, 128, 2, 2, 2, 2);
+        GEMM_CASE_N(26, 128, 64, 2, 2, 6, 1);
+        GEMM_CASE_N(27, 64, 64, 2, 2, 8, 1);
+        GEMM_CASE_N(28, 128, 128, 2, 2, 4, 1);
         default: asd_set_error("bad tile configuration %d", cfg); return ASD_ERR_ARG;
     }
 #undef GEMM_CASE

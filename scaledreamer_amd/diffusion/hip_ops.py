@@ -32,8 +32,8 @@ def _p(t: Optional[torch.Tensor]):
 # split_k = 0 uses the recorded plan of the shape, else its cost model.  The winners for the shapes of the shipped configs are
 # committed in gemm_plans.json and pushed into the library when this module is imported; a shape met for the first time is tuned
 # once (a few ms, never under graph capture) unless ASD_GEMM_AUTOTUNE=0.
-TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64, 64, 128, 64, 64, 64, 64, 128, 128, 256, 320, 128, 160, 64)
-TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64, 256, 256, 64, 64, 64, 128, 128, 512, 256, 256, 256, 256, 320)
+TILE_BN = (64, 128, 64, 128, 320, 256, 320, 128, 64, 128, 64, 128, 64, 64, 128, 64, 64, 64, 64, 128, 128, 256, 320, 128, 160, 64, 64, 64, 128)
+TILE_BM = (128, 128, 256, 256, 128, 256, 256, 320, 256, 256, 256, 256, 64, 256, 256, 64, 64, 64, 128, 128, 512, 256, 256, 256, 256, 320, 128, 64, 128)
 WS_TILE = 25                             # weight-streaming 3x3 convolution of the 8x8 level (csrc/gemm_ws.hip): split_k >= 2, Cin % (32 split_k) == 0
 WINDOW_TILES = (8, 9, 10, 11, 13, 14, 20, 21, 22, 23, 24)   # LDS-window 3x3 convolution (16x16-pixel patch x 64 / 128 channels); 10, 11: two blocks per CU; 13, 14: + four-wave form
 PP_TILES = (20, 21, 22, 23, 24)          # ping-pong window convolution (csrc/gemm_pp.hip): whole N tiles, image rows % (TILE_BM / 16) == 0

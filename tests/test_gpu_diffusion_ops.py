@@ -99,7 +99,7 @@ def test_upsample_conv_parity_form(B, hw, cin, cout, tile, sk):
     assert float((got.float() - nine.float()).abs().max()) <= 4e-3 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("tile", list(range(25)))      # 25 (weight streaming, 8x8 images only) has its own test below
+@pytest.mark.parametrize("tile", list(range(25)) + [26, 27, 28])      # 25 (weight streaming, 8x8 images only) has its own test below
 @pytest.mark.parametrize("B,HW,Cin,Cout,sk", [(2, 32, 128, 320, 1), (1, 16, 320, 256, 2), (3, 48, 64, 640, 1), (2, 64, 96, 128, 1), (1, 32, 160, 640, 5),
                                               (1, 64, 32, 128, 1)])
 def test_every_tile_configuration_computes_the_same_convolution(tile, B, HW, Cin, Cout, sk):
