@@ -1030,6 +1030,10 @@ static int asd_gemm_gn_apply_nv(const asd_gemm_args* a) {
     if (a->gn_cg < 4 || a->gn_cg % 4 || a->N != 32 * a->gn_cg || a->gn_rows < 1 || a->M % a->gn_rows || a->ldc % 4) return 0;
     if (a->conv && a->upsample == 3) return 0;      // parity-major row order
     const int need = (a->gn_rows * (a->gn_cg / 4) + GNA_THREADS - 1) / GNA_THREADS;
+    // rows x group of 1024 x 20 and more (the 32x32 level) stay on the records path: 160 blocks of that size took 32 us where the records
+    // epilogue + apply launch take ~20 (gpurun_out/r6m_on/step_breakdown.txt: 9 launches, 0.29 ms)
+    static const int max_nv = getenv("ASD_GNAPPLY_MAX_NV") ? atoi(getenv("ASD_GNAPPLY_MAX_NV")) : 3;
+    if (need > max_nv) return 0;
     return need <= 1 ? 1 : need <= 3 ? 3 : need <= ASD_GNAPPLY_MAX_NV ? ASD_GNAPPLY_MAX_NV : 0;
 }
 

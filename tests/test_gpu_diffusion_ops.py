@@ -376,7 +376,7 @@ def test_groupnorm_applied_by_the_split_k_reduction(B, hw, cin, cout, split, sil
         c, y, st = H.gemm(a, w, gn_rows=rows, gn_apply=spec, **kw)
         plain = H.gemm(a, w, **kw)
     cg = cout // 32
-    if cg % 4 or (rows * (cg // 4) + 1023) // 1024 > 5:
+    if cg % 4 or (rows * (cg // 4) + 1023) // 1024 > 3:
         assert y is None
         pytest.skip("group width / rows outside the fused reduction's range: the caller runs its own GroupNorm")
     assert y is not None and st is not None
