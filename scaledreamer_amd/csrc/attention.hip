@@ -47,6 +47,9 @@ __device__ __forceinline__ float rows_sum(float v) {
 }
 
 #define HD 64      // head dim
+#ifndef ATTN_DEFER_LOG2
+#define ATTN_DEFER_LOG2 8.0f   // 0: rescale whenever a maximum moves (the first form)
+#endif
 #define KT 64      // keys per tile
 // queries per wave = 16 * QS, per block = 64 * QS (4 waves).  QS = 2: 128 registers, four waves per SIMD.  QS = 4 (self-attention
 // over >= 2048 keys): every K / V^T fragment read from LDS and every tile brought from L2 serves twice the MFMAs, half the barriers
@@ -180,8 +183,14 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
             const float a4 = max3f(s[3][qs][0], s[3][qs][1], s[3][qs][2]);
             float mx = max3f(max3f(a0, a1, a2), max3f(a3, a4, s[3][qs][3]), -3.0e38f);
             mx = rows_max(mx);                                       // over the 4 lane groups that share this query column
-            const float m_new = max3f(m_run[qs], mx * sl2, -3.0e38f);   // running max of scale*log2e*s (scale > 0)
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
+            // Deferred running maximum (cdna_hip_programming.md T13): while no query's tile maximum exceeds its running maximum by more than
+            // DEFER (log2 domain: P <= 2^DEFER = 256, exact in fp16's range and precision), the old maximum stays and nothing is rescaled —
+            // on random data the accumulator rescale then runs on the first tiles only.  All of this tile's P and its row sum use the
+            // maximum decided HERE, before any of them is formed, and the previous tile's P V has completed (loop order).
+            const float cand = mx * sl2;
+            const bool grow = __builtin_amdgcn_ballot_w64(cand > m_run[qs] + ATTN_DEFER_LOG2) != 0;     // wave-uniform
+            const float m_new = grow ? max3f(m_run[qs], cand, -3.0e38f) : m_run[qs];
+            const float alpha = grow ? __builtin_amdgcn_exp2f(m_run[qs] - m_new) : 1.f;
             const float2_ sl2v = {sl2, sl2}, nm = {-m_new, -m_new};
             float2_ sum2 = {0.f, 0.f};
 #pragma unroll
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
             }
             const float sum = rows_sum(sum2[0] + sum2[1]);
             l_run[qs] = l_run[qs] * alpha + sum;
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {   // wave-uniform: some query's max moved
+            if (grow) {   // wave-uniform: some query's maximum moved by more than the deferral
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     oacc[qs][dt][0] *= alpha; oacc[qs][dt][1] *= alpha; oacc[qs][dt][2] *= alpha; oacc[qs][dt][3] *= alpha;

@@ -209,6 +209,38 @@ def test_attention(B, heads, lq, lk, lk_stride):
     _close(got, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("lq,lk,wide", [(4096, 4096, True), (512, 1024, False)])
+def test_attention_running_maximum_that_grows_late_and_by_every_amount(lq, lk, wide):
+    """The kernel defers the running maximum (no accumulator rescale while no query's tile maximum exceeds its running maximum by more than
+    2^8 in the exponent's log2 domain).  The branch is data dependent, so it is forced: chosen keys are made to score far above (spikes of
+    +3 ... +60 in the logit, planted at key tiles 1, 5 and the last one), just below and just above the deferral, against individual queries
+    and against whole query blocks — every path (defer, grow, grow after defer, spike in the last tile) against torch's fp32 attention."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    B, heads = 2, 3
+    C_ = heads * 64
+    q = _rand(B * lq, C_, seed=31).float()
+    k = _rand(B * lk, C_, seed=32).float()
+    v = _rand(B * lk, C_, seed=33)
+    kv = k.view(B, lk, heads, 64)
+    qv = q.view(B, lq, heads, 64)
+    g = torch.Generator().manual_seed(5)
+    for key, boost in ((70, 3.0), (64 * 5 + 3, 9.0), (64 * 5 + 40, 20.0), (lk - 2, 60.0), (lk - 1, 7.9), (lk // 2, 8.1)):
+        # make key `key` point along a few queries: q . k / 8 grows by about `boost` for them
+        rows = torch.randint(0, lq, (5,), generator=g).tolist() + list(range(128, 128 + 64))
+        for b in range(B):
+            for h in range(heads):
+                qq = qv[b, rows, h].mean(0)
+                kv[b, key, h] = kv[b, key, h] + qq / qq.norm() ** 2 * 8.0 * boost * (1.0 if (b + h) % 2 == 0 else 0.5)
+    qh, kh = q.half(), k.half()
+    got = H.attention(qh, kh, v.t().contiguous(), B, heads, lq, lk, lk)
+    qf = qh.float().view(B, lq, heads, 64).transpose(1, 2)
+    kf = kh.float().view(B, lk, heads, 64).transpose(1, 2)
+    vf = v.float().view(B, lk, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(B * lq, C_)
+    _close(got, ref, tol=3e-3)
+
+
 @pytest.mark.parametrize("rows,cols", [(64, 4096), (33, 1024), (7, 8192), (5, 264)])
 def test_softmax_and_its_gradient(rows, cols):
     from scaledreamer_amd.diffusion import hip_ops as H
