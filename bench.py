@@ -126,12 +126,21 @@ def to_device(batch, dev):
 
 
 # the kernel with the largest share of GPU time in the committed rocprofv3 summary of `python bench.py` (first row of
-# profiles/r05_kernel_stats.csv) and inside the timed steps (profiles/r05_step_breakdown.txt)
-DOMINANT = "pp_conv"
-DOMINANT_SOURCE = ("profiles/r05_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row conv3x3_pp_kernel<4,4>; inside the timed "
-                   "steps (profiles/r05_step_breakdown.txt) it is first too (24 launches on seven shapes, all in the VAE encoder's forward and input-gradient "
-                   "pass), then gemm_f16_kernel<256,64>, attention, and the hash-grid gradient (`roofline_field_bwd`: field_bwd_sample_kernel + the paged "
-                   "scatter of csrc/field_paged.hip)")
+# profiles/r06_kernel_stats.csv) and inside the timed steps (profiles/r06_step_breakdown.txt).  Round 6: the cold re-tune of the plan table
+# moved seven of the VAE's 24 ping-pong launches to other window kernels, so gemm_f16_kernel<256,64> (the 64x64 / 32x32 levels' linears)
+# now leads both tables; the ping-pong convolution keeps its own line (`roofline_pp_conv`).
+DOMINANT = "gemm256"
+DOMINANT_SOURCE = ("profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row gemm_f16_kernel<256,64,4,2> (10.1 % of the "
+                   "run, 26.5 us average); inside the timed steps (profiles/r06_step_breakdown.txt) it is first too (55 launches on 15 shapes: the linears of the "
+                   "UNet's 64x64 and 32x32 transformer blocks, 1.46 ms of each step), then conv3x3_pp_kernel<4,4> (17 launches, 1.21 ms: `roofline_pp_conv`), "
+                   "attention, and the hash-grid gradient (`roofline_field_bwd`)")
+
+# every launch of gemm_f16_kernel<256,64,4,2> (plain GEMM) in one step (tools/gemm_shapes.py trace, gpurun_out/gemm_order.txt of the round-6 tree):
+# (M, N, K, act [2 = fused GEGLU: output N / 2 columns], residual, GroupNorm records in the epilogue, launches per step)
+GEMM256_LAUNCHES = [(20480, 320, 320, 0, 0, 0, 9), (20480, 320, 320, 0, 1, 0, 9), (20480, 2560, 320, 2, 0, 0, 5), (20480, 320, 1280, 0, 1, 0, 5),
+                    (20480, 320, 320, 0, 1, 1, 5), (5120, 1280, 640, 0, 0, 0, 5), (5120, 5120, 640, 2, 0, 0, 5), (20480, 640, 320, 0, 0, 0, 4),
+                    (20480, 320, 640, 0, 0, 0, 2), (65536, 256, 128, 0, 0, 0, 1), (16384, 512, 256, 0, 0, 0, 1), (400, 12480, 1024, 0, 0, 0, 1),
+                    (320, 8192, 320, 0, 0, 0, 1), (20480, 320, 960, 0, 0, 0, 1), (65536, 128, 256, 0, 1, 0, 1)]
 
 # every launch of conv3x3_pp_kernel<4,4> in one step (tools/gemm_shapes.py trace of the step, gpurun_out/gemm_shapes.txt): (H = W, Cin, Cout,
 # residual, GroupNorm records in the epilogue: 0 none (the input-gradient launches) / 1 forward statistics / 2 the backward reductions of the
@@ -139,12 +148,12 @@ DOMINANT_SOURCE = ("profiles/r05_kernel_stats.csv (rocprofv3 --kernel-trace --st
 PP44_LAUNCHES = [(512, 128, 128, 0, 0, 4), (512, 128, 128, 1, 1, 2), (512, 128, 128, 0, 1, 2), (128, 512, 512, 0, 0, 3), (128, 512, 512, 1, 1, 2),
                  (128, 512, 512, 0, 1, 1), (256, 256, 256, 0, 0, 3), (256, 256, 256, 1, 1, 2), (256, 256, 256, 0, 1, 1), (128, 256, 512, 0, 1, 1),
                  (256, 128, 256, 0, 1, 1), (256, 256, 128, 0, 0, 1), (512, 32, 128, 0, 1, 1)]
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def pmc_traffic_of(*kernel_substrs: str):
     """HBM bytes per launch of a kernel (or the sum over several kernels that form one span) from the COMMITTED per-kernel PMC summaries of this
-    round (profiles/r05_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate rocprofv3 --pmc passes of `python bench.py`, tools/r5_pmc.sh; FETCH_SIZE
+    round (profiles/r06_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate rocprofv3 --pmc passes of `python bench.py`, tools/r6_pmc.sh; FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950) — read at run time, so the figure follows the profile committed next to
     the code; None when a kernel is missing from either file (no fall-back to an older round)."""
     import csv
@@ -229,11 +238,72 @@ def roofline_pp_kernel(reps: int = 3):
                       "step epilogue", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
             "traffic": pmc_traffic_of("conv3x3_pp_kernel<4, 4>"),
-            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r05_pmc_*_per_kernel.csv at run time)",
+            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r06_pmc_*_per_kernel.csv at run time)",
             "operands": "HBM-cold: >= 600 MB of distinct operand sets rotated per shape (as inside the step)",
             "launches_per_step": int(launches), "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": alg_bytes / launches,
             "avg_launch_ms": round(secs / launches * 1e3, 4), "ms_per_step": round(secs * 1e3, 3),
             "shapes_not_on_this_kernel_under_the_loaded_plans": skipped}
+
+
+def roofline_gemm256_kernel(reps: int = 3):
+    """gemm_f16_kernel<256,64,4,2> (csrc/gemm.hip) over ALL its 55 launches of one step, each with the epilogue it has in the step (bias,
+    residual, fused GEGLU, GroupNorm records), back to back between HIP events with HBM-cold operands (>= 600 MB of distinct sets rotated per
+    shape).  These are the K <= 1280 linears of the 64x64 / 32x32 transformer blocks: A + W + C (+ residual) once through HBM bounds them
+    (sum of bytes / 8 TB/s = 283 us per step against sum of flops / 2.5 PF/s = 255 us), so achieved = algorithmic bytes / summed duration;
+    avg_launch_ms is what the rocprofv3 summary's average for this kernel has to agree with."""
+    from scaledreamer_amd.diffusion import hip_ops as H
+
+    bytes_ = flops = secs = launches = 0.0
+    for M, N, K, act, res, gn, count in GEMM256_LAUNCHES:
+        n_out = N // 2 if act == 2 else N
+        set_bytes = 2.0 * (M * K + N * K + M * n_out * (1 + res))
+        nsets = int(min(24, max(2, -(-600e6 // set_bytes))))
+        sets = []
+        for _ in range(nsets):
+            a = torch.randn(M, K, device="cuda").half()
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+            b = torch.randn(N, device="cuda").half()
+            if act == 2:
+                w, b = H.pack_geglu_weight(w, b)
+            kw = dict(bias=b, act=act, tile_cfg=3, split_k=1)
+            if res:
+                kw["residual"] = torch.randn(M, n_out, device="cuda").half()
+            if gn:
+                kw["gn_rows"] = 4096
+            sets.append((a, w.contiguous(), kw))
+        for a, w, kw in sets[:2]:
+            H.gemm(a, w, **kw)
+        torch.cuda.synchronize()
+        # GPU-paced: these launches are shorter than the host side of an eager call, so the pass over the operand sets is captured into a HIP
+        # graph and the replay is timed (events on the stream the graph is launched on)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(reps * count):
+                a, w, kw = sets[i % nsets]
+                H.gemm(a, w, **kw)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        secs += e0.elapsed_time(e1) * 1e-3 / reps
+        del g
+        bytes_ += count * set_bytes
+        flops += count * 2.0 * M * N * K
+        launches += count
+        del sets
+    achieved = bytes_ / secs / 1e9
+    return {"kernel": "gemm_f16_kernel<256,64,4,2> (csrc/gemm.hip: 256 x 64 tile, eight waves, LDS-DMA operand tiles, two stages; bias / residual / fused GEGLU / "
+                      "GroupNorm-records epilogues); all its 55 launches of one step — the linears of the UNet's 64x64 and 32x32 transformer blocks (proj_in / "
+                      "proj_out, q|k, q, attention output projections, GEGLU projection, ff.net.2) — each with its step epilogue",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic_of("gemm_f16_kernel<256, 64, 4, 2, false, 2, 1, false>"),
+            "traffic_unit": "bytes/launch, average over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, read from profiles/r06_pmc_*_per_kernel.csv at run time)",
+            "operands": "HBM-cold: >= 600 MB of distinct operand sets rotated per shape (as inside the step)",
+            "launches_per_step": int(launches), "algorithmic_bytes_per_launch": bytes_ / launches, "flops_per_launch": flops / launches,
+            "mfma_floor_fraction": round(flops / 2.5e15 / secs, 4),
+            "avg_launch_ms": round(secs / launches * 1e3, 4), "ms_per_step": round(secs * 1e3, 3)}
 
 
 def roofline_conv3d(reps: int = 6):
@@ -428,7 +498,7 @@ def roofline_field_bwd(system, batch, reps: int = 10):
                       "per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None if traffic is None else round(traffic),
-            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/r05_pmc_*_per_kernel.csv)",
+            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/r06_pmc_*_per_kernel.csv)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
             "binding_limit": "inside the span: the sample kernel (arithmetic + ~3.5 M coarse-level atomic requests), then the item stream of the paged scatter "
@@ -691,6 +761,7 @@ def main():
         lines = {"gemm": roofline_gemm_kernel(), "vae_conv": roofline_conv_kernel("vae512"), "unet_conv": roofline_conv_kernel("unet64")}
         if args.workload == "asd_sd_nerf":
             lines["pp_conv"] = roofline_pp_kernel()
+            lines["gemm256"] = roofline_gemm256_kernel()
         if args.workload in ("asd_sd_nerf", "asd_mv_nerf"):
             lines["field_bwd"] = roofline_field_bwd(system, batch, reps=5)
             lines["renderer"] = roofline_field_kernel(system, batch)

@@ -937,6 +937,18 @@ const void* tx_zero_page() {
 // Zeroed counter words (absmax / column-max cells, the cells atomics add into).  Stand-alone entry points clear their own cells with a
 // memset; inside asd_tritx_fwd / _bwd ONE memset at the start of the pass clears a pool the ~25 entries per layer then carve up
 // (281 memset launches per step otherwise: 1.3 ms of GPU time and as many launch boundaries).
+// Zero fill as a KERNEL: inside asd_tritx_fwd / _bwd the passes are captured into HIP graphs (generators._TritxBuffers), and a captured
+// hipMemsetAsync node did not survive a second replay on ROCm 7.2 (first replay correct, every later one left NaNs behind it:
+// tools/tritx_graph_check.py, round 6); a fill kernel replays like every other launch of the pass.
+__global__ __launch_bounds__(256) void tx_fill_zero_kernel(unsigned* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline void tx_memset0(void* p, size_t bytes, hipStream_t s) {
+    const size_t words = (bytes + 3) / 4;
+    if (words == 0) return;
+    const unsigned blocks = (unsigned)((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256);
+    hipLaunchKernelGGL(tx_fill_zero_kernel, dim3(blocks), dim3(256), 0, s, (unsigned*)p, words);
+}
 struct TxPool { unsigned* p; size_t left; bool outputs_zeroed; };
 thread_local TxPool tx_pool = {nullptr, 0, false};
 unsigned* tx_zeroed(unsigned* own, size_t words, hipStream_t s) {
@@ -946,7 +958,7 @@ unsigned* tx_zeroed(unsigned* own, size_t words, hipStream_t s) {
         tx_pool.p += w; tx_pool.left -= w;
         return r;
     }
-    (void)hipMemsetAsync(own, 0, words * 4, s);
+    tx_memset0(own, words * 4, s);
     return own;
 }
 
@@ -1075,7 +1087,7 @@ static int tx_wgrad_core(const float* dy, int32_t ldy, const float* x, int32_t l
     float* c32 = p;
     cmax_a = tx_zeroed(cmax_a, (size_t)(tx_al(N) + tx_al(K)), s);
     unsigned* cmax_w = cmax_a + tx_al(N);
-    if (db && !tx_pool.outputs_zeroed && !accumulate) (void)hipMemsetAsync(db, 0, (size_t)N * 4, s);
+    if (db && !tx_pool.outputs_zeroed && !accumulate) tx_memset0(db, (size_t)N * 4, s);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(N, 64), asd_div_up(M, 256)), dim3(256), 0, s, dy, M, N, ldy, 256, cmax_a, db);
     hipLaunchKernelGGL((tx_split_cols_kernel<0>), dim3(asd_div_up(N, 64), Mp / 64), dim3(256), 0, s, dy, M, N, ldy, Mp, cmax_a, pa, ia);
     if (!x_planes) {
@@ -1408,7 +1420,7 @@ int asd_tritx_pack(const asd_tritx_desc* desc, const float* const* params, float
     // the column split of V, its plane for dx = dy W the row split of V
     const float* V = params[20 * d.layers + 3];
     unsigned* colmax = reinterpret_cast<unsigned*>(cws);
-    (void)hipMemsetAsync(colmax, 0, (size_t)d.O * 4, s);
+    tx_memset0(colmax, (size_t)d.O * 4, s);
     hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(d.O, 64), asd_div_up(d.D, 256)), dim3(256), 0, s, V, d.D, d.O, d.O, 256, colmax, (float*)nullptr);
     hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(d.O, 64), tx_rp(d.D) / 64), dim3(256), 0, s, V, d.D, d.O, d.O, tx_rp(d.D), colmax,
                        reinterpret_cast<h16*>(packed + hd.dc_w), packed + hd.dc_iw);
@@ -1432,7 +1444,7 @@ int asd_tritx_fwd(const asd_tritx_desc* desc, const float* const* params, const 
     struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
     unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
     for (int n = 0; n < batch; ++n) {
-        (void)hipMemsetAsync(pool, 0, (size_t)tx_pool_words(d) * 4, s);
+        tx_memset0(pool, (size_t)tx_pool_words(d) * 4, s);
         tx_pool = {pool, (size_t)tx_pool_words(d), false};
         float* sv = save + (int64_t)n * tx_save_per_sample(d);
         const float* cond = text_embed + (int64_t)n * d.Tc * d.Dc;
@@ -1505,10 +1517,10 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     if (!desc->grads_prezeroed) {
         for (int l = 0; l < d.layers; ++l) {
             float* const* G = grads + 17 * l;
-            for (int q : {0, 1, 6, 7, 11, 12}) (void)hipMemsetAsync(G[q], 0, (size_t)d.D * 4, s);
+            for (int q : {0, 1, 6, 7, 11, 12}) tx_memset0(G[q], (size_t)d.D * 4, s);
         }
-        (void)hipMemsetAsync(GH[1], 0, (size_t)d.D * 4, s);
-        (void)hipMemsetAsync(GH[2], 0, (size_t)d.D * 4, s);
+        tx_memset0(GH[1], (size_t)d.D * 4, s);
+        tx_memset0(GH[2], (size_t)d.D * 4, s);
     }
     struct PoolGuard { ~PoolGuard() { tx_pool = {nullptr, 0, false}; } } pool_guard;
     unsigned* pool = reinterpret_cast<unsigned*>(ws + (asd_tritx_workspace_floats(desc) - tx_pool_words(d) - 256));
@@ -1523,7 +1535,7 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
     };
     for (int n = 0; n < batch; ++n) {
         const bool acc = n > 0;
-        (void)hipMemsetAsync(pool, 0, (size_t)tx_pool_words(d) * 4, s);
+        tx_memset0(pool, (size_t)tx_pool_words(d) * 4, s);
         // bias gradients of the first batch element land in caller-zeroed cells; later elements go through the staging buffer (own memset)
         tx_pool = {pool, (size_t)tx_pool_words(d), desc->grads_prezeroed != 0 && !acc};
         const float* sv = save + (int64_t)n * tx_save_per_sample(d);
@@ -1532,7 +1544,7 @@ int asd_tritx_bwd(const asd_tritx_desc* desc, const float* const* params, const 
         const float* stF = xf + tx_al(TD);
         const float* nF = stF + tx_al(2 * d.T);
         {   // the text tokens' transposed planes, once per batch element
-            (void)hipMemsetAsync(cond_max, 0, (size_t)d.Dc * 4, s);
+            tx_memset0(cond_max, (size_t)d.Dc * 4, s);
             hipLaunchKernelGGL(tx_colstat_kernel, dim3(asd_div_up(d.Dc, 64), asd_div_up(d.Tc, 256)), dim3(256), 0, s, cond, d.Tc, d.Dc, d.Dc, 256, cond_max, (float*)nullptr);
             hipLaunchKernelGGL((tx_split_cols_kernel<1>), dim3(asd_div_up(d.Dc, 64), tx_rp(d.Tc) / 64), dim3(256), 0, s, cond, d.Tc, d.Dc, d.Dc, tx_rp(d.Tc), cond_max, cond_planes,
                                cond_inv);

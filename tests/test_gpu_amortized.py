@@ -221,6 +221,7 @@ def test_sampled_geometry_classes_match_reference_golden(name):
                                                                          img_channels=32, channel_multiplier=1)))
     else:
         geo = find("Triplane-transformer-sdf")(dict(common, space_generator_config=dict(
+            backend="library",      # head dim 16: outside the HIP generator's family, the reference fixtures meet the torch-op restatement
             inner_dim=64, condition_dim=128, triplane_low_res=8, triplane_high_res=16, triplane_dim=32, num_layers=2, num_heads=4,
             local_text=True, mlp_ratio=4)))
     geo = geo.cuda()
@@ -286,13 +287,9 @@ def test_generator_backed_amortized_step_runs(kind):
     data = find(cfg["data_type"])(cfg["data"], rank=0, n_ranks=1)
     gen_w = next(p for n, p in system.geometry.space_generator.named_parameters() if p.ndim >= 2)
     before = gen_w.detach().clone()
-    import warnings
-
-    with warnings.catch_warnings():
-        warnings.filterwarnings("error", message=".*library-op restatement.*")      # a silent drop to library ops fails this test
-        for _ in range(2):
-            batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
-            loss = system.train_one_step(batch)
+    for _ in range(2):         # (a configuration outside the HIP generator's family raises: no silent drop to library ops)
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.collate().items()}
+        loss = system.train_one_step(batch)
     assert torch.isfinite(loss).item()
     assert (gen_w.detach() != before).any().item(), "no gradient reached the generator"
 
@@ -324,7 +321,7 @@ def _triplane_field_float64(geo, pts, cache, gs, keys):
 
 
 _SAMPLED_COMMON = {"radius": 2.0, "normal_type": "finite_difference", "finite_difference_normal_eps": 0.01, "sdf_bias": "sphere", "sdf_bias_params": 0.8}
-_TRI_GEN = dict(inner_dim=64, condition_dim=128, triplane_low_res=32, triplane_high_res=64, triplane_dim=32, num_layers=1, num_heads=4, local_text=True, mlp_ratio=4)
+_TRI_GEN = dict(backend="library", inner_dim=64, condition_dim=128, triplane_low_res=32, triplane_high_res=64, triplane_dim=32, num_layers=1, num_heads=4, local_text=True, mlp_ratio=4)
 
 
 @pytest.mark.parametrize("kind", ["voxel", "triplane"])
