@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(const asd_grid_meta m
 #endif
 #define WG_TILE 64     // rows per LDS tile
 
-template <int L, int H, int C, int ENC = 0>
+// PRE: the MLP half already ran on the matrix pipe (csrc/field_mfma.hip: asd_field_bwd_mlp_mfma wrote DA, the second-layer weight gradients and
+// the encoding gradients denc_pre[n][2 L]); this kernel then only scatters — no finite-difference rows in that form.
+template <int L, int H, int C, int ENC = 0, bool PRE = false>
 __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_kernel(
     const asd_grid_meta m, const asd_field_cfg c, const float* __restrict__ grid, const float* __restrict__ w1d,
     const float* __restrict__ w2d, const float* __restrict__ w1f, const float* __restrict__ w2f,
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
     float* __restrict__ denc_out = nullptr /* ENC == 1: [rows', 2L] gradient w.r.t. the sampled features, row' = 4 i + pt (i with no normal) */,
     float* __restrict__ pts_out = nullptr /* ENC == 1: [rows', 3] the sampled positions in grid_sample's [-1, 1] */,
     float* __restrict__ pg_g = nullptr /* paged scatter (field_paged.h): [n_pts * n, 2 (L - NAGG)] gradient w.r.t. the fine levels' features, row = pt * n + i */,
-    float* __restrict__ pg_pos = nullptr /* ... and the rows' unit-cube positions [n_pts * n, 3] */) {
+    float* __restrict__ pg_pos = nullptr /* ... and the rows' unit-cube positions [n_pts * n, 3] */,
+    const float* __restrict__ denc_pre = nullptr /* PRE: [n, 2L] */) {
     constexpr int NIN = 2 * L;
     // second-layer weight-gradient sums of the block.  ASD_FIELD_W2_COPIES > 1: no wave-level reduction — every lane adds its own
     // term with an LDS atomic into copy (lane & 15) of the accumulator (row stride W2N + 1: the 16 copies of one h sit in 16 banks, the
@@ -437,6 +440,16 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
         float denc[NIN];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) denc[k] = 0.f;
+        if constexpr (PRE) {
+            if (active) {
+                const float4* src = reinterpret_cast<const float4*>(denc_pre + (size_t)i * NIN);
+#pragma unroll
+                for (int q = 0; q < NIN / 4; ++q) {
+                    const float4 v = src[q];
+                    denc[4 * q] = v.x; denc[4 * q + 1] = v.y; denc[4 * q + 2] = v.z; denc[4 * q + 3] = v.w;
+                }
+            }
+        } else {
         float* da_row = da_out + row * (2 * H);
         // ---- density MLP: da_h = draw * w2[h] * [a_h > 0] ------------------------------------------------------
 #pragma unroll 1
@@ -512,6 +525,7 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
                     *reinterpret_cast<float4*>(da_row + H + h0) = make_float4(dav[0], dav[1], dav[2], dav[3]);
             }
         }
+        }   // !PRE
         if constexpr (ENC == 1) {
             // the scatter into the feature volume is asd_voxel_sample_bwd's (run-aggregated, request-coalesced): leave it the rows
             if (active) {
@@ -559,6 +573,7 @@ __global__ __launch_bounds__(256, ASD_FIELD_BWD_BLOCKS) void field_bwd_sample_ke
         }
         __syncthreads();
     }
+    if constexpr (PRE) return;
     for (int q = tid; q < H; q += 256) atomicAdd(&dw2d[q], w2_acc[q]);
     if (C > 0 && dw2f)
         for (int q = tid; q < C * H; q += 256) atomicAdd(&dw2f[q], w2_acc[H + q]);
@@ -818,6 +833,10 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
     for (int q = threadIdx.x; q < H * NIN; q += 256) atomicAdd(&dw0[q], w_acc[3 * H + H * H + q]);
 }
 
+int asd_field_bwd_mlp_mfma(const asd_field_cfg* cfg, const float* w1d, const float* w2d, const float* w1f, const float* w2f, const float* enc, const float* sigma,
+                           int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, float* da_out, float* denc_out, float* dw2d, float* dw2f,
+                           hipStream_t s);      // field_mfma.hip
+
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
@@ -946,7 +965,8 @@ int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_no
     //   + the paged scatter of the fine levels (field_paged.h): their feature gradients [rows, 20], positions [rows, 3], item lists
     *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 +
                 (ASD_FIELD_NPRIV > 0 ? (int64_t)ASD_PRIV_COPIES * ASD_FIELD_PRIV_CAP : 0) +
-                rows * (2 * ASD_PG_NF_PAD + 3) + asd_paged_workspace_floats(rows);
+                rows * (2 * ASD_PG_NF_PAD + 3) + asd_paged_workspace_floats(rows) +
+                (with_normal ? 0 : rows * 32);       // encoding gradients between the matrix-pipe MLP pass and the scatter (field_mfma.hip)
     return ASD_OK;
 }
 
@@ -992,6 +1012,19 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     float* pg_ws = pg_pos + rows * 3;
     const dim3 grid(asd_div_up(n, 256)), block(256);
     ASD_PROBE_START(s);
+    // the MLP half on the matrix pipe (field_mfma.hip) where there are no finite-difference rows: the headline renderer (lambda_orient = 0)
+    static const int mfma_on = getenv("ASD_FIELD_MFMA") ? atoi(getenv("ASD_FIELD_MFMA")) : 1;     // 0: the vector-pipe form (A/B partner, tools/)
+    const bool mfma = mfma_on && !with_normal && cfg->n_feature_dims == 3;
+    if (mfma) {
+        float* denc = pg_ws + asd_paged_workspace_floats(rows);
+        const int rc = asd_field_bwd_mlp_mfma(cfg, w1_density, w2_density, w1_feature, w2_feature, enc_save, sigma, n, n_dev, d_sigma, d_features, da, denc,
+                                              dw2_density, dw2_feature, s);
+        if (rc != ASD_OK) return rc;
+        hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3, 0, true>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density, w2_density,
+                           w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features, d_normal, d_fd_grad,
+                           d_grid_params, da, enc_fd, dw2_density, dw2_feature, priv, priv_stride, (float*)nullptr, (float*)nullptr,
+                           paged ? pg_g : (float*)nullptr, paged ? pg_pos : (float*)nullptr, (const float*)denc);
+    } else {
 #define ASD_FIELD_BWD_LAUNCH(C_)                                                                                                     \
     hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, C_>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density, w2_density,  \
                        w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features, d_normal, d_fd_grad,        \
@@ -999,6 +1032,7 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
                        paged ? pg_g : (float*)nullptr, paged ? pg_pos : (float*)nullptr)
     if (cfg->n_feature_dims == 3) ASD_FIELD_BWD_LAUNCH(3); else ASD_FIELD_BWD_LAUNCH(0);
 #undef ASD_FIELD_BWD_LAUNCH
+    }
     if (priv_stride > 0)
         hipLaunchKernelGGL(asd_priv_reduce_kernel, dim3(asd_div_up(priv_stride / 4, 256)), block, 0, s, priv, priv_stride, priv_stride,
                            d_grid_params);
