@@ -835,7 +835,8 @@ __global__ __launch_bounds__(256) void envmap_bwd_kernel(const asd_grid_meta m, 
 
 int asd_field_bwd_mlp_mfma(const asd_field_cfg* cfg, const float* w1d, const float* w2d, const float* w1f, const float* w2f, const float* enc, const float* sigma,
                            int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, float* da_out, float* denc_out, float* dw2d, float* dw2f,
-                           hipStream_t s);      // field_mfma.hip
+                           float* dw1_slabs, hipStream_t s);      // field_mfma.hip
+int asd_field_bwd_mlp_mfma_blocks(int32_t n);
 
 // ---------------------------------------------------------------------------------------------------
 // C ABI
@@ -959,7 +960,8 @@ int asd_field_fwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
 int asd_field_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats) {
     ASD_CHECK_ARG(cfg && n_floats && n >= 0, "bad argument");
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
-    const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    if (!with_normal && chunks < 4 * 512) chunks = 4 * 512;      // the matrix-pipe MLP pass leaves one weight-gradient slab per wave (field_mfma.hip)
     // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs [chunks, 128*32]
     //   + the per-XCD copies of the gradient of the ASD_FIELD_NPRIV coarsest levels (ASD_FIELD_PRIV_CAP floats each)
     //   + the paged scatter of the fine levels (field_paged.h): their feature gradients [rows, 20], positions [rows, 3], item lists
@@ -986,7 +988,9 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     hipStream_t s = (hipStream_t)stream;
     const int with_normal = d_normal != nullptr || d_fd_grad != nullptr;
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
-    const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    const int wg_chunks = chunks;                                   // slabs field_wgrad_kernel writes
+    if (!with_normal && chunks < 4 * 512) chunks = 4 * 512;         // (the layout of asd_field_bwd_workspace)
     float* da = workspace;
     float* enc_fd = with_normal ? da + rows * 128 : nullptr;
     float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);
@@ -1013,12 +1017,14 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
     const dim3 grid(asd_div_up(n, 256)), block(256);
     ASD_PROBE_START(s);
     // the MLP half on the matrix pipe (field_mfma.hip) where there are no finite-difference rows: the headline renderer (lambda_orient = 0)
-    static const int mfma_on = getenv("ASD_FIELD_MFMA") ? atoi(getenv("ASD_FIELD_MFMA")) : 1;     // 0: the vector-pipe form (A/B partner, tools/)
+    static const int mfma_on = getenv("ASD_FIELD_MFMA") ? atoi(getenv("ASD_FIELD_MFMA")) : 2;     // 0: the vector-pipe form (A/B partner, tools/)
     const bool mfma = mfma_on && !with_normal && cfg->n_feature_dims == 3;
+    // ... and the first-layer weight gradient in the same pass (=2: no DA rows, no field_wgrad_kernel; 1: DA + field_wgrad_kernel, the A/B partner)
+    const bool mfma_wg = mfma && mfma_on >= 2;
     if (mfma) {
         float* denc = pg_ws + asd_paged_workspace_floats(rows);
         const int rc = asd_field_bwd_mlp_mfma(cfg, w1_density, w2_density, w1_feature, w2_feature, enc_save, sigma, n, n_dev, d_sigma, d_features, da, denc,
-                                              dw2_density, dw2_feature, s);
+                                              dw2_density, dw2_feature, mfma_wg ? slabs : nullptr, s);
         if (rc != ASD_OK) return rc;
         hipLaunchKernelGGL((field_bwd_sample_kernel<16, 64, 3, 0, true>), grid, block, 0, s, *meta, *cfg, grid_params, w1_density, w2_density,
                            w1_feature, w2_feature, points, enc_save, sigma, n, n_dev, d_sigma, d_features, d_normal, d_fd_grad,
@@ -1041,14 +1047,15 @@ int asd_field_bwd(const asd_grid_meta* meta, const asd_field_cfg* cfg, const flo
         if (rc != ASD_OK) return rc;
     }
     ASD_PROBE_STOP(s);
-    hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n,
-                       slabs);
-    // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks
+    int n_slabs = wg_chunks;
     const int* live = (n_dev && rows == (int64_t)n) ? n_dev : nullptr;      // every slab row is a centre row: dead chunks are skipped
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, chunks, 128 * 32, 64 * 32,
+    if (mfma_wg) { n_slabs = asd_field_bwd_mlp_mfma_blocks(n); live = nullptr; }      // one slab per block of the MLP pass, all of them written
+    else hipLaunchKernelGGL((field_wgrad_kernel<128, 32>), dim3(wg_chunks), block, 0, s, da, enc_save, enc_fd, n, (int)rows, n_dev, n, slabs);
+    // slab layout [h < 64: density | h >= 64: feature][k]; both halves are contiguous H*32 blocks
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs, n_slabs, 128 * 32, 64 * 32,
                        dw1_density, live, WG_ROWS);
     if (cfg->n_feature_dims == 3)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, chunks, 128 * 32,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(asd_div_up(64 * 32, 32)), dim3(1024), 0, s, slabs + 64 * 32, n_slabs, 128 * 32,
                            64 * 32, dw1_feature, live, WG_ROWS);
     ASD_LAUNCH_CHECK();
     return ASD_OK;
@@ -1088,7 +1095,8 @@ int asd_voxfield_fwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int
 int asd_voxfield_bwd_workspace(const asd_field_cfg* cfg, int32_t n, int32_t with_normal, int64_t* n_floats) {
     ASD_CHECK_ARG(cfg && n_floats && n >= 0, "bad argument");
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
-    const int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    int64_t chunks = (rows + WG_ROWS - 1) / WG_ROWS;
+    if (!with_normal && chunks < 4 * 512) chunks = 4 * 512;      // the matrix-pipe MLP pass leaves one weight-gradient slab per wave (field_mfma.hip)
     // DA [rows, 128] + finite-difference encodings [3n, 32] + wgrad slabs + feature-gradient rows [rows, 32] + their positions [rows, 3]
     *n_floats = rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0) + chunks * 128 * 32 + 64 + rows * 32 + rows * 3 + 16;
     return ASD_OK;
@@ -1106,7 +1114,9 @@ int asd_voxfield_bwd(const float* voxel_cl, int32_t D, int32_t H, int32_t W, int
     hipStream_t s = (hipStream_t)stream;
     const int with_normal = d_normal != nullptr || d_fd_grad != nullptr;
     const int64_t rows = (int64_t)n * (with_normal ? 4 : 1);
-    const int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    int chunks = (int)((rows + WG_ROWS - 1) / WG_ROWS);
+    const int wg_chunks = chunks;                                   // slabs field_wgrad_kernel writes
+    if (!with_normal && chunks < 4 * 512) chunks = 4 * 512;         // (the layout of asd_field_bwd_workspace)
     float* da = workspace;
     float* enc_fd = with_normal ? da + rows * 128 : nullptr;
     float* slabs = da + rows * 128 + (with_normal ? (int64_t)3 * n * 32 : 0);

@@ -77,18 +77,28 @@ struct FmArgs {
     float* denc_out;             // [n][32]
     float* dw2d;                 // [64]   +=
     float* dw2f;                 // [3][64] +=
+    float* dw1_slabs;            // WG: [gridDim][2][64][32]
 };
 
-__global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs a) {
+template <bool WG>
+__global__ __launch_bounds__(256, WG ? 1 : 2) void field_bwd_mlp_mfma_kernel(const FmArgs a) {
     __shared__ float w1s[2][FM_H][FM_K];          // 16 KB: fp32 weights (the transposed fragments are gathered from here)
     __shared__ float w2s[4][FM_H];                // w2d, w2f[0..2]
     __shared__ float gs[4][4][64];                // per wave: g_o[s] * inv scale of E (o = 0: draw, 1..3: df) for the Z pass
     __shared__ float red[4][4][FM_H];             // per wave: second-layer weight-gradient sums
     __shared__ fm_h8 frag[16][2][64];             // weight fragments (hi, lo), lane-linear
+    __shared__ float gp[WG ? 4 : 1][4][64];       // WG: per wave, the plain g_o[s]
+    __shared__ unsigned mb[WG ? 4 : 1][64][2];    // WG: per wave, every sample's 64-bit ReLU mask of the current head
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int nn = a.n_dev ? min(*a.n_dev, a.n) : a.n;
-    if ((int)blockIdx.x * 256 >= nn) return;      // capacity-sized launch: nothing lives in this block
+    if ((int)blockIdx.x * 256 >= nn) {             // capacity-sized launch: nothing lives in this block (its first tiles would be empty)
+        if constexpr (WG) {                        // ... but the slab reduction sums every wave's slab
+            float* slab = a.dw1_slabs + (size_t)blockIdx.x * (2 * FM_H * FM_K);
+            for (int q = tid; q < 2 * FM_H * FM_K; q += 256) slab[q] = 0.f;
+        }
+        return;
+    }
     for (int q = tid; q < 2 * FM_H * FM_K; q += 256) (&w1s[0][0][0])[q] = a.w1[q / (FM_H * FM_K)][q % (FM_H * FM_K)];
     if (tid < FM_H) w2s[0][tid] = a.w2d[tid];
     else if (tid < 4 * FM_H) w2s[tid / FM_H][tid % FM_H] = a.w2f[tid - FM_H];
@@ -127,12 +137,20 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
 #define WT_H(hd, mt, t) frag[((1 * 2 + (hd)) * 2 + (mt)) * 2 + (t)][0][lane]
 #define WT_L(hd, mt, t) frag[((1 * 2 + (hd)) * 2 + (mt)) * 2 + (t)][1][lane]
 
+    float dw1a[2][16], dw1b[2][16];      // WG: first-layer weight gradients of the wave's tiles, [ht][4 q + r] = dW1[32 ht + l31][8 q + 4 half + r] (density / feature)
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw1a[ht][r] = dw1b[ht][r] = 0.f;
     float dw2[4][2];           // [o][ht]: lanes < 32 after the half sum: hidden unit 32 ht + l31
 #pragma unroll
     for (int o = 0; o < 4; ++o) dw2[o][0] = dw2[o][1] = 0.f;
 
-    const int tile = (int)blockIdx.x * 4 + wave;
-    {
+    // a wave walks tiles of 64 samples: the staging of the weights and the fragment images (~25 KB of LDS traffic and a block barrier) is paid once
+    // per block, not once per 256 samples
+    const int n_tiles = (nn + 63) >> 6;
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int)gridDim.x * 4) {
         const int s0 = tile * 64;                 // first sample of the wave's tile
         // ---- the tile's encodings as fragments: ef[nt][ks]: sample 32 nt + l31, k = 16 ks + 8 half + j ------------------------------------
         fm_h8 efh[2][2], efl[2][2];
@@ -180,6 +198,10 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
             if (half == 0) {                       // for the Z pass: rows are samples, so every lane needs every sample's g (already divided by the scales)
 #pragma unroll
                 for (int o = 0; o < 4; ++o) gs[wave][o][32 * nt + l31] = g[nt][o] / (se[nt] * sw[o == 0 ? 0 : 1]);
+                if constexpr (WG) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) gp[wave][o][32 * nt + l31] = g[nt][o];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();           // gs is private to the wave: its LDS operations complete in order, the compiler must not reorder them
@@ -189,40 +211,40 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dencT[nt][r] = 0.f;
+        // WG: E^T fragments for the first-layer weight gradient dW1^T = E^T dA (contraction over the tile's samples: ONE scale for the tile).
+        // et[st][tp]: row k = l31 (encoding index), slot j <-> sample 32 st + 8 (2 tp + j / 4) + 4 half + j % 4 — the order in which a lane's
+        // accumulator registers of Z hold their samples; for a fixed j the 32 lanes of a half read one sample's 128-byte row.
+        fm_h8 eth[WG ? 2 : 1][2], etl[WG ? 2 : 1][2];
+        float sT = 1.f;
+        if constexpr (WG) {
+            float x[2][2][8];
+            float amax = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = s0 + 32 * st + 8 * (2 * tp + j / 4) + 4 * half + (j & 3);
+                        const float v = i < nn ? a.enc[(size_t)i * FM_K + l31] : 0.f;
+                        x[st][tp][j] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            sT = fm_pow2_scale(amax);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) fm_split8(x[st][tp], sT, eth[st][tp], etl[st][tp]);
+        }
 
 #pragma unroll 1                    // (one head at a time: both heads unrolled side by side need more than the 512 registers of a lone wave)
         for (int hd = 0; hd < 2; ++hd) {
-            // ---- Z = E W1^T: second-layer weight gradients as in-lane sums over the rows (samples) ---------------------------------------------
-#pragma unroll
-            for (int ht = 0; ht < 2; ++ht)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    fm_f16x z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) z = fm_mma3(efh[st][ks], efl[st][ks], WF_H(hd, ht, ks), WF_L(hd, ht, ks), z);
-                    // z[4 q + r] = scaled pre-activation of (sample 32 st + 8 q + 4 half + r, hidden unit 32 ht + l31)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int sb = 32 * st + 8 * q + 4 * half;
-                        if (hd == 0) {
-                            const fm_f4 gv = *reinterpret_cast<const fm_f4*>(&gs[wave][0][sb]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dw2[0][ht] = fmaf(fmaxf(z[4 * q + r], 0.f), gv[r], dw2[0][ht]);
-                        } else {
-#pragma unroll
-                            for (int o = 1; o < 4; ++o) {
-                                const fm_f4 gv = *reinterpret_cast<const fm_f4*>(&gs[wave][o][sb]);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) dw2[o][ht] = fmaf(fmaxf(z[4 * q + r], 0.f), gv[r], dw2[o][ht]);
-                            }
-                        }
-                    }
-                }
-            // ---- Z^T = W1 E^T -> dA^T (true scale) --------------------------------------------------------------------------------------------------
+            // ---- Z^T = W1 E^T -> ReLU masks -> dA^T (true scale) -------------------------------------------------------------------------------------
             float da[2][2][16];                    // [mt][nt][4 q + r]: hidden unit 32 mt + 8 q + 4 half + r of sample 32 nt + l31
             float damax[2] = {0.f, 0.f};
+            unsigned mword[2][2] = {{0u, 0u}, {0u, 0u}};      // [nt][mt]: this lane's nibbles of its sample's 64-bit ReLU mask (bit = hidden unit)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -240,7 +262,11 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { pos |= (z[r] > 0.f ? 1u : 0u) << r; zmin = fminf(zmin, fabsf(z[r])); }
                     const int si = s0 + 32 * nt + l31;
+#ifdef FM_ABL_NOSLOW
+                    const bool unsure = false;
+#else
                     const bool unsure = zmin < 4096.f && si < nn;
+#endif
                     if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
                         if (unsure) {
                             const float* erow = a.enc + (size_t)si * FM_K;
@@ -262,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int hb = 32 * mt + 8 * q + 4 * half;
+                        if constexpr (WG) mword[nt][mt] |= ((pos >> (4 * q)) & 15u) << (8 * q + 4 * half);
                         float gh[4];
                         if (hd == 0) {
                             const fm_f4 w = *reinterpret_cast<const fm_f4*>(&w2s[0][hb]);
@@ -281,6 +308,14 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
                         }
                     }
                 }
+            if constexpr (WG) {                    // every sample's whole mask, for the Z pass (lanes are hidden units there)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const unsigned w0 = mword[nt][0] | __shfl_xor(mword[nt][0], 32, 64), w1 = mword[nt][1] | __shfl_xor(mword[nt][1], 32, 64);
+                    if (half == 0) { mb[wave][32 * nt + l31][0] = w0; mb[wave][32 * nt + l31][1] = w1; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             float sd[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -308,21 +343,111 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dencT[nt][r] = fmaf(d[r], inv, dencT[nt][r]);
             }
-            // ---- DA rows: lane L leaves with hidden units 32 mt .. + 31 of sample L (swap: registers of tile 0 / tile 1 -> low / high four) ------------
+            if constexpr (!WG) {
+                // ---- DA rows: lane L leaves with hidden units 32 mt .. + 31 of sample L (swap: registers of tile 0 / tile 1 -> low / high four) --------
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) fm_swap(da[mt][0][r], da[mt][1][r]);
-                const int i = s0 + lane;
-                if (i < nn) {
-                    float* dst = a.da_out + (size_t)i * (2 * FM_H) + hd * FM_H + 32 * mt;
+                    for (int r = 0; r < 16; ++r) fm_swap(da[mt][0][r], da[mt][1][r]);
+                    const int i = s0 + lane;
+#ifdef FM_ABL_NODA
+                    if (i < nn && da[mt][0][0] == 12345.f) {
+#else
+                    if (i < nn) {
+#endif
+                        float* dst = a.da_out + (size_t)i * (2 * FM_H) + hd * FM_H + 32 * mt;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        *reinterpret_cast<fm_f4*>(dst + 8 * q) = fm_f4{da[mt][0][4 * q], da[mt][0][4 * q + 1], da[mt][0][4 * q + 2], da[mt][0][4 * q + 3]};
-                        *reinterpret_cast<fm_f4*>(dst + 8 * q + 4) = fm_f4{da[mt][1][4 * q], da[mt][1][4 * q + 1], da[mt][1][4 * q + 2], da[mt][1][4 * q + 3]};
+                        for (int q = 0; q < 4; ++q) {
+                            *reinterpret_cast<fm_f4*>(dst + 8 * q) = fm_f4{da[mt][0][4 * q], da[mt][0][4 * q + 1], da[mt][0][4 * q + 2], da[mt][0][4 * q + 3]};
+                            *reinterpret_cast<fm_f4*>(dst + 8 * q + 4) = fm_f4{da[mt][1][4 * q], da[mt][1][4 * q + 1], da[mt][1][4 * q + 2], da[mt][1][4 * q + 3]};
+                        }
                     }
                 }
             }
+            // ---- Z = E W1^T (hidden units are lanes, samples registers): second-layer weight gradients as in-lane sums; WG: dA in this layout is
+            //      the B operand of dW1^T = E^T dA ------------------------------------------------------------------------------------------------
+#ifndef FM_ABL_NOZ
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                float daz[WG ? 2 : 1][16];
+                float dzmax = 0.f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    fm_f16x z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) z = fm_mma3(efh[st][ks], efl[st][ks], WF_H(hd, ht, ks), WF_L(hd, ht, ks), z);
+                    // z[4 q + r] = scaled pre-activation of (sample 32 st + 8 q + 4 half + r, hidden unit 32 ht + l31)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sb = 32 * st + 8 * q + 4 * half;
+                        unsigned mk = 0u;
+                        if constexpr (WG) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mk |= ((mb[wave][sb + r][ht] >> l31) & 1u) << r;
+                        }
+                        if (hd == 0) {
+                            const fm_f4 gv = *reinterpret_cast<const fm_f4*>(&gs[wave][0][sb]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dw2[0][ht] = fmaf(fmaxf(z[4 * q + r], 0.f), gv[r], dw2[0][ht]);
+                            if constexpr (WG) {
+                                const fm_f4 gq = *reinterpret_cast<const fm_f4*>(&gp[wave][0][sb]);
+                                const float w = w2s[0][32 * ht + l31];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) daz[st][4 * q + r] = ((mk >> r) & 1u) ? gq[r] * w : 0.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int o = 1; o < 4; ++o) {
+                                const fm_f4 gv = *reinterpret_cast<const fm_f4*>(&gs[wave][o][sb]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dw2[o][ht] = fmaf(fmaxf(z[4 * q + r], 0.f), gv[r], dw2[o][ht]);
+                            }
+                            if constexpr (WG) {
+                                const fm_f4 g1 = *reinterpret_cast<const fm_f4*>(&gp[wave][1][sb]), g2 = *reinterpret_cast<const fm_f4*>(&gp[wave][2][sb]),
+                                            g3 = *reinterpret_cast<const fm_f4*>(&gp[wave][3][sb]);
+                                const float w0 = w2s[1][32 * ht + l31], w1 = w2s[2][32 * ht + l31], w2 = w2s[3][32 * ht + l31];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) daz[st][4 * q + r] = ((mk >> r) & 1u) ? fmaf(g3[r], w2, fmaf(g2[r], w1, g1[r] * w0)) : 0.f;
+                            }
+                        }
+                        if constexpr (WG) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dzmax = fmaxf(dzmax, fabsf(daz[st][4 * q + r]));
+                        }
+                    }
+                }
+                if constexpr (WG) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, off, 64));
+                    const float sD = fm_pow2_scale(dzmax);
+                    fm_f16x d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int tp = 0; tp < 2; ++tp) {
+                            float x[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) x[j] = daz[st][8 * tp + j];
+                            fm_h8 bh, bl;
+                            fm_split8(x, sD, bh, bl);
+                            d = fm_mma3(eth[st][tp], etl[st][tp], bh, bl, d);
+                        }
+                    // d[4 q + r] = scaled dW1[hidden unit 32 ht + l31][k = 8 q + 4 half + r]
+                    const float inv = 1.f / (sT * sD);
+                    if (hd == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dw1a[ht][r] = fmaf(d[r], inv, dw1a[ht][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dw1b[ht][r] = fmaf(d[r], inv, dw1b[ht][r]);
+                    }
+                }
+            }
+#endif
         }
         // ---- dE rows --------------------------------------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -335,6 +460,39 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
                 *reinterpret_cast<fm_f4*>(dst + 8 * q) = fm_f4{dencT[0][4 * q], dencT[0][4 * q + 1], dencT[0][4 * q + 2], dencT[0][4 * q + 3]};
                 *reinterpret_cast<fm_f4*>(dst + 8 * q + 4) = fm_f4{dencT[1][4 * q], dencT[1][4 * q + 1], dencT[1][4 * q + 2], dencT[1][4 * q + 3]};
             }
+        }
+    }
+    if constexpr (WG) {
+        // the block's slab [head][hidden unit][k] (the layout of field_wgrad_kernel's slabs: slab_reduce_kernel sums the blocks' slabs in a fixed order):
+        // the four waves' sums meet in the 32 KB of the fragment images, which nobody reads any more
+        __syncthreads();
+        float* buf = reinterpret_cast<float*>(&frag[0][0][0]) + (wave & 1) * (2 * FM_H * FM_K);
+        auto put = [&](bool add) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = (32 * ht + l31) * FM_K + 8 * q + 4 * half;
+                    fm_f4 va = fm_f4{dw1a[ht][4 * q], dw1a[ht][4 * q + 1], dw1a[ht][4 * q + 2], dw1a[ht][4 * q + 3]};
+                    fm_f4 vb = fm_f4{dw1b[ht][4 * q], dw1b[ht][4 * q + 1], dw1b[ht][4 * q + 2], dw1b[ht][4 * q + 3]};
+                    if (add) {
+                        const fm_f4 pa = *reinterpret_cast<fm_f4*>(buf + o), pb = *reinterpret_cast<fm_f4*>(buf + FM_H * FM_K + o);
+                        va[0] += pa[0]; va[1] += pa[1]; va[2] += pa[2]; va[3] += pa[3];
+                        vb[0] += pb[0]; vb[1] += pb[1]; vb[2] += pb[2]; vb[3] += pb[3];
+                    }
+                    *reinterpret_cast<fm_f4*>(buf + o) = va;
+                    *reinterpret_cast<fm_f4*>(buf + FM_H * FM_K + o) = vb;
+                }
+        };
+        if (wave < 2) put(false);
+        __syncthreads();
+        if (wave >= 2) put(true);
+        __syncthreads();
+        const float* b0 = reinterpret_cast<const float*>(&frag[0][0][0]);
+        float* slab = a.dw1_slabs + (size_t)blockIdx.x * (2 * FM_H * FM_K);
+        for (int q = tid; q < 2 * FM_H * FM_K / 4; q += 256) {
+            const fm_f4 x = reinterpret_cast<const fm_f4*>(b0)[q], y = reinterpret_cast<const fm_f4*>(b0 + 2 * FM_H * FM_K)[q];
+            reinterpret_cast<fm_f4*>(slab)[q] = fm_f4{x[0] + y[0], x[1] + y[1], x[2] + y[2], x[3] + y[3]};
         }
     }
     // ---- second-layer weight gradients: halves, waves, one atomic per weight and block -----------------------------------------------------------------
@@ -358,13 +516,22 @@ __global__ __launch_bounds__(256, 2) void field_bwd_mlp_mfma_kernel(const FmArgs
 
 // MLP half of asd_field_bwd on the matrix pipe (no finite-difference normal, 16 levels x 2 features, 64 hidden units, 3 feature outputs).
 // da_out [n, 128], denc_out [n, 32]; dw2d / dw2f are accumulated into.
+int asd_field_bwd_mlp_mfma_blocks(int32_t n) {
+    static const int max_blocks = getenv("ASD_FIELD_MFMA_BLOCKS") ? atoi(getenv("ASD_FIELD_MFMA_BLOCKS")) : 512;      // two per CU
+    return asd_div_up(n, 256) < max_blocks ? asd_div_up(n, 256) : max_blocks;
+}
+
+// dw1_slabs != NULL: the first-layer weight gradients leave as asd_field_bwd_mlp_mfma_blocks(n) slabs of [2][64][32] floats (one per block) and
+// da_out is not written; NULL: da_out [n, 128] is, for field_wgrad_kernel
 int asd_field_bwd_mlp_mfma(const asd_field_cfg* cfg, const float* w1d, const float* w2d, const float* w1f, const float* w2f, const float* enc, const float* sigma,
                            int32_t n, const int32_t* n_dev, const float* d_sigma, const float* d_features, float* da_out, float* denc_out, float* dw2d, float* dw2f,
-                           hipStream_t s) {
+                           float* dw1_slabs, hipStream_t s) {
     FmArgs a;
     a.c = *cfg;
     a.w1[0] = w1d; a.w1[1] = w1f; a.w2d = w2d; a.w2f = w2f; a.enc = enc; a.sigma = sigma; a.d_sigma = d_sigma; a.d_features = d_features;
-    a.n_dev = n_dev; a.n = n; a.da_out = da_out; a.denc_out = denc_out; a.dw2d = dw2d; a.dw2f = dw2f;
-    hipLaunchKernelGGL(field_bwd_mlp_mfma_kernel, dim3(asd_div_up(n, 256)), dim3(256), 0, s, a);
+    a.n_dev = n_dev; a.n = n; a.da_out = da_out; a.denc_out = denc_out; a.dw2d = dw2d; a.dw2f = dw2f; a.dw1_slabs = dw1_slabs;
+    const int blocks = asd_field_bwd_mlp_mfma_blocks(n);
+    if (dw1_slabs) hipLaunchKernelGGL(field_bwd_mlp_mfma_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(field_bwd_mlp_mfma_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
     return ASD_OK;
 }
