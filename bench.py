@@ -492,17 +492,19 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     # PMC: the span is field_bwd_sample_kernel (MLP backward + the coarse levels' run-aggregated atomics) + pg_fill_kernel + pg_accum_kernel (the
     # paged scatter of the eleven hashed levels); bytes per launch from this round's per-kernel passes, where every launch of these kernels has
     # the step's sample count
-    traffic = pmc_traffic_of("field_bwd_sample_kernel", "pg_fill_kernel", "pg_accum_kernel")
-    return {"kernel": "asd_field_bwd's gradient span: field_bwd_sample_kernel<16,64,3> (MLP backward, the dense levels 0-4 as run-aggregated fp32 atomics with per-XCD "
-                      "copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the eleven hashed levels 5-15 binned by 64 KB table page, one workgroup "
-                      "per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
+    traffic = pmc_traffic_of("field_bwd_mlp_mfma_kernel", "field_bwd_sample_kernel", "pg_fill_kernel", "pg_accum_kernel")
+    return {"kernel": "asd_field_bwd's gradient span: field_bwd_mlp_mfma_kernel (csrc/field_mfma.hip: both MLP heads' backward and the first-layer weight gradient as "
+                      "split-fp16 MFMA products, 64 samples per wave) + field_bwd_sample_kernel<16,64,3,0,PRE> (scatter only: the dense levels 0-4 as run-aggregated "
+                      "fp32 atomics with per-XCD copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the eleven hashed levels 5-15 binned by "
+                      "64 KB table page, one workgroup per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None if traffic is None else round(traffic),
-            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/r06_pmc_*_per_kernel.csv)",
+            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the four kernels, profiles/r06_pmc_*_per_kernel.csv)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
-            "binding_limit": "inside the span: the sample kernel (arithmetic + ~3.5 M coarse-level atomic requests), then the item stream of the paged scatter "
-                             "(128 B per sample and hashed level written + read) and its 640 pages on 512 workgroup slots (DESIGN.md 4.7)"}
+            "binding_limit": "inside the span (round 6): the scatter-only sample kernel (0.19 ms: ~3.5 M coarse-level atomic requests), the matrix-pipe MLP pass "
+                             "(0.17 ms incl. the first-layer weight gradient), then the item stream of the paged scatter (128 B per sample and hashed level written + "
+                             "read) and its 704 pages on 512 workgroup slots (DESIGN.md 4.7, 4.14)"}
 
 
 def cpu_baseline(system, batch, seed: int):
