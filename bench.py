@@ -175,6 +175,18 @@ def pmc_traffic_of(*kernel_substrs: str):
     return tot
 
 
+def pmc_shape_traffic(which: str):
+    """HBM bytes per launch of one of the single-shape loops below ("gemm", "vae512", "unet64") from this round's per-shape PMC passes
+    (profiles/r06_pmc_shapes.json: tools/r6_pmc_shapes.sh — separate FETCH_SIZE / WRITE_SIZE passes of that loop alone, FETCH_SIZE doubled); None without it"""
+    import json
+
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_shapes.json")
+    if not os.path.exists(path):
+        return None
+    v = json.load(open(path)).get(which, {}).get("bytes_per_launch")
+    return None if v is None else round(v)
+
+
 def trace_mark():
     """an empty launch named asd_trace_mark_kernel on the current stream: the per-step tables of profiles/ are cut between two of them"""
     import ctypes as C
@@ -376,7 +388,8 @@ def roofline_conv_kernel(which: str = "vae512", reps: int = 30):
     shape = "3x3 conv 128->128 @512x512 (VAE encoder)" if which == "vae512" else "3x3 conv 320->320 @64x64, UNet batch 5"
     return {"kernel": f"{kern} split_k={plan[1]} on {shape}; autotuned plan", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TF, 4),
-            "traffic": None, "traffic_unit": "bytes/launch (no per-shape PMC pass in round 5: null rather than an older round's figure)", "flops_per_launch": flops,
+            "traffic": pmc_shape_traffic(which), "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE of this loop alone, operands cache-warm: profiles/r06_pmc_shapes.json)",
+            "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * (B * hw * hw * (cin + cout) + 9 * cin * cout),
             "avg_launch_ms": round(ms, 4)}
 
 
@@ -404,7 +417,8 @@ def roofline_gemm_kernel(reps: int = 50):
     return {"kernel": f"gemm_f16_kernel<{H.TILE_BM[plan[0] - 1]}x{H.TILE_BN[plan[0] - 1]}> split_k={plan[1]} on linear 320->320, M=20480 (UNet 64x64 tokens x batch 5)"
                       if plan[0] else "gemm_f16_kernel<model tile> on linear 320->320, M=20480",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "traffic_unit": "bytes/launch (no per-shape PMC pass in round 5: null rather than an older round's figure)", "bytes_per_launch": nbytes,
+            "traffic": pmc_shape_traffic("gemm"), "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE of this loop alone, operands cache-warm: profiles/r06_pmc_shapes.json)",
+            "bytes_per_launch": nbytes,
             "avg_launch_ms": round(ms, 4)}
 
 

@@ -13,7 +13,8 @@ cp ${P}_mfma/pmc_mfma_by_kernel_and_grid.txt profiles/r06_pmc_mfma_by_kernel_and
 cp ${P}_c5/asd_mv_triplane_step_breakdown.txt profiles/r06_c5_triplane_step_breakdown.txt
 cp ${P}_c4/asd_sd_3dconv_net_step_breakdown.txt profiles/r06_c4_3dconv_step_breakdown.txt
 cat ${P}_tritx/tritx_sq_summary.txt ${P}_tritx/tritx_sq_counters.txt > profiles/r06_tritx_sq_counters.txt
-ls -la profiles | grep r05
 cp $P/ws_conv_8x8_time.txt profiles/r06_ws_conv_8x8_time.txt
 cp $P/gemm_shapes_time_lost.txt profiles/r06_gemm_shapes_time_lost.txt
 [ -f gpurun_out/tritx_full_size_vs_float64.txt ] && cp gpurun_out/tritx_full_size_vs_float64.txt profiles/r06_tritx_full_size_vs_float64.txt
+cp ${P}_shapes/pmc_shapes.json profiles/r06_pmc_shapes.json
+cp $P/vendor_library_compare.txt profiles/r06_vendor_library_compare.txt

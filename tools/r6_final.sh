@@ -23,3 +23,5 @@ bash tools/workload_breakdown.sh ${1:-r6_final}_c4 asd_sd_3dconv_net 8 8 > /dev/
 bash tools/tritx_pmc.sh ${1:-r6_final}_tritx > /dev/null 2>&1; head -12 gpurun_out/${1:-r6_final}_tritx/tritx_sq_counters.txt | cut -c1-160
 python tools/r6_ws_time.py $O/ws_conv_8x8_time.txt > /dev/null 2>&1; tail -4 $O/ws_conv_8x8_time.txt | cut -c1-200
 (timeout 900 python tools/gemm_shapes.py > $O/gemm_shapes_stdout.txt 2> $O/gemm_shapes.err; cp gpurun_out/gemm_shapes.txt $O/gemm_shapes_time_lost.txt); head -5 $O/gemm_shapes_time_lost.txt
+bash tools/r6_pmc_shapes.sh ${1:-r6_final}_shapes > /dev/null 2>&1; cat gpurun_out/${1:-r6_final}_shapes/pmc_shapes.json
+(timeout 300 python tools/lib_gemm_compare.py 30 > /dev/null 2>&1; cp gpurun_out/lib_gemm_compare.txt $O/vendor_library_compare.txt); tail -1 $O/vendor_library_compare.txt
