@@ -130,9 +130,9 @@ def to_device(batch, dev):
 # moved seven of the VAE's 24 ping-pong launches to other window kernels, so gemm_f16_kernel<256,64> (the 64x64 / 32x32 levels' linears)
 # now leads both tables; the ping-pong convolution keeps its own line (`roofline_pp_conv`).
 DOMINANT = "gemm256"
-DOMINANT_SOURCE = ("profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row gemm_f16_kernel<256,64,4,2> (10.1 % of the "
-                   "run, 26.5 us average); inside the timed steps (profiles/r06_step_breakdown.txt) it is first too (55 launches on 15 shapes: the linears of the "
-                   "UNet's 64x64 and 32x32 transformer blocks, 1.46 ms of each step), then conv3x3_pp_kernel<4,4> (17 launches, 1.21 ms: `roofline_pp_conv`), "
+DOMINANT_SOURCE = ("profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row gemm_f16_kernel<256,64,4,2> (10.95 % of the "
+                   "run, 27.0 us average); inside the timed steps (profiles/r06_step_breakdown.txt) it is first too (55 launches on 15 shapes: the linears of the "
+                   "UNet's 64x64 and 32x32 transformer blocks, 1.48 ms of each step), then conv3x3_pp_kernel<4,4> (17 launches, 1.23 ms: `roofline_pp_conv`), "
                    "attention, and the hash-grid gradient (`roofline_field_bwd`)")
 
 # every launch of gemm_f16_kernel<256,64,4,2> (plain GEMM) in one step (tools/gemm_shapes.py trace, gpurun_out/gemm_order.txt of the round-6 tree):
@@ -173,6 +173,39 @@ def pmc_traffic_of(*kernel_substrs: str):
                 return None
             tot += val
     return tot
+
+
+def pmc_span_traffic(span_kernel: str, *other_kernels: str):
+    """HBM bytes per SPAN of several kernels (one launch of `span_kernel` + however many launches of the others belong to it: the paged scatter runs
+    once or twice per field gradient, depending on the row capacity) from the committed per-kernel PMC summaries: the kernels' summed counters divided by
+    the dispatches of `span_kernel`; FETCH_SIZE doubled (see pmc_traffic_of).  None when a kernel is missing."""
+    import csv
+
+    tot, spans = 0.0, None
+    for cnt, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{cnt}_per_kernel.csv")
+        if not os.path.exists(path):
+            return None
+        rows = [r for r in csv.reader(open(path)) if len(r) >= 5 and r[1].isdigit()]
+        for name in (span_kernel,) + other_kernels:
+            hit = next((r for r in rows if name in r[0]), None)
+            if hit is None:
+                return None
+            tot += float(hit[2]) * 1024.0 * scale
+            if name == span_kernel:
+                if spans is not None and spans != int(hit[1]):
+                    return None          # the two passes must have seen the same launches
+                spans = int(hit[1])
+    return tot / spans if spans else None
+
+
+def pmc_span_samples():
+    """samples per field-gradient span in the PMC passes behind pmc_span_traffic (profiles/r06_pmc_field_span.json: the sample count drifts with the
+    occupancy grid, so the counters' bytes belong to THAT count, not to the one of this run)"""
+    import json
+
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_field_span.json")
+    return json.load(open(path)).get("samples_per_launch") if os.path.exists(path) else None
 
 
 def pmc_shape_traffic(which: str):
@@ -506,14 +539,14 @@ def roofline_field_bwd(system, batch, reps: int = 10):
     # PMC: the span is field_bwd_sample_kernel (MLP backward + the coarse levels' run-aggregated atomics) + pg_fill_kernel + pg_accum_kernel (the
     # paged scatter of the eleven hashed levels); bytes per launch from this round's per-kernel passes, where every launch of these kernels has
     # the step's sample count
-    traffic = pmc_traffic_of("field_bwd_mlp_mfma_kernel", "field_bwd_sample_kernel", "pg_fill_kernel", "pg_accum_kernel")
+    traffic = pmc_span_traffic("field_bwd_sample_kernel", "field_bwd_mlp_mfma_kernel", "pg_fill_kernel", "pg_accum_kernel")
     return {"kernel": "asd_field_bwd's gradient span: field_bwd_mlp_mfma_kernel (csrc/field_mfma.hip: both MLP heads' backward and the first-layer weight gradient as "
                       "split-fp16 MFMA products, 64 samples per wave) + field_bwd_sample_kernel<16,64,3,0,PRE> (scatter only: the dense levels 0-4 as run-aggregated "
                       "fp32 atomics with per-XCD copies of levels 0-2) + pg_fill_kernel + pg_accum_kernel (csrc/field_paged.hip: the eleven hashed levels 5-15 binned by "
                       "64 KB table page, one workgroup per page, tag-arbitrated plain LDS adds — no global atomics); one span per step", "bound": "hbm",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None if traffic is None else round(traffic),
-            "traffic_unit": "bytes/span (PMC FETCH_SIZE x2 + WRITE_SIZE of the four kernels, profiles/r06_pmc_*_per_kernel.csv)",
+            "traffic": None if traffic is None else round(traffic), "traffic_samples_per_launch": pmc_span_samples(),
+            "traffic_unit": "bytes/span at traffic_samples_per_launch samples (PMC FETCH_SIZE x2 + WRITE_SIZE summed over the four kernels' launches / spans, profiles/r06_pmc_*_per_kernel.csv)",
             "samples_per_launch": n, "avg_launch_ms": round(ms, 4), "asd_field_bwd_call_ms": round(ms_call, 4),
             "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_bytes_per_launch": n * bytes_per_sample,
             "binding_limit": "inside the span (round 6): the scatter-only sample kernel (0.19 ms: ~3.5 M coarse-level atomic requests), the matrix-pipe MLP pass "

@@ -18,3 +18,8 @@ cp $P/gemm_shapes_time_lost.txt profiles/r06_gemm_shapes_time_lost.txt
 [ -f gpurun_out/tritx_full_size_vs_float64.txt ] && cp gpurun_out/tritx_full_size_vs_float64.txt profiles/r06_tritx_full_size_vs_float64.txt
 cp ${P}_shapes/pmc_shapes.json profiles/r06_pmc_shapes.json
 cp $P/vendor_library_compare.txt profiles/r06_vendor_library_compare.txt
+python - <<PY
+import json
+d = json.loads(open("${P}_pmc/bench_under_pmc_FETCH_SIZE.json").read().strip().splitlines()[-1])
+json.dump({"samples_per_launch": d["roofline_field_bwd"]["samples_per_launch"], "source": "roofline_field_bwd.samples_per_launch of the bench line printed under the FETCH_SIZE pass"}, open("profiles/r06_pmc_field_span.json", "w"), indent=1)
+PY
