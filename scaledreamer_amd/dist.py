@@ -135,7 +135,9 @@ class GradientExchange:
         ex.prepare(sync=k == 1) -> backward -> [ex.prepare(zero=False, sync=last) -> backward] * (k - 1) -> ex.finish() -> optimizer.step()
     — the gradients are summed in place in the persistent buckets / large `.grad`s and only the LAST backward launches collectives."""
 
-    def __init__(self, params, bucket_bytes: int = None, in_place_bytes: int = None):
+    def __init__(self, params, bucket_bytes: int = None, in_place_bytes: int = None, own=None):
+        """own: a collective object with OwnCollective's interface (launch(flat) / wait() / close()) to run the units on instead of
+        torch.distributed's all_reduce — what ASD_OWN_ALLREDUCE=1 builds on GPU ranks; given explicitly by the CPU test of the hand-off order"""
         self.params = [p for p in params if p.requires_grad]
         bucket_bytes = BUCKET_BYTES if bucket_bytes is None else bucket_bytes
         in_place_bytes = IN_PLACE_BYTES if in_place_bytes is None else in_place_bytes
@@ -176,8 +178,8 @@ class GradientExchange:
         self._order_learned = False
         self._seen_order: List[int] = []
         # opt-in: the library's own communicator instead of torch.distributed's (GPU, fp32 gradients only)
-        self._own = None
-        if (os.environ.get("ASD_OWN_ALLREDUCE", "0") == "1" and is_distributed() and dist.get_backend() == "nccl" and self.params
+        self._own = own
+        if (own is None and os.environ.get("ASD_OWN_ALLREDUCE", "0") == "1" and is_distributed() and dist.get_backend() == "nccl" and self.params
                 and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)):
             self._own = OwnCollective(self.params[0].device)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]

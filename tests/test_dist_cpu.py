@@ -50,6 +50,79 @@ def test_two_rank_gradient_mean_allreduce(tmp_path):
         torch.testing.assert_close(a1, a0)
 
 
+def _own_worker(rank, world, port, out_dir):
+    """GradientExchange on a collective object of its own (the ASD_OWN_ALLREDUCE=1 path: OwnCollective over asd_allreduce_mean_f32 on GPU ranks) —
+    here a stand-in with the same interface over gloo that logs what the exchange asks of it: every unit must go through launch() in the
+    fixed order both ranks share (learned in step 1, reused in step 2), wait() must come after the last launch of a step and before
+    finish() returns, close() with the exchange."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from scaledreamer_amd import dist as asd_dist
+
+    assert asd_dist.init_from_env("gloo") == world
+
+    class FakeOwn:
+        def __init__(self):
+            self.log, self.works = [], []
+
+        def launch(self, flat):
+            assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.dim() == 1
+            self.log.append(("launch", flat.numel()))
+            self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))     # (the exchange divides by the world size on gloo)
+
+        def wait(self):
+            self.log.append(("wait", len(self.works)))
+            for w in self.works:
+                w.wait()
+            self.works = []
+
+        def close(self):
+            self.log.append(("close", 0))
+
+    torch.manual_seed(3 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    model.register_parameter("table", torch.nn.Parameter(torch.randn(300_000)))
+    asd_dist.broadcast_parameters(model)
+    own = FakeOwn()
+    ex = asd_dist.GradientExchange(list(model.parameters()), bucket_bytes=256, in_place_bytes=1 << 20, own=own)
+    steps = []
+    for step in range(2):
+        x = torch.randn(5, 8)
+        loss = model(x).pow(2).mean() + (model.table[:1000] * (rank + 1 + step)).sum()
+        local = torch.autograd.grad(loss, list(model.parameters()), retain_graph=True)
+        ex.prepare()
+        n0 = len(own.log)
+        loss.backward()
+        launched_in_backward = sum(1 for op, _ in own.log[n0:] if op == "launch")
+        ex.finish()
+        steps.append({"local": [g.clone() for g in local], "avg": [p.grad.clone() for p in model.parameters()], "log": list(own.log[n0:]),
+                      "launched_in_backward": launched_in_backward})
+    n_units = len(ex.units)
+    ex.close()
+    torch.save({"steps": steps, "n_units": n_units, "closed": own.log[-1][0] == "close", "order": ex.order}, os.path.join(out_dir, f"o{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_on_an_own_collective(tmp_path):
+    port = 29500 + ((os.getpid() + 17) % 2000)
+    mp.spawn(_own_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "o0.pt"), torch.load(tmp_path / "o1.pt")
+    assert r0["n_units"] == r1["n_units"] >= 3 and r0["closed"] and r1["closed"] and r0["order"] == r1["order"]
+    for step in range(2):
+        s0, s1 = r0["steps"][step], r1["steps"][step]
+        for log in (s0["log"], s1["log"]):
+            ops = [op for op, _ in log]
+            assert ops.count("launch") == r0["n_units"] and ops.count("wait") == 1 and ops[-1] == "wait", ops     # every unit, then ONE wait, nothing after it
+            assert log[-1][1] == r0["n_units"]                                                                    # ... which covered all of them
+        assert [n for op, n in s0["log"] if op == "launch"] == [n for op, n in s1["log"] if op == "launch"]       # same collectives in the same order
+        for g0, g1, a0, a1 in zip(s0["local"], s1["local"], s0["avg"], s1["avg"]):
+            torch.testing.assert_close(a0, (g0 + g1) / 2)
+            torch.testing.assert_close(a1, a0)
+    # step 2 uses the learned order: units are launched from the backward hooks, not held back for finish()
+    assert r0["steps"][1]["launched_in_backward"] >= 1 and r1["steps"][1]["launched_in_backward"] >= 1
+
+
 def _system_worker(rank, world, port, out_dir):
     """the REAL StableDreamer.train_one_step wiring (update hooks -> GradientExchange.prepare -> training_step -> backward with
     the exchange's hooks -> finish -> optimizer.step -> end hooks) with a stub renderer / guidance: per-rank seed, broadcast
