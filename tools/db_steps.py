@@ -76,6 +76,22 @@ if "--gaps" in sys.argv:     # idle gaps above a threshold (us) inside the last 
         end = max(end, e_)
     print(f"idle total {tot_idle / 1e6:.3f} ms")
 
+if "--idle-by-next" in sys.argv:     # idle time of the analysed steps by the kernel the GPU was waiting for, and the 25 longest gaps
+    agg, gaps, end, prev = {}, [], seg[0][0], ""
+    for s_, e_, nm in seg:
+        if s_ > end:
+            k = short(nm)[:70]
+            agg[k] = agg.get(k, [0, 0]); agg[k][0] += 1; agg[k][1] += s_ - end
+            gaps.append((s_ - end, prev, k))
+        if e_ > end:
+            end, prev = e_, short(nm)[:50]
+    print(f"idle per step by the kernel that ended the gap ({n} steps):")
+    for k, (cn, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+        print(f"  {t / n / 1e3:8.1f} us/step  {cn / n:6.1f} gaps/step  {k}")
+    print("longest gaps:")
+    for g, a_, b_ in sorted(gaps, reverse=True)[:25]:
+        print(f"  {g / 1e3:8.1f} us  after {a_}  before {b_}")
+
 if "--list" in sys.argv:     # durations (us) of the launches of one kernel name inside the last analysed steps, in program order, averaged over the steps
     pat = sys.argv[sys.argv.index("--list") + 1]      # regular expression on the kernel name
     per = []

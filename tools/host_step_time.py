@@ -1,6 +1,6 @@
 """Host side of the headline step: wall time of the calls that ENQUEUE one training step (no synchronisation inside the loop), next to the GPU time per
 step.  If the host needs about as long as the GPU, the GPU idles wherever the host has to walk through Python between launches.
-    python tools/host_step_time.py"""
+    python tools/host_step_time.py [workload]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,7 @@ import bench
 torch.cuda.set_device(0)
 torch.set_num_threads(1)
 dev = torch.device("cuda", 0)
-cfg, system, data = bench.build_system("hip", seed=10, workload="asd_sd_nerf")
+cfg, system, data = bench.build_system("hip", seed=10, workload=sys.argv[1] if len(sys.argv) > 1 else "asd_sd_nerf")
 batch = bench.to_device(data.collate(), dev)
 for _ in range(10):
     system.train_one_step(batch)
