@@ -51,6 +51,9 @@ __device__ __forceinline__ float rows_sum(float v) {
 #define ATTN_DEFER_LOG2 8.0f   // 0: rescale whenever a maximum moves (the first form)
 #endif
 #define KT 64      // keys per tile
+#ifndef ATTN_SUM_MFMA
+#define ATTN_SUM_MFMA 1   // 0: row sums on the vector pipe (the first form; A/B partner)
+#endif
 // queries per wave = 16 * QS, per block = 64 * QS (4 waves).  QS = 2: 128 registers, four waves per SIMD.  QS = 4 (self-attention
 // over >= 2048 keys): every K / V^T fragment read from LDS and every tile brought from L2 serves twice the MFMAs, half the barriers
 // per flop; 218 registers, two waves per SIMD: 210 -> 196 us at L = 4096 (same-box A/B), nothing at L = 1024, slower below.
@@ -127,9 +130,29 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
     for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[qs][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run[QS], l_run[QS];
+    float m_run[QS];
 #pragma unroll
-    for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -1e30f; l_run[qs] = 0.f; }
+    for (int qs = 0; qs < QS; ++qs) m_run[qs] = -1e30f;
+#if ATTN_SUM_MFMA
+    // Row sums on the matrix pipe: one more V^T fragment whose row 0 is all ones makes sum_k P[q][k] row 0 of a fifth output tile — the loop issues
+    // ~112 vector slots per 16 scores (64 of them the exponentials) against 64 MFMAs per tile, and the matrix pipe is a third busy: 13 slots per query
+    // group and tile (pairwise adds, the cross-lane sum, the running-sum update) become two MFMAs.  The sum is then the sum of the fp16-rounded
+    // probabilities that multiply V (the normaliser of exactly what was accumulated).  Lane (q, lg = 0) holds it in register 0.
+    // Same-box: attention per step 1.35 -> 1.24 ms (tools/attn_bench.py), the step -0.085 ms in three pairs (gpurun_out/attn1/ab.txt).
+    // Measured on top of it and NOT kept: scale and shift folded into the S MFMA (Q pre-multiplied by scale * log2 e, accumulator started at
+    // -m_run: L = 4096 179 -> 164 us, but a rounding of Q per element that costs 2e-2 absolute on the large-score test — the probabilities of
+    // scores ~60 move by 1 %); the rescale factor behind a wave-uniform branch (nothing); k-step 0's V^T fragments requested in front of the
+    // softmax (187.5 -> 185.6 us).
+    floatx4 lacc[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) lacc[qs] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const half_t one_or_zero = lq16 == 0 ? (half_t)1.f : (half_t)0.f;
+    const half8 ones_row0 = {one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero};
+#else
+    float l_run[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) l_run[qs] = 0.f;
+#endif
 
     const int n_tiles = (p.lk + KT - 1) / KT;
     const float sl2 = p.scale * 1.44269504088896340736f;   // softmax in the log2 domain
@@ -192,7 +215,9 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
             const float m_new = grow ? max3f(m_run[qs], cand, -3.0e38f) : m_run[qs];
             const float alpha = grow ? __builtin_amdgcn_exp2f(m_run[qs] - m_new) : 1.f;
             const float2_ sl2v = {sl2, sl2}, nm = {-m_new, -m_new};
+#if !ATTN_SUM_MFMA
             float2_ sum2 = {0.f, 0.f};
+#endif
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 // v_pk_fma_f32: two exponents per instruction
@@ -200,18 +225,25 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
                 const float2_ x23 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 2, 3), sl2v, nm);
                 const float2_ e01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
                 const float2_ e23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+#if !ATTN_SUM_MFMA
                 sum2 += e01 + e23;
+#endif
                 half8& dst = pb[kt >> 1][qs];                              // v_cvt_pk_f16_f32 (RNE) x2, written in place
                 dst[(kt & 1) * 4 + 0] = (half_t)e01[0]; dst[(kt & 1) * 4 + 1] = (half_t)e01[1];
                 dst[(kt & 1) * 4 + 2] = (half_t)e23[0]; dst[(kt & 1) * 4 + 3] = (half_t)e23[1];
             }
+#if !ATTN_SUM_MFMA
             const float sum = rows_sum(sum2[0] + sum2[1]);
             l_run[qs] = l_run[qs] * alpha + sum;
+#endif
             if (grow) {   // wave-uniform: some query's maximum moved by more than the deferral
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     oacc[qs][dt][0] *= alpha; oacc[qs][dt][1] *= alpha; oacc[qs][dt][2] *= alpha; oacc[qs][dt][3] *= alpha;
                 }
+#if ATTN_SUM_MFMA
+                lacc[qs][0] *= alpha;
+#endif
             }
             m_run[qs] = m_new;
         }
@@ -232,6 +264,10 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) oacc[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[j][qs], oacc[qs][dt], 0, 0, 0);
             }
+#if ATTN_SUM_MFMA
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) lacc[qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones_row0, pb[j][qs], lacc[qs], 0, 0, 0);
+#endif
         }
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done with this buffer
     }
@@ -240,8 +276,12 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         const int qi = q0 + qs * 16 + lq16;
-        if (qi >= p.lq) continue;
+#if ATTN_SUM_MFMA
+        const float inv = 1.f / __shfl(lacc[qs][0], lq16, 64);          // lane (q, lg = 0) = lane q holds the query's sum (all lanes take part)
+#else
         const float inv = 1.f / l_run[qs];
+#endif
+        if (qi >= p.lq) continue;
         half_t* dst = p.o + ((size_t)b * p.lq + qi) * p.ldo + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
