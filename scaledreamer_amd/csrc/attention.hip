@@ -31,6 +31,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // Reductions over the four 16-lane rows of the wave (the lanes l, l^16, l^32, l^48 hold the same query column): gfx950's row swaps
 // (v_permlane16_swap / v_permlane32_swap: VALU, no LDS round trip) instead of two ds_bpermute + s_waitcnt lgkmcnt(0) each.
 __device__ __forceinline__ float rows_max(float v) {
@@ -51,6 +56,9 @@ __device__ __forceinline__ float rows_sum(float v) {
 #define ATTN_DEFER_LOG2 8.0f   // 0: rescale whenever a maximum moves (the first form)
 #endif
 #define KT 64      // keys per tile
+#ifndef ATTN_SCALAR_FMA
+#define ATTN_SCALAR_FMA 1
+#endif
 #ifndef ATTN_SUM_MFMA
 #define ATTN_SUM_MFMA 1   // 0: row sums on the vector pipe (the first form; A/B partner)
 #endif
@@ -220,9 +228,17 @@ __global__ __launch_bounds__(256, QS == 2 ? 4 : 2) void attention_fwd_kernel(con
 #endif
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                // v_pk_fma_f32: two exponents per instruction
-                const float2_ x01 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 0, 1), sl2v, nm);
-                const float2_ x23 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 2, 3), sl2v, nm);
+                // wide form: single v_fma_f32 (asm: -O3 would pack neighbours into v_pk_fma_f32 again, which costs more than two plain FMAs beside
+                // MFMAs: MI355X_MICROARCH.md, per-instruction cycle constants — L = 4096: 179 -> 171 us); narrow form (four waves per SIMD at 128
+                // registers): v_pk_fma_f32, two exponents per instruction (with single FMAs L = 1024 goes 31 -> 38 us)
+                float2_ x01, x23;
+                if constexpr (QS == 4 && ATTN_SCALAR_FMA) {
+                    x01 = float2_{fma1(s[kt][qs][0], sl2, -m_new), fma1(s[kt][qs][1], sl2, -m_new)};
+                    x23 = float2_{fma1(s[kt][qs][2], sl2, -m_new), fma1(s[kt][qs][3], sl2, -m_new)};
+                } else {
+                    x01 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 0, 1), sl2v, nm);
+                    x23 = __builtin_elementwise_fma(__builtin_shufflevector(s[kt][qs], s[kt][qs], 2, 3), sl2v, nm);
+                }
                 const float2_ e01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
                 const float2_ e23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
 #if !ATTN_SUM_MFMA
