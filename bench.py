@@ -130,9 +130,9 @@ def to_device(batch, dev):
 # moved seven of the VAE's 24 ping-pong launches to other window kernels, so gemm_f16_kernel<256,64> (the 64x64 / 32x32 levels' linears)
 # now leads both tables; the ping-pong convolution keeps its own line (`roofline_pp_conv`).
 DOMINANT = "gemm256"
-DOMINANT_SOURCE = ("profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row gemm_f16_kernel<256,64,4,2> (10.98 % of the "
-                   "run, 26.9 us average); inside the timed steps (profiles/r06_step_breakdown.txt) it is first too (55 launches on 15 shapes: the linears of the "
-                   "UNet's 64x64 and 32x32 transformer blocks, 1.48 ms of each step), then conv3x3_pp_kernel<4,4> (17 launches, 1.23 ms: `roofline_pp_conv`), "
+DOMINANT_SOURCE = ("profiles/r06_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`): first row gemm_f16_kernel<256,64,4,2> (11.05 % of the "
+                   "run, 26.7 us average); inside the timed steps (profiles/r06_step_breakdown.txt) it is first too (55 launches on 15 shapes: the linears of the "
+                   "UNet's 64x64 and 32x32 transformer blocks, 1.48 ms of each step), then conv3x3_pp_kernel<4,4> (17 launches, 1.22 ms: `roofline_pp_conv`), "
                    "attention, and the hash-grid gradient (`roofline_field_bwd`)")
 
 # every launch of gemm_f16_kernel<256,64,4,2> (plain GEMM) in one step (tools/gemm_shapes.py trace, gpurun_out/gemm_order.txt of the round-6 tree):
