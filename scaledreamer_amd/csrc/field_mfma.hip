@@ -517,7 +517,9 @@ __global__ __launch_bounds__(256, WG ? 1 : 2) void field_bwd_mlp_mfma_kernel(con
 // MLP half of asd_field_bwd on the matrix pipe (no finite-difference normal, 16 levels x 2 features, 64 hidden units, 3 feature outputs).
 // da_out [n, 128], denc_out [n, 32]; dw2d / dw2f are accumulated into.
 int asd_field_bwd_mlp_mfma_blocks(int32_t n) {
-    static const int max_blocks = getenv("ASD_FIELD_MFMA_BLOCKS") ? atoi(getenv("ASD_FIELD_MFMA_BLOCKS")) : 512;      // two per CU
+    // one per CU: the all-in-one form holds one wave per SIMD (442 registers), so 512 blocks were two rounds of 256 with twice the weight staging
+    // and twice the slabs to reduce (same box, span of 140 k samples: 0.338 -> 0.326 ms; 1024 blocks 0.35)
+    static const int max_blocks = getenv("ASD_FIELD_MFMA_BLOCKS") ? atoi(getenv("ASD_FIELD_MFMA_BLOCKS")) : 256;
     return asd_div_up(n, 256) < max_blocks ? asd_div_up(n, 256) : max_blocks;
 }
 
